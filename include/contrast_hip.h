@@ -1,0 +1,236 @@
+/* contrast_hip.h — C ABI of the MI355X-native tessellate + raster hot path of contrast_renderer.
+ *
+ * Every entry point names the reference interface it replaces (file:line relative to the
+ * reference tree, contrast_renderer v0.1.4). The reference has no FFI; its seam for this path is
+ * `Shape::from_paths` / `Shape::render` (renderer.rs:177, :267) over the private modules
+ * fill / stroke / vertex (lib.rs:12,16,20). A Rust shim that keeps those signatures binds exactly
+ * the functions below (see INTEGRATION.md for the `extern "C"` block).
+ *
+ * Conventions: plain pointers and sizes, host memory unless a name ends in `_dev`; all functions
+ * return crh_status; handles are thread-compatible (one HIP stream per renderer), not thread-safe.
+ * Batch first: the unit of work is a *scene* = many Shapes built and rendered together, because one
+ * kernel launch per Shape would be launch-bound on a 256-CU part. A scene with n_shapes == 1 is the
+ * reference's single `Shape`.
+ */
+#ifndef CONTRAST_HIP_H
+#define CONTRAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: 1..5 are error.rs:5-16 in declaration order ---------------------------------- */
+typedef enum crh_status {
+    CRH_OK = 0,
+    CRH_ERR_NUMBER_OF_STENCIL_BITS_IS_UNSUPPORTED = 1,    /* renderer.rs:433-435 */
+    CRH_ERR_CLIP_STACK_OVERFLOW = 2,                      /* renderer.rs:934 (clip ops: out of scope, never raised) */
+    CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS = 3,           /* renderer.rs:948,981 (out of scope, never raised) */
+    CRH_ERR_TOO_MANY_DASH_INTERVALS = 4,                  /* renderer.rs:32-34 */
+    CRH_ERR_DYNAMIC_STROKE_OPTIONS_INDEX_OUT_OF_BOUNDS = 5, /* renderer.rs:189-191, :366-368 */
+    CRH_ERR_NON_FINITE = 6,        /* the reference panics: safe_float.rs:46,114 */
+    CRH_ERR_DEGENERATE_CUBIC = 7,  /* the reference panics: fill.rs:174,178 */
+    CRH_ERR_UNSUPPORTED = 8,       /* documented limit of this implementation */
+    CRH_ERR_HIP = 9,               /* a HIP runtime call failed; crh_last_error() has the text */
+    CRH_ERR_INVALID_ARGUMENT = 10
+} crh_status;
+
+/* ---- the Path data model (path.rs:15-230) -------------------------------------------------------- */
+
+/* SegmentType discriminants, path.rs:56-67 */
+enum {
+    CRH_SEGMENT_LINE = 0,               /* control data: x y                          (path.rs:15-18)  */
+    CRH_SEGMENT_INTEGRAL_QUADRATIC = 1, /* control data: c0x c0y c1x c1y              (path.rs:22-25)  */
+    CRH_SEGMENT_INTEGRAL_CUBIC = 2,     /* control data: c0x c0y c1x c1y c2x c2y      (path.rs:29-32)  */
+    CRH_SEGMENT_RATIONAL_QUADRATIC = 3, /* control data: weight c0x c0y c1x c1y       (path.rs:36-43)  */
+    CRH_SEGMENT_RATIONAL_CUBIC = 4      /* control data: w0 w1 w2 w3 c0x c0y .. c2y   (path.rs:47-52)  */
+};
+/* Join, path.rs:71-82 ; Cap, path.rs:86-101 */
+enum { CRH_JOIN_MITER = 0, CRH_JOIN_BEVEL = 1, CRH_JOIN_ROUND = 2 };
+enum { CRH_CAP_SQUARE = 0, CRH_CAP_ROUND = 1, CRH_CAP_OUT = 2, CRH_CAP_IN = 3, CRH_CAP_RIGHT = 4, CRH_CAP_LEFT = 5, CRH_CAP_BUTT = 6 };
+/* CurveApproximation, path.rs:153-167 */
+enum { CRH_CURVE_UNIFORMLY_SPACED_PARAMETERS = 0, CRH_CURVE_UNIFORM_TANGENT_ANGLE = 1 };
+#define CRH_MAX_DASH_INTERVALS 4 /* path.rs:121 */
+
+/* StrokeOptions, path.rs:171-192 (already legalize()d by the caller, path.rs:196-200) */
+typedef struct crh_stroke_options {
+    float width;
+    float offset;
+    float miter_clip;
+    uint32_t closed;
+    uint32_t dynamic_stroke_options_group;
+    uint32_t curve_approximation; /* CRH_CURVE_* */
+    uint32_t steps;               /* UniformlySpacedParameters(steps) */
+    float angle_step;             /* UniformTangentAngle(angle_step) */
+} crh_stroke_options;
+
+/* DashInterval, path.rs:105-118 */
+typedef struct crh_dash_interval {
+    float gap_start;
+    float gap_end;
+    uint32_t dash_start; /* CRH_CAP_* */
+    uint32_t dash_end;   /* CRH_CAP_* */
+} crh_dash_interval;
+
+/* DynamicStrokeOptions, path.rs:127-149 */
+typedef struct crh_dynamic_stroke_options {
+    uint32_t dashed;      /* 1 = Dashed{join, pattern, phase}, 0 = Solid{join, start, end} */
+    uint32_t join;        /* CRH_JOIN_* */
+    uint32_t pattern_len; /* > CRH_MAX_DASH_INTERVALS -> CRH_ERR_TOO_MANY_DASH_INTERVALS; 0 is invalid as in the reference */
+    crh_dash_interval pattern[CRH_MAX_DASH_INTERVALS];
+    float phase;
+    uint32_t start; /* CRH_CAP_* (Solid) */
+    uint32_t end;   /* CRH_CAP_* (Solid) */
+} crh_dynamic_stroke_options;
+
+/* DynamicStrokeDescriptor, renderer.rs:20-27: the 48-byte record the raster reads */
+typedef struct crh_dynamic_stroke_descriptor {
+    float gap_start[CRH_MAX_DASH_INTERVALS];
+    float gap_end[CRH_MAX_DASH_INTERVALS];
+    uint32_t caps;
+    uint32_t count_dashed_join;
+    float phase;
+    uint32_t _padding;
+} crh_dynamic_stroke_descriptor;
+
+/* A batch of Shapes, each a contiguous run of Paths (the argument `paths: &[Path]` of
+ * renderer.rs:181, for many shapes at once). Struct-of-arrays flattening of path.rs:213-230:
+ * `control_data` holds the segments' floats in path order, one record per segment with the layout
+ * given at CRH_SEGMENT_* above; `path_start` is Path::start. All floats must be finite; -0.0 is
+ * canonicalised to +0.0 on upload (SafeFloat::from, safe_float.rs:44-52). */
+typedef struct crh_path_batch {
+    uint32_t n_shapes;
+    const uint32_t* shape_path_begin; /* [n_shapes + 1] */
+    uint32_t n_paths;
+    const uint32_t* path_segment_begin;  /* [n_paths + 1] into segment_types */
+    const float* path_start;             /* [n_paths][2] */
+    const int32_t* path_stroke_options;  /* [n_paths]: index into stroke_options, or -1 = filled (Path::stroke_options == None) */
+    uint32_t n_segments;
+    const uint8_t* segment_types; /* [n_segments] CRH_SEGMENT_* */
+    const float* control_data;    /* sum over segments of {2,4,6,5,10}[type] floats */
+    uint32_t n_control_floats;
+    uint32_t n_stroke_options;
+    const crh_stroke_options* stroke_options;
+    const uint32_t* shape_dynamic_begin; /* [n_shapes + 1] into dynamic_stroke_options (the per-shape `&[DynamicStrokeOptions]`, renderer.rs:180) */
+    uint32_t n_dynamic_stroke_options;
+    const crh_dynamic_stroke_options* dynamic_stroke_options;
+} crh_path_batch;
+
+/* ---- Renderer (renderer.rs:380-435) --------------------------------------------------------------- */
+
+/* Configuration, renderer.rs:380-405. Only the fields that change results on this path are kept:
+ * blending is fixed to premultiplied "over" (One, OneMinusSrcAlpha — examples/showcase/main.rs:32-43);
+ * depth / cull / alpha layers are out of scope. */
+typedef struct crh_config {
+    uint32_t msaa_sample_count;         /* 1 or 4 */
+    uint32_t clip_nesting_counter_bits; /* validated as in renderer.rs:433 */
+    uint32_t winding_counter_bits;      /* >= 1, sum <= 8 */
+    uint32_t alpha_layer_count;         /* accepted, unused */
+} crh_config;
+
+typedef struct crh_renderer crh_renderer; /* Renderer, renderer.rs:408 */
+typedef struct crh_scene crh_scene;       /* n Shapes (renderer.rs:163-171) built together */
+typedef struct crh_frame crh_frame;       /* the caller-owned colour + stencil attachments of the render pass */
+
+/* RenderOperation, renderer.rs:145-160, same order */
+typedef enum crh_render_op {
+    CRH_OP_STENCIL = 0,
+    CRH_OP_CLIP = 1,
+    CRH_OP_UNCLIP = 2,
+    CRH_OP_COLOR = 3,
+    CRH_OP_SAVE_ALPHA_CONTEXT = 4,
+    CRH_OP_SCALE_ALPHA_CONTEXT = 5,
+    CRH_OP_RESTORE_ALPHA_CONTEXT = 6
+} crh_render_op;
+
+/* Renderer::new, renderer.rs:432-435. device_ordinal = HIP device (cuda:N). */
+crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh_renderer** out);
+void crh_renderer_destroy(crh_renderer* renderer);
+/* Renderer::get_config, renderer.rs:887 */
+crh_status crh_renderer_get_config(const crh_renderer* renderer, crh_config* out);
+
+/* convert_dynamic_stroke_options, renderer.rs:29-60 (host-side, pure) */
+crh_status crh_convert_dynamic_stroke_options(const crh_dynamic_stroke_options* options, crh_dynamic_stroke_descriptor* out);
+
+/* ---- Shape::from_paths (renderer.rs:177-249) ------------------------------------------------------ */
+
+/* Host -> HBM: validates (finite, stroke-group bounds renderer.rs:188-191, dash count renderer.rs:32-34),
+ * canonicalises -0, lays the batch out for the kernels and copies it to the device. This is the part of
+ * from_paths that is not arithmetic; it is outside bench.py's timed region. `existing` may be NULL; when
+ * given, its device allocations are reused if large enough (Buffer::update, renderer.rs:89-95). */
+crh_status crh_scene_upload(crh_renderer* renderer, const crh_path_batch* batch, crh_scene* existing, crh_scene** out);
+/* The arithmetic of from_paths for every shape of the scene, on the GPU:
+ * StrokeBuilder::add_path (stroke.rs:205-465), FillBuilder::add_path (fill.rs:263-367),
+ * convex_hull::andrew + triangle_fan_to_strip (convex_hull.rs:7-40, vertex.rs:28-35) and the
+ * concat_buffers! offsets (renderer.rs:198-209). Asynchronous on the renderer's stream. */
+crh_status crh_scene_tessellate(crh_scene* scene);
+/* Waits for the stream and returns the first per-path error raised by the kernels (codes 6, 7, 8). */
+crh_status crh_scene_status(crh_scene* scene);
+void crh_scene_destroy(crh_scene* scene);
+
+/* The reference's single-shape entry point: upload + tessellate of a batch with n_shapes == 1. */
+crh_status crh_shape_from_paths(crh_renderer* renderer, const crh_path_batch* one_shape, crh_scene* existing, crh_scene** out);
+
+/* Parity tap: exactly the byte image renderer.rs:198-209 uploads for shape `shape_index`.
+ * vertex_offsets[8] / index_offsets[3] are the cumulative byte END offsets of
+ * [line, joint, solid, integral_quadratic, integral_cubic, rational_quadratic, rational_cubic, hull]
+ * and [line_indices, joint_indices, solid_indices]. Call with NULL byte pointers to query sizes. */
+crh_status crh_scene_shape_layout(crh_scene* scene, uint32_t shape_index, uint64_t vertex_offsets[8], uint64_t index_offsets[3]);
+crh_status crh_scene_shape_download(crh_scene* scene, uint32_t shape_index, void* vertex_bytes, void* index_bytes);
+/* All shapes at once: layout[shape][11] u64 (8 vertex + 3 index END offsets); sizes in bytes of the
+ * concatenation over shapes are returned so the caller can allocate, then download. */
+crh_status crh_scene_layout_all(crh_scene* scene, uint64_t* layout /* [n_shapes][11] */, uint64_t* total_vertex_bytes, uint64_t* total_index_bytes);
+crh_status crh_scene_download_all(crh_scene* scene, void* vertex_bytes, void* index_bytes);
+/* Bytes the tessellation kernels read and wrote (the algorithmic traffic of SURVEY.md §8(d)). */
+crh_status crh_scene_traffic(crh_scene* scene, uint64_t* bytes_read, uint64_t* bytes_written);
+
+/* Shape::set_dynamic_stroke_options, renderer.rs:360-376 */
+crh_status crh_scene_set_dynamic_stroke_options(crh_scene* scene, uint32_t shape_index, uint32_t group_index, const crh_dynamic_stroke_options* options);
+
+/* ---- render pass (renderer.rs:267-355 + shaders.wgsl) --------------------------------------------- */
+
+/* The colour target (RGBA8 unorm, premultiplied) plus the per-sample winding ("stencil") state. */
+crh_status crh_frame_create(crh_renderer* renderer, uint32_t width, uint32_t height, crh_frame** out);
+void crh_frame_destroy(crh_frame* frame);
+/* LoadOp::Clear(TRANSPARENT) + stencil clear 0 (examples/showcase/main.rs:217-230) */
+crh_status crh_frame_clear(crh_frame* frame);
+
+/* For every shape i of the scene, in index order: Shape::render(Stencil) then Shape::render(Color)
+ * with instance transform `transforms[i]` (column-major mat4, 64 B: shaders.wgsl:13-27) and colour
+ * `colors[i]` (straight RGBA, 16 B: shaders.wgsl:304-309) — the loop of examples/showcase/main.rs:236-250.
+ * Round 1 supports affine transforms (clip.w == 1, z ignored); others give CRH_ERR_UNSUPPORTED.
+ * Pointers are host memory; they are copied to the device when they change. Asynchronous. */
+crh_status crh_scene_render(crh_scene* scene, crh_frame* frame, const float* transforms, const float* colors);
+/* Same, with per-shape data already in HBM (used by bench.py so that PCIe is outside the step). */
+crh_status crh_scene_set_instances(crh_scene* scene, const float* transforms, const float* colors);
+crh_status crh_scene_render_resident(crh_scene* scene, crh_frame* frame);
+
+/* MSAA resolve (box average, examples/showcase/main.rs:215) + copy to host, `rgba8` = width*height*4 bytes, row 0 = top. */
+crh_status crh_frame_download(crh_frame* frame, void* rgba8);
+/* Device pointer of the resolved RGBA8 image (for the RCCL tile exchange); valid until the frame is destroyed. */
+crh_status crh_frame_device_pointer(crh_frame* frame, void** rgba8_dev);
+/* Ordered premultiplied "over" of n_layers RGBA8 images that live in HBM: dst = layers[0] under layers[1] .... */
+crh_status crh_composite_over(crh_renderer* renderer, const void* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, void* dst_dev);
+
+/* ---- stream plumbing ------------------------------------------------------------------------------- */
+crh_status crh_renderer_synchronize(crh_renderer* renderer);
+/* hipStream_t of the renderer, as void* (for HIP events in bench.py). */
+void* crh_renderer_stream(crh_renderer* renderer);
+/* Milliseconds spent by the last crh_scene_tessellate / crh_scene_render* on the GPU, per kernel,
+ * measured with HIP events on the renderer's stream when timing is enabled. */
+crh_status crh_renderer_enable_timing(crh_renderer* renderer, int enabled);
+typedef struct crh_kernel_time {
+    char name[48];
+    float ms;
+    uint64_t algorithmic_bytes;
+} crh_kernel_time;
+crh_status crh_renderer_kernel_times(crh_renderer* renderer, crh_kernel_time* out, uint32_t capacity, uint32_t* count);
+const char* crh_last_error(void);
+const char* crh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONTRAST_HIP_H */

@@ -1,0 +1,160 @@
+"""ctypes binding of oracle/liboracle.so (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from contrast_renderer_amd import _ffi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(HERE, "liboracle.so")
+
+
+def build(force=False):
+    """Compiles oracle/liboracle.so with g++ (building the checker is not using it)."""
+    sources = [os.path.join(HERE, f) for f in ("api.cpp", "raster.hpp", "tessellate.hpp", "curve.hpp", "ga.hpp")]
+    sources += [os.path.join(HERE, "..", "include", f) for f in ("crh_fmath.h", "contrast_hip.h")]
+    out = lib_path()
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in sources if os.path.exists(s)):
+        return out
+    subprocess.check_call(["make", "-C", HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return out
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path()):
+            build()
+        lib = C.CDLL(lib_path())
+        V = C.c_void_p
+        lib.oracle_tessellate.restype = V
+        lib.oracle_tessellate.argtypes = [C.POINTER(_ffi.PathBatchC), C.c_int]
+        lib.oracle_free.argtypes = [V]
+        lib.oracle_n_shapes.restype = C.c_uint32
+        lib.oracle_n_shapes.argtypes = [V]
+        lib.oracle_shape_status.argtypes = [V, C.c_uint32]
+        lib.oracle_status.argtypes = [V]
+        lib.oracle_shape_layout.argtypes = [V, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.oracle_shape_download.argtypes = [V, C.c_uint32, V, V]
+        lib.oracle_layout_all.argtypes = [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.oracle_download_all.argtypes = [V, V, V]
+        lib.oracle_shape_descriptors.restype = C.c_uint32
+        lib.oracle_shape_descriptors.argtypes = [V, C.c_uint32, C.POINTER(_ffi.DynamicStrokeDescriptorC), C.c_uint32]
+        lib.oracle_convert_dynamic_stroke_options.argtypes = [C.POINTER(_ffi.DynamicStrokeOptionsC), C.POINTER(_ffi.DynamicStrokeDescriptorC)]
+        lib.oracle_render.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32,
+                                      C.c_uint32, V]
+        lib.oracle_time_tessellate.restype = C.c_double
+        lib.oracle_time_tessellate.argtypes = [C.POINTER(_ffi.PathBatchC), C.c_int, C.c_int]
+        lib.oracle_fmath_eval.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
+        lib.oracle_solve.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib = lib
+    return _lib
+
+
+VERTEX_NAMES = ("line", "joint", "solid", "integral_quadratic", "integral_cubic", "rational_quadratic", "rational_cubic", "hull")
+INDEX_NAMES = ("line_indices", "joint_indices", "solid_indices")
+VERTEX_SIZES = (20, 24, 8, 16, 20, 20, 24, 8)
+
+
+class Oracle:
+    """Restatement of Shape::from_paths (CPU part) for every shape of a batch, plus the software rasterizer."""
+
+    def __init__(self, batch: _ffi.PathBatch, n_threads: int = 1):
+        self.lib = _load()
+        self.batch = batch
+        self.handle = self.lib.oracle_tessellate(C.byref(batch.c), n_threads)
+        self.n_shapes = self.lib.oracle_n_shapes(self.handle)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.oracle_free(self.handle)
+            self.handle = None
+
+    def status(self):
+        return self.lib.oracle_status(self.handle)
+
+    def shape_status(self, shape):
+        return self.lib.oracle_shape_status(self.handle, shape)
+
+    def shape(self, shape):
+        """-> (vertex_offsets[8], index_offsets[3], vertex_bytes, index_bytes) exactly as renderer.rs:198-209 builds them."""
+        vo = (C.c_uint64 * 8)()
+        io = (C.c_uint64 * 3)()
+        self.lib.oracle_shape_layout(self.handle, shape, vo, io)
+        vb = np.zeros(vo[7], dtype=np.uint8)
+        ib = np.zeros(io[2], dtype=np.uint8)
+        self.lib.oracle_shape_download(self.handle, shape, vb.ctypes.data, ib.ctypes.data)
+        return np.array(vo[:], dtype=np.uint64), np.array(io[:], dtype=np.uint64), vb, ib
+
+    def all_shapes(self):
+        """-> (layout[n_shapes, 11] END offsets, vertex bytes of all shapes concatenated, index bytes concatenated)."""
+        layout = np.zeros((self.n_shapes, 11), dtype=np.uint64)
+        tv, ti = C.c_uint64(), C.c_uint64()
+        self.lib.oracle_layout_all(self.handle, layout.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tv), C.byref(ti))
+        vb = np.zeros(tv.value, dtype=np.uint8)
+        ib = np.zeros(ti.value, dtype=np.uint8)
+        self.lib.oracle_download_all(self.handle, vb.ctypes.data, ib.ctypes.data)
+        return layout, vb, ib
+
+    def descriptors(self, shape):
+        out = (_ffi.DynamicStrokeDescriptorC * 64)()
+        n = self.lib.oracle_shape_descriptors(self.handle, shape, out, 64)
+        return [out[i] for i in range(n)]
+
+    def render(self, width, height, msaa, winding_bits, transforms, colors, shape_begin=0, shape_end=None):
+        """Stencil + Color of shapes [begin, end) in index order into a cleared frame -> RGBA8 [h, w, 4] premultiplied."""
+        shape_end = self.n_shapes if shape_end is None else shape_end
+        t = np.ascontiguousarray(transforms, dtype=np.float32)
+        c = np.ascontiguousarray(colors, dtype=np.float32)
+        out = np.zeros((height, width, 4), dtype=np.uint8)
+        rc = self.lib.oracle_render(self.handle, width, height, msaa, winding_bits, t.ctypes.data_as(C.POINTER(C.c_float)),
+                                    c.ctypes.data_as(C.POINTER(C.c_float)), shape_begin, shape_end, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle_render failed: {rc}")
+        return out
+
+
+def split_shape(vo, io, vb, ib):
+    """Names the 8 + 3 sub-buffers of a shape's byte image."""
+    out = {}
+    begin = 0
+    for name, end in zip(VERTEX_NAMES, vo):
+        out[name] = vb[int(begin):int(end)]
+        begin = end
+    begin = 0
+    for name, end in zip(INDEX_NAMES, io):
+        out[name] = ib[int(begin):int(end)].view(np.uint16)
+        begin = end
+    return out
+
+
+def time_tessellate(batch, n_threads, repeats):
+    return _load().oracle_time_tessellate(C.byref(batch.c), n_threads, repeats)
+
+
+def fmath_eval(fn, a, b=None):
+    lib = _load()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+    out = np.zeros_like(a)
+    fp = C.POINTER(C.c_float)
+    lib.oracle_fmath_eval(fn, a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp), a.size)
+    return out
+
+
+def solve(degree, coefficients):
+    lib = _load()
+    c = np.ascontiguousarray(coefficients, dtype=np.float32)
+    roots = np.zeros(12, dtype=np.float32)
+    disc = C.c_float()
+    fp = C.POINTER(C.c_float)
+    n = lib.oracle_solve(degree, c.ctypes.data_as(fp), roots.ctypes.data_as(fp), C.byref(disc))
+    return disc.value, roots[:3 * n].reshape(n, 3)
