@@ -230,6 +230,7 @@ def load_library():
         "crh_renderer_stream": (V, [V]),
         "crh_renderer_enable_timing": (C.c_int, [V, C.c_int]),
         "crh_renderer_kernel_times": (C.c_int, [V, C.POINTER(KernelTimeC), C.c_uint32, C.POINTER(C.c_uint32)]),
+        "crh_selftest_fmath": (C.c_int, [V, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]),
         "crh_last_error": (C.c_char_p, []),
         "crh_version": (C.c_char_p, []),
     }

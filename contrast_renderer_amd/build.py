@@ -1,0 +1,52 @@
+"""Builds libcontrast_hip.so in-tree with hipcc for gfx950 (the .so travels to the GPU box with the snapshot).
+
+-ffp-contract=off is part of the numerical contract: Rust never fuses a*b+c, and the parity tests compare bytes.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ("tessellate.hip", "raster.hip", "api.hip")
+HEADERS = ("ga.hpp", "fill.hpp", "stroke.hpp", "scene.hpp", "raster_params.hpp", "../../include/contrast_hip.h", "../../include/crh_fmath.h")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function"]
+OUT = os.path.join(HERE, "libcontrast_hip.so")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    objects = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for src in SOURCES:
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        objects.append(obj)
+        if not force and _newer(obj, [os.path.join(CSRC, src)] + headers):
+            continue
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, proc in procs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+        if verbose and out:
+            print(out.decode(), file=sys.stderr)
+    if procs or not os.path.exists(OUT):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", OUT]
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

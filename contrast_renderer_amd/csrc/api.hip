@@ -1,0 +1,892 @@
+// csrc/api.hip — the C ABI of include/contrast_hip.h: host-side orchestration only (validation, HBM buffers, launches,
+// parity taps). Every arithmetic step of the hot path runs in the HIP kernels of tessellate.hip / raster.hip; there is no
+// CPU fallback here and nothing under oracle/ is referenced.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "raster_params.hpp"
+#include "scene.hpp"
+
+namespace crh {
+typedef void (*MarkFn)(void*, const char*, uint64_t);
+void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4]);
+void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
+void launch_bin(const SceneDev& s, const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
+void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes);
+void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
+void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
+} // namespace crh
+
+using namespace crh;
+
+namespace {
+thread_local std::string g_error;
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    g_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        if (!hip_ok((expr), #expr)) return CRH_ERR_HIP; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            if (e != hipSuccess) return e;
+            p = nullptr;
+            cap = 0;
+        }
+        const size_t want = bytes < 256 ? 256 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+struct Mark {
+    hipEvent_t event;
+    std::string name;
+    uint64_t bytes;
+};
+} // namespace
+
+struct crh_renderer {
+    crh_config config;
+    int device;
+    hipStream_t stream;
+    bool timing = false;
+    std::vector<hipEvent_t> event_pool;
+    std::vector<Mark> marks;
+    size_t events_used = 0;
+
+    hipEvent_t next_event() {
+        if (events_used == event_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            event_pool.push_back(e);
+        }
+        return event_pool[events_used++];
+    }
+    void begin_marks() {
+        if (!timing) return;
+        marks.clear();
+        events_used = 0;
+        hipEvent_t e = next_event();
+        (void)hipEventRecord(e, stream);
+        marks.push_back({e, "", 0});
+    }
+    static void mark_cb(void* ctx, const char* name, uint64_t bytes) {
+        crh_renderer* r = static_cast<crh_renderer*>(ctx);
+        hipEvent_t e = r->next_event();
+        (void)hipEventRecord(e, r->stream);
+        r->marks.push_back({e, name, bytes});
+    }
+    MarkFn mark_fn() const { return timing ? &crh_renderer::mark_cb : nullptr; }
+};
+
+struct crh_frame {
+    crh_renderer* renderer;
+    uint32_t width, height, tiles_x, tiles_y, n_tiles;
+    DevBuf rgba8, tile_count, tile_offset, tile_cursor, tile_list, overflow;
+    bool cleared = true;
+    bool pairs_known = false;
+    // last render, for the transparent re-run after a bin-capacity overflow
+    crh_scene* last_scene = nullptr;
+    bool check_pending = false;
+};
+
+struct crh_scene {
+    crh_renderer* renderer;
+    SceneDev d;
+    uint32_t n_segments = 0;
+    bool has_stroke = false, big_shapes = false;
+    bool capacity_known = false;
+    uint64_t input_bytes = 0, emitted_bytes = 0;
+    uint32_t totals_host[NCH] = {};
+    std::vector<uint32_t> shape_dyn_begin_host;
+    // inputs
+    DevBuf elem_type, elem_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
+    // scan state
+    DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, status;
+    // outputs
+    DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
+    // instances + binning
+    DevBuf transforms, colors, shape_rect, shape_rect_hi;
+    bool instances_set = false;
+    // host copies for the parity taps
+    std::vector<uint32_t> shape_base_host, hull_count_host;
+    bool layout_valid = false;
+
+    void release_all() {
+        DevBuf* all[] = {&elem_type, &elem_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
+                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &status, &line_v, &joint_v,
+                         &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
+                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_rect, &shape_rect_hi};
+        for (DevBuf* b : all) b->release();
+    }
+};
+
+namespace {
+const int kSegmentFloats[5] = {2, 4, 6, 5, 10};
+
+// renderer.rs:29-60
+crh_status convert_options(const crh_dynamic_stroke_options& o, crh_dynamic_stroke_descriptor& out) {
+    std::memset(&out, 0, sizeof(out));
+    if (o.dashed) {
+        if (o.pattern_len > CRH_MAX_DASH_INTERVALS) return CRH_ERR_TOO_MANY_DASH_INTERVALS;
+        if (o.pattern_len == 0) return CRH_ERR_INVALID_ARGUMENT;
+        out.count_dashed_join = ((o.pattern_len - 1u) << 3) | 4u | o.join;
+        out.phase = o.phase;
+        for (uint32_t i = 0; i < o.pattern_len; ++i) {
+            out.gap_start[i] = o.pattern[i].gap_start;
+            out.gap_end[i] = o.pattern[i].gap_end;
+            out.caps |= o.pattern[i].dash_start << (((i + o.pattern_len - 1u) % o.pattern_len) * 8u);
+            out.caps |= o.pattern[i].dash_end << (i * 8u + 4u);
+        }
+    } else {
+        out.caps = o.start | (o.end << 4);
+        out.count_dashed_join = o.join;
+        out.phase = 0.0f;
+    }
+    return CRH_OK;
+}
+
+template <typename T>
+crh_status upload_vector(DevBuf& buf, const std::vector<T>& v, hipStream_t stream) {
+    HIP_TRY(buf.ensure(v.size() * sizeof(T)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    return CRH_OK;
+}
+
+crh_status decode_status(crh_scene* scene, uint32_t word) {
+    (void)scene;
+    if (word == 0xFFFFFFFFu) return CRH_OK;
+    const uint32_t code = word & 0xFFu;
+    if (code >= 0x80u) return CRH_ERR_UNSUPPORTED;
+    return static_cast<crh_status>(code);
+}
+
+crh_status ensure_outputs(crh_scene* sc) {
+    const uint32_t* t = sc->totals_host;
+    SceneDev& d = sc->d;
+    const size_t pairs = t[CH_LINE_V] / 2 + 1;
+    HIP_TRY(sc->line_v.ensure((size_t)t[CH_LINE_V] * 20));
+    HIP_TRY(sc->line_i.ensure(((size_t)t[CH_LINE_V] + t[CH_LINE_CUT]) * 2));
+    HIP_TRY(sc->line_inc.ensure(pairs * 4));
+    HIP_TRY(sc->line_pair_cut.ensure(pairs));
+    HIP_TRY(sc->line_pair_mode.ensure(pairs));
+    HIP_TRY(sc->joint_v.ensure((size_t)t[CH_JOINT] * 5 * 24));
+    HIP_TRY(sc->joint_i.ensure((size_t)t[CH_JOINT] * 6 * 2));
+    HIP_TRY(sc->solid_v.ensure((size_t)t[CH_SOLID_V] * 8));
+    HIP_TRY(sc->solid_i.ensure(((size_t)t[CH_SOLID_V] + t[CH_SOLID_END]) * 2));
+    HIP_TRY(sc->solid_flag.ensure((size_t)t[CH_SOLID_V] + 2));
+    HIP_TRY(sc->iq_v.ensure((size_t)t[CH_IQ] * 3 * 16));
+    HIP_TRY(sc->ic_v.ensure((size_t)t[CH_IC_V] * 20));
+    HIP_TRY(sc->rq_v.ensure((size_t)t[CH_RQ] * 3 * 20));
+    HIP_TRY(sc->rc_v.ensure((size_t)t[CH_RC_V] * 24));
+    HIP_TRY(sc->hull_cand.ensure((size_t)t[CH_HULL] * 8));
+    HIP_TRY(sc->hull_v.ensure((size_t)t[CH_HULL] * 8));
+    for (int c = 0; c < NCH; ++c) d.capacity[c] = t[c];
+    d.line_v = sc->line_v.as<Vertex2f1i>();
+    d.joint_v = sc->joint_v.as<Vertex3f1i>();
+    d.solid_v = sc->solid_v.as<Vertex0>();
+    d.iq_v = sc->iq_v.as<Vertex2f>();
+    d.ic_v = sc->ic_v.as<Vertex3f>();
+    d.rq_v = sc->rq_v.as<Vertex3f>();
+    d.rc_v = sc->rc_v.as<Vertex4f>();
+    d.hull_cand = sc->hull_cand.as<Vertex0>();
+    d.hull_v = sc->hull_v.as<Vertex0>();
+    d.line_i = sc->line_i.as<uint16_t>();
+    d.joint_i = sc->joint_i.as<uint16_t>();
+    d.solid_i = sc->solid_i.as<uint16_t>();
+    d.solid_flag = sc->solid_flag.as<uint8_t>();
+    d.line_pair_cut = sc->line_pair_cut.as<uint8_t>();
+    d.line_pair_mode = sc->line_pair_mode.as<uint8_t>();
+    d.line_inc = sc->line_inc.as<float>();
+    sc->emitted_bytes = (uint64_t)t[CH_LINE_V] * 20 + ((uint64_t)t[CH_LINE_V] + t[CH_LINE_CUT]) * 2 + (uint64_t)t[CH_JOINT] * (5 * 24 + 6 * 2) +
+                        (uint64_t)t[CH_SOLID_V] * 8 + ((uint64_t)t[CH_SOLID_V] + t[CH_SOLID_END]) * 2 + (uint64_t)t[CH_IQ] * 48 + (uint64_t)t[CH_IC_V] * 20 +
+                        (uint64_t)t[CH_RQ] * 60 + (uint64_t)t[CH_RC_V] * 24;
+    return CRH_OK;
+}
+
+crh_status run_tessellation(crh_scene* sc) {
+    crh_renderer* r = sc->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    SceneDev& d = sc->d;
+    r->begin_marks();
+    HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, r->stream));
+    const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
+    launch_tessellate(d, r->stream, r->mark_fn(), r, bytes);
+    if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
+        HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        crh_status st = ensure_outputs(sc);
+        if (st != CRH_OK) return st;
+        sc->capacity_known = true;
+    }
+    if (sc->has_stroke) HIP_TRY(hipMemsetAsync(d.line_pair_cut, 0, sc->line_pair_cut.cap, r->stream));
+    const uint64_t bytes2[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, (uint64_t)sc->totals_host[CH_HULL] * 8};
+    launch_emit(d, r->stream, r->mark_fn(), r, bytes2, sc->has_stroke, sc->big_shapes);
+    HIP_TRY(hipGetLastError());
+    sc->layout_valid = false;
+    return CRH_OK;
+}
+
+// after a sync: did the optimistic (no read-back) run overflow its buffers? then size them from the fresh totals and re-run.
+crh_status settle_tessellation(crh_scene* sc, uint32_t* status_word) {
+    crh_renderer* r = sc->renderer;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        uint32_t word = 0;
+        HIP_TRY(hipMemcpyAsync(&word, sc->d.status, 4, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (word != 0xFFFFFFFFu && (word & 0xFFu) >= 0x80u && attempt == 0) {
+            sc->capacity_known = false;
+            crh_status st = run_tessellation(sc);
+            if (st != CRH_OK) return st;
+            continue;
+        }
+        *status_word = word;
+        return CRH_OK;
+    }
+    return CRH_ERR_UNSUPPORTED;
+}
+
+crh_status fetch_layout(crh_scene* sc) {
+    if (sc->layout_valid) return CRH_OK;
+    crh_renderer* r = sc->renderer;
+    uint32_t word;
+    crh_status st = settle_tessellation(sc, &word);
+    if (st != CRH_OK) return st;
+    sc->shape_base_host.resize((size_t)(sc->d.n_shapes + 1) * NCH);
+    sc->hull_count_host.resize(sc->d.n_shapes);
+    HIP_TRY(hipMemcpyAsync(sc->shape_base_host.data(), sc->d.shape_base, sc->shape_base_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
+    if (sc->d.n_shapes) HIP_TRY(hipMemcpyAsync(sc->hull_count_host.data(), sc->d.hull_count, sc->hull_count_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipMemcpyAsync(sc->totals_host, sc->d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    sc->layout_valid = true;
+    return CRH_OK;
+}
+
+void shape_layout(const crh_scene* sc, uint32_t s, uint64_t vo[8], uint64_t io[3]) {
+    const uint32_t* a = &sc->shape_base_host[(size_t)s * NCH];
+    const uint32_t* b = a + NCH;
+    auto n = [&](int c) { return (uint64_t)(b[c] - a[c]); };
+    uint64_t v = 0;
+    v += n(CH_LINE_V) * 20;
+    vo[0] = v;
+    v += n(CH_JOINT) * 5 * 24;
+    vo[1] = v;
+    v += n(CH_SOLID_V) * 8;
+    vo[2] = v;
+    v += n(CH_IQ) * 3 * 16;
+    vo[3] = v;
+    v += n(CH_IC_V) * 20;
+    vo[4] = v;
+    v += n(CH_RQ) * 3 * 20;
+    vo[5] = v;
+    v += n(CH_RC_V) * 24;
+    vo[6] = v;
+    v += (uint64_t)sc->hull_count_host[s] * 8;
+    vo[7] = v;
+    uint64_t i = 0;
+    i += (n(CH_LINE_V) + n(CH_LINE_CUT)) * 2;
+    io[0] = i;
+    i += n(CH_JOINT) * 6 * 2;
+    io[1] = i;
+    i += (n(CH_SOLID_V) + n(CH_SOLID_END)) * 2;
+    io[2] = i;
+}
+
+struct HostCopy {
+    std::vector<uint8_t> line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_v, line_i, joint_i, solid_i;
+};
+crh_status fetch_outputs(crh_scene* sc, HostCopy& h) {
+    const uint32_t* t = sc->totals_host;
+    hipStream_t st = sc->renderer->stream;
+    auto get = [&](std::vector<uint8_t>& dst, const void* src, size_t bytes) -> crh_status {
+        dst.resize(bytes);
+        if (bytes) HIP_TRY(hipMemcpyAsync(dst.data(), src, bytes, hipMemcpyDeviceToHost, st));
+        return CRH_OK;
+    };
+    crh_status rc;
+    if ((rc = get(h.line_v, sc->d.line_v, (size_t)t[CH_LINE_V] * 20)) != CRH_OK) return rc;
+    if ((rc = get(h.joint_v, sc->d.joint_v, (size_t)t[CH_JOINT] * 120)) != CRH_OK) return rc;
+    if ((rc = get(h.solid_v, sc->d.solid_v, (size_t)t[CH_SOLID_V] * 8)) != CRH_OK) return rc;
+    if ((rc = get(h.iq_v, sc->d.iq_v, (size_t)t[CH_IQ] * 48)) != CRH_OK) return rc;
+    if ((rc = get(h.ic_v, sc->d.ic_v, (size_t)t[CH_IC_V] * 20)) != CRH_OK) return rc;
+    if ((rc = get(h.rq_v, sc->d.rq_v, (size_t)t[CH_RQ] * 60)) != CRH_OK) return rc;
+    if ((rc = get(h.rc_v, sc->d.rc_v, (size_t)t[CH_RC_V] * 24)) != CRH_OK) return rc;
+    if ((rc = get(h.hull_v, sc->d.hull_v, (size_t)t[CH_HULL] * 8)) != CRH_OK) return rc;
+    if ((rc = get(h.line_i, sc->d.line_i, ((size_t)t[CH_LINE_V] + t[CH_LINE_CUT]) * 2)) != CRH_OK) return rc;
+    if ((rc = get(h.joint_i, sc->d.joint_i, (size_t)t[CH_JOINT] * 12)) != CRH_OK) return rc;
+    if ((rc = get(h.solid_i, sc->d.solid_i, ((size_t)t[CH_SOLID_V] + t[CH_SOLID_END]) * 2)) != CRH_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return CRH_OK;
+}
+
+// the byte image of renderer.rs:198-209 for shape s, assembled from the scene-wide streams
+void assemble_shape(const crh_scene* sc, const HostCopy& h, uint32_t s, uint8_t* vb, uint8_t* ib) {
+    const uint32_t* a = &sc->shape_base_host[(size_t)s * NCH];
+    const uint32_t* b = a + NCH;
+    auto put = [](uint8_t*& dst, const std::vector<uint8_t>& src, size_t begin, size_t bytes) {
+        if (dst && bytes) {
+            std::memcpy(dst, src.data() + begin, bytes);
+            dst += bytes;
+        }
+    };
+    put(vb, h.line_v, (size_t)a[CH_LINE_V] * 20, (size_t)(b[CH_LINE_V] - a[CH_LINE_V]) * 20);
+    put(vb, h.joint_v, (size_t)a[CH_JOINT] * 120, (size_t)(b[CH_JOINT] - a[CH_JOINT]) * 120);
+    put(vb, h.solid_v, (size_t)a[CH_SOLID_V] * 8, (size_t)(b[CH_SOLID_V] - a[CH_SOLID_V]) * 8);
+    put(vb, h.iq_v, (size_t)a[CH_IQ] * 48, (size_t)(b[CH_IQ] - a[CH_IQ]) * 48);
+    put(vb, h.ic_v, (size_t)a[CH_IC_V] * 20, (size_t)(b[CH_IC_V] - a[CH_IC_V]) * 20);
+    put(vb, h.rq_v, (size_t)a[CH_RQ] * 60, (size_t)(b[CH_RQ] - a[CH_RQ]) * 60);
+    put(vb, h.rc_v, (size_t)a[CH_RC_V] * 24, (size_t)(b[CH_RC_V] - a[CH_RC_V]) * 24);
+    put(vb, h.hull_v, (size_t)a[CH_HULL] * 8, (size_t)sc->hull_count_host[s] * 8);
+    put(ib, h.line_i, ((size_t)a[CH_LINE_V] + a[CH_LINE_CUT]) * 2, ((size_t)(b[CH_LINE_V] - a[CH_LINE_V]) + (b[CH_LINE_CUT] - a[CH_LINE_CUT])) * 2);
+    put(ib, h.joint_i, (size_t)a[CH_JOINT] * 12, (size_t)(b[CH_JOINT] - a[CH_JOINT]) * 12);
+    put(ib, h.solid_i, ((size_t)a[CH_SOLID_V] + a[CH_SOLID_END]) * 2, ((size_t)(b[CH_SOLID_V] - a[CH_SOLID_V]) + (b[CH_SOLID_END] - a[CH_SOLID_END])) * 2);
+}
+
+crh_status render_impl(crh_scene* sc, crh_frame* f) {
+    crh_renderer* r = sc->renderer;
+    if (!sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
+    if (!sc->capacity_known) return CRH_ERR_INVALID_ARGUMENT; // tessellate first
+    HIP_TRY(hipSetDevice(r->device));
+    RasterParams p;
+    p.width = f->width;
+    p.height = f->height;
+    p.tiles_x = f->tiles_x;
+    p.tiles_y = f->tiles_y;
+    p.n_tiles = f->n_tiles;
+    p.winding_mask = (1u << r->config.winding_counter_bits) - 1u;
+    p.load_existing = f->cleared ? 0u : 1u;
+    p.transforms = sc->transforms.as<float>();
+    p.colors = sc->colors.as<float>();
+    p.shape_rect = sc->shape_rect.as<uint32_t>();
+    p.shape_rect_hi = sc->shape_rect_hi.as<uint32_t>();
+    p.tile_count = f->tile_count.as<uint32_t>();
+    p.tile_offset = f->tile_offset.as<uint32_t>();
+    p.tile_cursor = f->tile_cursor.as<uint32_t>();
+    p.overflow = f->overflow.as<uint32_t>();
+    p.rgba8 = f->rgba8.as<uint8_t>();
+    r->begin_marks();
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        p.tile_list = f->tile_list.as<uint32_t>();
+        p.pair_capacity = (uint32_t)(f->tile_list.cap / 4);
+        launch_bin(sc->d, p, r->stream, r->mark_fn(), r);
+        if (f->pairs_known) break;
+        uint32_t ov[2];
+        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 8, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        f->pairs_known = true;
+        if (ov[0] == 0) break;
+        HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
+        r->begin_marks();
+    }
+    // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
+    // the framebuffer written once
+    const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)sc->d.n_shapes * 80 + (uint64_t)f->width * f->height * 4;
+    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes);
+    HIP_TRY(hipGetLastError());
+    f->cleared = false;
+    f->last_scene = sc;
+    f->check_pending = true;
+    return CRH_OK;
+}
+
+// after a sync: if the optimistic bin capacity was too small, grow it and render again (the frame content is recomputed from scratch)
+crh_status settle_frame(crh_frame* f) {
+    if (!f->check_pending) return CRH_OK;
+    crh_renderer* r = f->renderer;
+    uint32_t ov[2];
+    HIP_TRY(hipMemcpyAsync(ov, f->overflow.p, 8, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    f->check_pending = false;
+    if (ov[0] != 0 && f->last_scene) {
+        HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
+        f->cleared = true; // a frame rendered over existing content cannot be recovered exactly; documented in DESIGN.md
+        crh_status st = render_impl(f->last_scene, f);
+        if (st != CRH_OK) return st;
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        f->check_pending = false;
+    }
+    return CRH_OK;
+}
+} // namespace
+
+extern "C" {
+
+const char* crh_last_error(void) { return g_error.c_str(); }
+const char* crh_version(void) { return "contrast_hip 0.1 (gfx950)"; }
+
+crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh_renderer** out) {
+    if (!config || !out) return CRH_ERR_INVALID_ARGUMENT;
+    // renderer.rs:433-435
+    if (config->winding_counter_bits == 0 || config->clip_nesting_counter_bits + config->winding_counter_bits > 8) return CRH_ERR_NUMBER_OF_STENCIL_BITS_IS_UNSUPPORTED;
+    if (!(config->msaa_sample_count == 1 || config->msaa_sample_count == 4)) return CRH_ERR_UNSUPPORTED;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) {
+        g_error = "no HIP device: contrast_hip has no CPU fallback";
+        return CRH_ERR_HIP;
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(device_ordinal));
+    crh_renderer* r = new crh_renderer;
+    r->config = *config;
+    r->device = device_ordinal;
+    if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        delete r;
+        return CRH_ERR_HIP;
+    }
+    *out = r;
+    return CRH_OK;
+}
+void crh_renderer_destroy(crh_renderer* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->stream);
+    for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+crh_status crh_renderer_get_config(const crh_renderer* r, crh_config* out) {
+    if (!r || !out) return CRH_ERR_INVALID_ARGUMENT;
+    *out = r->config;
+    return CRH_OK;
+}
+crh_status crh_convert_dynamic_stroke_options(const crh_dynamic_stroke_options* o, crh_dynamic_stroke_descriptor* out) {
+    if (!o || !out) return CRH_ERR_INVALID_ARGUMENT;
+    return convert_options(*o, *out);
+}
+
+crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene* existing, crh_scene** out) {
+    if (!r || !b || !out) return CRH_ERR_INVALID_ARGUMENT;
+    // ---- validation: what the reference rejects with Err(..) before any arithmetic (renderer.rs:188-191, :210-215)
+    std::vector<crh_dynamic_stroke_descriptor> descriptors(b->n_dynamic_stroke_options);
+    for (uint32_t i = 0; i < b->n_dynamic_stroke_options; ++i) {
+        const crh_status st = convert_options(b->dynamic_stroke_options[i], descriptors[i]);
+        if (st != CRH_OK) return st;
+    }
+    bool has_stroke = false;
+    for (uint32_t s = 0; s < b->n_shapes; ++s) {
+        const uint32_t n_dyn = b->shape_dynamic_begin ? b->shape_dynamic_begin[s + 1] - b->shape_dynamic_begin[s] : 0u;
+        for (uint32_t p = b->shape_path_begin[s]; p < b->shape_path_begin[s + 1]; ++p) {
+            const int32_t so = b->path_stroke_options[p];
+            if (so < 0) continue;
+            if ((uint32_t)so >= b->n_stroke_options) return CRH_ERR_INVALID_ARGUMENT;
+            has_stroke = true;
+            const crh_stroke_options& o = b->stroke_options[so];
+            if (o.dynamic_stroke_options_group >= n_dyn) return CRH_ERR_DYNAMIC_STROKE_OPTIONS_INDEX_OUT_OF_BOUNDS;
+            if (!std::isfinite(o.width) || !std::isfinite(o.offset) || !std::isfinite(o.miter_clip) || !std::isfinite(o.angle_step)) return CRH_ERR_NON_FINITE;
+        }
+    }
+    // ---- element stream: MOVE, segments..., END per path; pool = start point + records, -0 canonicalised (safe_float.rs:44-52)
+    const uint32_t n_elems = b->n_segments + 2u * b->n_paths;
+    std::vector<uint8_t> elem_type(n_elems);
+    std::vector<uint32_t> elem_off(n_elems), elem_path(n_elems), path_elem_begin(b->n_paths + 1), path_shape(b->n_paths), shape_elem_begin(b->n_shapes + 1);
+    std::vector<float> pool;
+    pool.reserve((size_t)b->n_control_floats + 2u * b->n_paths);
+    auto push = [&](float v) -> bool {
+        if (!std::isfinite(v)) return false;
+        pool.push_back(v == 0.0f ? 0.0f : v);
+        return true;
+    };
+    uint32_t e = 0;
+    size_t cursor = 0;
+    bool finite = true;
+    for (uint32_t s = 0; s < b->n_shapes; ++s) {
+        shape_elem_begin[s] = e;
+        for (uint32_t p = b->shape_path_begin[s]; p < b->shape_path_begin[s + 1]; ++p) {
+            path_elem_begin[p] = e;
+            path_shape[p] = s;
+            elem_type[e] = ELEM_MOVE;
+            elem_off[e] = (uint32_t)pool.size();
+            elem_path[e] = p;
+            ++e;
+            finite &= push(b->path_start[2 * (size_t)p]);
+            finite &= push(b->path_start[2 * (size_t)p + 1]);
+            for (uint32_t g = b->path_segment_begin[p]; g < b->path_segment_begin[p + 1]; ++g) {
+                const uint8_t t = b->segment_types[g];
+                if (t > 4) return CRH_ERR_INVALID_ARGUMENT;
+                elem_type[e] = t;
+                elem_off[e] = (uint32_t)pool.size();
+                elem_path[e] = p;
+                ++e;
+                for (int k = 0; k < kSegmentFloats[t]; ++k) finite &= push(b->control_data[cursor++]);
+            }
+            elem_type[e] = ELEM_END;
+            elem_off[e] = (uint32_t)pool.size();
+            elem_path[e] = p;
+            ++e;
+        }
+    }
+    if (!finite) return CRH_ERR_NON_FINITE; // the reference panics in SafeFloat::from (safe_float.rs:46,114)
+    if (cursor != b->n_control_floats || e != n_elems) return CRH_ERR_INVALID_ARGUMENT;
+    path_elem_begin[b->n_paths] = e;
+    shape_elem_begin[b->n_shapes] = e;
+
+    HIP_TRY(hipSetDevice(r->device));
+    crh_scene* sc = existing ? existing : new crh_scene;
+    sc->renderer = r;
+    sc->n_segments = b->n_segments;
+    sc->has_stroke = has_stroke;
+    sc->capacity_known = false;
+    sc->instances_set = false;
+    sc->layout_valid = false;
+    // control bytes + 1 type byte per segment, 8 B start per path, 32 B options per stroked path
+    uint64_t stroked = 0;
+    for (uint32_t p = 0; p < b->n_paths; ++p) stroked += b->path_stroke_options[p] >= 0;
+    sc->input_bytes = (uint64_t)b->n_control_floats * 4 + b->n_segments + 8ull * b->n_paths + 32ull * stroked;
+    // a Shape whose hull candidates may exceed the small-LDS hull kernel
+    sc->big_shapes = false;
+    for (uint32_t s = 0; s < b->n_shapes; ++s) {
+        const uint32_t p0 = b->shape_path_begin[s], p1 = b->shape_path_begin[s + 1];
+        const uint64_t segs = b->path_segment_begin[p1] - b->path_segment_begin[p0];
+        if (3 * segs + (p1 - p0) > 128) sc->big_shapes = true;
+    }
+    SceneDev& d = sc->d;
+    std::memset(&d, 0, sizeof(d));
+    d.n_elems = n_elems;
+    d.n_paths = b->n_paths;
+    d.n_shapes = b->n_shapes;
+    d.n_wg = (n_elems + kTessBlock - 1) / kTessBlock;
+    hipStream_t st = r->stream;
+    crh_status rc;
+#define UP(buf, vec)                                                  \
+    if ((rc = upload_vector(sc->buf, vec, st)) != CRH_OK) goto fail;
+    {
+        std::vector<int32_t> path_stroke(b->path_stroke_options, b->path_stroke_options + b->n_paths);
+        std::vector<crh_stroke_options> options(b->stroke_options, b->stroke_options + b->n_stroke_options);
+        std::vector<uint32_t> dyn_begin(b->n_shapes + 1, 0u);
+        if (b->shape_dynamic_begin) dyn_begin.assign(b->shape_dynamic_begin, b->shape_dynamic_begin + b->n_shapes + 1);
+        sc->shape_dyn_begin_host = dyn_begin;
+        UP(elem_type, elem_type)
+        UP(elem_off, elem_off)
+        UP(elem_path, elem_path)
+        UP(pool, pool)
+        UP(path_elem_begin, path_elem_begin)
+        UP(path_shape, path_shape)
+        UP(path_stroke, path_stroke)
+        UP(shape_elem_begin, shape_elem_begin)
+        UP(shape_dyn_begin, dyn_begin)
+        UP(stroke_options, options)
+        UP(descriptors, descriptors)
+        // the staging vectors must outlive the async copies
+        if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) {
+            rc = CRH_ERR_HIP;
+            goto fail;
+        }
+    }
+#undef UP
+    if (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
+        !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") ||
+        !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
+        !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
+        !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
+        !hip_ok(sc->shape_rect.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->shape_rect_hi.ensure((size_t)b->n_shapes * 4), "hipMalloc")) {
+        rc = CRH_ERR_HIP;
+        goto fail;
+    }
+    d.elem_type = sc->elem_type.as<uint8_t>();
+    d.elem_off = sc->elem_off.as<uint32_t>();
+    d.elem_path = sc->elem_path.as<uint32_t>();
+    d.pool = sc->pool.as<float>();
+    d.path_elem_begin = sc->path_elem_begin.as<uint32_t>();
+    d.path_shape = sc->path_shape.as<uint32_t>();
+    d.path_stroke = sc->path_stroke.as<int32_t>();
+    d.shape_elem_begin = sc->shape_elem_begin.as<uint32_t>();
+    d.shape_dyn_begin = sc->shape_dyn_begin.as<uint32_t>();
+    d.stroke_options = sc->stroke_options.as<crh_stroke_options>();
+    d.descriptors = sc->descriptors.as<crh_dynamic_stroke_descriptor>();
+    d.elem_scan = sc->elem_scan.as<ElemScan>();
+    d.wg_total = sc->wg_total.as<uint32_t>();
+    d.wg_base = sc->wg_base.as<uint32_t>();
+    d.totals = sc->totals.as<uint32_t>();
+    d.shape_base = sc->shape_base.as<uint32_t>();
+    d.hull_count = sc->hull_count.as<uint32_t>();
+    d.status = sc->status.as<uint32_t>();
+    if (!hip_ok(hipMemsetAsync(d.status, 0xFF, 4, st), "hipMemset")) {
+        rc = CRH_ERR_HIP;
+        goto fail;
+    }
+    *out = sc;
+    return CRH_OK;
+fail:
+    if (!existing) {
+        sc->release_all();
+        delete sc;
+    }
+    return rc;
+}
+
+crh_status crh_scene_tessellate(crh_scene* sc) {
+    if (!sc) return CRH_ERR_INVALID_ARGUMENT;
+    return run_tessellation(sc);
+}
+crh_status crh_scene_status(crh_scene* sc) {
+    if (!sc) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(sc->renderer->device));
+    uint32_t word = 0xFFFFFFFFu;
+    crh_status st = settle_tessellation(sc, &word);
+    if (st != CRH_OK) return st;
+    return decode_status(sc, word);
+}
+void crh_scene_destroy(crh_scene* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->renderer->device);
+    (void)hipStreamSynchronize(sc->renderer->stream);
+    sc->release_all();
+    delete sc;
+}
+crh_status crh_shape_from_paths(crh_renderer* r, const crh_path_batch* one_shape, crh_scene* existing, crh_scene** out) {
+    if (!one_shape || one_shape->n_shapes != 1) return CRH_ERR_INVALID_ARGUMENT;
+    crh_status st = crh_scene_upload(r, one_shape, existing, out);
+    if (st != CRH_OK) return st;
+    st = crh_scene_tessellate(*out);
+    if (st != CRH_OK) return st;
+    return crh_scene_status(*out); // from_paths is synchronous in the reference and returns its Err here
+}
+
+crh_status crh_scene_shape_layout(crh_scene* sc, uint32_t shape, uint64_t vo[8], uint64_t io[3]) {
+    if (!sc || shape >= sc->d.n_shapes) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(sc->renderer->device));
+    crh_status st = fetch_layout(sc);
+    if (st != CRH_OK) return st;
+    shape_layout(sc, shape, vo, io);
+    return CRH_OK;
+}
+crh_status crh_scene_shape_download(crh_scene* sc, uint32_t shape, void* vb, void* ib) {
+    if (!sc || shape >= sc->d.n_shapes) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(sc->renderer->device));
+    crh_status st = fetch_layout(sc);
+    if (st != CRH_OK) return st;
+    HostCopy h;
+    if ((st = fetch_outputs(sc, h)) != CRH_OK) return st;
+    assemble_shape(sc, h, shape, static_cast<uint8_t*>(vb), static_cast<uint8_t*>(ib));
+    return CRH_OK;
+}
+crh_status crh_scene_layout_all(crh_scene* sc, uint64_t* layout, uint64_t* total_v, uint64_t* total_i) {
+    if (!sc) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(sc->renderer->device));
+    crh_status st = fetch_layout(sc);
+    if (st != CRH_OK) return st;
+    uint64_t tv = 0, ti = 0;
+    for (uint32_t s = 0; s < sc->d.n_shapes; ++s) {
+        uint64_t vo[8], io[3];
+        shape_layout(sc, s, vo, io);
+        if (layout) {
+            for (int k = 0; k < 8; ++k) layout[(size_t)s * 11 + k] = vo[k];
+            for (int k = 0; k < 3; ++k) layout[(size_t)s * 11 + 8 + k] = io[k];
+        }
+        tv += vo[7];
+        ti += io[2];
+    }
+    if (total_v) *total_v = tv;
+    if (total_i) *total_i = ti;
+    return CRH_OK;
+}
+crh_status crh_scene_download_all(crh_scene* sc, void* vb, void* ib) {
+    if (!sc) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(sc->renderer->device));
+    crh_status st = fetch_layout(sc);
+    if (st != CRH_OK) return st;
+    HostCopy h;
+    if ((st = fetch_outputs(sc, h)) != CRH_OK) return st;
+    uint8_t* v = static_cast<uint8_t*>(vb);
+    uint8_t* i = static_cast<uint8_t*>(ib);
+    for (uint32_t s = 0; s < sc->d.n_shapes; ++s) {
+        uint64_t vo[8], io[3];
+        shape_layout(sc, s, vo, io);
+        assemble_shape(sc, h, s, v, i);
+        if (v) v += vo[7];
+        if (i) i += io[2];
+    }
+    return CRH_OK;
+}
+crh_status crh_scene_traffic(crh_scene* sc, uint64_t* bytes_read, uint64_t* bytes_written) {
+    if (!sc) return CRH_ERR_INVALID_ARGUMENT;
+    if (bytes_read) *bytes_read = sc->input_bytes;
+    if (bytes_written) *bytes_written = sc->emitted_bytes;
+    return CRH_OK;
+}
+crh_status crh_scene_set_dynamic_stroke_options(crh_scene* sc, uint32_t shape, uint32_t group, const crh_dynamic_stroke_options* o) {
+    if (!sc || !o || shape >= sc->d.n_shapes) return CRH_ERR_INVALID_ARGUMENT;
+    const uint32_t begin = sc->shape_dyn_begin_host[shape], end = sc->shape_dyn_begin_host[shape + 1];
+    if (group >= end - begin) return CRH_ERR_DYNAMIC_STROKE_OPTIONS_INDEX_OUT_OF_BOUNDS; // renderer.rs:366-368
+    crh_dynamic_stroke_descriptor d;
+    const crh_status st = convert_options(*o, d);
+    if (st != CRH_OK) return st;
+    HIP_TRY(hipSetDevice(sc->renderer->device));
+    HIP_TRY(hipMemcpyAsync(sc->d.descriptors + begin + group, &d, sizeof(d), hipMemcpyHostToDevice, sc->renderer->stream));
+    HIP_TRY(hipStreamSynchronize(sc->renderer->stream));
+    return CRH_OK;
+}
+
+crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, crh_frame** out) {
+    if (!r || !out || width == 0 || height == 0 || width > 65535u * 16u || height > 65535u * 16u) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    crh_frame* f = new crh_frame;
+    f->renderer = r;
+    f->width = width;
+    f->height = height;
+    f->tiles_x = (width + 15) / 16;
+    f->tiles_y = (height + 15) / 16;
+    f->n_tiles = f->tiles_x * f->tiles_y;
+    if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count.ensure((size_t)f->n_tiles * 4), "hipMalloc") ||
+        !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_cursor.ensure((size_t)f->n_tiles * 4), "hipMalloc") ||
+        !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") || !hip_ok(f->overflow.ensure(8), "hipMalloc")) {
+        delete f;
+        return CRH_ERR_HIP;
+    }
+    HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)width * height * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(f->overflow.p, 0, 8, r->stream));
+    *out = f;
+    return CRH_OK;
+}
+void crh_frame_destroy(crh_frame* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->renderer->device);
+    (void)hipStreamSynchronize(f->renderer->stream);
+    DevBuf* all[] = {&f->rgba8, &f->tile_count, &f->tile_offset, &f->tile_cursor, &f->tile_list, &f->overflow};
+    for (DevBuf* b : all) b->release();
+    delete f;
+}
+crh_status crh_frame_clear(crh_frame* f) {
+    if (!f) return CRH_ERR_INVALID_ARGUMENT;
+    f->cleared = true; // LoadOp::Clear: the next render does not read the target, every tile is written
+    return CRH_OK;
+}
+
+crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const float* colors) {
+    if (!sc || !transforms || !colors) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = sc->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    for (size_t i = 0; i < (size_t)sc->d.n_shapes * 16; ++i)
+        if (!std::isfinite(transforms[i])) return CRH_ERR_NON_FINITE;
+    for (size_t i = 0; i < (size_t)sc->d.n_shapes * 4; ++i)
+        if (!std::isfinite(colors[i])) return CRH_ERR_NON_FINITE; // Color = SafeFloat<f32, 4> (renderer.rs:16)
+    if (sc->d.n_shapes) {
+        HIP_TRY(hipMemcpyAsync(sc->transforms.p, transforms, (size_t)sc->d.n_shapes * 64, hipMemcpyHostToDevice, r->stream));
+        HIP_TRY(hipMemcpyAsync(sc->colors.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+    }
+    sc->instances_set = true;
+    return CRH_OK;
+}
+crh_status crh_scene_render_resident(crh_scene* sc, crh_frame* f) {
+    if (!sc || !f || f->renderer != sc->renderer) return CRH_ERR_INVALID_ARGUMENT;
+    return render_impl(sc, f);
+}
+crh_status crh_scene_render(crh_scene* sc, crh_frame* f, const float* transforms, const float* colors) {
+    crh_status st = crh_scene_set_instances(sc, transforms, colors);
+    if (st != CRH_OK) return st;
+    return crh_scene_render_resident(sc, f);
+}
+crh_status crh_frame_download(crh_frame* f, void* rgba8) {
+    if (!f || !rgba8) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = f->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    crh_status st = settle_frame(f);
+    if (st != CRH_OK) return st;
+    HIP_TRY(hipMemcpyAsync(rgba8, f->rgba8.p, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return CRH_OK;
+}
+crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
+    if (!f || !out) return CRH_ERR_INVALID_ARGUMENT;
+    crh_status st = settle_frame(f);
+    if (st != CRH_OK) return st;
+    *out = f->rgba8.p;
+    return CRH_OK;
+}
+crh_status crh_composite_over(crh_renderer* r, const void* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, void* dst_dev) {
+    if (!r || !layers_dev || !dst_dev || n_layers == 0) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    void* table = nullptr;
+    HIP_TRY(hipMalloc(&table, sizeof(void*) * n_layers));
+    hipError_t e = hipMemcpyAsync(table, layers_dev, sizeof(void*) * n_layers, hipMemcpyHostToDevice, r->stream);
+    if (e == hipSuccess) {
+        launch_composite(static_cast<const uint8_t* const*>(table), n_layers, n_pixels, static_cast<uint8_t*>(dst_dev), r->stream);
+        e = hipStreamSynchronize(r->stream);
+    }
+    (void)hipFree(table);
+    HIP_TRY(e);
+    return CRH_OK;
+}
+
+crh_status crh_selftest_fmath(crh_renderer* r, int fn, const float* a, const float* b, float* out, uint64_t n) {
+    if (!r || !a || !b || !out) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    DevBuf da, db, dout;
+    crh_status rc = CRH_OK;
+    if (!hip_ok(da.ensure(n * 4), "hipMalloc") || !hip_ok(db.ensure(n * 4), "hipMalloc") || !hip_ok(dout.ensure(n * 4), "hipMalloc")) rc = CRH_ERR_HIP;
+    if (rc == CRH_OK && n) {
+        if (!hip_ok(hipMemcpyAsync(da.p, a, n * 4, hipMemcpyHostToDevice, r->stream), "memcpy") ||
+            !hip_ok(hipMemcpyAsync(db.p, b, n * 4, hipMemcpyHostToDevice, r->stream), "memcpy"))
+            rc = CRH_ERR_HIP;
+        if (rc == CRH_OK) {
+            launch_fmath(fn, da.as<float>(), db.as<float>(), dout.as<float>(), n, r->stream);
+            if (!hip_ok(hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, r->stream), "memcpy") || !hip_ok(hipStreamSynchronize(r->stream), "sync")) rc = CRH_ERR_HIP;
+        }
+    }
+    da.release();
+    db.release();
+    dout.release();
+    return rc;
+}
+
+crh_status crh_renderer_synchronize(crh_renderer* r) {
+    if (!r) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return CRH_OK;
+}
+void* crh_renderer_stream(crh_renderer* r) { return r ? (void*)r->stream : nullptr; }
+crh_status crh_renderer_enable_timing(crh_renderer* r, int enabled) {
+    if (!r) return CRH_ERR_INVALID_ARGUMENT;
+    r->timing = enabled != 0;
+    r->marks.clear();
+    r->events_used = 0;
+    return CRH_OK;
+}
+crh_status crh_renderer_kernel_times(crh_renderer* r, crh_kernel_time* out, uint32_t capacity, uint32_t* count) {
+    if (!r || !count) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    uint32_t n = 0;
+    for (size_t i = 1; i < r->marks.size(); ++i) {
+        if (n < capacity && out) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, r->marks[i - 1].event, r->marks[i].event));
+            std::snprintf(out[n].name, sizeof(out[n].name), "%s", r->marks[i].name.c_str());
+            out[n].ms = ms;
+            out[n].algorithmic_bytes = r->marks[i].bytes;
+        }
+        ++n;
+    }
+    *count = n;
+    return CRH_OK;
+}
+}

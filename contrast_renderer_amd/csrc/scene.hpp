@@ -1,0 +1,105 @@
+// csrc/scene.hpp — HBM layout of a scene (a batch of Shapes) shared by the tessellation kernels, the tile rasterizer
+// and the C ABI. See DESIGN.md "Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/contrast_hip.h"
+
+namespace crh {
+
+// Element stream: every Path becomes  MOVE, segment, segment, ..., END  — one lane per element.
+enum : uint8_t { ELEM_LINE = 0, ELEM_IQ = 1, ELEM_IC = 2, ELEM_RQ = 3, ELEM_RC = 4, ELEM_MOVE = 5, ELEM_END = 6 };
+
+// Scan channels: how many records of each output stream an element emits.
+enum {
+    CH_LINE_V = 0,   // stroke line vertices (Vertex2f1i, 20 B)
+    CH_HULL = 1,     // hull candidates (SafeFloat<f32,2>, 8 B)
+    CH_LINE_CUT = 2, // 0xFFFF restart markers in the line index stream
+    CH_JOINT = 3,    // stroke joins (5 x Vertex3f1i + 6 x u16 each)
+    CH_SOLID_V = 4,  // fill polygon vertices (Vertex0, 8 B)
+    CH_SOLID_END = 5,// filled paths closed (one restart marker each)
+    CH_IQ = 6,       // integral quadratic segments (3 x Vertex2f)
+    CH_IC_V = 7,     // integral cubic vertices (Vertex3f)
+    CH_RQ = 8,       // rational quadratic segments (3 x Vertex3f)
+    CH_RC_V = 9,     // rational cubic vertices (Vertex4f)
+    NCH = 10
+};
+
+// vertex.rs:1-26
+struct Vertex0 {
+    float x, y;
+};
+struct Vertex2f {
+    float x, y, u, v;
+};
+struct Vertex2f1i {
+    float x, y, u, v;
+    uint32_t i;
+};
+struct Vertex3f {
+    float x, y, u, v, w;
+};
+struct Vertex3f1i {
+    float x, y, u, v, w;
+    uint32_t i;
+};
+struct Vertex4f {
+    float x, y, k, l, m, n;
+};
+
+// Per-element exclusive prefix inside its 256-element workgroup (global prefix = wg_base[e >> 8] + this).
+struct ElemScan {
+    uint32_t v[NCH];
+};
+
+constexpr int kTessBlock = 256;
+
+struct SceneDev {
+    // ---- inputs (written once by crh_scene_upload) ----
+    uint32_t n_elems, n_paths, n_shapes, n_wg;
+    const uint8_t* elem_type;          // [n_elems]
+    const uint32_t* elem_off;          // [n_elems] float offset of the element's record in `pool`
+    const uint32_t* elem_path;         // [n_elems]
+    const float* pool;                 // per path: start.x start.y then the segment records (contrast_hip.h layouts)
+    const uint32_t* path_elem_begin;   // [n_paths + 1] index of the path's MOVE element
+    const uint32_t* path_shape;        // [n_paths]
+    const int32_t* path_stroke;        // [n_paths] index into stroke_options or -1
+    const uint32_t* shape_elem_begin;  // [n_shapes + 1]
+    const uint32_t* shape_dyn_begin;   // [n_shapes + 1] into descriptors
+    const crh_stroke_options* stroke_options;
+    crh_dynamic_stroke_descriptor* descriptors; // 48 B records (renderer.rs:20-27)
+    // ---- scan state ----
+    ElemScan* elem_scan;   // [n_elems]
+    uint32_t* wg_total;    // [n_wg][NCH]
+    uint32_t* wg_base;     // [n_wg][NCH]
+    uint32_t* totals;      // [NCH]
+    uint32_t* shape_base;  // [n_shapes + 1][NCH] global exclusive prefix at each shape's first element
+    // ---- outputs ----
+    uint32_t capacity[NCH];
+    Vertex2f1i* line_v;
+    Vertex3f1i* joint_v;
+    Vertex0* solid_v;
+    Vertex2f* iq_v;
+    Vertex3f* ic_v;
+    Vertex3f* rq_v;
+    Vertex4f* rc_v;
+    Vertex0* hull_cand; // proto_hull, in reference order
+    Vertex0* hull_v;    // per shape at hull_cand offset: andrew() output in strip order
+    uint32_t* hull_count; // [n_shapes]
+    uint16_t* line_i;   // line_v + line_cut entries
+    uint16_t* joint_i;  // 6 per join
+    uint16_t* solid_i;  // solid_v + solid_end entries
+    uint8_t* solid_flag; // per solid vertex: bit0 = parity of the position in its strip, bit1 = last vertex of the strip
+    uint8_t* line_pair_cut; // per line vertex pair: 1 = the strip is cut after this pair (written only by the cutting lane)
+    uint8_t* line_pair_mode; // per line vertex pair: PAIR_* (how k_stroke_lengths treats the pair)
+    float* line_inc;    // per line vertex pair: length increment replayed by k_stroke_lengths
+    uint32_t* status;   // atomicMin of (path_index << 8 | code); 0xFFFFFFFF = ok
+};
+
+__device__ __forceinline__ void raise_error(const SceneDev& s, uint32_t path, uint32_t code) { atomicMin(s.status, (path << 8) | code); }
+
+// global exclusive prefix of channel ch at element e
+__device__ __forceinline__ uint32_t gscan(const SceneDev& s, uint32_t e, int ch) { return s.wg_base[(e >> 8) * NCH + ch] + s.elem_scan[e].v[ch]; }
+
+} // namespace crh

@@ -1,0 +1,422 @@
+// csrc/tessellate.hip — the GPU side of Shape::from_paths (renderer.rs:177-215) for a whole scene at once.
+//
+//   k_count   one lane per path element: how many records of each stream will it emit  -> workgroup-local exclusive scan
+//   k_scan    one workgroup: exclusive scan of the per-workgroup totals                 -> global offsets
+//   k_emit    one lane per path element: recompute and write at the scanned offsets     (fill.rs, stroke.rs)
+//   k_stroke_lengths  one lane per stroked path: replay the f32 running length sum in reference order (stroke.rs:156,307,111)
+//   k_hull    one wavefront per Shape: sort proto_hull in LDS + monotone chain         (convex_hull.rs, vertex.rs:28-35)
+//
+// Two-phase emission reproduces the sequential `start_index` bookkeeping of the reference (fill.rs:361-365,
+// stroke.rs:95,108,126-129) exactly: offsets are exclusive prefix sums in element order.
+#include "fill.hpp"
+#include "scene.hpp"
+#include "stroke.hpp"
+
+namespace crh {
+
+// ------------------------------------------------------------------------------------------------ sinks
+struct CountSink {
+    uint32_t curve_n = 0, solid_n = 0, hull_n = 0;
+    CRH_D void curve(float2, const float*) { curve_n += 1; }
+    CRH_D void solid(float2) { solid_n += 1; }
+    CRH_D void hull(float2) { hull_n += 1; }
+};
+
+// Where a filled path's polygon vertices go: triangle_fan_to_strip (vertex.rs:28-35) applied on the fly.
+struct SolidCursor {
+    const SceneDev* s;
+    uint32_t vertex_base; // global index of the path's first strip vertex
+    uint32_t index_base;  // global index-stream position of the path's first entry
+    uint32_t first_value; // index value of the path's first vertex, relative to its shape (fill.rs:361)
+    uint32_t n;           // vertices of the path
+    uint32_t j;           // position in path_solid_vertices of the next vertex
+    CRH_D void push(float2 v) {
+        const uint32_t pos = (j < ((n + 1) >> 1)) ? 2u * j : 2u * (n - 1u - j) + 1u;
+        s->solid_v[vertex_base + pos] = {v.x, v.y};
+        s->solid_i[index_base + pos] = (uint16_t)(first_value + pos);
+        s->solid_flag[vertex_base + pos] = (uint8_t)((pos & 1u) | (pos + 1u == n ? 2u : 0u));
+        j += 1;
+    }
+};
+
+struct HullCursor {
+    const SceneDev* s;
+    uint32_t at;
+    uint32_t path;
+    CRH_D void push(float2 v) { // SafeFloat::from, safe_float.rs:111-120
+        if (!is_finite(v.x) || !is_finite(v.y)) raise_error(*s, path, CRH_ERR_NON_FINITE);
+        s->hull_cand[at] = {v.x == 0.0f ? 0.0f : v.x, v.y == 0.0f ? 0.0f : v.y};
+        at += 1;
+    }
+};
+
+template <bool RATIONAL>
+struct CubicEmitSink {
+    SolidCursor solid_cursor;
+    HullCursor hull_cursor;
+    uint32_t curve_at;
+    CRH_D void curve(float2 v, const float* w) {
+        if constexpr (RATIONAL)
+            solid_cursor.s->rc_v[curve_at] = {v.x, v.y, w[0], w[1], w[2], w[3]};
+        else
+            solid_cursor.s->ic_v[curve_at] = {v.x, v.y, w[0], w[1], w[2]};
+        curve_at += 1;
+    }
+    CRH_D void solid(float2 v) { solid_cursor.push(v); }
+    CRH_D void hull(float2 v) { hull_cursor.push(v); }
+};
+
+CRH_D void load_cubic(const SceneDev& s, uint32_t off, bool rational, Pt cp[4]) {
+    const float* p = s.pool + off;
+    if (rational) { // fill.rs:337-342
+        cp[0] = weighted_vec_to_point(p[0], p[-2], p[-1]);
+        cp[1] = weighted_vec_to_point(p[1], p[4], p[5]);
+        cp[2] = weighted_vec_to_point(p[2], p[6], p[7]);
+        cp[3] = weighted_vec_to_point(p[3], p[8], p[9]);
+    } else { // fill.rs:299-304
+        cp[0] = vec_to_point(p[-2], p[-1]);
+        cp[1] = vec_to_point(p[0], p[1]);
+        cp[2] = vec_to_point(p[2], p[3]);
+        cp[3] = vec_to_point(p[4], p[5]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_count
+CRH_D void count_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, uint32_t cnt[NCH]) {
+    switch (type) {
+        case ELEM_MOVE: // fill.rs:271-272
+        case ELEM_LINE: // fill.rs:280-284
+            cnt[CH_SOLID_V] = 1;
+            cnt[CH_HULL] = 1;
+            break;
+        case ELEM_IQ: // fill.rs:285-296
+            cnt[CH_SOLID_V] = 1;
+            cnt[CH_HULL] = 2;
+            cnt[CH_IQ] = 1;
+            break;
+        case ELEM_RQ: // fill.rs:321-333
+            cnt[CH_SOLID_V] = 1;
+            cnt[CH_HULL] = 2;
+            cnt[CH_RQ] = 1;
+            break;
+        case ELEM_IC:
+        case ELEM_RC: {
+            Pt cp[4];
+            load_cubic(s, s.elem_off[e], type == ELEM_RC, cp);
+            CountSink sink;
+            uint32_t err = 0;
+            cubic_fill(cp, type == ELEM_IC, sink, err);
+            if (err) raise_error(s, path, err);
+            cnt[CH_SOLID_V] = sink.solid_n;
+            cnt[CH_HULL] = sink.hull_n;
+            cnt[type == ELEM_IC ? CH_IC_V : CH_RC_V] = sink.curve_n;
+            break;
+        }
+        default: // ELEM_END: fill.rs:361-365 appends one restart marker per path
+            cnt[CH_SOLID_END] = 1;
+            break;
+    }
+}
+
+__global__ __launch_bounds__(kTessBlock) void k_count(SceneDev s) {
+    __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
+    const uint32_t e = blockIdx.x * kTessBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t cnt[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cnt[c] = 0;
+    if (e < s.n_elems) {
+        const uint32_t type = s.elem_type[e];
+        const uint32_t path = s.elem_path[e];
+        const int32_t stroke = s.path_stroke[path];
+        if (stroke < 0)
+            count_fill_element(s, e, type, path, cnt);
+        else
+            count_stroke_element(s, e, type, path, s.stroke_options[stroke], cnt);
+    }
+    uint32_t excl[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t v = cnt[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += up;
+        }
+        excl[c] = v - cnt[c];
+        if (lane == 63) wave_total[wave][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < wave; ++w) base += wave_total[w][c];
+        excl[c] += base;
+    }
+    if (e < s.n_elems) {
+        ElemScan out;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) out.v[c] = excl[c];
+        s.elem_scan[e] = out;
+    }
+    if (threadIdx.x == kTessBlock - 1) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s.wg_total[blockIdx.x * NCH + c] = excl[c] + cnt[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_scan
+__global__ __launch_bounds__(256) void k_scan(SceneDev s) {
+    __shared__ uint32_t partial[256];
+    const uint32_t chunk = (s.n_wg + 255u) / 256u;
+    const uint32_t begin = threadIdx.x * chunk;
+    const uint32_t end = min(begin + chunk, s.n_wg);
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t sum = 0;
+        for (uint32_t w = begin; w < end; ++w) sum += s.wg_total[w * NCH + c];
+        partial[threadIdx.x] = sum;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const uint32_t v = threadIdx.x >= (uint32_t)d ? partial[threadIdx.x - d] : 0u;
+            __syncthreads();
+            partial[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = partial[threadIdx.x] - sum;
+        for (uint32_t w = begin; w < end; ++w) {
+            s.wg_base[w * NCH + c] = run;
+            run += s.wg_total[w * NCH + c];
+        }
+        if (threadIdx.x == 255) {
+            s.totals[c] = partial[255];
+            s.shape_base[s.n_shapes * NCH + c] = partial[255];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_emit
+CRH_D bool fits(const SceneDev& s) {
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ok = ok && s.totals[c] <= s.capacity[c];
+    return ok;
+}
+
+CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, const uint32_t g[NCH]) {
+    const uint32_t shape = s.path_shape[path];
+    const uint32_t shape_first = s.shape_elem_begin[shape];
+    const uint32_t move = s.path_elem_begin[path];
+    const uint32_t end = s.path_elem_begin[path + 1] - 1u;
+    const uint32_t shape_solid = gscan(s, shape_first, CH_SOLID_V), shape_ends = gscan(s, shape_first, CH_SOLID_END);
+    const uint32_t move_solid = gscan(s, move, CH_SOLID_V), move_ends = gscan(s, move, CH_SOLID_END);
+    SolidCursor solid;
+    solid.s = &s;
+    solid.vertex_base = move_solid;
+    solid.index_base = move_solid + move_ends;
+    solid.first_value = move_solid - shape_solid;
+    solid.n = gscan(s, end, CH_SOLID_V) - move_solid;
+    solid.j = g[CH_SOLID_V] - move_solid;
+    (void)shape_ends;
+    HullCursor hull = {&s, g[CH_HULL], path};
+    const float* p = s.pool + s.elem_off[e];
+    switch (type) {
+        case ELEM_MOVE:
+        case ELEM_LINE: {
+            const float2 v = make_float2(p[0], p[1]);
+            hull.push(v);
+            solid.push(v);
+            break;
+        }
+        case ELEM_IQ: { // fill.rs:285-296
+            const uint32_t at = 3u * g[CH_IQ];
+            s.iq_v[at + 0] = {p[2], p[3], 1.0f, 1.0f};
+            s.iq_v[at + 1] = {p[0], p[1], 0.5f, 0.0f};
+            s.iq_v[at + 2] = {p[-2], p[-1], 0.0f, 0.0f};
+            hull.push(make_float2(p[0], p[1]));
+            hull.push(make_float2(p[2], p[3]));
+            solid.push(make_float2(p[2], p[3]));
+            break;
+        }
+        case ELEM_RQ: { // fill.rs:321-333
+            const uint32_t at = 3u * g[CH_RQ];
+            const float weight = 1.0f / p[0];
+            s.rq_v[at + 0] = {p[3], p[4], 1.0f, 1.0f, 1.0f};
+            s.rq_v[at + 1] = {p[1], p[2], 0.5f * weight, 0.0f, weight};
+            s.rq_v[at + 2] = {p[-2], p[-1], 0.0f, 0.0f, 1.0f};
+            hull.push(make_float2(p[1], p[2]));
+            hull.push(make_float2(p[3], p[4]));
+            solid.push(make_float2(p[3], p[4]));
+            break;
+        }
+        case ELEM_IC: {
+            Pt cp[4];
+            load_cubic(s, s.elem_off[e], false, cp);
+            CubicEmitSink<false> sink = {solid, hull, g[CH_IC_V]};
+            uint32_t err = 0;
+            cubic_fill(cp, true, sink, err);
+            break;
+        }
+        case ELEM_RC: {
+            Pt cp[4];
+            load_cubic(s, s.elem_off[e], true, cp);
+            CubicEmitSink<true> sink = {solid, hull, g[CH_RC_V]};
+            uint32_t err = 0;
+            cubic_fill(cp, false, sink, err);
+            break;
+        }
+        default: { // ELEM_END: the restart marker that replaces the last index (fill.rs:363-364)
+            s.solid_i[solid.index_base + solid.n] = 0xFFFFu;
+            break;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
+    const uint32_t e = blockIdx.x * kTessBlock + threadIdx.x;
+    if (e >= s.n_elems) return;
+    if (!fits(s)) {
+        if (e == 0) raise_error(s, 0, CRH_ERR_UNSUPPORTED + 0x80u); // capacity overflow: the host reallocates and re-runs
+        return;
+    }
+    uint32_t g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) g[c] = gscan(s, e, c);
+    const uint32_t type = s.elem_type[e];
+    const uint32_t path = s.elem_path[e];
+    if (type == ELEM_MOVE && s.shape_elem_begin[s.path_shape[path]] == e) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s.shape_base[s.path_shape[path] * NCH + c] = g[c];
+    }
+    const int32_t stroke = s.path_stroke[path];
+    if (stroke < 0)
+        emit_fill_element(s, e, type, path, g);
+    else
+        emit_stroke_element(s, e, type, path, s.stroke_options[stroke], g);
+}
+
+// ------------------------------------------------------------------------------------------------ k_hull
+// convex_hull::andrew (convex_hull.rs:7-40) + triangle_fan_to_strip (renderer.rs:197): one wavefront per Shape.
+// The candidates are sorted with a bitonic network in LDS (SafeFloat's lexicographic Ord, safe_float.rs:163-173;
+// equal keys are bit-identical after -0 canonicalisation, so stability is moot), then lane 0 walks the chain.
+constexpr uint32_t kHullSmall = 128;  // candidates per Shape handled by the small-LDS variant (1 KiB + 2 KiB)
+constexpr uint32_t kHullMax = 2048;   // candidates per Shape that fit the large LDS sort (16 KiB + 32 KiB chain stack)
+
+CRH_D bool lex_less(float2 a, float2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
+CRH_D float turn(float2 a, float2 b, float2 c) { return triple(vec_to_point(a.x, a.y), vec_to_point(b.x, b.y), vec_to_point(c.x, c.y)); }
+
+template <uint32_t CAP, uint32_t MIN_N>
+__global__ __launch_bounds__(64) void k_hull(SceneDev s) {
+    __shared__ float2 pts[CAP];
+    __shared__ float2 chain[2 * CAP];
+    __shared__ uint32_t chain_n;
+    const uint32_t shape = blockIdx.x;
+    if (!fits(s)) return;
+    const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
+    const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
+    const uint32_t lane = threadIdx.x;
+    if (n < MIN_N || (CAP < kHullMax && n > CAP)) return; // the other variant owns this Shape
+    if (n > kHullMax) {
+        if (lane == 0) {
+            raise_error(s, s.elem_path[s.shape_elem_begin[shape]], CRH_ERR_UNSUPPORTED);
+            s.hull_count[shape] = 0;
+        }
+        return;
+    }
+    uint32_t h = n;
+    if (n < 3) { // returned as is (convex_hull.rs:9-11)
+        for (uint32_t i = lane; i < n; i += 64) chain[i] = make_float2(s.hull_cand[base + i].x, s.hull_cand[base + i].y);
+    } else {
+        uint32_t padded = 1;
+        while (padded < n) padded <<= 1;
+        const float inf = __uint_as_float(0x7f800000u);
+        for (uint32_t i = lane; i < padded; i += 64) pts[i] = i < n ? make_float2(s.hull_cand[base + i].x, s.hull_cand[base + i].y) : make_float2(inf, inf);
+        __syncthreads();
+        for (uint32_t k = 2; k <= padded; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = lane; i < padded; i += 64) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const float2 a = pts[i], b = pts[partner];
+                        const bool ascending = (i & k) == 0;
+                        if (ascending ? lex_less(b, a) : lex_less(a, b)) {
+                            pts[i] = b;
+                            pts[partner] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (lane == 0) {
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float2 p = pts[i];
+                while (m > 1 && turn(chain[m - 2], chain[m - 1], p) <= kErrorMargin) m -= 1;
+                chain[m++] = p;
+            }
+            m -= 1;
+            const uint32_t t = m + 1;
+            for (uint32_t i = n; i-- > 0;) {
+                const float2 p = pts[i];
+                while (m > t && turn(chain[m - 2], chain[m - 1], p) <= kErrorMargin) m -= 1;
+                chain[m++] = p;
+            }
+            m -= 1;
+            chain_n = m;
+        }
+        __syncthreads();
+        h = chain_n;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < h; i += 64) { // triangle_fan_to_strip gather (vertex.rs:29)
+        const uint32_t src = (i & 1u) == 0 ? (i >> 1) : h - 1u - (i >> 1);
+        const float2 p = chain[src];
+        s.hull_v[base + i] = {p.x, p.y};
+    }
+    if (lane == 0) s.hull_count[shape] = h;
+}
+
+// ------------------------------------------------------------------------------------------------ self test
+__global__ void k_fmath(int fn, const float* a, const float* b, float* out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    switch (fn) {
+        case 0: out[i] = crh_atan2f(a[i], b[i]); break;
+        case 1: out[i] = crh_acosf(a[i]); break;
+        case 2: crh_sincosf(a[i], &s, &c); out[i] = s; break;
+        case 3: crh_sincosf(a[i], &s, &c); out[i] = c; break;
+        case 4: out[i] = crh_powf(a[i], b[i]); break;
+        default: out[i] = crh_wgsl_mod(a[i], b[i]); break;
+    }
+}
+void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fmath, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, fn, a, b, out, n);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4]) {
+    if (s.n_elems == 0) return;
+    hipLaunchKernelGGL(k_count, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
+    if (mark) mark(ctx, "tess_count", bytes[0]);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream, s);
+    if (mark) mark(ctx, "tess_scan", bytes[1]);
+}
+void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes) {
+    if (s.n_elems == 0) return;
+    hipLaunchKernelGGL(k_emit, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
+    if (mark) mark(ctx, "tess_emit", bytes[2]);
+    if (has_stroke) {
+        hipLaunchKernelGGL(k_stroke_lengths, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
+        if (mark) mark(ctx, "stroke_lengths", 0);
+    }
+    hipLaunchKernelGGL((k_hull<kHullSmall, 0>), dim3(s.n_shapes), dim3(64), 0, stream, s);
+    if (mark) mark(ctx, "tess_hull", bytes[3]);
+    if (has_stroke || big_shapes) {
+        hipLaunchKernelGGL((k_hull<kHullMax, kHullSmall + 1>), dim3(s.n_shapes), dim3(64), 0, stream, s);
+        if (mark) mark(ctx, "tess_hull_large", 0);
+    }
+}
+
+} // namespace crh

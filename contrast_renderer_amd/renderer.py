@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's renderer.rs API over the C ABI (ctypes): Renderer, Shape, RenderOperation — plus the
+batch forms (Scene = many Shapes built and rendered together, Frame = the render pass attachments).
+
+All arithmetic runs in libcontrast_hip.so on the GPU; this module only marshals arguments.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from enum import IntEnum
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import ContrastError, check
+from .path import batch_from_shapes
+
+
+class RenderOperation(IntEnum):  # renderer.rs:145-160
+    Stencil = 0
+    Clip = 1
+    UnClip = 2
+    Color = 3
+    SaveAlphaContext = 4
+    ScaleAlphaContext = 5
+    RestoreAlphaContext = 6
+
+
+@dataclass
+class Configuration:  # renderer.rs:380-405 (fields that change results on this path)
+    msaa_sample_count: int = 1
+    clip_nesting_counter_bits: int = 4
+    winding_counter_bits: int = 4
+    alpha_layer_count: int = 0
+
+
+class Renderer:
+    """Renderer::new (renderer.rs:432): validates the stencil bit budget, owns one HIP stream on `device`."""
+
+    def __init__(self, config: Configuration = None, device: int = 0):
+        self.lib = _ffi.load_library()
+        config = config or Configuration()
+        c = _ffi.ConfigC(config.msaa_sample_count, config.clip_nesting_counter_bits, config.winding_counter_bits, config.alpha_layer_count)
+        handle = C.c_void_p()
+        check(self.lib.crh_renderer_create(C.byref(c), device, C.byref(handle)))
+        self.handle = handle
+        self.config = config
+        self.device = device
+
+    def get_config(self):
+        return self.config
+
+    def synchronize(self):
+        check(self.lib.crh_renderer_synchronize(self.handle))
+
+    def enable_timing(self, enabled=True):
+        check(self.lib.crh_renderer_enable_timing(self.handle, 1 if enabled else 0))
+
+    def kernel_times(self):
+        """[(kernel name, milliseconds, algorithmic bytes)] of the last tessellate / render call (HIP events on the renderer's stream)."""
+        out = (_ffi.KernelTimeC * 32)()
+        n = C.c_uint32()
+        check(self.lib.crh_renderer_kernel_times(self.handle, out, 32, C.byref(n)))
+        return [(out[i].name.decode(), out[i].ms, out[i].algorithmic_bytes) for i in range(min(n.value, 32))]
+
+    def selftest_fmath(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(a if b is None else b, dtype=np.float32)
+        out = np.zeros_like(a)
+        fp = C.POINTER(C.c_float)
+        check(self.lib.crh_selftest_fmath(self.handle, fn, a.ctypes.data_as(fp), b.ctypes.data_as(fp), out.ctypes.data_as(fp), a.size))
+        return out
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.lib is not None:
+            self.lib.crh_renderer_destroy(self.handle)
+            self.handle = None
+
+
+class Frame:
+    """The colour attachment (RGBA8, premultiplied) and per-sample winding state of one render pass."""
+
+    def __init__(self, renderer: Renderer, width: int, height: int):
+        self.renderer = renderer
+        self.lib = renderer.lib
+        self.width, self.height = width, height
+        handle = C.c_void_p()
+        check(self.lib.crh_frame_create(renderer.handle, width, height, C.byref(handle)))
+        self.handle = handle
+
+    def clear(self):
+        check(self.lib.crh_frame_clear(self.handle))
+
+    def download(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        check(self.lib.crh_frame_download(self.handle, out.ctypes.data))
+        return out
+
+    def device_pointer(self):
+        p = C.c_void_p()
+        check(self.lib.crh_frame_device_pointer(self.handle, C.byref(p)))
+        return p.value
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.crh_frame_destroy(self.handle)
+            self.handle = None
+
+
+class Scene:
+    """A batch of Shapes in HBM: upload + tessellate once, render many times."""
+
+    def __init__(self, renderer: Renderer, batch: _ffi.PathBatch, tessellate=True, existing: "Scene" = None):
+        self.renderer = renderer
+        self.lib = renderer.lib
+        self.batch = batch
+        handle = C.c_void_p()
+        check(self.lib.crh_scene_upload(renderer.handle, C.byref(batch.c), existing.handle if existing else None, C.byref(handle)))
+        if existing is not None:
+            existing.handle = None  # moved in, as `existing_shape` is in renderer.rs:182
+        self.handle = handle
+        self.n_shapes = batch.n_shapes
+        if tessellate:
+            self.tessellate()
+
+    def tessellate(self):
+        check(self.lib.crh_scene_tessellate(self.handle))
+
+    def status(self):
+        return self.lib.crh_scene_status(self.handle)
+
+    def check(self):
+        check(self.status())
+
+    def shape(self, index):
+        """-> (vertex_offsets[8], index_offsets[3], vertex bytes, index bytes): the byte image of renderer.rs:198-209."""
+        vo = (C.c_uint64 * 8)()
+        io = (C.c_uint64 * 3)()
+        check(self.lib.crh_scene_shape_layout(self.handle, index, vo, io))
+        vb = np.zeros(vo[7], dtype=np.uint8)
+        ib = np.zeros(io[2], dtype=np.uint8)
+        check(self.lib.crh_scene_shape_download(self.handle, index, vb.ctypes.data, ib.ctypes.data))
+        return np.array(vo[:], dtype=np.uint64), np.array(io[:], dtype=np.uint64), vb, ib
+
+    def all_shapes(self):
+        layout = np.zeros((self.n_shapes, 11), dtype=np.uint64)
+        tv, ti = C.c_uint64(), C.c_uint64()
+        check(self.lib.crh_scene_layout_all(self.handle, layout.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tv), C.byref(ti)))
+        vb = np.zeros(tv.value, dtype=np.uint8)
+        ib = np.zeros(ti.value, dtype=np.uint8)
+        check(self.lib.crh_scene_download_all(self.handle, vb.ctypes.data, ib.ctypes.data))
+        return layout, vb, ib
+
+    def traffic(self):
+        r, w = C.c_uint64(), C.c_uint64()
+        check(self.lib.crh_scene_traffic(self.handle, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def set_instances(self, transforms, colors):
+        t = np.ascontiguousarray(transforms, dtype=np.float32).reshape(self.n_shapes, 16)
+        c = np.ascontiguousarray(colors, dtype=np.float32).reshape(self.n_shapes, 4)
+        fp = C.POINTER(C.c_float)
+        check(self.lib.crh_scene_set_instances(self.handle, t.ctypes.data_as(fp), c.ctypes.data_as(fp)))
+
+    def render(self, frame: Frame, transforms=None, colors=None):
+        """Stencil + Color of every shape in index order (the loop of examples/showcase/main.rs:236-250)."""
+        if transforms is not None:
+            self.set_instances(transforms, colors)
+        check(self.lib.crh_scene_render_resident(self.handle, frame.handle))
+
+    def set_dynamic_stroke_options(self, shape_index, group_index, options):
+        c = options.to_c()
+        check(self.lib.crh_scene_set_dynamic_stroke_options(self.handle, shape_index, group_index, C.byref(c)))
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.crh_scene_destroy(self.handle)
+            self.handle = None
+
+
+class Shape(Scene):
+    """contrast_renderer::renderer::Shape — `Shape.from_paths` mirrors renderer.rs:177-249 (synchronous, raises ContrastError)."""
+
+    @staticmethod
+    def from_paths(renderer: Renderer, dynamic_stroke_options, paths, existing_shape: "Shape" = None):
+        batch = batch_from_shapes([(list(dynamic_stroke_options), list(paths))])
+        shape = Shape.__new__(Shape)
+        Scene.__init__(shape, renderer, batch, tessellate=True, existing=existing_shape)
+        shape.check()
+        return shape
+
+    def buffers(self):
+        return self.shape(0)
+
+    def render_instance(self, frame: Frame, transform, color):
+        """render(Stencil) followed by render(Color) for one instance."""
+        self.render(frame, np.asarray(transform, dtype=np.float32).reshape(1, 16), np.asarray(color, dtype=np.float32).reshape(1, 4))

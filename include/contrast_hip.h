@@ -227,6 +227,9 @@ typedef struct crh_kernel_time {
     uint64_t algorithmic_bytes;
 } crh_kernel_time;
 crh_status crh_renderer_kernel_times(crh_renderer* renderer, crh_kernel_time* out, uint32_t capacity, uint32_t* count);
+/* Self-test tap: evaluates include/crh_fmath.h ON THE GPU (fn 0 atan2(a,b), 1 acos(a), 2 sin(a), 3 cos(a), 4 pow(a,b), 5 wgsl_mod(a,b))
+ * so that tests can check device results bit for bit against the host evaluation of the same header. Host pointers. */
+crh_status crh_selftest_fmath(crh_renderer* renderer, int fn, const float* a, const float* b, float* out, uint64_t n);
 const char* crh_last_error(void);
 const char* crh_version(void);
 
