@@ -88,10 +88,9 @@ struct crh_renderer {
         }
         return event_pool[events_used++];
     }
+    // marks accumulate over calls (so a benchmark can time K steps without a sync per step); kernel_times() drains them
     void begin_marks() {
         if (!timing) return;
-        marks.clear();
-        events_used = 0;
         hipEvent_t e = next_event();
         (void)hipEventRecord(e, stream);
         marks.push_back({e, "", 0});
@@ -236,6 +235,11 @@ crh_status run_tessellation(crh_scene* sc) {
     SceneDev& d = sc->d;
     r->begin_marks();
     HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, r->stream));
+    if (d.n_elems == 0) { // nothing to tessellate: every offset is zero
+        HIP_TRY(hipMemsetAsync(d.totals, 0, NCH * 4, r->stream));
+        HIP_TRY(hipMemsetAsync(d.shape_base, 0, (size_t)(d.n_shapes + 1) * NCH * 4, r->stream));
+        if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.hull_count, 0, (size_t)d.n_shapes * 4, r->stream));
+    }
     const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
     launch_tessellate(d, r->stream, r->mark_fn(), r, bytes);
     if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
@@ -877,6 +881,7 @@ crh_status crh_renderer_kernel_times(crh_renderer* r, crh_kernel_time* out, uint
     HIP_TRY(hipStreamSynchronize(r->stream));
     uint32_t n = 0;
     for (size_t i = 1; i < r->marks.size(); ++i) {
+        if (r->marks[i].name.empty()) continue; // a begin mark: the gap before it is host time, not a kernel
         if (n < capacity && out) {
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, r->marks[i - 1].event, r->marks[i].event));
@@ -887,6 +892,10 @@ crh_status crh_renderer_kernel_times(crh_renderer* r, crh_kernel_time* out, uint
         ++n;
     }
     *count = n;
+    if (out) { // drained
+        r->marks.clear();
+        r->events_used = 0;
+    }
     return CRH_OK;
 }
 }

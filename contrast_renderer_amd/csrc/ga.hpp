@@ -14,7 +14,9 @@ namespace crh {
 constexpr float kErrorMargin = 0.0001f; // error.rs:19
 constexpr float kEpsilon = 1.1920929e-7f; // f32::EPSILON
 
-#define CRH_D __device__ __forceinline__
+// Host+device so that tools/ can exercise the very same arithmetic on a CPU when bisecting a parity failure;
+// the product only ever calls these from kernels.
+#define CRH_D __host__ __device__ __forceinline__
 
 // ppga2d::Point = (w, x*w, y*w) (utils.rs:111-118); ppga2d::Plane = (e0, nx, ny) (utils.rs:101-103)
 struct Pt {
@@ -54,9 +56,9 @@ CRH_D Pt line_line_intersection(Pl a, Pl b) { // utils.rs:67-70
     const Pt p = meet(a, b);
     return p * (1.0f / p.w);
 }
-CRH_D float f32_signum(float x) { return (x != x) ? x : ((__float_as_uint(x) >> 31) ? -1.0f : 1.0f); }
+CRH_D float f32_signum(float x) { return (x != x) ? x : ((crh_f2u(x) >> 31) ? -1.0f : 1.0f); }
 CRH_D bool is_nan(float x) { return x != x; }
-CRH_D bool is_finite(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+CRH_D bool is_finite(float x) { return (crh_f2u(x) & 0x7f800000u) != 0x7f800000u; }
 
 // mat_vec_transform! (curve.rs:12-23): right-nested sums
 CRH_D Pt mvt2(const Pt* p, float a0, float a1) { return p[0] * a0 + p[1] * a1; }
@@ -133,7 +135,7 @@ CRH_D float solve_quadratic(float c0, float c1, float c2, Root* r, int& n) {
     }
     return D;
 }
-__device__ __noinline__ float solve_cubic(float f0, float f1, float f2, float f3, Root* r, int& n) {
+inline __host__ __device__ __noinline__ float solve_cubic(float f0, float f1, float f2, float f3, Root* r, int& n) {
     if (fabsf(f3) <= kErrorMargin) return solve_quadratic(f0, f1, f2, r, n);
     const double a = f3, b = f2, c = f1, d = f0;
     const double d0 = b * b - 3.0 * a * c;
@@ -178,7 +180,7 @@ CRH_D void push_monic_quadratic(Root* r, double s1, double s0, double shift) {
         r[1] = {(float)(0.5 * (-s1 - sq) + shift), 0.0f, 1.0f};
     }
 }
-__device__ __noinline__ float solve_quartic(const float cf[5], Root* r, int& n) {
+inline __host__ __device__ __noinline__ float solve_quartic(const float cf[5], Root* r, int& n) {
     if (fabsf(cf[4]) <= kErrorMargin) return solve_cubic(cf[0], cf[1], cf[2], cf[3], r, n);
     const double a4 = cf[4];
     const double b = cf[3] / a4, c = cf[2] / a4, d = cf[1] / a4, e = cf[0] / a4;

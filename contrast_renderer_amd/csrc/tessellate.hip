@@ -66,15 +66,30 @@ struct CubicEmitSink {
     CRH_D void hull(float2 v) { hull_cursor.push(v); }
 };
 
-CRH_D void load_cubic(const SceneDev& s, uint32_t off, bool rational, Pt cp[4]) {
-    const float* p = s.pool + off;
+// The start point of a filled segment is `path_solid_vertices.last()` (fill.rs:292,300,329,338): the END of the previous
+// segment as it was pushed to the polygon. Lines, quadratics and integral cubics push their end point verbatim (x / 1 == x), but a
+// rational cubic pushes point_to_vec(weighted point) = ((x * w) / w, (y * w) / w) (fill.rs:248, utils.rs:106-118), which may be
+// one ulp away from x. The lane re-derives that round trip from the previous record instead of carrying sequential state.
+CRH_D float2 fill_start_point(const SceneDev& s, uint32_t e) {
+    const float* q = s.pool + s.elem_off[e - 1u];
+    if (s.elem_type[e - 1u] == ELEM_RC) {
+        const float w = q[3];
+        return make_float2((q[8] * w) / w, (q[9] * w) / w);
+    }
+    const float* p = s.pool + s.elem_off[e];
+    return make_float2(p[-2], p[-1]);
+}
+
+CRH_D void load_cubic(const SceneDev& s, uint32_t e, bool rational, Pt cp[4]) {
+    const float* p = s.pool + s.elem_off[e];
+    const float2 start = fill_start_point(s, e);
     if (rational) { // fill.rs:337-342
-        cp[0] = weighted_vec_to_point(p[0], p[-2], p[-1]);
+        cp[0] = weighted_vec_to_point(p[0], start.x, start.y);
         cp[1] = weighted_vec_to_point(p[1], p[4], p[5]);
         cp[2] = weighted_vec_to_point(p[2], p[6], p[7]);
         cp[3] = weighted_vec_to_point(p[3], p[8], p[9]);
     } else { // fill.rs:299-304
-        cp[0] = vec_to_point(p[-2], p[-1]);
+        cp[0] = vec_to_point(start.x, start.y);
         cp[1] = vec_to_point(p[0], p[1]);
         cp[2] = vec_to_point(p[2], p[3]);
         cp[3] = vec_to_point(p[4], p[5]);
@@ -102,7 +117,7 @@ CRH_D void count_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint
         case ELEM_IC:
         case ELEM_RC: {
             Pt cp[4];
-            load_cubic(s, s.elem_off[e], type == ELEM_RC, cp);
+            load_cubic(s, e, type == ELEM_RC, cp);
             CountSink sink;
             uint32_t err = 0;
             cubic_fill(cp, type == ELEM_IC, sink, err);
@@ -189,7 +204,11 @@ __global__ __launch_bounds__(256) void k_scan(SceneDev s) {
         }
         if (threadIdx.x == 255) {
             s.totals[c] = partial[255];
-            s.shape_base[s.n_shapes * NCH + c] = partial[255];
+            // the sentinel row, and the rows of trailing empty Shapes (they have no element to publish them)
+            for (uint32_t shape = s.n_shapes;; --shape) {
+                s.shape_base[shape * NCH + c] = partial[255];
+                if (shape == 0 || s.shape_elem_begin[shape - 1u] != s.n_elems) break;
+            }
         }
         __syncthreads();
     }
@@ -232,7 +251,8 @@ CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint3
             const uint32_t at = 3u * g[CH_IQ];
             s.iq_v[at + 0] = {p[2], p[3], 1.0f, 1.0f};
             s.iq_v[at + 1] = {p[0], p[1], 0.5f, 0.0f};
-            s.iq_v[at + 2] = {p[-2], p[-1], 0.0f, 0.0f};
+            const float2 start = fill_start_point(s, e);
+            s.iq_v[at + 2] = {start.x, start.y, 0.0f, 0.0f};
             hull.push(make_float2(p[0], p[1]));
             hull.push(make_float2(p[2], p[3]));
             solid.push(make_float2(p[2], p[3]));
@@ -243,7 +263,8 @@ CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint3
             const float weight = 1.0f / p[0];
             s.rq_v[at + 0] = {p[3], p[4], 1.0f, 1.0f, 1.0f};
             s.rq_v[at + 1] = {p[1], p[2], 0.5f * weight, 0.0f, weight};
-            s.rq_v[at + 2] = {p[-2], p[-1], 0.0f, 0.0f, 1.0f};
+            const float2 start = fill_start_point(s, e);
+            s.rq_v[at + 2] = {start.x, start.y, 0.0f, 0.0f, 1.0f};
             hull.push(make_float2(p[1], p[2]));
             hull.push(make_float2(p[3], p[4]));
             solid.push(make_float2(p[3], p[4]));
@@ -251,7 +272,7 @@ CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint3
         }
         case ELEM_IC: {
             Pt cp[4];
-            load_cubic(s, s.elem_off[e], false, cp);
+            load_cubic(s, e, false, cp);
             CubicEmitSink<false> sink = {solid, hull, g[CH_IC_V]};
             uint32_t err = 0;
             cubic_fill(cp, true, sink, err);
@@ -259,7 +280,7 @@ CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint3
         }
         case ELEM_RC: {
             Pt cp[4];
-            load_cubic(s, s.elem_off[e], true, cp);
+            load_cubic(s, e, true, cp);
             CubicEmitSink<true> sink = {solid, hull, g[CH_RC_V]};
             uint32_t err = 0;
             cubic_fill(cp, false, sink, err);
@@ -285,8 +306,14 @@ __global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
     const uint32_t type = s.elem_type[e];
     const uint32_t path = s.elem_path[e];
     if (type == ELEM_MOVE && s.shape_elem_begin[s.path_shape[path]] == e) {
+        // the first lane of a Shape publishes the Shape's base offsets — also for the empty Shapes (no paths) right before it
+        uint32_t shape = s.path_shape[path];
+        for (;;) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) s.shape_base[s.path_shape[path] * NCH + c] = g[c];
+            for (int c = 0; c < NCH; ++c) s.shape_base[shape * NCH + c] = g[c];
+            if (shape == 0 || s.shape_elem_begin[shape - 1u] != e) break;
+            shape -= 1u;
+        }
     }
     const int32_t stroke = s.path_stroke[path];
     if (stroke < 0)
@@ -388,6 +415,10 @@ __global__ void k_fmath(int fn, const float* a, const float* b, float* out, uint
         case 2: crh_sincosf(a[i], &s, &c); out[i] = s; break;
         case 3: crh_sincosf(a[i], &s, &c); out[i] = c; break;
         case 4: out[i] = crh_powf(a[i], b[i]); break;
+        case 6: out[i] = sqrtf(a[i]); break;
+        case 7: out[i] = a[i] / b[i]; break;
+        case 8: out[i] = 1.0f / sqrtf(a[i] * a[i] + b[i] * b[i]); break;
+        case 9: out[i] = a[i] * b[i] - 4.0f * a[i] * b[i] * b[i]; break;
         default: out[i] = crh_wgsl_mod(a[i], b[i]); break;
     }
 }

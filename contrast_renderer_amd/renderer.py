@@ -56,10 +56,11 @@ class Renderer:
 
     def kernel_times(self):
         """[(kernel name, milliseconds, algorithmic bytes)] of the last tessellate / render call (HIP events on the renderer's stream)."""
-        out = (_ffi.KernelTimeC * 32)()
         n = C.c_uint32()
-        check(self.lib.crh_renderer_kernel_times(self.handle, out, 32, C.byref(n)))
-        return [(out[i].name.decode(), out[i].ms, out[i].algorithmic_bytes) for i in range(min(n.value, 32))]
+        check(self.lib.crh_renderer_kernel_times(self.handle, None, 0, C.byref(n)))
+        out = (_ffi.KernelTimeC * max(1, n.value))()
+        check(self.lib.crh_renderer_kernel_times(self.handle, out, n.value, C.byref(n)))
+        return [(out[i].name.decode(), out[i].ms, out[i].algorithmic_bytes) for i in range(n.value)]
 
     def selftest_fmath(self, fn, a, b=None):
         a = np.ascontiguousarray(a, dtype=np.float32)
