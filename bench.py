@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric: paths/sec (+ Mpixel/s) of the tessellate + tile-raster hot path.
+
+One step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+crh_scene_tessellate (count / scan / emit / hull kernels) + crh_scene_render_resident (bin + tile raster kernels) of
+BASELINE.json configs[1]: 10 000 mixed integral / rational cubic paths at 4096x4096 on one MI355X.
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the paths shard by contiguous index range — every rank
+renders its own 10 000-path shard (weak scaling) into a private layer — followed by the tile-sliced RCCL exchange, the ordered
+"over" composite and the gather to rank 0.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+class _DeviceArray:
+    """Wraps a raw HIP pointer for torch.as_tensor (zero copy)."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--paths", type=int, default=10000, help="paths per GPU (configs[1] = 10000)")
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from contrast_renderer_amd import distributed as D
+    from contrast_renderer_amd import scenes
+    from contrast_renderer_amd.renderer import Configuration, Frame, Renderer, Scene
+
+    size = (args.size, args.size)
+    sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
+    batch = sc["batch"]
+    renderer = Renderer(Configuration(msaa_sample_count=1, clip_nesting_counter_bits=4, winding_counter_bits=4), device=local_rank)
+    scene = Scene(renderer, batch, tessellate=True)  # host -> HBM + first tessellation (sizes the output buffers): outside the timed region
+    scene.check()
+    scene.set_instances(sc["transforms"], sc["colors"])
+    frame = Frame(renderer, *size)
+    lib = renderer.lib
+    import ctypes as C
+
+    layer = slab = None
+    if world > 1:
+        layer = torch.as_tensor(_DeviceArray(frame.device_pointer(), (size[1], size[0], 4)), device=f"cuda:{local_rank}")
+        r0, r1 = D.slab_rows(size[1], world)[rank]
+        slab = torch.empty((r1 - r0, size[0], 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
+
+    def step():
+        scene.tessellate()
+        frame.clear()
+        scene.render(frame)
+        if world > 1:
+            renderer.synchronize()  # our kernels run on the renderer's own HIP stream
+            received, _ = D.exchange_layers(layer, rank, world)
+            torch.cuda.synchronize()
+            ptrs = (C.c_void_p * world)(*[received[i].data_ptr() for i in range(world)])
+            rc = lib.crh_composite_over(renderer.handle, ptrs, world, received[0].numel() // 4, C.c_void_p(slab.data_ptr()))
+            assert rc == 0, rc
+            return D.gather_slabs(slab, rank, world, size[1])
+        return None
+
+    def sync():
+        renderer.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    scene.check()
+    renderer.enable_timing(True)  # HIP events on the renderer's stream between kernels; drained once after the timed region
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_times = renderer.kernel_times()
+    renderer.enable_timing(False)
+    scene.check()
+    image = frame.download()
+    covered = float((image[..., 3] > 0).mean())
+
+    # per-kernel averages
+    agg = {}
+    for name, ms, nbytes in kernel_times:
+        a = agg.setdefault(name, [0.0, 0, nbytes])
+        a[0] += ms
+        a[1] += 1
+        a[2] = max(a[2], nbytes)
+    kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1], "algorithmic_bytes": v[2]} for k, v in agg.items()}
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    dk = kernels[dominant]
+    achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
+
+    total_paths = args.paths * world
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)",
+        "value": total_paths / (elapsed / args.steps),
+        "unit": "paths/s",
+        "mpixel_per_s": size[0] * size[1] / (elapsed / args.steps) / 1e6,
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[1]: {args.paths} filled closed paths x 8 cubic segments (alternating integral / rational), {size[0]}x{size[1]}, "
+                        "msaa 1, winding_counter_bits 4; step = tessellate (count/scan/emit/hull) + bin + tile raster, inputs resident in HBM",
+            "paths_per_gpu": args.paths,
+            "segments_per_gpu": int(batch.n_segments),
+            "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} + tile-sliced RCCL all-to-all + ordered over-composite + gather",
+            "covered_fraction": covered,
+        },
+        "roofline": {
+            "kernel": dominant,
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "note": "algorithmic bytes (SURVEY.md §8(d)) / HIP-event kernel time; the kernel is VALU-bound (per-sample polynomial evaluation), see DESIGN.md",
+        },
+        "kernels": kernels,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.binding import time_tessellate
+        t1 = time_tessellate(batch, 1, 1)
+        repeats = max(2, min(200, int(math.ceil(10.0 / max(t1, 1e-3)))))
+        ts = time_tessellate(batch, 1, repeats)
+        cores = os.cpu_count() or 1
+        tall = time_tessellate(batch, cores, max(2, repeats))
+        out["cpu_baseline"] = {
+            "value": args.paths * repeats / ts,
+            "unit": "paths/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{repeats} x full tessellation of the same {args.paths}-path scene by the C++ restatement of the reference's CPU tessellation "
+                      f"(Shape::from_paths minus the wgpu upload; the reference itself cannot be built here), single thread as in renderer.rs:187; "
+                      "tessellation only — the reference rasterizes on a GPU",
+            "all_cores": {"value": args.paths * max(2, repeats) / tall, "cores": cores},
+        }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

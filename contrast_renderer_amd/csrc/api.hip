@@ -13,6 +13,7 @@
 #include "scene.hpp"
 
 namespace crh {
+struct PrimRec;
 typedef void (*MarkFn)(void*, const char*, uint64_t);
 void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4]);
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
@@ -107,7 +108,7 @@ struct crh_renderer {
 struct crh_frame {
     crh_renderer* renderer;
     uint32_t width, height, tiles_x, tiles_y, n_tiles;
-    DevBuf rgba8, tile_count, tile_offset, tile_cursor, tile_list, overflow;
+    DevBuf rgba8, tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
     bool cleared = true;
     bool pairs_known = false;
     // last render, for the transparent re-run after a bin-capacity overflow
@@ -131,7 +132,7 @@ struct crh_scene {
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
-    DevBuf transforms, colors, shape_rect, shape_rect_hi;
+    DevBuf transforms, colors, shape_rect, shape_rect_hi, shape_ncand, shape_prim_begin, prim_rec, prim_box;
     bool instances_set = false;
     // host copies for the parity taps
     std::vector<uint32_t> shape_base_host, hull_count_host;
@@ -141,7 +142,7 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_rect, &shape_rect_hi};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_rect, &shape_rect_hi, &shape_ncand, &shape_prim_begin, &prim_rec, &prim_box};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -389,9 +390,24 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.colors = sc->colors.as<float>();
     p.shape_rect = sc->shape_rect.as<uint32_t>();
     p.shape_rect_hi = sc->shape_rect_hi.as<uint32_t>();
-    p.tile_count = f->tile_count.as<uint32_t>();
+    p.tile_count = f->tile_count_cursor.as<uint32_t>();
     p.tile_offset = f->tile_offset.as<uint32_t>();
-    p.tile_cursor = f->tile_cursor.as<uint32_t>();
+    p.tile_cursor = f->tile_count_cursor.as<uint32_t>() + f->n_tiles;
+    {
+        // every candidate triangle gets a record slot: an upper bound follows from the tessellation totals
+        const uint32_t* t = sc->totals_host;
+        const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
+        HIP_TRY(sc->prim_rec.ensure(prim_capacity * 128));
+        HIP_TRY(sc->prim_box.ensure(prim_capacity * 8));
+        HIP_TRY(sc->shape_ncand.ensure((size_t)sc->d.n_shapes * 4 + 4));
+        HIP_TRY(sc->shape_prim_begin.ensure(((size_t)sc->d.n_shapes + 1) * 4));
+        HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + (sc->d.n_shapes + 1023) / 1024 + 2) * 4));
+    }
+    p.shape_ncand = sc->shape_ncand.as<uint32_t>();
+    p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
+    p.scan_scratch = f->scan_scratch.as<uint32_t>();
+    p.prim_rec = static_cast<PrimRec*>(sc->prim_rec.p);
+    p.prim_box = sc->prim_box.as<ushort4>();
     p.overflow = f->overflow.as<uint32_t>();
     p.rgba8 = f->rgba8.as<uint8_t>();
     r->begin_marks();
@@ -758,9 +774,9 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     f->tiles_x = (width + 15) / 16;
     f->tiles_y = (height + 15) / 16;
     f->n_tiles = f->tiles_x * f->tiles_y;
-    if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count.ensure((size_t)f->n_tiles * 4), "hipMalloc") ||
-        !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_cursor.ensure((size_t)f->n_tiles * 4), "hipMalloc") ||
-        !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") || !hip_ok(f->overflow.ensure(8), "hipMalloc")) {
+    if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") ||
+        !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") ||
+        !hip_ok(f->overflow.ensure(8), "hipMalloc")) {
         delete f;
         return CRH_ERR_HIP;
     }
@@ -773,7 +789,7 @@ void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->renderer->device);
     (void)hipStreamSynchronize(f->renderer->stream);
-    DevBuf* all[] = {&f->rgba8, &f->tile_count, &f->tile_offset, &f->tile_cursor, &f->tile_list, &f->overflow};
+    DevBuf* all[] = {&f->rgba8, &f->tile_count_cursor, &f->tile_offset, &f->tile_list, &f->overflow, &f->scan_scratch};
     for (DevBuf* b : all) b->release();
     delete f;
 }
