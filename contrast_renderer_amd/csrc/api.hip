@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -410,6 +411,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.prim_box = sc->prim_box.as<ushort4>();
     p.overflow = f->overflow.as<uint32_t>();
     p.rgba8 = f->rgba8.as<uint8_t>();
+    p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
+    if (p.debug & 4u) HIP_TRY(hipMemsetAsync(f->overflow.as<uint32_t>() + 2, 0, 24, r->stream));
     r->begin_marks();
     for (int attempt = 0; attempt < 2; ++attempt) {
         p.tile_list = f->tile_list.as<uint32_t>();
@@ -776,12 +779,12 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     f->n_tiles = f->tiles_x * f->tiles_y;
     if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") ||
         !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") ||
-        !hip_ok(f->overflow.ensure(8), "hipMalloc")) {
+        !hip_ok(f->overflow.ensure(64), "hipMalloc")) {
         delete f;
         return CRH_ERR_HIP;
     }
     HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)width * height * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(f->overflow.p, 0, 8, r->stream));
+    HIP_TRY(hipMemsetAsync(f->overflow.p, 0, 64, r->stream));
     *out = f;
     return CRH_OK;
 }
@@ -832,6 +835,12 @@ crh_status crh_frame_download(crh_frame* f, void* rgba8) {
     if (st != CRH_OK) return st;
     HIP_TRY(hipMemcpyAsync(rgba8, f->rgba8.p, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
+    return CRH_OK;
+}
+extern "C" crh_status crh_debug_frame_counters(crh_frame* f, uint32_t out[8]) { // tools only (not in the public header)
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    HIP_TRY(hipStreamSynchronize(f->renderer->stream));
+    HIP_TRY(hipMemcpy(out, f->overflow.p, 32, hipMemcpyDeviceToHost));
     return CRH_OK;
 }
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {

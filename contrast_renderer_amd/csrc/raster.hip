@@ -360,16 +360,18 @@ __global__ __launch_bounds__(64) void k_shape_emit(SceneDev s, RasterParams r) {
 }
 
 // ---------------------------------------------------------------------------------------------- per-tile raster
-// One primitive staged in LDS (struct of arrays over the 256 slots of a chunk; every lane reads the same slot => broadcast).
+// One primitive staged in LDS. Every lane reads the same slot (broadcast), so the fields a coverage step needs together are
+// packed into float4s (one ds_read_b128 each) instead of one array per scalar.
 struct PrimList {
-    float e_nay[3][256], e_bx[3][256], e_c[3][256]; // edge i: E = fma(rx, nay, fma(ry, bx, c))
-    float a_gx[4][256], a_gy[4][256], a_c[4][256];  // attribute planes, tile relative
-    uint32_t flags[256];  // PrimRec.flags | bits 8-23: pixel range nibbles x0 x1 y0 y1 inside the tile
-    uint32_t flat_u[256];
-    float end_y[256];
-    uint32_t desc[256];
-    float color[4][256];  // cover: premultiplied source colour
+    float4 e0[256]; // nay0 bx0 c0 nay1      edge i: E = fma(rx, nay_i, fma(ry, bx_i, c_i))
+    float4 e1[256]; // bx1 c1 nay2 bx2
+    float4 e2[256]; // c2, flags (bits), flat_u (bits), end_y
+    float4 a[4][256]; // attribute plane k: gx gy c, (k == 0: descriptor index bits in .w)
+    float4 color[256]; // cover: premultiplied source colour
 };
+// flags: bits 0-2 top-left per edge, bit 3 front, bits 4-6 kind, bits 8-23 pixel range nibbles x0 x1 y0 y1 inside the tile,
+//        bits 24-27 bands (pixel rows 4b..4b+3 = the rows wave b owns) that may contain covered samples,
+//        bits 28-31 bands in which EVERY sample of the pixel range is inside the triangle (edge evaluation can be skipped)
 
 CRH_D bool cap_test(float x, float y, uint32_t cap_type) { // shaders.wgsl:165-189
     switch (cap_type & 15u) {
@@ -496,7 +498,16 @@ __global__ __launch_bounds__(256) void k_raster(SceneDev s, RasterParams r) {
             __syncthreads();
         }
     }
-    const uint32_t n_candidates = n_list ? cand_end[n_list - 1u] : 0u;
+    uint32_t n_candidates = n_list ? cand_end[n_list - 1u] : 0u;
+    if (r.debug & 4u) {
+        if (tid == 0) {
+            atomicAdd(&r.overflow[2], n_list);
+            atomicAdd(&r.overflow[3], n_candidates);
+            atomicMax(&r.overflow[5], n_list);
+            atomicMax(&r.overflow[6], n_candidates);
+        }
+    }
+    if (r.debug & 1u) n_candidates = 0;
 
     for (uint32_t chunk = 0; chunk < n_candidates; chunk += 256u) {
         // ---------------- gather: candidates of several consecutive shapes fill the 256 lanes; survivors of the box test are
@@ -525,129 +536,179 @@ __global__ __launch_bounds__(256) void k_raster(SceneDev s, RasterParams r) {
                 keep = rx0 <= rx1 && ry0 <= ry1;
             }
         }
+        // exact cull + band classification: an edge function is monotone in rx and in ry (fmaf rounds monotonically), so its
+        // extremes over a box of sample positions sit at the corners; a primitive is dropped when some edge rejects its best
+        // corner, and a band is "full" when every edge accepts its worst corner.
+        PrimRec rec;
+        float ec[3];
+        uint32_t bands = 0, full = 0;
+        if (keep) {
+            rec = r.prim_rec[prim];
+            const float s_lo = S == 1 ? 0.5f : 0.125f, s_hi = S == 1 ? 0.5f : 0.875f;
+            const float x_lo = (float)rx0 + s_lo, x_hi = (float)rx1 + s_hi;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ec[i] = rec.bx[i] * (ty0 - rec.lo_y[i]) + rec.nay[i] * (tx0 - rec.lo_x[i]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int by0 = max(ry0, 4 * b), by1 = min(ry1, 4 * b + 3);
+                if (by0 > by1) continue;
+                const float y_lo = (float)by0 + s_lo, y_hi = (float)by1 + s_hi;
+                bool some = true, all = true;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const bool tl = (rec.flags >> i) & 1u;
+                    const float xa = rec.nay[i] > 0.0f ? x_hi : x_lo, xb = rec.nay[i] > 0.0f ? x_lo : x_hi;
+                    const float ya = rec.bx[i] > 0.0f ? y_hi : y_lo, yb = rec.bx[i] > 0.0f ? y_lo : y_hi;
+                    const float e_max = fmaf(xa, rec.nay[i], fmaf(ya, rec.bx[i], ec[i]));
+                    const float e_min = fmaf(xb, rec.nay[i], fmaf(yb, rec.bx[i], ec[i]));
+                    some = some && (e_max > 0.0f || (e_max == 0.0f && tl));
+                    all = all && (e_min > 0.0f || (e_min == 0.0f && tl));
+                }
+                if (some) bands |= 1u << b;
+                if (all) full |= 1u << b;
+            }
+            keep = bands != 0u;
+        }
         const unsigned long long ballot = __ballot(keep);
         if (lane == 0) wave_count[wave] = (uint32_t)__popcll(ballot);
         if (keep) {
             const uint32_t slot = wave * 64u + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-            const PrimRec rec = r.prim_rec[prim];
+            const uint32_t flags = (rec.flags & 0xFFu) | ((uint32_t)rx0 << 8) | ((uint32_t)rx1 << 12) | ((uint32_t)ry0 << 16) | ((uint32_t)ry1 << 20) |
+                                   (bands << 24) | (full << 28);
+            prims.e0[slot] = make_float4(rec.nay[0], rec.bx[0], ec[0], rec.nay[1]);
+            prims.e1[slot] = make_float4(rec.bx[1], ec[1], rec.nay[2], rec.bx[2]);
+            prims.e2[slot] = make_float4(ec[2], __uint_as_float(flags), __uint_as_float(rec.flat_u), rec.end_y);
+            const uint32_t kind = (rec.flags >> 4) & 7u;
+            if (kind != KIND_SOLID && kind != KIND_COVER) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                prims.e_nay[i][slot] = rec.nay[i];
-                prims.e_bx[i][slot] = rec.bx[i];
-                prims.e_c[i][slot] = rec.bx[i] * (ty0 - rec.lo_y[i]) + rec.nay[i] * (tx0 - rec.lo_x[i]);
+                for (int a = 0; a < 4; ++a)
+                    prims.a[a][slot] = make_float4(rec.gx[a], rec.gy[a], (rec.a0[a] + (tx0 - rec.v0x) * rec.gx[a]) + (ty0 - rec.v0y) * rec.gy[a],
+                                                   a == 0 ? __uint_as_float(rec.desc) : 0.0f);
             }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                prims.a_gx[a][slot] = rec.gx[a];
-                prims.a_gy[a][slot] = rec.gy[a];
-                prims.a_c[a][slot] = (rec.a0[a] + (tx0 - rec.v0x) * rec.gx[a]) + (ty0 - rec.v0y) * rec.gy[a];
-            }
-            prims.flags[slot] = (rec.flags & 0xFFu) | ((uint32_t)rx0 << 8) | ((uint32_t)rx1 << 12) | ((uint32_t)ry0 << 16) | ((uint32_t)ry1 << 20);
-            prims.flat_u[slot] = rec.flat_u;
-            prims.end_y[slot] = rec.end_y;
-            prims.desc[slot] = rec.desc;
-            if (((rec.flags >> 4) & 7u) == KIND_COVER) {
+            if (kind == KIND_COVER) {
                 const float ca = r.colors[4u * shape + 3];
-                prims.color[0][slot] = r.colors[4u * shape] * ca;
-                prims.color[1][slot] = r.colors[4u * shape + 1] * ca;
-                prims.color[2][slot] = r.colors[4u * shape + 2] * ca;
-                prims.color[3][slot] = ca;
+                prims.color[slot] = make_float4(r.colors[4u * shape] * ca, r.colors[4u * shape + 1] * ca, r.colors[4u * shape + 2] * ca, ca);
             }
         }
         __syncthreads();
+        if ((r.debug & 4u) && tid == 0) atomicAdd(&r.overflow[4], wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3]);
         // ---------------- coverage: every lane walks the survivors, wave region by wave region (= candidate order)
         for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t cnt = wave_count[w];
+            const uint32_t cnt = (r.debug & 2u) ? 0u : wave_count[w];
             for (uint32_t q = 0; q < cnt; ++q) {
                 const uint32_t slot = w * 64u + q;
-                const uint32_t flags = prims.flags[slot];
-                // this wave owns pixel rows 4*wave .. 4*wave+3: skip primitives whose box misses them (wave-uniform branch)
-                if (((flags >> 20) & 15u) < 4u * wave || ((flags >> 16) & 15u) > 4u * wave + 3u) continue;
+                const float4 e2 = prims.e2[slot];
+                const uint32_t flags = __float_as_uint(e2.y);
+                if (!((flags >> (24u + wave)) & 1u)) continue; // nothing of this primitive in the 4 rows this wave owns (wave-uniform)
+                const float4 e0 = prims.e0[slot], e1 = prims.e1[slot];
                 const uint32_t kind = (flags >> 4) & 7u;
-                const bool in_range = px >= ((flags >> 8) & 15u) && px <= ((flags >> 12) & 15u) && py >= ((flags >> 16) & 15u) && py <= ((flags >> 20) & 15u);
-                bool inside[S];
-                bool any_inside = false;
+                // Straight-line predicates (bitwise, no short-circuit): the compiler otherwise emits an exec-mask branch ladder per '&&'.
+                const uint32_t bx0 = (flags >> 8) & 15u, bx1 = (flags >> 12) & 15u, by0 = (flags >> 16) & 15u, by1 = (flags >> 20) & 15u;
+                const int in_range = (int)((px - bx0) <= (bx1 - bx0)) & (int)((py - by0) <= (by1 - by0));
+                const int full = (int)((flags >> (28u + wave)) & 1u); // every sample of the pixel range in this band is covered
+                const int tl0 = (int)(flags & 1u), tl1 = (int)((flags >> 1) & 1u), tl2 = (int)((flags >> 2) & 1u);
+                int inside[S];
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    bool in = in_range;
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const float e = fmaf(sx[k], prims.e_nay[i][slot], fmaf(sy[k], prims.e_bx[i][slot], prims.e_c[i][slot]));
-                        in = in && (e > 0.0f || (e == 0.0f && ((flags >> i) & 1u)));
-                    }
-                    inside[k] = in;
-                    any_inside = any_inside || in;
+                    const float ea = fmaf(sx[k], e0.x, fmaf(sy[k], e0.y, e0.z));
+                    const float eb = fmaf(sx[k], e0.w, fmaf(sy[k], e1.x, e1.y));
+                    const float ecv = fmaf(sx[k], e1.z, fmaf(sy[k], e1.w, e2.x));
+                    const int ia = (int)(ea > 0.0f) | ((int)(ea == 0.0f) & tl0);
+                    const int ib = (int)(eb > 0.0f) | ((int)(eb == 0.0f) & tl1);
+                    const int ic = (int)(ecv > 0.0f) | ((int)(ecv == 0.0f) & tl2);
+                    inside[k] = in_range & (full | (ia & ib & ic));
                 }
-                if (!__any(any_inside)) continue;
-                const bool front = (flags & 8u) != 0u;
-                if (kind == KIND_COVER) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
-                    const float one_minus_a = 1.0f - prims.color[3][slot];
+                const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+                switch (kind) {
+                    case KIND_SOLID: { // stencil_solid
 #pragma unroll
-                    for (int k = 0; k < S; ++k) {
-                        if (inside[k]) {
-                            if ((winding[k] & (int)r.winding_mask) != 0) {
-#pragma unroll
-                                for (int ch = 0; ch < 4; ++ch) col[k][ch] = prims.color[ch][slot] + col[k][ch] * one_minus_a;
-                            }
-                            winding[k] = 0;
-                        }
+                        for (int k = 0; k < S; ++k) winding[k] += inside[k] ? delta : 0;
+                        break;
                     }
-                } else if (kind == KIND_SOLID) { // stencil_solid: front +1, back -1 (renderer.rs:577-582)
-#pragma unroll
-                    for (int k = 0; k < S; ++k)
-                        if (inside[k]) winding[k] += front ? 1 : -1;
-                } else {
-                    float a0[S], a1[S], a2[S], a3[S];
-#pragma unroll
-                    for (int k = 0; k < S; ++k) {
-                        a0[k] = fmaf(sy[k], prims.a_gy[0][slot], fmaf(sx[k], prims.a_gx[0][slot], prims.a_c[0][slot]));
-                        a1[k] = fmaf(sy[k], prims.a_gy[1][slot], fmaf(sx[k], prims.a_gx[1][slot], prims.a_c[1][slot]));
-                        a2[k] = fmaf(sy[k], prims.a_gy[2][slot], fmaf(sx[k], prims.a_gx[2][slot], prims.a_c[2][slot]));
-                        a3[k] = fmaf(sy[k], prims.a_gy[3][slot], fmaf(sx[k], prims.a_gx[3][slot], prims.a_c[3][slot]));
-                    }
-                    if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
+                    case KIND_COVER: { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
+                        const float4 src = prims.color[slot];
+                        const float one_minus_a = 1.0f - src.w;
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
-                            bool fill;
-                            if (kind == KIND_IQ)
-                                fill = a0[k] * a0[k] - a1[k] <= 0.0f;
-                            else if (kind == KIND_IC)
-                                fill = a0[k] * a0[k] * a0[k] - a1[k] * a2[k] <= 0.0f;
-                            else if (kind == KIND_RQ)
-                                fill = a0[k] * a0[k] - a1[k] * a2[k] <= 0.0f;
-                            else
-                                fill = a0[k] * a0[k] * a0[k] - a1[k] * a2[k] * a3[k] <= 0.0f;
-                            if (inside[k] && fill) winding[k] += front ? 1 : -1;
+                            const bool blend = inside[k] && (winding[k] & (int)r.winding_mask) != 0;
+                            const float n0 = src.x + col[k][0] * one_minus_a, n1 = src.y + col[k][1] * one_minus_a;
+                            const float n2 = src.z + col[k][2] * one_minus_a, n3 = src.w + col[k][3] * one_minus_a;
+                            col[k][0] = blend ? n0 : col[k][0];
+                            col[k][1] = blend ? n1 : col[k][1];
+                            col[k][2] = blend ? n2 : col[k][2];
+                            col[k][3] = blend ? n3 : col[k][3];
+                            winding[k] = inside[k] ? 0 : winding[k];
                         }
-                    } else {
-                        const crh_dynamic_stroke_descriptor d = s.descriptors[prims.desc[slot]];
-                        const uint32_t flat_u = prims.flat_u[slot];
-                        const float end_y = prims.end_y[slot];
+                        break;
+                    }
+                    case KIND_IQ: { // u^2 - v <= 0 (shaders.wgsl:236-242)
+                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot];
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
+                            winding[k] += (inside[k] & (int)(a0 * a0 - a1 <= 0.0f)) ? delta : 0;
+                        }
+                        break;
+                    }
+                    case KIND_IC:   // k^3 - l m <= 0 (shaders.wgsl:244-250)
+                    case KIND_RQ: { // u^2 - v w <= 0 (shaders.wgsl:252-258)
+                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot], p2 = prims.a[2][slot];
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
+                            const float a2 = fmaf(sy[k], p2.y, fmaf(sx[k], p2.x, p2.z));
+                            const float lhs = kind == KIND_IC ? a0 * a0 * a0 : a0 * a0;
+                            winding[k] += (inside[k] & (int)(lhs - a1 * a2 <= 0.0f)) ? delta : 0;
+                        }
+                        break;
+                    }
+                    case KIND_RC: { // k^3 - l m n <= 0 (shaders.wgsl:260-266)
+                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot], p2 = prims.a[2][slot], p3 = prims.a[3][slot];
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
+                            const float a2 = fmaf(sy[k], p2.y, fmaf(sx[k], p2.x, p2.z)), a3 = fmaf(sy[k], p3.y, fmaf(sx[k], p3.x, p3.z));
+                            winding[k] += (inside[k] & (int)(a0 * a0 * a0 - a1 * a2 * a3 <= 0.0f)) ? delta : 0;
+                        }
+                        break;
+                    }
+                    default: { // KIND_LINE / KIND_JOINT: the stroke fragment stages
+                        int any_inside = 0;
+#pragma unroll
+                        for (int k = 0; k < S; ++k) any_inside |= inside[k];
+                        if (!__any(any_inside)) break;
+                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot], p2 = prims.a[2][slot];
+                        const crh_dynamic_stroke_descriptor d = s.descriptors[__float_as_uint(p0.w)];
+                        const uint32_t flat_u = __float_as_uint(e2.z);
+                        const float end_y = e2.w;
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
                             if (!inside[k]) continue;
+                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
+                            const float a2 = fmaf(sy[k], p2.y, fmaf(sx[k], p2.x, p2.z));
                             bool fill;
                             if (kind == KIND_LINE) { // stencil_stroke_line, shaders.wgsl:268-285
                                 if ((d.count_dashed_join & 4u) != 0u)
-                                    fill = stroke_dashed(d, a0[k], a1[k]);
+                                    fill = stroke_dashed(d, a0, a1);
                                 else if ((flat_u & 65536u) != 0u)
-                                    fill = cap_test(a0[k], a1[k] - end_y, d.caps >> 4);
-                                else if (a1[k] < 0.0f)
-                                    fill = cap_test(a0[k], -a1[k], d.caps);
+                                    fill = cap_test(a0, a1 - end_y, d.caps >> 4);
+                                else if (a1 < 0.0f)
+                                    fill = cap_test(a0, -a1, d.caps);
                                 else
                                     fill = true;
                             } else { // stencil_stroke_joint, shaders.wgsl:287-300
-                                const float radius = sqrtf(a0[k] * a0[k] + a1[k] * a1[k]);
+                                const float radius = sqrtf(a0 * a0 + a1 * a1);
                                 const uint32_t join = d.count_dashed_join & 3u;
                                 fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
                                 if (fill && (d.count_dashed_join & 4u) != 0u) {
                                     const float tau = crh_acosf(-1.0f) * 2.0f;
-                                    fill = stroke_dashed(d, radius, a2[k] + crh_atan2f(a1[k], a0[k]) / tau);
+                                    fill = stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
                                 }
                             }
                             // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
                             if (fill && (winding[k] & (int)r.winding_mask) == 0) winding[k] += 1;
                         }
+                        break;
                     }
                 }
             }

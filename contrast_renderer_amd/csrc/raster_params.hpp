@@ -25,6 +25,7 @@ struct RasterParams {
     uint32_t pair_capacity;
     uint32_t* overflow;      // [2]: {flag, required pairs}
     uint8_t* rgba8;          // [height][width][4]
+    uint32_t debug;          // CRH_RASTER_DEBUG ablation bits (tools only): 1 stop after the sort, 2 skip coverage, 4 count work into overflow[2..]
 };
 
 } // namespace crh
