@@ -14,11 +14,11 @@
 #include "scene.hpp"
 
 namespace crh {
-struct PrimRec;
 typedef void (*MarkFn)(void*, const char*, uint64_t);
 void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4]);
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
-void launch_bin(const SceneDev& s, const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
+void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
+void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx);
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -108,7 +108,7 @@ struct crh_renderer {
 
 struct crh_frame {
     crh_renderer* renderer;
-    uint32_t width, height, tiles_x, tiles_y, n_tiles;
+    uint32_t width, height, tiles_x, tiles_y, n_tiles, n_bands;
     DevBuf rgba8, tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
     bool cleared = true;
     bool pairs_known = false;
@@ -133,7 +133,7 @@ struct crh_scene {
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
-    DevBuf transforms, colors, shape_rect, shape_rect_hi, shape_ncand, shape_prim_begin, prim_rec, prim_box;
+    DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch, prim_rec;
     bool instances_set = false;
     // host copies for the parity taps
     std::vector<uint32_t> shape_base_host, hull_count_host;
@@ -143,7 +143,7 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_rect, &shape_rect_hi, &shape_ncand, &shape_prim_begin, &prim_rec, &prim_box};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -254,6 +254,9 @@ crh_status run_tessellation(crh_scene* sc) {
     if (sc->has_stroke) HIP_TRY(hipMemsetAsync(d.line_pair_cut, 0, sc->line_pair_cut.cap, r->stream));
     const uint64_t bytes2[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, (uint64_t)sc->totals_host[CH_HULL] * 8};
     launch_emit(d, r->stream, r->mark_fn(), r, bytes2, sc->has_stroke, sc->big_shapes);
+    // contiguous primitive ids per Shape, in draw order (transform independent, so it belongs to the tessellation)
+    launch_prim_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), r->stream);
+    if (r->timing) crh_renderer::mark_cb(r, "tess_prim_ranges", 0);
     HIP_TRY(hipGetLastError());
     sc->layout_valid = false;
     return CRH_OK;
@@ -385,39 +388,35 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.tiles_x = f->tiles_x;
     p.tiles_y = f->tiles_y;
     p.n_tiles = f->n_tiles;
+    p.n_bands = f->n_bands;
     p.winding_mask = (1u << r->config.winding_counter_bits) - 1u;
     p.load_existing = f->cleared ? 0u : 1u;
     p.transforms = sc->transforms.as<float>();
     p.colors = sc->colors.as<float>();
-    p.shape_rect = sc->shape_rect.as<uint32_t>();
-    p.shape_rect_hi = sc->shape_rect_hi.as<uint32_t>();
     p.tile_count = f->tile_count_cursor.as<uint32_t>();
-    p.tile_offset = f->tile_offset.as<uint32_t>();
     p.tile_cursor = f->tile_count_cursor.as<uint32_t>() + f->n_tiles;
+    p.tile_offset = f->tile_offset.as<uint32_t>();
     {
         // every candidate triangle gets a record slot: an upper bound follows from the tessellation totals
         const uint32_t* t = sc->totals_host;
         const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
         HIP_TRY(sc->prim_rec.ensure(prim_capacity * 128));
-        HIP_TRY(sc->prim_box.ensure(prim_capacity * 8));
-        HIP_TRY(sc->shape_ncand.ensure((size_t)sc->d.n_shapes * 4 + 4));
-        HIP_TRY(sc->shape_prim_begin.ensure(((size_t)sc->d.n_shapes + 1) * 4));
-        HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + (sc->d.n_shapes + 1023) / 1024 + 2) * 4));
+        if (prim_capacity >= (1u << 24)) return CRH_ERR_UNSUPPORTED; // tile list entries hold 24-bit primitive ids
+        HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
+        p.prim_capacity = (uint32_t)prim_capacity;
     }
     p.shape_ncand = sc->shape_ncand.as<uint32_t>();
     p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
     p.scan_scratch = f->scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec.p);
-    p.prim_box = sc->prim_box.as<ushort4>();
     p.overflow = f->overflow.as<uint32_t>();
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
-    if (p.debug & 4u) HIP_TRY(hipMemsetAsync(f->overflow.as<uint32_t>() + 2, 0, 24, r->stream));
     r->begin_marks();
     for (int attempt = 0; attempt < 2; ++attempt) {
         p.tile_list = f->tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(f->tile_list.cap / 4);
-        launch_bin(sc->d, p, r->stream, r->mark_fn(), r);
+        launch_bin(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r);
         if (f->pairs_known) break;
         uint32_t ov[2];
         HIP_TRY(hipMemcpyAsync(ov, p.overflow, 8, hipMemcpyDeviceToHost, r->stream));
@@ -628,7 +627,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
         !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
-        !hip_ok(sc->shape_rect.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->shape_rect_hi.ensure((size_t)b->n_shapes * 4), "hipMalloc")) {
+        !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
+        !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 4), "hipMalloc")) {
         rc = CRH_ERR_HIP;
         goto fail;
     }
@@ -777,6 +777,7 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     f->tiles_x = (width + 15) / 16;
     f->tiles_y = (height + 15) / 16;
     f->n_tiles = f->tiles_x * f->tiles_y;
+    f->n_bands = f->n_tiles * 4u;
     if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") ||
         !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") ||
         !hip_ok(f->overflow.ensure(64), "hipMalloc")) {

@@ -1,22 +1,29 @@
-// csrc/raster.hip — tile-binned compute rasterizer that replaces the reference's stencil-then-cover passes
+// csrc/raster.hip — band-binned compute rasterizer that replaces the reference's stencil-then-cover passes
 // (Shape::render renderer.rs:267-355, stencil states renderer.rs:565-582,736-754, fragment stage shaders.wgsl:155-309).
 //
-//   k_shape_setup   one wavefront per Shape: framebuffer bounding box -> 16x16-tile rectangle, per-tile counts, candidate count
-//   k_scan_local/add two-kernel exclusive scans: tile offsets and per-Shape primitive ranges
-//   k_shape_emit    one wavefront per Shape: append the Shape to its tiles (atomic slot, sorted later) and set up every triangle
-//                   ONCE per frame (transform, edge functions, attribute planes -> 128-byte record + 8-byte pixel box)
-//   k_raster<S>     one workgroup per tile, one lane per pixel, S samples per lane:
-//        sort the tile's shape list (painter's order == shape index order); the candidate triangles of consecutive shapes fill
-//        256 lanes at a time: box test against the tile, survivors load their record, make it tile relative and are compacted
-//        IN ORDER into an LDS primitive list (ballot + popcount),
-//        - every lane walks the list and updates the winding counters of its own samples (registers, the reference's
-//          8-bit stencil), evaluating the implicit-curve / cap / join / dash fragment tests at the sample,
-//        - the cover primitives (hull strip) blend the shape's colour where winding != 0 and zero the counter.
-//   The arithmetic of coverage and attributes follows oracle/raster.hpp operation by operation (canonical edge
-//   orientation, tile-relative constants, explicit fmaf) so pixels are bit-identical to the CPU spec.
+// The frame is cut into 16x16-pixel tiles of four 16x4 BANDS; one wavefront owns one band (lane = pixel, S samples per lane), so the
+// winding counters (the reference's 8-bit stencil) and the colour of a pixel never leave the lane's registers, and no workgroup
+// barrier is needed anywhere.
 //
-// Roofline note: this kernel reads each emitted vertex once per overlapped tile from L2 and writes W*H*4 bytes once; it is
-// VALU-bound (polynomial evaluation per sample), not HBM-bound — no MFMA shape exists in it.
+//   k_scan_*         two-kernel exclusive scan (per-Shape primitive ranges at tessellation time, tile offsets per frame)
+//   k_prim_setup<S>  one wavefront per Shape, one lane per triangle: vertex stage (shaders.wgsl:66-151), edge functions in canonical
+//                    orientation, attribute planes -> a 128-byte record, ONCE per frame. Primitive ids are contiguous per Shape and
+//                    ascend in draw order (Shape index, then line / joint / solid / IQ / IC / RQ / RC / cover = renderer.rs:275-354).
+//                    Then the wave walks the tiles of the Shape's rectangle: every lane tests ITS triangle against the tile's four
+//                    bands (exact: an edge function is monotone in x and y, so its extremes over a band sit at sample corners),
+//                    ballot + popcount -> ONE atomic per (Shape, tile) instead of one per (triangle, tile).
+//   k_prim_bin<S>    same walk; lane 0 reserves popcount slots of the tile's list with one atomic, lanes write
+//                    (prim id << 8 | full-band mask << 4 | band mask) at their rank.
+//   k_raster_band<S> one wavefront per band: sorts the tile's list by prim id (= draw order) in registers / wave-private LDS and
+//                    walks it, skipping entries whose band bit is clear (two scalar instructions). The record is fetched with
+//                    scalar loads from the constant address space (wave-uniform), the next record is prefetched while the current
+//                    one is evaluated; coverage + fragment tests run per sample in VALU; stencil semantics are integer adds on
+//                    the lane's counters; the cover blends premultiplied "over" where winding != 0.
+//   Coverage and attribute arithmetic follow oracle/raster.hpp operation by operation (tile-relative constants, explicit fmaf),
+//   so pixels are bit-identical to the CPU spec.
+//
+// Roofline note: algorithmic traffic = emitted vertices read once + W*H*4 bytes written once; the kernels are VALU / latency
+// bound (polynomial evaluation per sample, integer bookkeeping), not HBM bound, and contain no GEMM shape for MFMA.
 #include "ga.hpp"
 #include "raster_params.hpp"
 #include "scene.hpp"
@@ -24,8 +31,7 @@
 namespace crh {
 
 constexpr int kTile = 16;
-constexpr int kMaxTileShapes = 1024; // shapes overlapping one tile that the in-LDS sort handles
-
+constexpr uint32_t kBandListMax = 1024; // primitives per band that the in-wave sort handles
 
 CRH_D float2 to_framebuffer(const float* m, float w, float h, float x, float y) { // oracle/raster.hpp to_framebuffer
     const float cx = (m[0] * x + m[4] * y) + m[12];
@@ -33,23 +39,47 @@ CRH_D float2 to_framebuffer(const float* m, float w, float h, float x, float y) 
     return make_float2((cx * 0.5f + 0.5f) * w, (0.5f - cy * 0.5f) * h);
 }
 
-// ---------------------------------------------------------------------------------------------- per-frame setup
 enum : uint32_t { KIND_SOLID = 0, KIND_IQ = 1, KIND_IC = 2, KIND_RQ = 3, KIND_RC = 4, KIND_LINE = 5, KIND_JOINT = 6, KIND_COVER = 7 };
 
-// One set-up triangle, tile independent (128 bytes). Edge i evaluates, relative to a tile origin (tx0, ty0):
+// One set-up triangle, tile independent: two 64-byte halves, each fetched with one scalar load.
+// Edge i evaluates, relative to a tile origin (tx0, ty0):
 //   c = bx*(ty0 - lo_y) + nay*(tx0 - lo_x);  E = fma(rx, nay, fma(ry, bx, c))   — the canonical-orientation sign is folded in.
-struct PrimRec {
+struct PrimCoverage { // everything the coverage test needs
+    uint32_t flags; // bits 0-2 top-left per edge, bit 3 front (ccw on screen), bits 4-6 kind
+    uint32_t desc;  // stroke: index of the 48-byte descriptor
+    ushort4 box;    // inclusive pixel box x0 x1 y0 y1; x0 == 0xFFFF: nothing to draw
     float lo_x[3], lo_y[3], bx[3], nay[3];
-    float a0[4], gx[4], gy[4]; // attribute planes through vertex 0
+};
+struct PrimFragment { // what the fragment stage needs
+    float a0[4], gx[4], gy[4]; // attribute planes through vertex 0; cover: a0 = premultiplied source colour
     float v0x, v0y;
-    uint32_t flags;  // bits 0-2 top-left per edge, bit 3 front (ccw on screen), bits 4-6 kind
     uint32_t flat_u; // stroke: provoking vertex' u32 (group | 0x10000)
     float end_y;     // stroke line: provoking vertex' texcoord.y
-    uint32_t shape;
-    uint32_t desc;   // stroke: index of the 48-byte descriptor
-    uint32_t pad;
 };
-static_assert(sizeof(PrimRec) == 128, "PrimRec");
+struct PrimRec {
+    PrimCoverage cov;
+    PrimFragment frag;
+};
+static_assert(sizeof(PrimCoverage) == 64 && sizeof(PrimFragment) == 64 && sizeof(PrimRec) == 128, "PrimRec");
+
+// Wave-uniform loads through the constant address space become s_load_dwordx4..x16 (the records are written by an earlier kernel,
+// so the scalar cache is coherent with them). The host pass of the compiler never runs this code.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRH_CONST __attribute__((address_space(4)))
+#else
+#define CRH_CONST
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+CRH_D T load_uniform(const T* p) { // p must be wave uniform
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiples");
+    T out;
+    const u32x4 CRH_CONST* src = (const u32x4 CRH_CONST*)p;
+    u32x4* dst = reinterpret_cast<u32x4*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; ++i) dst[i] = src[i];
+    return out;
+}
 
 CRH_D uint32_t shape_candidates(const SceneDev& s, uint32_t shape, uint32_t c[8]) {
     const uint32_t* b0 = s.shape_base + shape * NCH;
@@ -66,67 +96,24 @@ CRH_D uint32_t shape_candidates(const SceneDev& s, uint32_t shape, uint32_t c[8]
     return c[7];
 }
 
-// k_shape_setup — one wavefront per Shape: framebuffer bounding box of everything the Shape draws (every vertex of every primitive is
-// a hull candidate: fill.rs:245-247,272,282,293; stroke.rs:89-92,125) -> tile rectangle, per-tile counts, candidate count.
-__global__ __launch_bounds__(64) void k_shape_setup(SceneDev s, RasterParams r) {
-    const uint32_t shape = blockIdx.x, lane = threadIdx.x;
-    const float* m = r.transforms + 16u * shape;
-    if (lane == 0 && !(m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f)) // affine instances only this round (clip.w == 1)
-        raise_error(s, s.elem_path[min(s.shape_elem_begin[shape], s.n_elems - 1u)], CRH_ERR_UNSUPPORTED);
-    const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
-    const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
-    const float W = (float)r.width, H = (float)r.height;
-    const float inf = __uint_as_float(0x7f800000u);
-    float minx = inf, miny = inf, maxx = -inf, maxy = -inf;
-    for (uint32_t i = lane; i < n; i += 64u) {
-        const Vertex0 c = s.hull_cand[base + i];
-        const float2 f = to_framebuffer(m, W, H, c.x, c.y);
-        minx = fminf(minx, f.x);
-        maxx = fmaxf(maxx, f.x);
-        miny = fminf(miny, f.y);
-        maxy = fmaxf(maxy, f.y);
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        minx = fminf(minx, __shfl_xor(minx, d, 64));
-        maxx = fmaxf(maxx, __shfl_xor(maxx, d, 64));
-        miny = fminf(miny, __shfl_xor(miny, d, 64));
-        maxy = fmaxf(maxy, __shfl_xor(maxy, d, 64));
-    }
-    uint32_t lo = 0xFFFFFFFFu, hi = 0;
-    minx = fmaxf(minx, 0.0f);
-    miny = fmaxf(miny, 0.0f);
-    maxx = fminf(maxx, W - 1.0f);
-    maxy = fminf(maxy, H - 1.0f);
-    if (n > 0 && minx <= maxx && miny <= maxy) {
-        const uint32_t tx0 = (uint32_t)floorf(minx) / kTile, tx1 = (uint32_t)floorf(maxx) / kTile;
-        const uint32_t ty0 = (uint32_t)floorf(miny) / kTile, ty1 = (uint32_t)floorf(maxy) / kTile;
-        lo = tx0 | (ty0 << 16);
-        hi = tx1 | (ty1 << 16);
-        const uint32_t tw = tx1 - tx0 + 1u, count = tw * (ty1 - ty0 + 1u);
-        for (uint32_t i = lane; i < count; i += 64u) atomicAdd(&r.tile_count[(ty0 + i / tw) * r.tiles_x + tx0 + i % tw], 1u);
-    }
-    if (lane == 0) {
-        uint32_t c[8];
-        r.shape_rect[shape] = lo;
-        r.shape_rect_hi[shape] = hi;
-        r.shape_ncand[shape] = lo == 0xFFFFFFFFu ? 0u : shape_candidates(s, shape, c); // off-screen Shapes draw nothing
-    }
-}
-
-// Two-kernel exclusive scan over u32 arrays (1024 items per block), used for the tile offsets and the per-Shape primitive ranges.
+// ---------------------------------------------------------------------------------------------- scans
+// Two-kernel exclusive scan over a u32 array (1024 items per block): out[i] = sum of in[0..i), out[n] = total.
 struct ScanJob {
     const uint32_t* in;
-    uint32_t* out; // [n + 1]
+    uint32_t* out;
     uint32_t* block_sum;
     uint32_t n, blocks;
 };
-__global__ __launch_bounds__(256) void k_scan_local(ScanJob a, ScanJob b) {
+// candidate counts are transform independent: one lane per Shape (runs at the end of tessellation, before the scan)
+__global__ __launch_bounds__(256) void k_shape_ncand(SceneDev s, uint32_t* shape_ncand) {
+    const uint32_t shape = blockIdx.x * 256u + threadIdx.x;
+    if (shape >= s.n_shapes) return;
+    uint32_t c[8];
+    shape_ncand[shape] = shape_candidates(s, shape, c);
+}
+__global__ __launch_bounds__(256) void k_scan_local(ScanJob j) {
     __shared__ uint32_t wave_sum[4];
-    const bool second = blockIdx.x >= a.blocks;
-    const ScanJob j = second ? b : a;
-    const uint32_t block = second ? blockIdx.x - a.blocks : blockIdx.x;
-    const uint32_t i0 = block * 1024u + threadIdx.x * 4u;
+    const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
     uint32_t v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = i0 + k < j.n ? j.in[i0 + k] : 0u;
@@ -148,15 +135,13 @@ __global__ __launch_bounds__(256) void k_scan_local(ScanJob a, ScanJob b) {
         if (i0 + k < j.n) j.out[i0 + k] = run;
         run += v[k];
     }
-    if (threadIdx.x == 255) j.block_sum[block] = run;
+    if (threadIdx.x == 255) j.block_sum[blockIdx.x] = run;
 }
-__global__ __launch_bounds__(256) void k_scan_add(ScanJob a, ScanJob b, RasterParams r) {
+// mode 0: primitive ranges; mode 1: band offsets (also publishes the pair count and the overflow flag)
+__global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int mode) {
     __shared__ uint32_t partial[256];
-    const bool second = blockIdx.x >= a.blocks;
-    const ScanJob j = second ? b : a;
-    const uint32_t block = second ? blockIdx.x - a.blocks : blockIdx.x;
     uint32_t sum = 0;
-    for (uint32_t k = threadIdx.x; k < block; k += 256u) sum += j.block_sum[k];
+    for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 256u) sum += j.block_sum[k];
     partial[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 128; d > 0; d >>= 1) {
@@ -164,45 +149,113 @@ __global__ __launch_bounds__(256) void k_scan_add(ScanJob a, ScanJob b, RasterPa
         __syncthreads();
     }
     const uint32_t base = partial[0];
-    const uint32_t i0 = block * 1024u + threadIdx.x * 4u;
+    const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (i0 + k < j.n) j.out[i0 + k] += base;
-    if (block + 1u == j.blocks && threadIdx.x == 0) {
-        const uint32_t total = base + j.block_sum[block];
+    if (blockIdx.x + 1u == j.blocks && threadIdx.x == 0) {
+        const uint32_t total = base + j.block_sum[blockIdx.x];
         j.out[j.n] = total;
-        if (!second) { // job a = tiles: publish the pair count and the overflow flag
+        if (mode == 1) {
             r.overflow[1] = total;
             r.overflow[0] = total > r.pair_capacity ? 1u : 0u;
         }
     }
 }
 
-// k_shape_emit — one wavefront per Shape: (1) append the Shape to every tile of its rectangle, (2) set up its triangles once
-// for the whole frame: transform (vertex stage, shaders.wgsl:66-151), edge functions, attribute planes, pixel box.
-__global__ __launch_bounds__(64) void k_shape_emit(SceneDev s, RasterParams r) {
-    const uint32_t shape = blockIdx.x, lane = threadIdx.x;
-    const uint32_t lo = r.shape_rect[shape], hi = r.shape_rect_hi[shape];
-    if (lo == 0xFFFFFFFFu) return;
-    if (!r.overflow[0]) {
-        const uint32_t tx0 = lo & 0xFFFFu, ty0 = lo >> 16, tw = (hi & 0xFFFFu) - tx0 + 1u, count = tw * ((hi >> 16) - ty0 + 1u);
-        for (uint32_t i = lane; i < count; i += 64u) {
-            const uint32_t tile = (ty0 + i / tw) * r.tiles_x + tx0 + i % tw;
-            const uint32_t slot = atomicAdd(&r.tile_cursor[tile], 1u);
-            r.tile_list[r.tile_offset[tile] + slot] = shape;
+// ---------------------------------------------------------------------------------------------- exact tile / band tests
+// An edge function E = fma(rx, nay, fma(ry, bx, c)) is monotone in rx and in ry (fmaf rounds monotonically), so its extremes over a
+// box of sample positions sit at the corners. Sample positions inside a tile span [s_lo, 15 + s_hi] in x; band b spans rows
+// [4b + s_lo, 4b + 3 + s_hi].
+//   tile_hit : the triangle's pixel box overlaps the tile and no edge rejects its best tile corner (count pass; a superset of
+//              "some band is hit", so the lists may hold entries whose band mask is 0 — the raster skips them)
+//   band_masks: bit b of `bands` = no edge rejects the best corner of band b and the pixel box reaches its rows;
+//              bit b of `full`  = the pixel box spans band b and every edge accepts its worst corner (no per-sample test needed)
+template <int S>
+struct TileTest {
+    float ec[3];
+    bool overlap;
+    CRH_D TileTest(const PrimCoverage& cov, uint32_t tx, uint32_t ty) {
+        const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
+        overlap = (int)cov.box.x <= tpx + kTile - 1 && (int)cov.box.y >= tpx && (int)cov.box.z <= tpy + kTile - 1 && (int)cov.box.w >= tpy;
+        const float tx0 = (float)tpx, ty0 = (float)tpy;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ec[i] = cov.bx[i] * (ty0 - cov.lo_y[i]) + cov.nay[i] * (tx0 - cov.lo_x[i]);
+    }
+    CRH_D bool accepts(const PrimCoverage& cov, int i, float x, float y) const {
+        const float e = fmaf(x, cov.nay[i], fmaf(y, cov.bx[i], ec[i]));
+        return e > 0.0f || (e == 0.0f && ((cov.flags >> i) & 1u));
+    }
+    CRH_D bool tile_hit(const PrimCoverage& cov) const {
+        const float lo = S == 1 ? 0.5f : 0.125f, hi = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f);
+        bool hit = overlap;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hit = hit && accepts(cov, i, cov.nay[i] > 0.0f ? hi : lo, cov.bx[i] > 0.0f ? hi : lo);
+        return hit;
+    }
+    CRH_D void band_masks(const PrimCoverage& cov, uint32_t tx, uint32_t ty, uint32_t& bands, uint32_t& full) const {
+        bands = 0;
+        full = 0;
+        if (!overlap) return;
+        const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
+        const float s_lo = S == 1 ? 0.5f : 0.125f, s_hi = S == 1 ? 0.5f : 0.875f;
+        const float x_lo = s_lo, x_hi = (float)(kTile - 1) + s_hi;
+        const bool wide = (int)cov.box.x <= tpx && (int)cov.box.y >= tpx + kTile - 1;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int row0 = tpy + 4 * b, row1 = row0 + 3;
+            if ((int)cov.box.z > row1 || (int)cov.box.w < row0) continue;
+            const float y_lo = (float)(4 * b) + s_lo, y_hi = (float)(4 * b + 3) + s_hi;
+            bool some = true, all = wide && (int)cov.box.z <= row0 && (int)cov.box.w >= row1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bool xp = cov.nay[i] > 0.0f, yp = cov.bx[i] > 0.0f;
+                some = some && accepts(cov, i, xp ? x_hi : x_lo, yp ? y_hi : y_lo);
+                all = all && accepts(cov, i, xp ? x_lo : x_hi, yp ? y_lo : y_hi);
+            }
+            if (some) bands |= 1u << b;
+            if (some && all) full |= 1u << b;
         }
     }
+};
+
+// tile rectangle that bounds the pixel boxes of the wave's (up to 64) triangles; false when no lane draws anything
+CRH_D bool wave_tile_rect(bool valid, const PrimCoverage& cov, uint32_t& tx0, uint32_t& tx1, uint32_t& ty0, uint32_t& ty1) {
+    uint32_t x0 = valid ? cov.box.x : 0xFFFFu, x1 = valid ? cov.box.y : 0u, y0 = valid ? cov.box.z : 0xFFFFu, y1 = valid ? cov.box.w : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        x0 = min(x0, (uint32_t)__shfl_xor((int)x0, d, 64));
+        y0 = min(y0, (uint32_t)__shfl_xor((int)y0, d, 64));
+        x1 = max(x1, (uint32_t)__shfl_xor((int)x1, d, 64));
+        y1 = max(y1, (uint32_t)__shfl_xor((int)y1, d, 64));
+    }
+    tx0 = x0 / kTile;
+    tx1 = x1 / kTile;
+    ty0 = y0 / kTile;
+    ty1 = y1 / kTile;
+    return x0 != 0xFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------- k_prim_setup
+template <int S>
+__global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
+    const uint32_t shape = blockIdx.x, lane = threadIdx.x;
+    const float* m = r.transforms + 16u * shape;
+    if (lane == 0 && !(m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f)) // affine instances only this round (clip.w == 1)
+        raise_error(s, s.elem_path[min(s.shape_elem_begin[shape], s.n_elems - 1u)], CRH_ERR_UNSUPPORTED);
     uint32_t cb[8];
     const uint32_t n_candidates = shape_candidates(s, shape, cb);
     const uint32_t prim0 = r.shape_prim_begin[shape];
+    if (prim0 + n_candidates > r.prim_capacity) return; // cannot happen: the capacity is an upper bound derived from the totals
     const uint32_t* b0 = s.shape_base + shape * NCH;
     const uint32_t lv0 = b0[CH_LINE_V], j0 = b0[CH_JOINT], sv0 = b0[CH_SOLID_V], iq0 = b0[CH_IQ], ic0 = b0[CH_IC_V], rq0 = b0[CH_RQ], rc0 = b0[CH_RC_V],
                    hull0 = b0[CH_HULL];
     const uint32_t dyn0 = s.shape_dyn_begin[shape];
-    const float* m = r.transforms + 16u * shape;
     const float W = (float)r.width, H = (float)r.height;
-    for (uint32_t c = lane; c < n_candidates; c += 64u) {
-        float2 p[3];
+    for (uint32_t c0 = 0; c0 < n_candidates; c0 += 64u) { // all 64 lanes stay in the loop: the tile walk below is wave-wide
+        const uint32_t c = c0 + lane;
+        const bool in_range_c = c < n_candidates;
+        float2 p[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
         float attr[3][4];
         uint32_t kind = KIND_SOLID, flat_u = 0, desc = 0;
         float end_y = 0.0f;
@@ -214,7 +267,9 @@ __global__ __launch_bounds__(64) void k_shape_emit(SceneDev s, RasterParams r) {
             i1 = base + ((k & 1u) ? k + 2u : k + 1u);
             i2 = base + ((k & 1u) ? k + 1u : k + 2u);
         };
-        if (c < cb[0]) { // stroke line strips (vertex2f1u / stencil_stroke_line)
+        if (!in_range_c) {
+            valid = false;
+        } else if (c < cb[0]) { // stroke line strips (vertex2f1u / stencil_stroke_line)
             const uint32_t k = c;
             valid = s.line_pair_cut[(lv0 + k) >> 1] == 0;
             strip(k, lv0);
@@ -301,11 +356,13 @@ __global__ __launch_bounds__(64) void k_shape_emit(SceneDev s, RasterParams r) {
             kind = KIND_COVER;
         }
         // ---- oracle/raster.hpp setup_triangle + setup_attribute
-        ushort4 box = make_ushort4(0xFFFFu, 0, 0, 0);
+        PrimRec rec;
+        rec.cov.box = make_ushort4(0xFFFFu, 0, 0, 0);
+        bool drawn = false;
         const float d1x = p[1].x - p[0].x, d1y = p[1].y - p[0].y;
         const float d2x = p[2].x - p[0].x, d2y = p[2].y - p[0].y;
         const float det = d1x * d2y - d2x * d1y;
-        if (valid && det != 0.0f && det == det && is_finite(det)) {
+        if (in_range_c && valid && det != 0.0f && det == det && is_finite(det)) {
             float minx = fminf(p[0].x, fminf(p[1].x, p[2].x)), maxx = fmaxf(p[0].x, fmaxf(p[1].x, p[2].x));
             float miny = fminf(p[0].y, fminf(p[1].y, p[2].y)), maxy = fmaxf(p[0].y, fmaxf(p[1].y, p[2].y));
             const bool nan_free = minx == minx && maxx == maxx && miny == miny && maxy == maxy;
@@ -314,8 +371,8 @@ __global__ __launch_bounds__(64) void k_shape_emit(SceneDev s, RasterParams r) {
             maxx = fminf(maxx, W - 1.0f);
             maxy = fminf(maxy, H - 1.0f);
             if (nan_free && minx <= maxx && miny <= maxy) {
-                box = make_ushort4((unsigned short)floorf(minx), (unsigned short)floorf(maxx), (unsigned short)floorf(miny), (unsigned short)floorf(maxy));
-                PrimRec rec;
+                drawn = true;
+                rec.cov.box = make_ushort4((unsigned short)floorf(minx), (unsigned short)floorf(maxx), (unsigned short)floorf(miny), (unsigned short)floorf(maxy));
                 const float inv_det = 1.0f / det;
                 const bool front = det < 0.0f; // y-down cross < 0 == counter-clockwise on screen (FrontFace::Ccw, renderer.rs:477)
                 const float2 nv[3] = {p[0], det < 0.0f ? p[2] : p[1], det < 0.0f ? p[1] : p[2]}; // clockwise-in-y-down edge walk
@@ -328,51 +385,104 @@ __global__ __launch_bounds__(64) void k_shape_emit(SceneDev s, RasterParams r) {
                     const bool flip = !(a.x < b.x || (a.x == b.x && a.y < b.y));   // canonical (lexicographic) endpoint order
                     const float2 el = flip ? b : a, eh = flip ? a : b;
                     const float sg = flip ? -1.0f : 1.0f;
-                    rec.lo_x[i] = el.x;
-                    rec.lo_y[i] = el.y;
-                    rec.bx[i] = (eh.x - el.x) * sg;
-                    rec.nay[i] = -(eh.y - el.y) * sg;
+                    rec.cov.lo_x[i] = el.x;
+                    rec.cov.lo_y[i] = el.y;
+                    rec.cov.bx[i] = (eh.x - el.x) * sg;
+                    rec.cov.nay[i] = -(eh.y - el.y) * sg;
                 }
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (a < n_attr) {
                         const float da1 = attr[1][a] - attr[0][a], da2 = attr[2][a] - attr[0][a];
-                        rec.a0[a] = attr[0][a];
-                        rec.gx[a] = (da1 * d2y - da2 * d1y) * inv_det;
-                        rec.gy[a] = (da2 * d1x - da1 * d2x) * inv_det;
+                        rec.frag.a0[a] = attr[0][a];
+                        rec.frag.gx[a] = (da1 * d2y - da2 * d1y) * inv_det;
+                        rec.frag.gy[a] = (da2 * d1x - da1 * d2x) * inv_det;
                     } else {
-                        rec.a0[a] = rec.gx[a] = rec.gy[a] = 0.0f;
+                        rec.frag.a0[a] = rec.frag.gx[a] = rec.frag.gy[a] = 0.0f;
                     }
                 }
-                rec.v0x = p[0].x;
-                rec.v0y = p[0].y;
-                rec.flags = flags;
-                rec.flat_u = flat_u;
-                rec.end_y = end_y;
-                rec.shape = shape;
-                rec.desc = desc;
-                rec.pad = 0;
-                r.prim_rec[prim0 + c] = rec;
+                if (kind == KIND_COVER) { // color_cover: (rgb * a, a), shaders.wgsl:304-309
+                    const float* color = r.colors + 4u * shape;
+                    rec.frag.a0[0] = color[0] * color[3];
+                    rec.frag.a0[1] = color[1] * color[3];
+                    rec.frag.a0[2] = color[2] * color[3];
+                    rec.frag.a0[3] = color[3];
+                }
+                rec.frag.v0x = p[0].x;
+                rec.frag.v0y = p[0].y;
+                rec.frag.flat_u = flat_u;
+                rec.frag.end_y = end_y;
+                rec.cov.flags = flags;
+                rec.cov.desc = desc;
             }
         }
-        r.prim_box[prim0 + c] = box;
+        if (in_range_c) {
+            if (drawn)
+                r.prim_rec[prim0 + c] = rec;
+            else
+                r.prim_rec[prim0 + c].cov.box = rec.cov.box;
+        }
     }
 }
 
-// ---------------------------------------------------------------------------------------------- per-tile raster
-// One primitive staged in LDS. Every lane reads the same slot (broadcast), so the fields a coverage step needs together are
-// packed into float4s (one ds_read_b128 each) instead of one array per scalar.
-struct PrimList {
-    float4 e0[256]; // nay0 bx0 c0 nay1      edge i: E = fma(rx, nay_i, fma(ry, bx_i, c_i))
-    float4 e1[256]; // bx1 c1 nay2 bx2
-    float4 e2[256]; // c2, flags (bits), flat_u (bits), end_y
-    float4 a[4][256]; // attribute plane k: gx gy c, (k == 0: descriptor index bits in .w)
-    float4 color[256]; // cover: premultiplied source colour
-};
-// flags: bits 0-2 top-left per edge, bit 3 front, bits 4-6 kind, bits 8-23 pixel range nibbles x0 x1 y0 y1 inside the tile,
-//        bits 24-27 bands (pixel rows 4b..4b+3 = the rows wave b owns) that may contain covered samples,
-//        bits 28-31 bands in which EVERY sample of the pixel range is inside the triangle (edge evaluation can be skipped)
+// ---------------------------------------------------------------------------------------------- k_tile_walk
+// Count pass (FILL = false) and fill pass (FILL = true) of the tile lists. One workgroup of 16 wavefronts per Shape; the Shape's
+// triangles are taken 64 at a time (lane = triangle) and wavefront w walks every 16th tile ROW of the chunk's tile rectangle, so the
+// largest Shapes (hundreds of tiles) do not leave one long serial tail.
+//   count: ballot of the lanes whose triangle can touch the tile -> ONE atomic per (chunk, tile)
+//   fill : lane 0 reserves popcount(ballot) slots of the tile's list with one returning atomic (consumed one iteration later, after
+//          the next tile's masks have been computed, so its latency is hidden); every hit lane writes
+//          prim id << 8 | full-band mask << 4 | band mask at its rank.
+constexpr uint32_t kWalkWaves = 16;
+template <int S, bool FILL>
+__global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, RasterParams r) {
+    const uint32_t shape = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (FILL && r.overflow[0]) return;
+    const uint32_t prim0 = r.shape_prim_begin[shape], n_candidates = r.shape_prim_begin[shape + 1] - prim0;
+    if (prim0 + n_candidates > r.prim_capacity) return;
+    for (uint32_t c0 = 0; c0 < n_candidates; c0 += 64u) {
+        const uint32_t c = c0 + lane;
+        ushort4 box = make_ushort4(0xFFFFu, 0, 0, 0);
+        if (c < n_candidates) box = r.prim_rec[prim0 + c].cov.box;
+        PrimCoverage cov;
+        cov.box = box;
+        const bool drawn = box.x != 0xFFFFu;
+        uint32_t tx_a, tx_b, ty_a, ty_b;
+        if (!wave_tile_rect(drawn, cov, tx_a, tx_b, ty_a, ty_b)) continue;
+        if (ty_a + wave > ty_b) continue; // this wavefront has no row in the chunk's rectangle
+        if (drawn) cov = r.prim_rec[prim0 + c].cov;
+        unsigned long long pending_ballot = 0;
+        uint32_t pending_entry = 0, pending_base = 0;
+        auto flush = [&]() {
+            if (!pending_ballot) return;
+            const uint32_t base = __shfl(pending_base, 0, 64);
+            if ((pending_ballot >> lane) & 1ull) r.tile_list[base + (uint32_t)__popcll(pending_ballot & ((1ull << lane) - 1ull))] = pending_entry;
+        };
+        for (uint32_t ty = ty_a + wave; ty <= ty_b; ty += kWalkWaves)
+            for (uint32_t tx = tx_a; tx <= tx_b; ++tx) {
+                const TileTest<S> test(cov, tx, ty);
+                const bool hit = drawn && test.tile_hit(cov);
+                const unsigned long long ballot = __ballot(hit);
+                if (!ballot) continue;
+                const uint32_t tile = ty * r.tiles_x + tx;
+                if (!FILL) {
+                    if (lane == 0) atomicAdd(&r.tile_count[tile], (uint32_t)__popcll(ballot));
+                } else {
+                    uint32_t bands = 0, full = 0;
+                    if (hit) test.band_masks(cov, tx, ty, bands, full);
+                    uint32_t base = 0;
+                    if (lane == 0) base = r.tile_offset[tile] + atomicAdd(&r.tile_cursor[tile], (uint32_t)__popcll(ballot));
+                    flush(); // the previous tile's atomic has had a whole iteration to return
+                    pending_ballot = ballot;
+                    pending_entry = ((prim0 + c) << 8) | (full << 4) | bands;
+                    pending_base = base;
+                }
+            }
+        if (FILL) flush();
+    }
+}
 
+// ---------------------------------------------------------------------------------------------- k_raster_band
 CRH_D bool cap_test(float x, float y, uint32_t cap_type) { // shaders.wgsl:165-189
     switch (cap_type & 15u) {
         case 0: return y > 0.5f;
@@ -407,16 +517,13 @@ CRH_D bool stroke_dashed(const crh_dynamic_stroke_descriptor& d, float tx, float
 }
 
 template <int S>
-__global__ __launch_bounds__(256) void k_raster(SceneDev s, RasterParams r) {
-    __shared__ PrimList prims;
-    __shared__ uint32_t order[kMaxTileShapes];       // the tile's shapes in painter's order
-    __shared__ uint32_t cand_end[kMaxTileShapes];    // inclusive prefix of their candidate counts
-    __shared__ uint32_t wave_count[4];
+__global__ __launch_bounds__(256) void k_raster_band(SceneDev s, RasterParams r) {
+    __shared__ uint32_t sort_buffer[4][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % r.tiles_x, ty = tile / r.tiles_x;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t px = tid & 15u, py = tid >> 4;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px = lane & 15u, py = 4u * wave + (lane >> 4);
     const uint32_t gx = tx * kTile + px, gy = ty * kTile + py;
     const bool in_frame = gx < r.width && gy < r.height;
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
@@ -452,273 +559,183 @@ __global__ __launch_bounds__(256) void k_raster(SceneDev s, RasterParams r) {
         }
     }
 
-    const bool overflowed = r.overflow[0] != 0u;
     const uint32_t list_begin = r.tile_offset[tile];
-    uint32_t n_list = overflowed ? 0u : r.tile_offset[tile + 1] - list_begin;
-    if (n_list > (uint32_t)kMaxTileShapes) {
-        if (tid == 0) raise_error(s, 0, CRH_ERR_UNSUPPORTED);
-        n_list = 0;
+    uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
+    if (n > kBandListMax) {
+        if (lane == 0) raise_error(s, 0, CRH_ERR_UNSUPPORTED);
+        n = 0;
     }
-    // ---- painter's order: sort the shape indices of this tile (bitonic, padded with 0xFFFFFFFF)
-    if (n_list > 0) {
-        uint32_t padded = 1;
-        while (padded < n_list) padded <<= 1;
-        for (uint32_t i = tid; i < padded; i += 256) order[i] = i < n_list ? r.tile_list[list_begin + i] : 0xFFFFFFFFu;
-        __syncthreads();
+    // ---- draw order = ascending prim id: every wave sorts its own copy of the tile's list (no workgroup barrier):
+    // bitonic network in registers (<= 64 entries) or in wave-private LDS
+    uint32_t my_key = 0xFFFFFFFFu;
+    uint32_t* keys = sort_buffer[wave];
+    if (n <= 64u) {
+        if (lane < n) my_key = r.tile_list[list_begin + lane];
+#pragma unroll
+        for (uint32_t k = 2; k <= 64u; k <<= 1) {
+#pragma unroll
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t other = __shfl_xor(my_key, j, 64);
+                const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+                my_key = keep_min ? min(my_key, other) : max(my_key, other);
+            }
+        }
+    } else {
+        uint32_t padded = 128;
+        while (padded < n) padded <<= 1;
+        for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < n ? r.tile_list[list_begin + i] : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t k = 2; k <= padded; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = tid; i < padded; i += 256) {
+                for (uint32_t i = lane; i < padded; i += 64u) {
                     const uint32_t partner = i ^ j;
                     if (partner > i) {
-                        const uint32_t a = order[i], b = order[partner];
+                        const uint32_t a = keys[i], b = keys[partner];
                         if (((i & k) == 0) ? (a > b) : (a < b)) {
-                            order[i] = b;
-                            order[partner] = a;
+                            keys[i] = b;
+                            keys[partner] = a;
                         }
                     }
                 }
-                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-        // inclusive prefix of the candidate counts (Hillis-Steele in LDS; lists are short)
-        for (uint32_t i = tid; i < n_list; i += 256) cand_end[i] = r.shape_prim_begin[order[i] + 1u] - r.shape_prim_begin[order[i]];
-        __syncthreads();
-        for (uint32_t d = 1; d < n_list; d <<= 1) {
-            uint32_t add[kMaxTileShapes / 256];
-#pragma unroll
-            for (uint32_t q = 0; q < kMaxTileShapes / 256; ++q) {
-                const uint32_t i = tid + q * 256u;
-                add[q] = (i < n_list && i >= d) ? cand_end[i - d] : 0u;
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t q = 0; q < kMaxTileShapes / 256; ++q) {
-                const uint32_t i = tid + q * 256u;
-                if (i < n_list) cand_end[i] += add[q];
-            }
-            __syncthreads();
-        }
     }
-    uint32_t n_candidates = n_list ? cand_end[n_list - 1u] : 0u;
-    if (r.debug & 4u) {
-        if (tid == 0) {
-            atomicAdd(&r.overflow[2], n_list);
-            atomicAdd(&r.overflow[3], n_candidates);
-            atomicMax(&r.overflow[5], n_list);
-            atomicMax(&r.overflow[6], n_candidates);
-        }
-    }
-    if (r.debug & 1u) n_candidates = 0;
 
-    for (uint32_t chunk = 0; chunk < n_candidates; chunk += 256u) {
-        // ---------------- gather: candidates of several consecutive shapes fill the 256 lanes; survivors of the box test are
-        // packed per wave into the LDS list in candidate (= draw) order
-        const uint32_t c = chunk + tid;
-        bool keep = false;
-        uint32_t prim = 0, shape = 0;
-        int rx0 = 0, rx1 = 0, ry0 = 0, ry1 = 0;
-        if (c < n_candidates) {
-            uint32_t lo_i = 0, hi_i = n_list - 1u; // first i with cand_end[i] > c
-            while (lo_i < hi_i) {
-                const uint32_t mid = (lo_i + hi_i) >> 1;
-                if (cand_end[mid] > c)
-                    hi_i = mid;
-                else
-                    lo_i = mid + 1u;
-            }
-            shape = order[lo_i];
-            prim = r.shape_prim_begin[shape] + (c - (lo_i ? cand_end[lo_i - 1u] : 0u));
-            const ushort4 box = r.prim_box[prim];
-            if (box.x != 0xFFFFu) {
-                rx0 = max((int)box.x, tpx) - tpx;
-                rx1 = min((int)box.y, tpx + kTile - 1) - tpx;
-                ry0 = max((int)box.z, tpy) - tpy;
-                ry1 = min((int)box.w, tpy + kTile - 1) - tpy;
-                keep = rx0 <= rx1 && ry0 <= ry1;
-            }
+    const PrimRec* recs = r.prim_rec;
+    const uint32_t band_bit = 1u << wave, full_bit = 16u << wave;
+    for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+        if (n > 64u) my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
+        // keep only the entries that touch THIS band, packed to the low lanes in order (ballot + prefix popcount)
+        const bool mine = (q0 + lane < n) && (my_key & band_bit) != 0u;
+        const unsigned long long ballot = __ballot(mine);
+        const uint32_t count = (uint32_t)__popcll(ballot);
+        const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
+        // compaction through a permute: lane `rank` receives this lane's key
+        uint32_t packed = 0;
+        {
+            const int dst = mine ? (int)rank : 63; // losers all write lane 63's slot; fixed below
+            packed = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)my_key);
+            if (count < 64u && lane >= count) packed = 0;
         }
-        // exact cull + band classification: an edge function is monotone in rx and in ry (fmaf rounds monotonically), so its
-        // extremes over a box of sample positions sit at the corners; a primitive is dropped when some edge rejects its best
-        // corner, and a band is "full" when every edge accepts its worst corner.
-        PrimRec rec;
-        float ec[3];
-        uint32_t bands = 0, full = 0;
-        if (keep) {
-            rec = r.prim_rec[prim];
-            const float s_lo = S == 1 ? 0.5f : 0.125f, s_hi = S == 1 ? 0.5f : 0.875f;
-            const float x_lo = (float)rx0 + s_lo, x_hi = (float)rx1 + s_hi;
+        if (count == 0u) continue;
+        PrimCoverage cur = load_uniform(&recs[__builtin_amdgcn_readlane(packed, 0) >> 8].cov);
+        for (uint32_t j = 0; j < count; ++j) {
+            const uint32_t key = __builtin_amdgcn_readlane(packed, j);
+            const uint32_t prim = key >> 8;
+            const int full = (int)((key & full_bit) != 0u); // every sample of this band is inside the triangle
+            const PrimCoverage cov = cur;
+            if (j + 1u < count) cur = load_uniform(&recs[__builtin_amdgcn_readlane(packed, j + 1u) >> 8].cov); // prefetch the next record (scalar load)
+            const uint32_t flags = cov.flags;
+            const uint32_t kind = (flags >> 4) & 7u;
+            // inside[k] > 0  <=>  sample k of this lane's pixel is covered. Everything stays in VALU integer math: comparing floats
+            // and combining the lane masks would run on the scalar unit (64-bit mask ops), which dominated this loop.
+            //   edge i accepts e  <=>  e > 0 || (e == 0 && top_left_i)  <=>  as_int(e + 0.0f) + top_left_i > 0
+            //   (e + 0.0f turns -0 into +0; edge values are finite by construction of the record)
+            int inside[S];
+            if (full) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) ec[i] = rec.bx[i] * (ty0 - rec.lo_y[i]) + rec.nay[i] * (tx0 - rec.lo_x[i]);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int by0 = max(ry0, 4 * b), by1 = min(ry1, 4 * b + 3);
-                if (by0 > by1) continue;
-                const float y_lo = (float)by0 + s_lo, y_hi = (float)by1 + s_hi;
-                bool some = true, all = true;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const bool tl = (rec.flags >> i) & 1u;
-                    const float xa = rec.nay[i] > 0.0f ? x_hi : x_lo, xb = rec.nay[i] > 0.0f ? x_lo : x_hi;
-                    const float ya = rec.bx[i] > 0.0f ? y_hi : y_lo, yb = rec.bx[i] > 0.0f ? y_lo : y_hi;
-                    const float e_max = fmaf(xa, rec.nay[i], fmaf(ya, rec.bx[i], ec[i]));
-                    const float e_min = fmaf(xb, rec.nay[i], fmaf(yb, rec.bx[i], ec[i]));
-                    some = some && (e_max > 0.0f || (e_max == 0.0f && tl));
-                    all = all && (e_min > 0.0f || (e_min == 0.0f && tl));
-                }
-                if (some) bands |= 1u << b;
-                if (all) full |= 1u << b;
-            }
-            keep = bands != 0u;
-        }
-        const unsigned long long ballot = __ballot(keep);
-        if (lane == 0) wave_count[wave] = (uint32_t)__popcll(ballot);
-        if (keep) {
-            const uint32_t slot = wave * 64u + (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-            const uint32_t flags = (rec.flags & 0xFFu) | ((uint32_t)rx0 << 8) | ((uint32_t)rx1 << 12) | ((uint32_t)ry0 << 16) | ((uint32_t)ry1 << 20) |
-                                   (bands << 24) | (full << 28);
-            prims.e0[slot] = make_float4(rec.nay[0], rec.bx[0], ec[0], rec.nay[1]);
-            prims.e1[slot] = make_float4(rec.bx[1], ec[1], rec.nay[2], rec.bx[2]);
-            prims.e2[slot] = make_float4(ec[2], __uint_as_float(flags), __uint_as_float(rec.flat_u), rec.end_y);
-            const uint32_t kind = (rec.flags >> 4) & 7u;
-            if (kind != KIND_SOLID && kind != KIND_COVER) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    prims.a[a][slot] = make_float4(rec.gx[a], rec.gy[a], (rec.a0[a] + (tx0 - rec.v0x) * rec.gx[a]) + (ty0 - rec.v0y) * rec.gy[a],
-                                                   a == 0 ? __uint_as_float(rec.desc) : 0.0f);
-            }
-            if (kind == KIND_COVER) {
-                const float ca = r.colors[4u * shape + 3];
-                prims.color[slot] = make_float4(r.colors[4u * shape] * ca, r.colors[4u * shape + 1] * ca, r.colors[4u * shape + 2] * ca, ca);
-            }
-        }
-        __syncthreads();
-        if ((r.debug & 4u) && tid == 0) atomicAdd(&r.overflow[4], wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3]);
-        // ---------------- coverage: every lane walks the survivors, wave region by wave region (= candidate order)
-        for (uint32_t w = 0; w < 4; ++w) {
-            const uint32_t cnt = (r.debug & 2u) ? 0u : wave_count[w];
-            for (uint32_t q = 0; q < cnt; ++q) {
-                const uint32_t slot = w * 64u + q;
-                const float4 e2 = prims.e2[slot];
-                const uint32_t flags = __float_as_uint(e2.y);
-                if (!((flags >> (24u + wave)) & 1u)) continue; // nothing of this primitive in the 4 rows this wave owns (wave-uniform)
-                const float4 e0 = prims.e0[slot], e1 = prims.e1[slot];
-                const uint32_t kind = (flags >> 4) & 7u;
-                // Straight-line predicates (bitwise, no short-circuit): the compiler otherwise emits an exec-mask branch ladder per '&&'.
-                const uint32_t bx0 = (flags >> 8) & 15u, bx1 = (flags >> 12) & 15u, by0 = (flags >> 16) & 15u, by1 = (flags >> 20) & 15u;
-                const int in_range = (int)((px - bx0) <= (bx1 - bx0)) & (int)((py - by0) <= (by1 - by0));
-                const int full = (int)((flags >> (28u + wave)) & 1u); // every sample of the pixel range in this band is covered
+                for (int k = 0; k < S; ++k) inside[k] = 1;
+            } else {
+                const int bx0 = max((int)cov.box.x, tpx) - tpx, bx1 = min((int)cov.box.y, tpx + kTile - 1) - tpx;
+                const int by0 = max((int)cov.box.z, tpy) - tpy, by1 = min((int)cov.box.w, tpy + kTile - 1) - tpy;
+                const int dx = (int)px - bx0, dy = (int)py - by0;
+                const int range = ((dx | (bx1 - bx0 - dx)) | (dy | (by1 - by0 - dy))) + 1; // > 0 <=> 0 <= dx <= w && 0 <= dy <= h
+                const float c0 = cov.bx[0] * (ty0 - cov.lo_y[0]) + cov.nay[0] * (tx0 - cov.lo_x[0]);
+                const float c1 = cov.bx[1] * (ty0 - cov.lo_y[1]) + cov.nay[1] * (tx0 - cov.lo_x[1]);
+                const float c2 = cov.bx[2] * (ty0 - cov.lo_y[2]) + cov.nay[2] * (tx0 - cov.lo_x[2]);
                 const int tl0 = (int)(flags & 1u), tl1 = (int)((flags >> 1) & 1u), tl2 = (int)((flags >> 2) & 1u);
-                int inside[S];
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    const float ea = fmaf(sx[k], e0.x, fmaf(sy[k], e0.y, e0.z));
-                    const float eb = fmaf(sx[k], e0.w, fmaf(sy[k], e1.x, e1.y));
-                    const float ecv = fmaf(sx[k], e1.z, fmaf(sy[k], e1.w, e2.x));
-                    const int ia = (int)(ea > 0.0f) | ((int)(ea == 0.0f) & tl0);
-                    const int ib = (int)(eb > 0.0f) | ((int)(eb == 0.0f) & tl1);
-                    const int ic = (int)(ecv > 0.0f) | ((int)(ecv == 0.0f) & tl2);
-                    inside[k] = in_range & (full | (ia & ib & ic));
+                    const float ea = fmaf(sx[k], cov.nay[0], fmaf(sy[k], cov.bx[0], c0)) + 0.0f;
+                    const float eb = fmaf(sx[k], cov.nay[1], fmaf(sy[k], cov.bx[1], c1)) + 0.0f;
+                    const float ecv = fmaf(sx[k], cov.nay[2], fmaf(sy[k], cov.bx[2], c2)) + 0.0f;
+                    const int ia = __float_as_int(ea) + tl0, ib = __float_as_int(eb) + tl1, ic = __float_as_int(ecv) + tl2;
+                    inside[k] = min(min(ia, ib), min(ic, range));
                 }
-                const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
-                switch (kind) {
-                    case KIND_SOLID: { // stencil_solid
+            }
+            const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+            if (kind == KIND_SOLID) { // stencil_solid
 #pragma unroll
-                        for (int k = 0; k < S; ++k) winding[k] += inside[k] ? delta : 0;
-                        break;
-                    }
-                    case KIND_COVER: { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
-                        const float4 src = prims.color[slot];
-                        const float one_minus_a = 1.0f - src.w;
+                for (int k = 0; k < S; ++k) winding[k] += inside[k] > 0 ? delta : 0;
+                continue;
+            }
+            const PrimFragment frag = load_uniform(&recs[prim].frag); // second half of the record: attribute planes / cover colour
+            if (kind == KIND_COVER) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
+                const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
+                const float one_minus_a = 1.0f - ca;
 #pragma unroll
-                        for (int k = 0; k < S; ++k) {
-                            const bool blend = inside[k] && (winding[k] & (int)r.winding_mask) != 0;
-                            const float n0 = src.x + col[k][0] * one_minus_a, n1 = src.y + col[k][1] * one_minus_a;
-                            const float n2 = src.z + col[k][2] * one_minus_a, n3 = src.w + col[k][3] * one_minus_a;
-                            col[k][0] = blend ? n0 : col[k][0];
-                            col[k][1] = blend ? n1 : col[k][1];
-                            col[k][2] = blend ? n2 : col[k][2];
-                            col[k][3] = blend ? n3 : col[k][3];
-                            winding[k] = inside[k] ? 0 : winding[k];
-                        }
-                        break;
-                    }
-                    case KIND_IQ: { // u^2 - v <= 0 (shaders.wgsl:236-242)
-                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot];
+                for (int k = 0; k < S; ++k) {
+                    const bool blend = inside[k] > 0 && (winding[k] & (int)r.winding_mask) != 0;
+                    const float n0 = s0 + col[k][0] * one_minus_a, n1 = s1 + col[k][1] * one_minus_a;
+                    const float n2 = s2 + col[k][2] * one_minus_a, n3 = ca + col[k][3] * one_minus_a;
+                    col[k][0] = blend ? n0 : col[k][0];
+                    col[k][1] = blend ? n1 : col[k][1];
+                    col[k][2] = blend ? n2 : col[k][2];
+                    col[k][3] = blend ? n3 : col[k][3];
+                    winding[k] = inside[k] > 0 ? 0 : winding[k];
+                }
+                continue;
+            }
+            // attribute planes, tile relative: ac = (a0 + (tx0 - v0x) * gx) + (ty0 - v0y) * gy
+            const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
+            float a[4][S];
 #pragma unroll
-                        for (int k = 0; k < S; ++k) {
-                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
-                            winding[k] += (inside[k] & (int)(a0 * a0 - a1 <= 0.0f)) ? delta : 0;
-                        }
-                        break;
-                    }
-                    case KIND_IC:   // k^3 - l m <= 0 (shaders.wgsl:244-250)
-                    case KIND_RQ: { // u^2 - v w <= 0 (shaders.wgsl:252-258)
-                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot], p2 = prims.a[2][slot];
+            for (int t = 0; t < 4; ++t) {
+                const float ac = (frag.a0[t] + dx0 * frag.gx[t]) + dy0 * frag.gy[t];
 #pragma unroll
-                        for (int k = 0; k < S; ++k) {
-                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
-                            const float a2 = fmaf(sy[k], p2.y, fmaf(sx[k], p2.x, p2.z));
-                            const float lhs = kind == KIND_IC ? a0 * a0 * a0 : a0 * a0;
-                            winding[k] += (inside[k] & (int)(lhs - a1 * a2 <= 0.0f)) ? delta : 0;
-                        }
-                        break;
-                    }
-                    case KIND_RC: { // k^3 - l m n <= 0 (shaders.wgsl:260-266)
-                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot], p2 = prims.a[2][slot], p3 = prims.a[3][slot];
+                for (int k = 0; k < S; ++k) a[t][k] = fmaf(sy[k], frag.gy[t], fmaf(sx[k], frag.gx[t], ac));
+            }
+            if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
 #pragma unroll
-                        for (int k = 0; k < S; ++k) {
-                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
-                            const float a2 = fmaf(sy[k], p2.y, fmaf(sx[k], p2.x, p2.z)), a3 = fmaf(sy[k], p3.y, fmaf(sx[k], p3.x, p3.z));
-                            winding[k] += (inside[k] & (int)(a0 * a0 * a0 - a1 * a2 * a3 <= 0.0f)) ? delta : 0;
-                        }
-                        break;
-                    }
-                    default: { // KIND_LINE / KIND_JOINT: the stroke fragment stages
-                        int any_inside = 0;
+                for (int k = 0; k < S; ++k) {
+                    const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a[0][k] * a[0][k] : a[0][k] * a[0][k] * a[0][k];
+                    const float rhs = kind == KIND_IQ ? a[1][k] : (kind == KIND_RC ? a[1][k] * a[2][k] * a[3][k] : a[1][k] * a[2][k]);
+                    winding[k] += (inside[k] > 0 && lhs - rhs <= 0.0f) ? delta : 0;
+                }
+            } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
+                int any_inside = 0;
 #pragma unroll
-                        for (int k = 0; k < S; ++k) any_inside |= inside[k];
-                        if (!__any(any_inside)) break;
-                        const float4 p0 = prims.a[0][slot], p1 = prims.a[1][slot], p2 = prims.a[2][slot];
-                        const crh_dynamic_stroke_descriptor d = s.descriptors[__float_as_uint(p0.w)];
-                        const uint32_t flat_u = __float_as_uint(e2.z);
-                        const float end_y = e2.w;
+                for (int k = 0; k < S; ++k) any_inside |= (int)(inside[k] > 0);
+                if (__any(any_inside)) {
+                    const crh_dynamic_stroke_descriptor d = s.descriptors[cov.desc];
+                    const uint32_t flat_u = frag.flat_u;
+                    const float end_y = frag.end_y;
 #pragma unroll
-                        for (int k = 0; k < S; ++k) {
-                            if (!inside[k]) continue;
-                            const float a0 = fmaf(sy[k], p0.y, fmaf(sx[k], p0.x, p0.z)), a1 = fmaf(sy[k], p1.y, fmaf(sx[k], p1.x, p1.z));
-                            const float a2 = fmaf(sy[k], p2.y, fmaf(sx[k], p2.x, p2.z));
-                            bool fill;
-                            if (kind == KIND_LINE) { // stencil_stroke_line, shaders.wgsl:268-285
-                                if ((d.count_dashed_join & 4u) != 0u)
-                                    fill = stroke_dashed(d, a0, a1);
-                                else if ((flat_u & 65536u) != 0u)
-                                    fill = cap_test(a0, a1 - end_y, d.caps >> 4);
-                                else if (a1 < 0.0f)
-                                    fill = cap_test(a0, -a1, d.caps);
-                                else
-                                    fill = true;
-                            } else { // stencil_stroke_joint, shaders.wgsl:287-300
-                                const float radius = sqrtf(a0 * a0 + a1 * a1);
-                                const uint32_t join = d.count_dashed_join & 3u;
-                                fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
-                                if (fill && (d.count_dashed_join & 4u) != 0u) {
-                                    const float tau = crh_acosf(-1.0f) * 2.0f;
-                                    fill = stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
-                                }
+                    for (int k = 0; k < S; ++k) {
+                        if (inside[k] <= 0) continue;
+                        const float a0 = a[0][k], a1 = a[1][k], a2 = a[2][k];
+                        bool fill;
+                        if (kind == KIND_LINE) { // stencil_stroke_line, shaders.wgsl:268-285
+                            if ((d.count_dashed_join & 4u) != 0u)
+                                fill = stroke_dashed(d, a0, a1);
+                            else if ((flat_u & 65536u) != 0u)
+                                fill = cap_test(a0, a1 - end_y, d.caps >> 4);
+                            else if (a1 < 0.0f)
+                                fill = cap_test(a0, -a1, d.caps);
+                            else
+                                fill = true;
+                        } else { // stencil_stroke_joint, shaders.wgsl:287-300
+                            const float radius = sqrtf(a0 * a0 + a1 * a1);
+                            const uint32_t join = d.count_dashed_join & 3u;
+                            fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
+                            if (fill && (d.count_dashed_join & 4u) != 0u) {
+                                const float tau = crh_acosf(-1.0f) * 2.0f;
+                                fill = stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
                             }
-                            // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
-                            if (fill && (winding[k] & (int)r.winding_mask) == 0) winding[k] += 1;
                         }
-                        break;
+                        // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
+                        if (fill && (winding[k] & (int)r.winding_mask) == 0) winding[k] += 1;
                     }
                 }
             }
         }
-        __syncthreads();
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
     if (in_frame) {
         const float inv = 1.0f / (float)S;
-        uint32_t packed = 0;
+        uint32_t packed_px = 0;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             float sum = 0.0f;
@@ -727,9 +744,9 @@ __global__ __launch_bounds__(256) void k_raster(SceneDev s, RasterParams r) {
             float x = sum * inv;
             x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
             if (!(x == x)) x = 0.0f;
-            packed |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+            packed_px |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
         }
-        reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed;
+        reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed_px;
     }
 }
 
@@ -755,25 +772,53 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* const* layers,
 // ---------------------------------------------------------------------------------------------- launchers
 static ScanJob scan_job(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uint32_t n) { return ScanJob{in, out, block_sum, n, (n + 1023u) / 1024u}; }
 
-void launch_bin(const SceneDev& s, const RasterParams& r, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
-    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * (r.n_tiles + r.n_tiles), stream); // tile_count and tile_cursor are adjacent
-    hipLaunchKernelGGL(k_shape_setup, dim3(s.n_shapes), dim3(64), 0, stream, s, r);
-    if (mark) mark(ctx, "raster_shape_setup", 0);
-    const ScanJob tiles = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles);
-    const ScanJob prims = scan_job(r.shape_ncand, r.shape_prim_begin, r.scan_scratch + tiles.blocks, s.n_shapes);
-    hipLaunchKernelGGL(k_scan_local, dim3(tiles.blocks + prims.blocks), dim3(256), 0, stream, tiles, prims);
-    hipLaunchKernelGGL(k_scan_add, dim3(tiles.blocks + prims.blocks), dim3(256), 0, stream, tiles, prims, r);
-    if (mark) mark(ctx, "raster_scans", 0);
+// transform independent: contiguous primitive ids per Shape (runs at the end of tessellation)
+void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream) {
+    if (s.n_shapes == 0) {
+        (void)hipMemsetAsync(shape_prim_begin, 0, 4, stream);
+        return;
+    }
+    hipLaunchKernelGGL(k_shape_ncand, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s, shape_ncand);
+    const ScanJob j = scan_job(shape_ncand, shape_prim_begin, scratch, s.n_shapes);
+    RasterParams unused = {};
+    hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
+    hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, unused, 0);
+}
+void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
+    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
+    if (s.n_shapes) {
+        if (samples == 4)
+            hipLaunchKernelGGL(k_prim_setup<4>, dim3(s.n_shapes), dim3(64), 0, stream, s, r);
+        else
+            hipLaunchKernelGGL(k_prim_setup<1>, dim3(s.n_shapes), dim3(64), 0, stream, s, r);
+    }
+    if (mark) mark(ctx, "raster_prim_setup", 0);
+    if (s.n_shapes) {
+        if (samples == 4)
+            hipLaunchKernelGGL((k_tile_walk<4, false>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+        else
+            hipLaunchKernelGGL((k_tile_walk<1, false>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+    }
+    if (mark) mark(ctx, "raster_tile_count", 0);
+    const ScanJob j = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles);
+    hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
+    hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, r, 1);
+    if (mark) mark(ctx, "raster_tile_scan", 0);
 }
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
                    uint64_t raster_bytes) {
-    hipLaunchKernelGGL(k_shape_emit, dim3(s.n_shapes), dim3(64), 0, stream, s, r);
-    if (mark) mark(ctx, "raster_shape_emit", 0);
+    if (s.n_shapes) {
+        if (samples == 4)
+            hipLaunchKernelGGL((k_tile_walk<4, true>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+        else
+            hipLaunchKernelGGL((k_tile_walk<1, true>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+    }
+    if (mark) mark(ctx, "raster_tile_fill", 0);
     if (samples == 4)
-        hipLaunchKernelGGL(k_raster<4>, dim3(r.n_tiles), dim3(256), 0, stream, s, r);
+        hipLaunchKernelGGL(k_raster_band<4>, dim3(r.n_tiles), dim3(256), 0, stream, s, r);
     else
-        hipLaunchKernelGGL(k_raster<1>, dim3(r.n_tiles), dim3(256), 0, stream, s, r);
-    if (mark) mark(ctx, "raster_tiles", raster_bytes);
+        hipLaunchKernelGGL(k_raster_band<1>, dim3(r.n_tiles), dim3(256), 0, stream, s, r);
+    if (mark) mark(ctx, "raster_bands", raster_bytes);
 }
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream) {
     hipLaunchKernelGGL(k_composite, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, stream, layers_dev, n_layers, n_pixels, dst);
