@@ -468,13 +468,11 @@ __global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, Raste
                 if (!FILL) {
                     if (lane == 0) atomicAdd(&r.tile_count[tile], (uint32_t)__popcll(ballot));
                 } else {
-                    uint32_t bands = 0, full = 0;
-                    if (hit) test.band_masks(cov, tx, ty, bands, full);
                     uint32_t base = 0;
                     if (lane == 0) base = r.tile_offset[tile] + atomicAdd(&r.tile_cursor[tile], (uint32_t)__popcll(ballot));
                     flush(); // the previous tile's atomic has had a whole iteration to return
                     pending_ballot = ballot;
-                    pending_entry = ((prim0 + c) << 8) | (full << 4) | bands;
+                    pending_entry = prim0 + c;
                     pending_base = base;
                 }
             }
@@ -482,7 +480,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, Raste
     }
 }
 
-// ---------------------------------------------------------------------------------------------- k_raster_band
+// ---------------------------------------------------------------------------------------------- k_raster_tile
 CRH_D bool cap_test(float x, float y, uint32_t cap_type) { // shaders.wgsl:165-189
     switch (cap_type & 15u) {
         case 0: return y > 0.5f;
@@ -494,68 +492,84 @@ CRH_D bool cap_test(float x, float y, uint32_t cap_type) { // shaders.wgsl:165-1
         default: return y < 0.0f;
     }
 }
-CRH_D bool stroke_dashed(const crh_dynamic_stroke_descriptor& d, float tx, float ty) { // shaders.wgsl:205-231
-    const uint32_t last = d.count_dashed_join >> 3;
-    const float pattern_length = d.gap_end[last & 3u];
+// The dashed pattern walk is the cold, long part of the stroke stages: kept out of line, and it indexes the descriptor through its
+// global pointer (a register copy indexed by `interval` would be demoted to scratch memory).
+__device__ __noinline__ bool stroke_dashed(const crh_dynamic_stroke_descriptor* d, float tx, float ty) { // shaders.wgsl:205-231
+    const uint32_t last = d->count_dashed_join >> 3;
+    const float pattern_length = d->gap_end[last & 3u];
     uint32_t interval = 0;
-    float position = crh_wgsl_mod(ty - d.phase, pattern_length);
+    float position = crh_wgsl_mod(ty - d->phase, pattern_length);
     if (position < 0.0f) position = position + pattern_length;
     float gap_end;
     for (;;) {
-        gap_end = d.gap_end[interval & 3u] - position;
+        gap_end = d->gap_end[interval & 3u] - position;
         if (gap_end >= 0.0f || interval >= last) break;
         interval = interval + 1u;
     }
-    const float gap_start = position - d.gap_start[interval & 3u];
+    const float gap_start = position - d->gap_start[interval & 3u];
     if (gap_start > 0.0f) {
-        const uint32_t caps = d.caps >> (interval * 8u);
+        const uint32_t caps = d->caps >> (interval * 8u);
         const bool start_cap = cap_test(tx, gap_start, caps >> 4);
         const bool end_cap = cap_test(tx, gap_end, caps);
         return start_cap || end_cap;
     }
     return true;
 }
+__device__ __noinline__ bool stroke_dashed_joint(const crh_dynamic_stroke_descriptor* d, float radius, float a0, float a1, float a2) { // shaders.wgsl:296-299
+    const float tau = crh_acosf(-1.0f) * 2.0f;
+    return stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
+}
 
+// One wavefront per 16x16 tile: lane = (column px, row group rq); the lane owns the four pixels (px, 4k + rq), k = 0..3, so a
+// primitive's record load, tile constants and kind dispatch are paid once per (tile, primitive) and only the per-sample arithmetic
+// is repeated per row.
 template <int S>
-__global__ __launch_bounds__(256) void k_raster_band(SceneDev s, RasterParams r) {
-    __shared__ uint32_t sort_buffer[4][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
+__global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) {
+    __shared__ uint32_t keys[kBandListMax]; // only used by tiles with more than 64 primitives
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % r.tiles_x, ty = tile / r.tiles_x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t px = lane & 15u, py = 4u * wave + (lane >> 4);
-    const uint32_t gx = tx * kTile + px, gy = ty * kTile + py;
-    const bool in_frame = gx < r.width && gy < r.height;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t px = lane & 15u, rq = lane >> 4;
+    const uint32_t gx = tx * kTile + px;
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
     const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
 
-    float sx[S], sy[S];
+    float sx[S], sy0[S]; // sample positions of row rq; row 4k + rq adds 4k (exact in f32)
     if (S == 1) {
         sx[0] = (float)px + 0.5f;
-        sy[0] = (float)py + 0.5f;
+        sy0[0] = (float)rq + 0.5f;
     } else {
         const float ox[4] = {0.375f, 0.875f, 0.125f, 0.625f}, oy[4] = {0.125f, 0.375f, 0.625f, 0.875f};
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             sx[k] = (float)px + ox[k & 3];
-            sy[k] = (float)py + oy[k & 3];
+            sy0[k] = (float)rq + oy[k & 3];
         }
     }
-    int winding[S];
-    float col[S][4];
+    int winding[4][S];
+    float col[4][S][4];
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
-        winding[k] = 0;
-        col[k][0] = col[k][1] = col[k][2] = col[k][3] = 0.0f;
-    }
-    if (r.load_existing && in_frame) {
-        const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[(size_t)gy * r.width + gx];
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            col[k][0] = (float)d.x * (1.0f / 255.0f);
-            col[k][1] = (float)d.y * (1.0f / 255.0f);
-            col[k][2] = (float)d.z * (1.0f / 255.0f);
-            col[k][3] = (float)d.w * (1.0f / 255.0f);
+            winding[b][k] = 0;
+            col[b][k][0] = col[b][k][1] = col[b][k][2] = col[b][k][3] = 0.0f;
+        }
+    if (r.load_existing) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t gy = ty * kTile + 4u * b + rq;
+            if (gx < r.width && gy < r.height) {
+                const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[(size_t)gy * r.width + gx];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    col[b][k][0] = (float)d.x * (1.0f / 255.0f);
+                    col[b][k][1] = (float)d.y * (1.0f / 255.0f);
+                    col[b][k][2] = (float)d.z * (1.0f / 255.0f);
+                    col[b][k][3] = (float)d.w * (1.0f / 255.0f);
+                }
+            }
         }
     }
 
@@ -565,10 +579,8 @@ __global__ __launch_bounds__(256) void k_raster_band(SceneDev s, RasterParams r)
         if (lane == 0) raise_error(s, 0, CRH_ERR_UNSUPPORTED);
         n = 0;
     }
-    // ---- draw order = ascending prim id: every wave sorts its own copy of the tile's list (no workgroup barrier):
-    // bitonic network in registers (<= 64 entries) or in wave-private LDS
+    // ---- draw order = ascending prim id: bitonic network in registers (<= 64 entries) or in LDS
     uint32_t my_key = 0xFFFFFFFFu;
-    uint32_t* keys = sort_buffer[wave];
     if (n <= 64u) {
         if (lane < n) my_key = r.tile_list[list_begin + lane];
 #pragma unroll
@@ -604,149 +616,157 @@ __global__ __launch_bounds__(256) void k_raster_band(SceneDev s, RasterParams r)
     }
 
     const PrimRec* recs = r.prim_rec;
-    const uint32_t band_bit = 1u << wave, full_bit = 16u << wave;
+    const int wmask = (int)r.winding_mask;
     for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
         if (n > 64u) my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
-        // keep only the entries that touch THIS band, packed to the low lanes in order (ballot + prefix popcount)
-        const bool mine = (q0 + lane < n) && (my_key & band_bit) != 0u;
-        const unsigned long long ballot = __ballot(mine);
-        const uint32_t count = (uint32_t)__popcll(ballot);
-        const uint32_t rank = (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull));
-        // compaction through a permute: lane `rank` receives this lane's key
-        uint32_t packed = 0;
-        {
-            const int dst = mine ? (int)rank : 63; // losers all write lane 63's slot; fixed below
-            packed = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)my_key);
-            if (count < 64u && lane >= count) packed = 0;
-        }
-        if (count == 0u) continue;
-        PrimCoverage cur = load_uniform(&recs[__builtin_amdgcn_readlane(packed, 0) >> 8].cov);
+        const uint32_t count = min(64u, n - q0);
+        PrimCoverage cur = load_uniform(&recs[__builtin_amdgcn_readlane(my_key, 0)].cov);
         for (uint32_t j = 0; j < count; ++j) {
-            const uint32_t key = __builtin_amdgcn_readlane(packed, j);
-            const uint32_t prim = key >> 8;
-            const int full = (int)((key & full_bit) != 0u); // every sample of this band is inside the triangle
+            const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
             const PrimCoverage cov = cur;
-            if (j + 1u < count) cur = load_uniform(&recs[__builtin_amdgcn_readlane(packed, j + 1u) >> 8].cov); // prefetch the next record (scalar load)
             const uint32_t flags = cov.flags;
             const uint32_t kind = (flags >> 4) & 7u;
-            // inside[k] > 0  <=>  sample k of this lane's pixel is covered. Everything stays in VALU integer math: comparing floats
-            // and combining the lane masks would run on the scalar unit (64-bit mask ops), which dominated this loop.
+            // scalar loads issued up front: the second half of this record and the first half of the next one
+            PrimFragment frag;
+            if (kind != KIND_SOLID) frag = load_uniform(&recs[prim].frag);
+            if (j + 1u < count) cur = load_uniform(&recs[__builtin_amdgcn_readlane(my_key, j + 1u)].cov);
+            // inside[b][k] > 0  <=>  sample k of pixel (px, 4b + rq) is covered. Everything stays in VALU integer math:
             //   edge i accepts e  <=>  e > 0 || (e == 0 && top_left_i)  <=>  as_int(e + 0.0f) + top_left_i > 0
             //   (e + 0.0f turns -0 into +0; edge values are finite by construction of the record)
-            int inside[S];
-            if (full) {
-#pragma unroll
-                for (int k = 0; k < S; ++k) inside[k] = 1;
-            } else {
+            int inside[4][S];
+            {
                 const int bx0 = max((int)cov.box.x, tpx) - tpx, bx1 = min((int)cov.box.y, tpx + kTile - 1) - tpx;
                 const int by0 = max((int)cov.box.z, tpy) - tpy, by1 = min((int)cov.box.w, tpy + kTile - 1) - tpy;
-                const int dx = (int)px - bx0, dy = (int)py - by0;
-                const int range = ((dx | (bx1 - bx0 - dx)) | (dy | (by1 - by0 - dy))) + 1; // > 0 <=> 0 <= dx <= w && 0 <= dy <= h
+                const int dx = (int)px - bx0;
+                const int range_x = dx | (bx1 - bx0 - dx);
                 const float c0 = cov.bx[0] * (ty0 - cov.lo_y[0]) + cov.nay[0] * (tx0 - cov.lo_x[0]);
                 const float c1 = cov.bx[1] * (ty0 - cov.lo_y[1]) + cov.nay[1] * (tx0 - cov.lo_x[1]);
                 const float c2 = cov.bx[2] * (ty0 - cov.lo_y[2]) + cov.nay[2] * (tx0 - cov.lo_x[2]);
                 const int tl0 = (int)(flags & 1u), tl1 = (int)((flags >> 1) & 1u), tl2 = (int)((flags >> 2) & 1u);
 #pragma unroll
-                for (int k = 0; k < S; ++k) {
-                    const float ea = fmaf(sx[k], cov.nay[0], fmaf(sy[k], cov.bx[0], c0)) + 0.0f;
-                    const float eb = fmaf(sx[k], cov.nay[1], fmaf(sy[k], cov.bx[1], c1)) + 0.0f;
-                    const float ecv = fmaf(sx[k], cov.nay[2], fmaf(sy[k], cov.bx[2], c2)) + 0.0f;
-                    const int ia = __float_as_int(ea) + tl0, ib = __float_as_int(eb) + tl1, ic = __float_as_int(ecv) + tl2;
-                    inside[k] = min(min(ia, ib), min(ic, range));
+                for (int b = 0; b < 4; ++b) {
+                    const int dy = (int)rq + 4 * b - by0;
+                    const int range = (range_x | (dy | (by1 - by0 - dy))) + 1; // > 0 <=> the pixel is inside the clamped box
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const float y = sy0[k] + (float)(4 * b);
+                        const float ea = fmaf(sx[k], cov.nay[0], fmaf(y, cov.bx[0], c0)) + 0.0f;
+                        const float eb = fmaf(sx[k], cov.nay[1], fmaf(y, cov.bx[1], c1)) + 0.0f;
+                        const float ecv = fmaf(sx[k], cov.nay[2], fmaf(y, cov.bx[2], c2)) + 0.0f;
+                        const int ia = __float_as_int(ea) + tl0, ib = __float_as_int(eb) + tl1, ic = __float_as_int(ecv) + tl2;
+                        inside[b][k] = min(min(ia, ib), min(ic, range));
+                    }
                 }
             }
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
             if (kind == KIND_SOLID) { // stencil_solid
 #pragma unroll
-                for (int k = 0; k < S; ++k) winding[k] += inside[k] > 0 ? delta : 0;
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) winding[b][k] += inside[b][k] > 0 ? delta : 0;
                 continue;
             }
-            const PrimFragment frag = load_uniform(&recs[prim].frag); // second half of the record: attribute planes / cover colour
             if (kind == KIND_COVER) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
                 const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
                 const float one_minus_a = 1.0f - ca;
 #pragma unroll
-                for (int k = 0; k < S; ++k) {
-                    const bool blend = inside[k] > 0 && (winding[k] & (int)r.winding_mask) != 0;
-                    const float n0 = s0 + col[k][0] * one_minus_a, n1 = s1 + col[k][1] * one_minus_a;
-                    const float n2 = s2 + col[k][2] * one_minus_a, n3 = ca + col[k][3] * one_minus_a;
-                    col[k][0] = blend ? n0 : col[k][0];
-                    col[k][1] = blend ? n1 : col[k][1];
-                    col[k][2] = blend ? n2 : col[k][2];
-                    col[k][3] = blend ? n3 : col[k][3];
-                    winding[k] = inside[k] > 0 ? 0 : winding[k];
-                }
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const bool blend = inside[b][k] > 0 && (winding[b][k] & wmask) != 0;
+                        const float n0 = s0 + col[b][k][0] * one_minus_a, n1 = s1 + col[b][k][1] * one_minus_a;
+                        const float n2 = s2 + col[b][k][2] * one_minus_a, n3 = ca + col[b][k][3] * one_minus_a;
+                        col[b][k][0] = blend ? n0 : col[b][k][0];
+                        col[b][k][1] = blend ? n1 : col[b][k][1];
+                        col[b][k][2] = blend ? n2 : col[b][k][2];
+                        col[b][k][3] = blend ? n3 : col[b][k][3];
+                        winding[b][k] = inside[b][k] > 0 ? 0 : winding[b][k];
+                    }
                 continue;
             }
-            // attribute planes, tile relative: ac = (a0 + (tx0 - v0x) * gx) + (ty0 - v0y) * gy
+            // attribute planes, tile relative: ac = (a0 + (tx0 - v0x) * gx) + (ty0 - v0y) * gy; a = fma(sy, gy, fma(sx, gx, ac))
             const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
-            float a[4][S];
+            float hx[4][S]; // the row-independent inner fma
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const float ac = (frag.a0[t] + dx0 * frag.gx[t]) + dy0 * frag.gy[t];
 #pragma unroll
-                for (int k = 0; k < S; ++k) a[t][k] = fmaf(sy[k], frag.gy[t], fmaf(sx[k], frag.gx[t], ac));
+                for (int k = 0; k < S; ++k) hx[t][k] = fmaf(sx[k], frag.gx[t], ac);
             }
             if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
 #pragma unroll
-                for (int k = 0; k < S; ++k) {
-                    const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a[0][k] * a[0][k] : a[0][k] * a[0][k] * a[0][k];
-                    const float rhs = kind == KIND_IQ ? a[1][k] : (kind == KIND_RC ? a[1][k] * a[2][k] * a[3][k] : a[1][k] * a[2][k]);
-                    winding[k] += (inside[k] > 0 && lhs - rhs <= 0.0f) ? delta : 0;
-                }
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const float y = sy0[k] + (float)(4 * b);
+                        const float a0 = fmaf(y, frag.gy[0], hx[0][k]), a1 = fmaf(y, frag.gy[1], hx[1][k]);
+                        const float a2 = fmaf(y, frag.gy[2], hx[2][k]), a3 = fmaf(y, frag.gy[3], hx[3][k]);
+                        const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
+                        const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
+                        winding[b][k] += (inside[b][k] > 0 && lhs - rhs <= 0.0f) ? delta : 0;
+                    }
             } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
                 int any_inside = 0;
 #pragma unroll
-                for (int k = 0; k < S; ++k) any_inside |= (int)(inside[k] > 0);
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) any_inside |= (int)(inside[b][k] > 0);
                 if (__any(any_inside)) {
-                    const crh_dynamic_stroke_descriptor d = s.descriptors[cov.desc];
+                    const crh_dynamic_stroke_descriptor* d = &s.descriptors[cov.desc];
+                    const uint32_t caps = d->caps, count_dashed_join = d->count_dashed_join; // wave uniform
                     const uint32_t flat_u = frag.flat_u;
                     const float end_y = frag.end_y;
+                    const bool dashed = (count_dashed_join & 4u) != 0u;
 #pragma unroll
-                    for (int k = 0; k < S; ++k) {
-                        if (inside[k] <= 0) continue;
-                        const float a0 = a[0][k], a1 = a[1][k], a2 = a[2][k];
-                        bool fill;
-                        if (kind == KIND_LINE) { // stencil_stroke_line, shaders.wgsl:268-285
-                            if ((d.count_dashed_join & 4u) != 0u)
-                                fill = stroke_dashed(d, a0, a1);
-                            else if ((flat_u & 65536u) != 0u)
-                                fill = cap_test(a0, a1 - end_y, d.caps >> 4);
-                            else if (a1 < 0.0f)
-                                fill = cap_test(a0, -a1, d.caps);
-                            else
-                                fill = true;
-                        } else { // stencil_stroke_joint, shaders.wgsl:287-300
-                            const float radius = sqrtf(a0 * a0 + a1 * a1);
-                            const uint32_t join = d.count_dashed_join & 3u;
-                            fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
-                            if (fill && (d.count_dashed_join & 4u) != 0u) {
-                                const float tau = crh_acosf(-1.0f) * 2.0f;
-                                fill = stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
+                            if (inside[b][k] > 0 && (winding[b][k] & wmask) == 0) {
+                                const float y = sy0[k] + (float)(4 * b);
+                                const float a0 = fmaf(y, frag.gy[0], hx[0][k]), a1 = fmaf(y, frag.gy[1], hx[1][k]), a2 = fmaf(y, frag.gy[2], hx[2][k]);
+                                bool fill;
+                                if (kind == KIND_LINE) { // stencil_stroke_line, shaders.wgsl:268-285
+                                    if (dashed)
+                                        fill = stroke_dashed(d, a0, a1);
+                                    else if ((flat_u & 65536u) != 0u)
+                                        fill = cap_test(a0, a1 - end_y, caps >> 4);
+                                    else if (a1 < 0.0f)
+                                        fill = cap_test(a0, -a1, caps);
+                                    else
+                                        fill = true;
+                                } else { // stencil_stroke_joint, shaders.wgsl:287-300
+                                    const float radius = sqrtf(a0 * a0 + a1 * a1);
+                                    const uint32_t join = count_dashed_join & 3u;
+                                    fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
+                                    if (fill && dashed) fill = stroke_dashed_joint(d, radius, a0, a1, a2);
+                                }
+                                winding[b][k] += fill ? 1 : 0;
                             }
                         }
-                        // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
-                        if (fill && (winding[k] & (int)r.winding_mask) == 0) winding[k] += 1;
-                    }
                 }
             }
         }
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
-    if (in_frame) {
-        const float inv = 1.0f / (float)S;
-        uint32_t packed_px = 0;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            float sum = 0.0f;
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t gy = ty * kTile + 4u * b + rq;
+        if (gx < r.width && gy < r.height) {
+            const float inv = 1.0f / (float)S;
+            uint32_t packed_px = 0;
 #pragma unroll
-            for (int k = 0; k < S; ++k) sum = sum + col[k][ch];
-            float x = sum * inv;
-            x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-            if (!(x == x)) x = 0.0f;
-            packed_px |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+            for (int ch = 0; ch < 4; ++ch) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int k = 0; k < S; ++k) sum = sum + col[b][k][ch];
+                float x = sum * inv;
+                x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+                if (!(x == x)) x = 0.0f;
+                packed_px |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+            }
+            reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed_px;
         }
-        reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed_px;
     }
 }
 
@@ -815,10 +835,10 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
     }
     if (mark) mark(ctx, "raster_tile_fill", 0);
     if (samples == 4)
-        hipLaunchKernelGGL(k_raster_band<4>, dim3(r.n_tiles), dim3(256), 0, stream, s, r);
+        hipLaunchKernelGGL(k_raster_tile<4>, dim3(r.n_tiles), dim3(64), 0, stream, s, r);
     else
-        hipLaunchKernelGGL(k_raster_band<1>, dim3(r.n_tiles), dim3(256), 0, stream, s, r);
-    if (mark) mark(ctx, "raster_bands", raster_bytes);
+        hipLaunchKernelGGL(k_raster_tile<1>, dim3(r.n_tiles), dim3(64), 0, stream, s, r);
+    if (mark) mark(ctx, "raster_tiles", raster_bytes);
 }
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream) {
     hipLaunchKernelGGL(k_composite, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, stream, layers_dev, n_layers, n_pixels, dst);
