@@ -22,6 +22,31 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+# timing mark (HIP events inside the library) -> kernel name as rocprofv3 prints it
+MARK_TO_KERNEL = {
+    "raster_tiles": "crh::k_raster_tile<1>",
+    "raster_tile_fill": "crh::k_tile_walk<1, true>",
+    "raster_tile_count": "crh::k_tile_walk<1, false>",
+    "raster_prim_setup": "crh::k_prim_setup<1>",
+    "tess_emit": "crh::k_emit",
+    "tess_count": "crh::k_count",
+    "tess_hull": "crh::k_hull<128u, 0u>",
+}
+
+
+def measured_traffic(mark):
+    """HBM bytes per launch of the kernel behind `mark`, from the newest committed PMC summary (profiles/rNN_traffic.json, produced by
+    tools/profile.sh: separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of the microarchitecture guide). The
+    counters cannot be collected from inside this process, so the committed file is the source; None when it does not cover the kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files or mark not in MARK_TO_KERNEL:
+        return None, None
+    with open(files[-1]) as f:
+        doc = json.load(f)
+    k = doc.get("kernels", {}).get(MARK_TO_KERNEL[mark])
+    return (k["hbm_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
+
 
 class _DeviceArray:
     """Wraps a raw HIP pointer for torch.as_tensor (zero copy)."""
@@ -130,6 +155,8 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
+    default_workload = args.paths == 10000 and args.size == 4096
+    traffic, traffic_source = measured_traffic(dominant) if default_workload else (None, None)
 
     total_paths = args.paths * world
     ms_per_step = elapsed / args.steps * 1e3
@@ -162,8 +189,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
-            "note": "algorithmic bytes (SURVEY.md §8(d)) / HIP-event kernel time; the kernel is VALU-bound (per-sample polynomial evaluation), see DESIGN.md",
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes": dk["algorithmic_bytes"],
+            "avg_launch_ms": dk["avg_ms"],
+            "note": "achieved = algorithmic bytes (SURVEY.md §8(d): emitted vertex/index bytes read once + 80 B per shape + W*H*4 written once) / "
+                    "HIP-event launch time of the dominant kernel; traffic = HBM bytes per launch from rocprofv3 PMC passes (committed under "
+                    "profiles/). The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
         },
         "kernels": kernels,
     }
