@@ -90,7 +90,10 @@ def main():
     sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
     batch = sc["batch"]
     renderer = Renderer(Configuration(msaa_sample_count=1, clip_nesting_counter_bits=4, winding_counter_bits=4), device=local_rank)
+    t_up = time.perf_counter()
     scene = Scene(renderer, batch, tessellate=True)  # host -> HBM + first tessellation (sizes the output buffers): outside the timed region
+    renderer.synchronize()
+    upload_s = time.perf_counter() - t_up  # validation + element stream + H2D + first tessellation, once per scene
     scene.check()
     scene.set_instances(sc["transforms"], sc["colors"])
     frame = Frame(renderer, *size)
@@ -198,6 +201,9 @@ def main():
                     "profiles/). The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
         },
         "kernels": kernels,
+        # the boundary hands over host buffers once per scene (crh_scene_upload); never part of `value`
+        "host_inclusive": {"upload_ms": upload_s * 1e3, "paths_per_s_first_frame": args.paths / (upload_s + elapsed / args.steps),
+                           "input_bytes": int(batch.input_bytes())},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.binding import time_tessellate
