@@ -15,7 +15,7 @@
 
 namespace crh {
 typedef void (*MarkFn)(void*, const char*, uint64_t);
-void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4]);
+void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke);
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx);
@@ -127,7 +127,7 @@ struct crh_scene {
     uint32_t totals_host[NCH] = {};
     std::vector<uint32_t> shape_dyn_begin_host;
     // inputs
-    DevBuf elem_type, elem_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
+    DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
     // scan state
     DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, status;
     // outputs
@@ -140,7 +140,7 @@ struct crh_scene {
     bool layout_valid = false;
 
     void release_all() {
-        DevBuf* all[] = {&elem_type, &elem_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
+        DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec};
@@ -243,7 +243,7 @@ crh_status run_tessellation(crh_scene* sc) {
         if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.hull_count, 0, (size_t)d.n_shapes * 4, r->stream));
     }
     const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
-    launch_tessellate(d, r->stream, r->mark_fn(), r, bytes);
+    launch_tessellate(d, r->stream, r->mark_fn(), r, bytes, sc->has_stroke);
     if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
         HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));
@@ -605,7 +605,11 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         if (b->shape_dynamic_begin) dyn_begin.assign(b->shape_dynamic_begin, b->shape_dynamic_begin + b->n_shapes + 1);
         sc->shape_dyn_begin_host = dyn_begin;
         UP(elem_type, elem_type)
+        std::vector<uint32_t> elem_prev_off(n_elems); // the point stored just before the record: end of the previous segment, or Path::start
+        for (size_t i = 0; i < n_elems; ++i) elem_prev_off[i] = elem_off[i] >= 2u ? elem_off[i] - 2u : 0u;
+        UP(elem_off0, elem_off)
         UP(elem_off, elem_off)
+        UP(elem_prev_off, elem_prev_off)
         UP(elem_path, elem_path)
         UP(pool, pool)
         UP(path_elem_begin, path_elem_begin)
@@ -633,7 +637,9 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         goto fail;
     }
     d.elem_type = sc->elem_type.as<uint8_t>();
+    d.elem_off0 = sc->elem_off0.as<uint32_t>();
     d.elem_off = sc->elem_off.as<uint32_t>();
+    d.elem_prev_off = sc->elem_prev_off.as<uint32_t>();
     d.elem_path = sc->elem_path.as<uint32_t>();
     d.pool = sc->pool.as<float>();
     d.path_elem_begin = sc->path_elem_begin.as<uint32_t>();

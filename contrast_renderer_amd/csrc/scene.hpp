@@ -59,7 +59,10 @@ struct SceneDev {
     // ---- inputs (written once by crh_scene_upload) ----
     uint32_t n_elems, n_paths, n_shapes, n_wg;
     const uint8_t* elem_type;          // [n_elems]
-    const uint32_t* elem_off;          // [n_elems] float offset of the element's record in `pool`
+    const uint32_t* elem_off0;         // [n_elems] float offset of the element's OWN record in `pool` (as uploaded)
+    uint32_t* elem_off;                // [n_elems] record the element is processed with: == elem_off0 except behind a skipped curve
+                                       //           segment of a stroked path (k_stroke_records: the reference's stale typed iterator)
+    uint32_t* elem_prev_off;           // [n_elems] float offset of previous_control_point when the element is processed
     const uint32_t* elem_path;         // [n_elems]
     const float* pool;                 // per path: start.x start.y then the segment records (contrast_hip.h layouts)
     const uint32_t* path_elem_begin;   // [n_paths + 1] index of the path's MOVE element

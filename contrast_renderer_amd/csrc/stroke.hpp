@@ -9,9 +9,11 @@
 //     kernel (k_stroke_lengths) replays the additions in the reference's order and patches texcoord.y / .z.
 // The path's MOVE element emits nothing; its END element emits the closing line + joins or the end cap.
 //
-// Round-1 limit (flagged CRH_ERR_UNSUPPORTED): a skipped (NaN-tangent, stroke.rs:267-269) segment must
-// be a Line whose end equals its start. Skipped curve segments trigger the reference's stale-iterator quirk
-// (peek() without next(), stroke.rs:229 vs :318), which needs a serial walk of the path.
+// Skipped (NaN-tangent, stroke.rs:267-269) segments: the reference `continue`s without updating previous_control_point and —
+// for curve segments — without advancing the typed iterator it peek()ed (stroke.rs:229,238,248,257 vs :318,337,357,376), so the
+// next segment of that type is stroked with the stale record. That is the one truly sequential dependency on *which data* a
+// segment sees; k_stroke_records resolves it with one lane per stroked path (a walk that only evaluates end tangents) and
+// publishes, per element, the record and the previous point it is processed with. Everything after that is per-element again.
 #pragma once
 #include "ga.hpp"
 #include "scene.hpp"
@@ -44,8 +46,9 @@ CRH_D void cubic_tangents(Pt a, Pt b, Pt c, Pt d, Pl& ts, Pl& te) { // stroke.rs
 
 CRH_D SegGeom segment_geometry(const SceneDev& s, uint32_t e, uint32_t type) {
     const float* p = s.pool + s.elem_off[e];
+    const float* q = s.pool + s.elem_prev_off[e];
     SegGeom g;
-    g.p0 = vec_to_point(p[-2], p[-1]);
+    g.p0 = vec_to_point(q[0], q[1]);
     switch (type) {
         case ELEM_LINE:
             g.p1 = vec_to_point(p[0], p[1]);
@@ -215,7 +218,8 @@ CRH_D CubicIntervals cubic_intervals(const Pt pb[4], bool integral) {
 
 CRH_D void stroke_power_basis(const SceneDev& s, uint32_t e, uint32_t type, Pt pb[4]) { // stroke.rs:319-383
     const float* p = s.pool + s.elem_off[e];
-    const Pt prev = vec_to_point(p[-2], p[-1]);
+    const float* q = s.pool + s.elem_prev_off[e];
+    const Pt prev = vec_to_point(q[0], q[1]);
     Pt cp[4];
     switch (type) {
         case ELEM_IQ:
@@ -268,6 +272,38 @@ CRH_D uint32_t curve_parameter_count(const SceneDev& s, uint32_t e, uint32_t typ
         n += (steps >= 2u ? steps - 1u : 0u) + 1u;
     }
     return n;
+}
+
+// ---- which record / previous point every element of a stroked path is processed with (see the header comment) ----------------
+__global__ __launch_bounds__(64) void k_stroke_records(SceneDev s) {
+    const uint32_t path = blockIdx.x * 64u + threadIdx.x;
+    if (path >= s.n_paths || s.path_stroke[path] < 0) return;
+    const uint32_t move = s.path_elem_begin[path], end = s.path_elem_begin[path + 1] - 1u;
+    uint32_t head_iq = ~0u, head_ic = ~0u, head_rq = ~0u, head_rc = ~0u; // element whose record is at the head of each typed iterator
+    uint32_t prev_off = s.elem_off0[move];                                // previous_control_point = path.start (stroke.rs:207)
+    for (uint32_t e = move + 1u; e < end; ++e) {
+        const uint32_t type = s.elem_type[e];
+        uint32_t* head = type == ELEM_IQ ? &head_iq : (type == ELEM_IC ? &head_ic : (type == ELEM_RQ ? &head_rq : &head_rc));
+        uint32_t src = e; // lines are taken with next() (stroke.rs:223): always their own record
+        if (type != ELEM_LINE) {
+            if (*head == ~0u) *head = e;
+            src = *head;
+        }
+        const uint32_t rec = s.elem_off0[src];
+        s.elem_off[e] = rec;
+        s.elem_prev_off[e] = prev_off;
+        const SegGeom g = segment_geometry(s, e, type);
+        if (g.skip) continue; // stroke.rs:267-269: neither the iterator nor previous_control_point move
+        if (type != ELEM_LINE) {
+            uint32_t j = *head + 1u;
+            while (j < end && s.elem_type[j] != type) ++j;
+            *head = j;
+        }
+        const uint32_t end_point = type == ELEM_LINE ? 0u : (type == ELEM_IQ ? 2u : (type == ELEM_IC ? 4u : (type == ELEM_RQ ? 3u : 8u)));
+        prev_off = rec + end_point;
+    }
+    s.elem_off[end] = s.elem_off0[end];
+    s.elem_prev_off[end] = prev_off;
 }
 
 // ---- count ---------------------------------------------------------------------------------------------------------
@@ -330,12 +366,7 @@ CRH_D void count_stroke_element(const SceneDev& s, uint32_t e, uint32_t type, ui
         return;
     }
     const SegGeom g = segment_geometry(s, e, type);
-    if (g.skip) {
-        const float* p = s.pool + s.elem_off[e];
-        const bool benign = type == ELEM_LINE && __float_as_uint(p[0]) == __float_as_uint(p[-2]) && __float_as_uint(p[1]) == __float_as_uint(p[-1]);
-        if (!benign) raise_error(s, path, CRH_ERR_UNSUPPORTED);
-        return;
-    }
+    if (g.skip) return;
     const uint32_t move = s.path_elem_begin[path];
     const PrevState st = previous_state(s, e, move);
     uint32_t verts = 0, cuts = 0, joints = 0, hull = 0;

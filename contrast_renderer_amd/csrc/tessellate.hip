@@ -427,8 +427,12 @@ void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4]) {
+void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke) {
     if (s.n_elems == 0) return;
+    if (has_stroke) {
+        hipLaunchKernelGGL(k_stroke_records, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
+        if (mark) mark(ctx, "stroke_records", 0);
+    }
     hipLaunchKernelGGL(k_count, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
     if (mark) mark(ctx, "tess_count", bytes[0]);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(256), 0, stream, s);
