@@ -188,6 +188,16 @@ class PathBatch:
         )
 
 
+class FontMetricsC(C.Structure):
+    _fields_ = [("units_per_em", C.c_uint32), ("number_of_glyphs", C.c_uint32), ("ascender", C.c_int32), ("descender", C.c_int32),
+                ("line_gap", C.c_int32), ("height", C.c_int32), ("has_x_height", C.c_int32), ("x_height", C.c_int32),
+                ("has_vertical_metrics", C.c_int32), ("vertical_height", C.c_int32), ("vertical_line_gap", C.c_int32), ("has_kerning", C.c_int32)]
+
+
+class TextLayoutC(C.Structure):
+    _fields_ = [("size", C.c_float), ("orientation", C.c_uint32), ("major_alignment", C.c_uint32), ("minor_alignment", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -231,6 +241,20 @@ def load_library():
         "crh_renderer_enable_timing": (C.c_int, [V, C.c_int]),
         "crh_renderer_kernel_times": (C.c_int, [V, C.POINTER(KernelTimeC), C.c_uint32, C.POINTER(C.c_uint32)]),
         "crh_selftest_fmath": (C.c_int, [V, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]),
+        "crh_font_create": (C.c_int, [V, C.c_size_t, C.POINTER(V)]),
+        "crh_font_destroy": (None, [V]),
+        "crh_font_get_metrics": (C.c_int, [V, C.POINTER(FontMetricsC)]),
+        "crh_font_glyph_index": (C.c_int, [V, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]),
+        "crh_font_glyph_advance": (C.c_int, [V, C.c_uint16, C.c_uint32, C.POINTER(C.c_uint16), C.POINTER(C.c_uint32)]),
+        "crh_font_glyph_bounding_box": (C.c_int, [V, C.c_uint16, C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]),
+        "crh_font_glyphs_kerning": (C.c_int, [V, C.c_uint16, C.c_uint16, C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]),
+        "crh_paths_of_glyph": (C.c_int, [V, C.c_uint16, C.POINTER(V)]),
+        "crh_paths_of_text": (C.c_int, [V, C.POINTER(TextLayoutC), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_float), C.c_size_t, C.POINTER(V)]),
+        "crh_text_aligned_positions": (C.c_int, [V, C.POINTER(TextLayoutC), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                                 C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "crh_path_list_transform": (C.c_int, [V, C.c_float, C.POINTER(C.c_float)]),
+        "crh_path_list_view": (C.c_int, [V, C.POINTER(PathBatchC)]),
+        "crh_path_list_destroy": (None, [V]),
         "crh_last_error": (C.c_char_p, []),
         "crh_version": (C.c_char_p, []),
     }

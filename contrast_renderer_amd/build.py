@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ("tessellate.hip", "raster.hip", "api.hip")
+SOURCES = ("tessellate.hip", "raster.hip", "api.hip", "text.cpp")  # text.cpp: host-only glyph producer (text.rs)
 HEADERS = ("ga.hpp", "fill.hpp", "stroke.hpp", "scene.hpp", "raster_params.hpp", "../../include/contrast_hip.h", "../../include/crh_fmath.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function"]
 OUT = os.path.join(HERE, "libcontrast_hip.so")
@@ -28,11 +28,12 @@ def build_library(force=False, verbose=False):
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in SOURCES:
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, "build", os.path.splitext(src)[0] + ".o")
         objects.append(obj)
         if not force and _newer(obj, [os.path.join(CSRC, src)] + headers):
             continue
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]  # plain C++ for host-only files
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -457,9 +457,14 @@ crh_status settle_frame(crh_frame* f) {
 }
 } // namespace
 
+namespace crh {
+void set_last_error(const std::string& text) { g_error = text; } // used by csrc/text.cpp
+} // namespace crh
+
 extern "C" {
 
 const char* crh_last_error(void) { return g_error.c_str(); }
+
 const char* crh_version(void) { return "contrast_hip 0.1 (gfx950)"; }
 
 crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh_renderer** out) {

@@ -230,6 +230,66 @@ crh_status crh_renderer_kernel_times(crh_renderer* renderer, crh_kernel_time* ou
 /* Self-test tap: evaluates include/crh_fmath.h ON THE GPU (fn 0 atan2(a,b), 1 acos(a), 2 sin(a), 3 cos(a), 4 pow(a,b), 5 wgsl_mod(a,b))
  * so that tests can check device results bit for bit against the host evaluation of the same header. Host pointers. */
 crh_status crh_selftest_fmath(crh_renderer* renderer, int fn, const float* a, const float* b, float* out, uint64_t n);
+/* ---- glyph producer: text.rs (config 3 input) ----------------------------------------------------
+ * Host-side code (the reference's is host-side too). The TrueType reading is done by the crate
+ * ttf-parser 0.14.0 in the reference (Cargo.toml:20, not vendored); src/csrc/text.cpp restates the
+ * published TrueType `glyf` outline walk and the tables text.rs queries. */
+typedef struct crh_font crh_font;           /* Font, text.rs:11-38 (ttf_parser::Face over owned bytes) */
+typedef struct crh_path_list crh_path_list; /* Vec<Path>, as returned by text.rs:97 and :236 */
+
+/* Font::new, text.rs:19-27. The bytes are copied. CRH_ERR_INVALID_ARGUMENT when the face cannot be parsed (the reference unwrap()s). */
+crh_status crh_font_create(const void* ttf_bytes, size_t n_bytes, crh_font** out);
+void crh_font_destroy(crh_font* font);
+
+/* The Face getters text.rs calls (text.rs:156-158, :209-211, :238); font units. */
+typedef struct crh_font_metrics {
+    uint32_t units_per_em;
+    uint32_t number_of_glyphs;
+    int32_t ascender, descender, line_gap, height; /* height = ascender - descender (Face::height) */
+    int32_t has_x_height, x_height;                /* Face::x_height() -> Option */
+    int32_t has_vertical_metrics, vertical_height, vertical_line_gap; /* Face::vertical_height() / vertical_line_gap() -> Option */
+    int32_t has_kerning;                           /* first subtable of `kern` usable (text.rs:148) */
+} crh_font_metrics;
+crh_status crh_font_get_metrics(const crh_font* font, crh_font_metrics* out);
+/* Face::glyph_index (text.rs:147,181): *found = 0 when no Unicode cmap subtable maps the code point. */
+crh_status crh_font_glyph_index(const crh_font* font, uint32_t code_point, uint16_t* glyph_id, uint32_t* found);
+/* Face::glyph_hor_advance / glyph_ver_advance (text.rs:189-191) */
+crh_status crh_font_glyph_advance(const crh_font* font, uint16_t glyph_id, uint32_t vertical, uint16_t* advance, uint32_t* found);
+/* Face::glyph_bounding_box (text.rs:244): x_min y_min x_max y_max */
+crh_status crh_font_glyph_bounding_box(const crh_font* font, uint16_t glyph_id, int16_t box[4], uint32_t* found);
+/* kerning_table.glyphs_kerning(left, right) (text.rs:183) */
+crh_status crh_font_glyphs_kerning(const crh_font* font, uint16_t left, uint16_t right, int16_t* kerning, uint32_t* found);
+
+/* Orientation text.rs:106-117, Alignment :119-131 (declaration order) */
+enum { CRH_ORIENTATION_RIGHT_TO_LEFT = 0, CRH_ORIENTATION_LEFT_TO_RIGHT = 1, CRH_ORIENTATION_TOP_TO_BOTTOM = 2, CRH_ORIENTATION_BOTTOM_TO_TOP = 3 };
+enum { CRH_ALIGNMENT_BEGIN = 0, CRH_ALIGNMENT_BASELINE = 1, CRH_ALIGNMENT_CENTER = 2, CRH_ALIGNMENT_END = 3 };
+/* Layout, text.rs:133-143 */
+typedef struct crh_text_layout {
+    float size;
+    uint32_t orientation;     /* CRH_ORIENTATION_* */
+    uint32_t major_alignment; /* CRH_ALIGNMENT_* */
+    uint32_t minor_alignment; /* CRH_ALIGNMENT_* */
+} crh_text_layout;
+
+/* paths_of_glyph, text.rs:97-104: one Path per contour, no stroke options; an empty list for glyphs without outline. */
+crh_status crh_paths_of_glyph(const crh_font* font, uint16_t glyph_id, crh_path_list** out);
+/* paths_of_text, text.rs:236-263. `text` = Unicode scalar values (Rust chars); `clipping_area` = n_clip (x, y) pairs of a convex
+ * polygon in clockwise order (utils.rs:83-98) or NULL. */
+crh_status crh_paths_of_text(const crh_font* font, const crh_text_layout* layout, const uint32_t* text, size_t n_chars, const float* clipping_area,
+                             size_t n_clip, crh_path_list** out);
+/* calculate_aligned_positions!, text.rs:145-230 (integer font units): `positions` receives, line by line, one (x, y, glyph_id) triple of
+ * int64 per character plus one terminating entry per line (the '\n' or the end of the text, glyph id 0), i.e. n_chars + 1 triples in
+ * total; line_ends[l] = the reference's `line_range_end` (text.rs:169,199). Pass NULL pointers to query *n_lines only. */
+crh_status crh_text_aligned_positions(const crh_font* font, const crh_text_layout* layout, const uint32_t* text, size_t n_chars, int64_t extent[2],
+                                      int64_t offset[2], int64_t* positions /* [n_chars + 1][3] */, uint64_t* line_ends, uint64_t* line_lengths,
+                                      uint64_t* n_lines);
+/* Path::transform(scale, &motor), path.rs:387-439, on every path of the list. motor = ppga2d::Motor [scalar, e12, e01, e02]
+ * (utils.rs:122-129: rotate2d, translate2d). */
+crh_status crh_path_list_transform(crh_path_list* list, float scale, const float motor[4]);
+/* Views the list as one Shape of a crh_path_batch (all paths filled); the pointers stay valid until the list is changed or destroyed. */
+crh_status crh_path_list_view(const crh_path_list* list, crh_path_batch* out);
+void crh_path_list_destroy(crh_path_list* list);
+
 const char* crh_last_error(void);
 const char* crh_version(void);
 
