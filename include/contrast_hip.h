@@ -286,7 +286,7 @@ crh_status crh_text_aligned_positions(const crh_font* font, const crh_text_layou
 /* Path::transform(scale, &motor), path.rs:387-439, on every path of the list. motor = ppga2d::Motor [scalar, e12, e01, e02]
  * (utils.rs:122-129: rotate2d, translate2d). */
 crh_status crh_path_list_transform(crh_path_list* list, float scale, const float motor[4]);
-/* Views the list as one Shape of a crh_path_batch (all paths filled); the pointers stay valid until the list is changed or destroyed. */
+/* Views the list as one Shape, all paths filled, in crh_path_batch form; the pointers stay valid until the list is changed or destroyed. */
 crh_status crh_path_list_view(const crh_path_list* list, crh_path_batch* out);
 void crh_path_list_destroy(crh_path_list* list);
 
