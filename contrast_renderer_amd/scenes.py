@@ -354,3 +354,82 @@ def scene_mixed(n_shapes=64, size=(512, 512), seed=7):
     transforms = place(size[0], size[1], centres[:, 0], centres[:, 1], np.asarray(radii))
     return dict(batch=batch, transforms=transforms, colors=np.asarray(colors, dtype=np.float32), width=size[0], height=size[1], msaa=4,
                 winding_bits=4, name="Smixed")
+
+
+def default_font_path():
+    """The bundled OpenSans-Regular.ttf data fixture (Apache-2.0; the reference ships the same file under examples/fonts/)."""
+    import os
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fonts", "OpenSans-Regular.ttf")
+
+
+def scene_glyphs(n_glyphs=50000, size=(2048, 2048), config_index=3, font_path=None, sizes=(12.0, 16.0, 24.0, 32.0, 48.0)):
+    """S50kg (BASELINE configs[2]): `n_glyphs` glyph instances produced by text::paths_of_text (native glyph producer, text.rs:236-263) —
+    many tiny line / quadratic paths, one filled Shape per glyph instance. The text cycles through every character of the font's cmap
+    whose glyph has an outline; it is set in bands of lines, Layout{size cycling 12..48 px, LeftToRight, Begin, Baseline}, stacked down
+    the frame (wrapping, so later bands overlay earlier ones). Glyph coordinates are layout coordinates (origin = frame centre, y up),
+    placed by Path::transform exactly as paths_of_text does; all Shapes share one instance transform."""
+    from . import text as T
+    width, height = size
+    data = open(font_path or default_font_path(), "rb").read()
+    font = T.Font("OpenSans", data)
+    chars, contours, advances = [], {}, {}
+    for code in range(0x21, 0x3000):
+        gid = font.glyph_index(code)
+        if gid is None or font.glyph_bounding_box(gid) is None:
+            continue
+        if gid not in contours:
+            contours[gid] = len(T.glyph_path_list(font, gid).arrays()[1])
+            advances[gid] = font.glyph_hor_advance(gid) or 0
+        if contours[gid] > 0:
+            chars.append((code, gid))
+    assert chars, "the font maps no outline glyph"
+    seg_begin_all, start_all, types_all, control_all, shape_paths = [np.zeros(1, np.int64)], [], [], [], []
+    produced, cursor, band, y_top = 0, 0, 0, 0.0
+    while produced < n_glyphs:
+        px = float(sizes[band % len(sizes)])
+        scale = px / font.height()
+        line_height = px
+        lines_in_band = max(1, int(96.0 // line_height))
+        text, counts = [], []
+        for _ in range(lines_in_band):
+            x = 0.0
+            while produced + len(counts) < n_glyphs:
+                code, gid = chars[cursor % len(chars)]
+                if x + advances[gid] * scale > width and x > 0.0:
+                    break
+                cursor += 1
+                text.append(code)
+                counts.append(contours[gid])
+                x += advances[gid] * scale
+            text.append(10)
+            if produced + len(counts) >= n_glyphs:
+                break
+        text = text[:-1] if text and text[-1] == 10 else text
+        plist = T.text_path_list(font, T.Layout(px, T.Orientation.LeftToRight, T.Alignment.Begin, T.Alignment.Baseline), np.asarray(text, dtype=np.uint32))
+        band_height = lines_in_band * line_height
+        # the block is centred on the origin by the layout; move its centre to the band's centre (frame centre = origin, y up)
+        centre_y = height / 2.0 - ((y_top + band_height / 2.0) % height)
+        plist.transform(1.0, (1.0, 0.0, -0.5 * float(np.float32(centre_y)), 0.0))  # translate2d((0, centre_y)), utils.rs:127-129
+        seg_begin, start, types, control = plist.arrays()
+        assert len(start) == sum(counts)
+        seg_begin_all.append(seg_begin[1:].astype(np.int64) + seg_begin_all[-1][-1])
+        start_all.append(start)
+        types_all.append(types)
+        control_all.append(control)
+        shape_paths.extend(counts)
+        produced += len(counts)
+        y_top += band_height
+        band += 1
+    n_shapes = len(shape_paths)
+    shape_path_begin = np.concatenate([[0], np.cumsum(shape_paths)]).astype(np.uint32)
+    n_paths = int(shape_path_begin[-1])
+    batch = _ffi.PathBatch(shape_path_begin, np.concatenate(seg_begin_all).astype(np.uint32), np.concatenate(start_all).astype(np.float32),
+                           np.full(n_paths, -1, dtype=np.int32), np.concatenate(types_all).astype(np.uint8), np.concatenate(control_all).astype(np.float32),
+                           [], np.zeros(n_shapes + 1, dtype=np.uint32), [])
+    m = np.zeros(16, dtype=np.float32)
+    m[0], m[5], m[10], m[15] = 2.0 / width, 2.0 / height, 1.0, 1.0
+    transforms = np.tile(m, (n_shapes, 1))
+    rng = PCG32(0xC0FFEE ^ config_index, n_shapes)
+    colors = _colors(rng, n_shapes)
+    return dict(batch=batch, transforms=transforms, colors=colors, width=width, height=height, msaa=1, winding_bits=4, name="S50kg",
+                n_glyphs=n_shapes, n_paths=n_paths)
