@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--paths", type=int, default=10000, help="paths per GPU (configs[1] = 10000)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed"),
+                    help="cubic = BASELINE configs[1] (the metric's configuration, default); glyphs = configs[2] (50 000 glyphs @ 2048^2); "
+                         "dashed = configs[4] (2 000 dashed rational-cubic strokes @ 4096^2, msaa 4). Only `cubic` is the headline line.")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,9 +90,22 @@ def main():
     from contrast_renderer_amd.renderer import Configuration, Frame, Renderer, Scene
 
     size = (args.size, args.size)
-    sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
+    if args.workload == "cubic":
+        sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
+        workload = (f"BASELINE configs[1]: {args.paths} filled closed paths x 8 cubic segments (alternating integral / rational), {size[0]}x{size[1]}, "
+                    "msaa 1, winding_counter_bits 4")
+    elif args.workload == "glyphs":
+        size = (2048, 2048)
+        sc = scenes.scene_glyphs(50000, size)
+        args.paths = sc["n_paths"]
+        workload = f"BASELINE configs[2]: 50000 glyph instances ({sc['n_paths']} line/quadratic paths) via text::paths_of_text, 2048x2048, msaa 1"
+    else:
+        size = (4096, 4096)
+        sc = scenes.scene_dashed_strokes(2000, size)
+        args.paths = 2000
+        workload = "BASELINE configs[4]: 2000 dashed rational-cubic strokes (UniformTangentAngle 0.1, miter/round joins), 4096x4096, msaa 4"
     batch = sc["batch"]
-    renderer = Renderer(Configuration(msaa_sample_count=1, clip_nesting_counter_bits=4, winding_counter_bits=4), device=local_rank)
+    renderer = Renderer(Configuration(msaa_sample_count=sc["msaa"], clip_nesting_counter_bits=4, winding_counter_bits=4), device=local_rank)
     t_up = time.perf_counter()
     scene = Scene(renderer, batch, tessellate=True)  # host -> HBM + first tessellation (sizes the output buffers): outside the timed region
     renderer.synchronize()
@@ -158,7 +174,7 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
-    default_workload = args.paths == 10000 and args.size == 4096
+    default_workload = args.workload == "cubic" and args.paths == 10000 and args.size == 4096
     traffic, traffic_source = measured_traffic(dominant) if default_workload else (None, None)
 
     total_paths = args.paths * world
@@ -178,8 +194,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[1]: {args.paths} filled closed paths x 8 cubic segments (alternating integral / rational), {size[0]}x{size[1]}, "
-                        "msaa 1, winding_counter_bits 4; step = tessellate (count/scan/emit/hull) + bin + tile raster, inputs resident in HBM",
+            "workload": workload + "; step = tessellate (count/scan/emit/hull) + bin + tile raster, inputs resident in HBM",
             "paths_per_gpu": args.paths,
             "segments_per_gpu": int(batch.n_segments),
             "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} + tile-sliced RCCL all-to-all + ordered over-composite + gather",

@@ -70,6 +70,10 @@ static_assert(sizeof(PrimCoverage) == 64 && sizeof(PrimFragment) == 64 && sizeof
 #define CRH_CONST
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+CRH_D f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); } // two IEEE fmas (v_pk_fma_f32)
+CRH_D f32x2 splat2(float v) { return f32x2{v, v}; }
+CRH_D float readlane_f(float v, uint32_t lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)lane)); }
 template <class T>
 CRH_D T load_uniform(const T* p) { // p must be wave uniform
     static_assert(sizeof(T) % 16 == 0, "16-byte multiples");
@@ -547,6 +551,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
             sy0[k] = (float)rq + oy[k & 3];
         }
     }
+    const uint32_t row_bit[4] = {1u << rq, 16u << rq, 256u << rq, 4096u << rq}; // bit of row 4b + rq in a 16-bit row mask
     int winding[4][S];
     float col[4][S][4];
 #pragma unroll
@@ -620,41 +625,61 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
     for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
         if (n > 64u) my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
         const uint32_t count = min(64u, n - q0);
-        PrimCoverage cur = load_uniform(&recs[__builtin_amdgcn_readlane(my_key, 0)].cov);
+        // ---- entry setup, vectorised across the chunk: lane j prepares entry j (one gathered 64-byte record per lane), so that the
+        // per-entry loop below only has to pull wave-uniform values out of these registers with v_readlane
+        uint32_t e_bits = 0, e_flags = 0, e_desc = 0;
+        float e_c[3] = {0.0f, 0.0f, 0.0f}, e_bx[3] = {0.0f, 0.0f, 0.0f}, e_nay[3] = {0.0f, 0.0f, 0.0f};
+        if (lane < count) {
+            const PrimCoverage mine = recs[my_key].cov;
+            const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
+            const int by0 = max((int)mine.box.z, tpy) - tpy, by1 = min((int)mine.box.w, tpy + kTile - 1) - tpy;
+            const uint32_t col_bits = bx1 >= bx0 ? (2u << bx1) - (1u << bx0) : 0u, row_bits = by1 >= by0 ? (2u << by1) - (1u << by0) : 0u;
+            e_bits = col_bits | (row_bits << 16); // columns / rows of the tile inside the triangle's clamped pixel box
+            e_flags = mine.flags;
+            e_desc = mine.desc;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                e_c[i] = mine.bx[i] * (ty0 - mine.lo_y[i]) + mine.nay[i] * (tx0 - mine.lo_x[i]);
+                e_bx[i] = mine.bx[i];
+                e_nay[i] = mine.nay[i];
+            }
+        }
         for (uint32_t j = 0; j < count; ++j) {
             const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
-            const PrimCoverage cov = cur;
-            const uint32_t flags = cov.flags;
+            const uint32_t flags = __builtin_amdgcn_readlane(e_flags, j);
             const uint32_t kind = (flags >> 4) & 7u;
-            // scalar loads issued up front: the second half of this record and the first half of the next one
+            // the second half of the record (attribute planes / cover colour) comes through a scalar load issued up front
             PrimFragment frag;
             if (kind != KIND_SOLID) frag = load_uniform(&recs[prim].frag);
-            if (j + 1u < count) cur = load_uniform(&recs[__builtin_amdgcn_readlane(my_key, j + 1u)].cov);
-            // inside[b][k] > 0  <=>  sample k of pixel (px, 4b + rq) is covered. Everything stays in VALU integer math:
-            //   edge i accepts e  <=>  e > 0 || (e == 0 && top_left_i)  <=>  as_int(e + 0.0f) + top_left_i > 0
-            //   (e + 0.0f turns -0 into +0; edge values are finite by construction of the record)
-            int inside[4][S];
+            // inside[b][k]  <=>  sample k of pixel (px, 4b + rq) is covered:
+            //   edge i accepts e  <=>  e > 0 || (e == 0 && top_left_i)  <=>  as_int(e) >= 1 - top_left_i
+            //   (edge values are finite and never -0: an exact zero sum rounds to +0 unless both addends are -0, which would need
+            //    bx == nay == 0, i.e. a zero-length edge, and those triangles have det == 0 and are never set up)
+            // The two rows 4p + rq and 4p + 4 + rq (p = 0, 2) are evaluated together with packed f32 FMAs (v_pk_fma_f32: two IEEE fmas
+            // per instruction, bit-identical to the scalar ones); the three compares produce lane masks that are combined on the scalar
+            // unit; "the pixel is inside the clamped box" is a bit lookup in (column mask, row mask).
+            bool inside[4][S];
             {
-                const int bx0 = max((int)cov.box.x, tpx) - tpx, bx1 = min((int)cov.box.y, tpx + kTile - 1) - tpx;
-                const int by0 = max((int)cov.box.z, tpy) - tpy, by1 = min((int)cov.box.w, tpy + kTile - 1) - tpy;
-                const int dx = (int)px - bx0;
-                const int range_x = dx | (bx1 - bx0 - dx);
-                const float c0 = cov.bx[0] * (ty0 - cov.lo_y[0]) + cov.nay[0] * (tx0 - cov.lo_x[0]);
-                const float c1 = cov.bx[1] * (ty0 - cov.lo_y[1]) + cov.nay[1] * (tx0 - cov.lo_x[1]);
-                const float c2 = cov.bx[2] * (ty0 - cov.lo_y[2]) + cov.nay[2] * (tx0 - cov.lo_x[2]);
-                const int tl0 = (int)(flags & 1u), tl1 = (int)((flags >> 1) & 1u), tl2 = (int)((flags >> 2) & 1u);
+                const uint32_t bits = __builtin_amdgcn_readlane(e_bits, j);
+                const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) : 0u;
+                const float c0 = readlane_f(e_c[0], j), c1 = readlane_f(e_c[1], j), c2 = readlane_f(e_c[2], j);
+                const float bx_0 = readlane_f(e_bx[0], j), bx_1 = readlane_f(e_bx[1], j), bx_2 = readlane_f(e_bx[2], j);
+                const float nay_0 = readlane_f(e_nay[0], j), nay_1 = readlane_f(e_nay[1], j), nay_2 = readlane_f(e_nay[2], j);
+                const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int dy = (int)rq + 4 * b - by0;
-                    const int range = (range_x | (dy | (by1 - by0 - dy))) + 1; // > 0 <=> the pixel is inside the clamped box
+                for (int p = 0; p < 4; p += 2) {
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
-                        const float y = sy0[k] + (float)(4 * b);
-                        const float ea = fmaf(sx[k], cov.nay[0], fmaf(y, cov.bx[0], c0)) + 0.0f;
-                        const float eb = fmaf(sx[k], cov.nay[1], fmaf(y, cov.bx[1], c1)) + 0.0f;
-                        const float ecv = fmaf(sx[k], cov.nay[2], fmaf(y, cov.bx[2], c2)) + 0.0f;
-                        const int ia = __float_as_int(ea) + tl0, ib = __float_as_int(eb) + tl1, ic = __float_as_int(ecv) + tl2;
-                        inside[b][k] = min(min(ia, ib), min(ic, range));
+                        const f32x2 y = {sy0[k] + (float)(4 * p), sy0[k] + (float)(4 * p + 4)};
+                        const f32x2 x = {sx[k], sx[k]};
+                        const f32x2 ea = fma2(x, splat2(nay_0), fma2(y, splat2(bx_0), splat2(c0)));
+                        const f32x2 eb = fma2(x, splat2(nay_1), fma2(y, splat2(bx_1), splat2(c1)));
+                        const f32x2 ec = fma2(x, splat2(nay_2), fma2(y, splat2(bx_2), splat2(c2)));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const bool in_box = (lane_rows & row_bit[p + h]) != 0u;
+                            inside[p + h][k] = (__float_as_int(ea[h]) >= thr0) & (__float_as_int(eb[h]) >= thr1) & (__float_as_int(ec[h]) >= thr2) & in_box;
+                        }
                     }
                 }
             }
@@ -663,7 +688,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
-                    for (int k = 0; k < S; ++k) winding[b][k] += inside[b][k] > 0 ? delta : 0;
+                    for (int k = 0; k < S; ++k) winding[b][k] += inside[b][k] ? delta : 0;
                 continue;
             }
             if (kind == KIND_COVER) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
@@ -673,14 +698,14 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
-                        const bool blend = inside[b][k] > 0 && (winding[b][k] & wmask) != 0;
+                        const bool blend = inside[b][k] && (winding[b][k] & wmask) != 0;
                         const float n0 = s0 + col[b][k][0] * one_minus_a, n1 = s1 + col[b][k][1] * one_minus_a;
                         const float n2 = s2 + col[b][k][2] * one_minus_a, n3 = ca + col[b][k][3] * one_minus_a;
                         col[b][k][0] = blend ? n0 : col[b][k][0];
                         col[b][k][1] = blend ? n1 : col[b][k][1];
                         col[b][k][2] = blend ? n2 : col[b][k][2];
                         col[b][k][3] = blend ? n3 : col[b][k][3];
-                        winding[b][k] = inside[b][k] > 0 ? 0 : winding[b][k];
+                        winding[b][k] = inside[b][k] ? 0 : winding[b][k];
                     }
                 continue;
             }
@@ -703,16 +728,16 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                         const float a2 = fmaf(y, frag.gy[2], hx[2][k]), a3 = fmaf(y, frag.gy[3], hx[3][k]);
                         const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
                         const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
-                        winding[b][k] += (inside[b][k] > 0 && lhs - rhs <= 0.0f) ? delta : 0;
+                        winding[b][k] += (inside[b][k] && lhs - rhs <= 0.0f) ? delta : 0;
                     }
             } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
                 int any_inside = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
-                    for (int k = 0; k < S; ++k) any_inside |= (int)(inside[b][k] > 0);
+                    for (int k = 0; k < S; ++k) any_inside |= (int)inside[b][k];
                 if (__any(any_inside)) {
-                    const crh_dynamic_stroke_descriptor* d = &s.descriptors[cov.desc];
+                    const crh_dynamic_stroke_descriptor* d = &s.descriptors[__builtin_amdgcn_readlane(e_desc, j)];
                     const uint32_t caps = d->caps, count_dashed_join = d->count_dashed_join; // wave uniform
                     const uint32_t flat_u = frag.flat_u;
                     const float end_y = frag.end_y;
@@ -722,7 +747,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
                             // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
-                            if (inside[b][k] > 0 && (winding[b][k] & wmask) == 0) {
+                            if (inside[b][k] && (winding[b][k] & wmask) == 0) {
                                 const float y = sy0[k] + (float)(4 * b);
                                 const float a0 = fmaf(y, frag.gy[0], hx[0][k]), a1 = fmaf(y, frag.gy[1], hx[1][k]), a2 = fmaf(y, frag.gy[2], hx[2][k]);
                                 bool fill;
