@@ -32,7 +32,7 @@ def build_library(force=False, verbose=False):
         objects.append(obj)
         if not force and _newer(obj, [os.path.join(CSRC, src)] + headers):
             continue
-        flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]  # plain C++ for host-only files
+        flags = (FLAGS + os.environ.get("CRH_EXTRA_FLAGS", "").split()) if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]  # plain C++ for host-only files
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -401,7 +401,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
         const uint32_t* t = sc->totals_host;
         const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
         HIP_TRY(sc->prim_rec.ensure(prim_capacity * 128));
-        if (prim_capacity >= (1u << 24)) return CRH_ERR_UNSUPPORTED; // tile list entries hold 24-bit primitive ids
+        if (prim_capacity == 0xFFFFFFFFu) return CRH_ERR_UNSUPPORTED; // 0xFFFFFFFF pads the tile sort
         HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
         p.prim_capacity = (uint32_t)prim_capacity;
     }

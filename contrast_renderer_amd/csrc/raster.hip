@@ -435,8 +435,8 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
 // largest Shapes (hundreds of tiles) do not leave one long serial tail.
 //   count: ballot of the lanes whose triangle can touch the tile -> ONE atomic per (chunk, tile)
 //   fill : lane 0 reserves popcount(ballot) slots of the tile's list with one returning atomic (consumed one iteration later, after
-//          the next tile's masks have been computed, so its latency is hidden); every hit lane writes
-//          prim id << 8 | full-band mask << 4 | band mask at its rank.
+//          the next tile's test has been computed, so its latency is hidden); every hit lane writes
+//          prim id at its rank.
 constexpr uint32_t kWalkWaves = 16;
 template <int S, bool FILL>
 __global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, RasterParams r) {
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                 const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
                 const float one_minus_a = 1.0f - ca;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < 4; ++b) {
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
                         const bool blend = inside[b][k] && (winding[b][k] & wmask) != 0;
@@ -707,6 +707,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                         col[b][k][3] = blend ? n3 : col[b][k][3];
                         winding[b][k] = inside[b][k] ? 0 : winding[b][k];
                     }
+                }
                 continue;
             }
             // attribute planes, tile relative: ac = (a0 + (tx0 - v0x) * gx) + (ty0 - v0y) * gy; a = fma(sy, gy, fma(sx, gx, ac))
@@ -720,7 +721,11 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
             }
             if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < 4; ++b) {
+                    bool row_touched = false;
+#pragma unroll
+                    for (int k = 0; k < S; ++k) row_touched = row_touched | inside[b][k];
+                    if (!__any(row_touched)) continue; // curve triangles are small: most rows of the tile are not touched
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
                         const float y = sy0[k] + (float)(4 * b);
@@ -730,6 +735,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                         const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
                         winding[b][k] += (inside[b][k] && lhs - rhs <= 0.0f) ? delta : 0;
                     }
+                }
             } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
                 int any_inside = 0;
 #pragma unroll
