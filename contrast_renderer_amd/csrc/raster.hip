@@ -524,38 +524,44 @@ __device__ __noinline__ bool stroke_dashed_joint(const crh_dynamic_stroke_descri
     return stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
 }
 
-// One wavefront per 16x16 tile: lane = (column px, row group rq); the lane owns the four pixels (px, 4k + rq), k = 0..3, so a
-// primitive's record load, tile constants and kind dispatch are paid once per (tile, primitive) and only the per-sample arithmetic
-// is repeated per row.
-template <int S>
-__global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) {
-    __shared__ uint32_t keys[kBandListMax]; // only used by tiles with more than 64 primitives
+// One workgroup per 16x16 tile, lane = (column px, row group rq), ROWS pixel rows per lane:
+//   ROWS == 4 (msaa 1): ONE wavefront per tile; the lane owns the pixels (px, 4b + rq), b = 0..3, so a primitive's entry setup, tile
+//                       constants and kind dispatch are paid once per (tile, primitive) and only the per-sample arithmetic repeats;
+//   ROWS == 1 (msaa 4): four wavefronts per tile, wavefront w owns rows 4w..4w+3 — 4 samples x 1 row per lane keeps the per-lane state
+//                       (winding + colour of every sample) at the same 20 registers instead of 80.
+template <int S, int ROWS>
+__global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, RasterParams r) {
+    __shared__ uint32_t sort_buffer[4 / ROWS][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % r.tiles_x, ty = tile / r.tiles_x;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* keys = sort_buffer[wave];
     const uint32_t px = lane & 15u, rq = lane >> 4;
+    const uint32_t first_row = ROWS == 4 ? 0u : 4u * wave; // local row b of this lane is pixel row first_row + 4b + rq
     const uint32_t gx = tx * kTile + px;
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
     const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
 
-    float sx[S], sy0[S]; // sample positions of row rq; row 4k + rq adds 4k (exact in f32)
+    float sx[S], sy0[S]; // sample positions of the lane's first row; local row b adds 4b (exact in f32)
     if (S == 1) {
         sx[0] = (float)px + 0.5f;
-        sy0[0] = (float)rq + 0.5f;
+        sy0[0] = (float)(first_row + rq) + 0.5f;
     } else {
         const float ox[4] = {0.375f, 0.875f, 0.125f, 0.625f}, oy[4] = {0.125f, 0.375f, 0.625f, 0.875f};
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             sx[k] = (float)px + ox[k & 3];
-            sy0[k] = (float)rq + oy[k & 3];
+            sy0[k] = (float)(first_row + rq) + oy[k & 3];
         }
     }
-    const uint32_t row_bit[4] = {1u << rq, 16u << rq, 256u << rq, 4096u << rq}; // bit of row 4b + rq in a 16-bit row mask
-    int winding[4][S];
-    float col[4][S][4];
+    uint32_t row_bit[ROWS]; // bit of the lane's row b in a 16-bit row mask
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < ROWS; ++b) row_bit[b] = 1u << (first_row + 4u * b + rq);
+    int winding[ROWS][S];
+    float col[ROWS][S][4];
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b)
 #pragma unroll
         for (int k = 0; k < S; ++k) {
             winding[b][k] = 0;
@@ -563,8 +569,8 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
         }
     if (r.load_existing) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t gy = ty * kTile + 4u * b + rq;
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
             if (gx < r.width && gy < r.height) {
                 const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[(size_t)gy * r.width + gx];
 #pragma unroll
@@ -655,10 +661,10 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
             //   edge i accepts e  <=>  e > 0 || (e == 0 && top_left_i)  <=>  as_int(e) >= 1 - top_left_i
             //   (edge values are finite and never -0: an exact zero sum rounds to +0 unless both addends are -0, which would need
             //    bx == nay == 0, i.e. a zero-length edge, and those triangles have det == 0 and are never set up)
-            // The two rows 4p + rq and 4p + 4 + rq (p = 0, 2) are evaluated together with packed f32 FMAs (v_pk_fma_f32: two IEEE fmas
+            // Two (row, sample) combinations are evaluated together with packed f32 FMAs (v_pk_fma_f32: two IEEE fmas
             // per instruction, bit-identical to the scalar ones); the three compares produce lane masks that are combined on the scalar
             // unit; "the pixel is inside the clamped box" is a bit lookup in (column mask, row mask).
-            bool inside[4][S];
+            bool inside[ROWS][S];
             {
                 const uint32_t bits = __builtin_amdgcn_readlane(e_bits, j);
                 const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) : 0u;
@@ -666,27 +672,23 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                 const float bx_0 = readlane_f(e_bx[0], j), bx_1 = readlane_f(e_bx[1], j), bx_2 = readlane_f(e_bx[2], j);
                 const float nay_0 = readlane_f(e_nay[0], j), nay_1 = readlane_f(e_nay[1], j), nay_2 = readlane_f(e_nay[2], j);
                 const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
+                // the ROWS * S (row, sample) combinations are taken two at a time
 #pragma unroll
-                for (int p = 0; p < 4; p += 2) {
-#pragma unroll
-                    for (int k = 0; k < S; ++k) {
-                        const f32x2 y = {sy0[k] + (float)(4 * p), sy0[k] + (float)(4 * p + 4)};
-                        const f32x2 x = {sx[k], sx[k]};
-                        const f32x2 ea = fma2(x, splat2(nay_0), fma2(y, splat2(bx_0), splat2(c0)));
-                        const f32x2 eb = fma2(x, splat2(nay_1), fma2(y, splat2(bx_1), splat2(c1)));
-                        const f32x2 ec = fma2(x, splat2(nay_2), fma2(y, splat2(bx_2), splat2(c2)));
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const bool in_box = (lane_rows & row_bit[p + h]) != 0u;
-                            inside[p + h][k] = (__float_as_int(ea[h]) >= thr0) & (__float_as_int(eb[h]) >= thr1) & (__float_as_int(ec[h]) >= thr2) & in_box;
-                        }
-                    }
+                for (int c = 0; c < ROWS * S; c += 2) {
+                    const int b0 = c / S, k0 = c % S, b1 = (c + 1) / S, k1 = (c + 1) % S;
+                    const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
+                    const f32x2 x = {sx[k0], sx[k1]};
+                    const f32x2 ea = fma2(x, splat2(nay_0), fma2(y, splat2(bx_0), splat2(c0)));
+                    const f32x2 eb = fma2(x, splat2(nay_1), fma2(y, splat2(bx_1), splat2(c1)));
+                    const f32x2 ec = fma2(x, splat2(nay_2), fma2(y, splat2(bx_2), splat2(c2)));
+                    inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & row_bit[b0]) != 0u);
+                    inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & row_bit[b1]) != 0u);
                 }
             }
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
             if (kind == KIND_SOLID) { // stencil_solid
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                     for (int k = 0; k < S; ++k) winding[b][k] += inside[b][k] ? delta : 0;
                 continue;
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                 const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
                 const float one_minus_a = 1.0f - ca;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < ROWS; ++b) {
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
                         const bool blend = inside[b][k] && (winding[b][k] & wmask) != 0;
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
             }
             if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < ROWS; ++b) {
                     bool row_touched = false;
 #pragma unroll
                     for (int k = 0; k < S; ++k) row_touched = row_touched | inside[b][k];
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
             } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
                 int any_inside = 0;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                     for (int k = 0; k < S; ++k) any_inside |= (int)inside[b][k];
                 if (__any(any_inside)) {
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
                     const float end_y = frag.end_y;
                     const bool dashed = (count_dashed_join & 4u) != 0u;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
                             // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
@@ -781,8 +783,8 @@ __global__ __launch_bounds__(64) void k_raster_tile(SceneDev s, RasterParams r) 
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const uint32_t gy = ty * kTile + 4u * b + rq;
+    for (int b = 0; b < ROWS; ++b) {
+        const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
         if (gx < r.width && gy < r.height) {
             const float inv = 1.0f / (float)S;
             uint32_t packed_px = 0;
@@ -866,9 +868,9 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
     }
     if (mark) mark(ctx, "raster_tile_fill", 0);
     if (samples == 4)
-        hipLaunchKernelGGL(k_raster_tile<4>, dim3(r.n_tiles), dim3(64), 0, stream, s, r);
+        hipLaunchKernelGGL((k_raster_tile<4, 1>), dim3(r.n_tiles), dim3(256), 0, stream, s, r);
     else
-        hipLaunchKernelGGL(k_raster_tile<1>, dim3(r.n_tiles), dim3(64), 0, stream, s, r);
+        hipLaunchKernelGGL((k_raster_tile<1, 4>), dim3(r.n_tiles), dim3(64), 0, stream, s, r);
     if (mark) mark(ctx, "raster_tiles", raster_bytes);
 }
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream) {
