@@ -188,6 +188,10 @@ class PathBatch:
         )
 
 
+class DrawC(C.Structure):
+    _fields_ = [("shape", C.c_uint32), ("instance", C.c_uint32), ("op", C.c_uint32), ("clip_depth", C.c_uint32), ("alpha_layer", C.c_uint32)]
+
+
 class FontMetricsC(C.Structure):
     _fields_ = [("units_per_em", C.c_uint32), ("number_of_glyphs", C.c_uint32), ("ascender", C.c_int32), ("descender", C.c_int32),
                 ("line_gap", C.c_int32), ("height", C.c_int32), ("has_x_height", C.c_int32), ("x_height", C.c_int32),
@@ -233,6 +237,7 @@ def load_library():
         "crh_scene_render": (C.c_int, [V, V, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "crh_scene_set_instances": (C.c_int, [V, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "crh_scene_render_resident": (C.c_int, [V, V]),
+        "crh_scene_render_draws": (C.c_int, [V, V, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(DrawC), C.c_uint32]),
         "crh_frame_download": (C.c_int, [V, V]),
         "crh_frame_device_pointer": (C.c_int, [V, C.POINTER(V)]),
         "crh_composite_over": (C.c_int, [V, C.POINTER(V), C.c_uint32, C.c_uint64, V]),

@@ -20,6 +20,7 @@ void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, 
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx);
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes);
+void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
 } // namespace crh
@@ -110,6 +111,9 @@ struct crh_frame {
     crh_renderer* renderer;
     uint32_t width, height, tiles_x, tiles_y, n_tiles, n_bands;
     DevBuf rgba8, tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
+    // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
+    DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
+    uint32_t n_items = 0;
     bool cleared = true;
     bool pairs_known = false;
     // last render, for the transparent re-run after a bin-capacity overflow
@@ -379,7 +383,8 @@ void assemble_shape(const crh_scene* sc, const HostCopy& h, uint32_t s, uint8_t*
 
 crh_status render_impl(crh_scene* sc, crh_frame* f) {
     crh_renderer* r = sc->renderer;
-    if (!sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
+    const bool recorded = f->n_items != 0; // crh_scene_render_draws stored a pass in the frame
+    if (!recorded && !sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
     if (!sc->capacity_known) return CRH_ERR_INVALID_ARGUMENT; // tessellate first
     HIP_TRY(hipSetDevice(r->device));
     RasterParams p;
@@ -390,13 +395,33 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.n_tiles = f->n_tiles;
     p.n_bands = f->n_bands;
     p.winding_mask = (1u << r->config.winding_counter_bits) - 1u;
+    p.clip_mask_count = (1u << r->config.clip_nesting_counter_bits) - 1u;
+    p.items = recorded ? f->items.as<DrawItem>() : nullptr;
+    p.n_items = recorded ? f->n_items : sc->d.n_shapes;
     p.load_existing = f->cleared ? 0u : 1u;
-    p.transforms = sc->transforms.as<float>();
-    p.colors = sc->colors.as<float>();
+    p.transforms = recorded ? f->item_transforms.as<float>() : sc->transforms.as<float>();
+    p.colors = recorded ? f->item_colors.as<float>() : sc->colors.as<float>();
     p.tile_count = f->tile_count_cursor.as<uint32_t>();
     p.tile_cursor = f->tile_count_cursor.as<uint32_t>() + f->n_tiles;
     p.tile_offset = f->tile_offset.as<uint32_t>();
-    {
+    p.shape_ncand = sc->shape_ncand.as<uint32_t>();
+    p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
+    if (recorded) {
+        // primitive ranges per draw item; a Shape may be drawn many times, so the record capacity comes from the scan's total
+        HIP_TRY(f->item_ncand.ensure((size_t)f->n_items * 4 + 4));
+        HIP_TRY(f->item_prim_begin.ensure(((size_t)f->n_items + 1) * 4));
+        HIP_TRY(f->item_scan_scratch.ensure(((size_t)(f->n_items + 1023) / 1024 + 2) * 4));
+        launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), r->stream);
+        uint32_t total = 0;
+        HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        if (total >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED;
+        HIP_TRY(sc->prim_rec.ensure(((size_t)total + 64) * 128));
+        HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
+        p.prim_capacity = total + 64u;
+        p.shape_ncand = f->item_ncand.as<uint32_t>();
+        p.shape_prim_begin = f->item_prim_begin.as<uint32_t>();
+    } else {
         // every candidate triangle gets a record slot: an upper bound follows from the tessellation totals
         const uint32_t* t = sc->totals_host;
         const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
@@ -405,8 +430,6 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
         HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
         p.prim_capacity = (uint32_t)prim_capacity;
     }
-    p.shape_ncand = sc->shape_ncand.as<uint32_t>();
-    p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
     p.scan_scratch = f->scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec.p);
     p.overflow = f->overflow.as<uint32_t>();
@@ -428,7 +451,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     }
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
-    const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)sc->d.n_shapes * 80 + (uint64_t)f->width * f->height * 4;
+    const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
     launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes);
     HIP_TRY(hipGetLastError());
     f->cleared = false;
@@ -804,7 +827,8 @@ void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->renderer->device);
     (void)hipStreamSynchronize(f->renderer->stream);
-    DevBuf* all[] = {&f->rgba8, &f->tile_count_cursor, &f->tile_offset, &f->tile_list, &f->overflow, &f->scan_scratch};
+    DevBuf* all[] = {&f->rgba8, &f->tile_count_cursor, &f->tile_offset, &f->tile_list, &f->overflow, &f->scan_scratch,
+                     &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
     for (DevBuf* b : all) b->release();
     delete f;
 }
@@ -832,6 +856,54 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
 }
 crh_status crh_scene_render_resident(crh_scene* sc, crh_frame* f) {
     if (!sc || !f || f->renderer != sc->renderer) return CRH_ERR_INVALID_ARGUMENT;
+    f->n_items = 0; // the plain pass: Stencil + Color of every Shape
+    return render_impl(sc, f);
+}
+crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* transforms, const float* colors, uint32_t n_instances, const crh_draw* draws,
+                                  uint32_t n_draws) {
+    if (!sc || !f || f->renderer != sc->renderer || (n_instances && (!transforms || !colors)) || (n_draws && !draws)) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = sc->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    if (r->config.alpha_layer_count > 4) return CRH_ERR_UNSUPPORTED;
+    for (size_t i = 0; i < (size_t)n_instances * 16; ++i)
+        if (!std::isfinite(transforms[i])) return CRH_ERR_NON_FINITE;
+    for (size_t i = 0; i < (size_t)n_instances * 4; ++i)
+        if (!std::isfinite(colors[i])) return CRH_ERR_NON_FINITE;
+    // validation in recording order, as the reference's calls would fail (renderer.rs:933-935, :947-949, :980-982)
+    std::vector<DrawItem> items;
+    for (uint32_t i = 0; i < n_draws; ++i) {
+        const crh_draw& d = draws[i];
+        if (d.shape >= sc->d.n_shapes || d.instance >= n_instances || d.op > CRH_OP_RESTORE_ALPHA_CONTEXT) return CRH_ERR_INVALID_ARGUMENT;
+        if (d.clip_depth >= (1u << r->config.clip_nesting_counter_bits)) return CRH_ERR_CLIP_STACK_OVERFLOW;
+        if (d.op >= CRH_OP_SAVE_ALPHA_CONTEXT && d.alpha_layer >= r->config.alpha_layer_count) return CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS;
+        if (d.op == CRH_OP_STENCIL) {
+            items.push_back(DrawItem{d.shape, d.instance, 1u, d.clip_depth});
+        } else {
+            const uint32_t cover = ((uint32_t)d.op + 1u) << 4, refs = (d.clip_depth << 8) | ((d.alpha_layer & 15u) << 16);
+            // Stencil immediately followed by a cover operation of the same Shape and instance is one item (one walk of its tiles)
+            if (!items.empty() && items.back().ops == 1u && items.back().shape == d.shape && items.back().instance == d.instance) {
+                items.back().ops |= cover;
+                items.back().refs |= refs;
+            } else {
+                items.push_back(DrawItem{d.shape, d.instance, cover, refs});
+            }
+        }
+    }
+    if (items.empty()) { // an empty pass still resolves a cleared frame
+        f->n_items = 0;
+        if (f->cleared) HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)f->width * f->height * 4, r->stream));
+        f->cleared = false;
+        return CRH_OK;
+    }
+    HIP_TRY(f->items.ensure(items.size() * sizeof(DrawItem)));
+    HIP_TRY(f->item_transforms.ensure((size_t)n_instances * 64 + 64));
+    HIP_TRY(f->item_colors.ensure((size_t)n_instances * 16 + 16));
+    HIP_TRY(hipMemcpyAsync(f->items.p, items.data(), items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipMemcpyAsync(f->item_transforms.p, transforms, (size_t)n_instances * 64, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipMemcpyAsync(f->item_colors.p, colors, (size_t)n_instances * 16, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream)); // `items` and the caller's arrays may go away
+    f->n_items = (uint32_t)items.size();
+    f->pairs_known = false; // a different pass: re-learn the tile list size
     return render_impl(sc, f);
 }
 crh_status crh_scene_render(crh_scene* sc, crh_frame* f, const float* transforms, const float* colors) {

@@ -100,6 +100,17 @@ CRH_D uint32_t shape_candidates(const SceneDev& s, uint32_t shape, uint32_t c[8]
     return c[7];
 }
 
+CRH_D DrawItem item_of(const RasterParams& r, uint32_t i) {
+    if (r.items) return r.items[i];
+    return DrawItem{i, i, 1u | ((uint32_t)(CRH_OP_COLOR + 1) << 4), 0u}; // the plain pass: Stencil + Color of Shape i at clip depth 0
+}
+// the candidate triangles of an item: [first, last) in the Shape's candidate numbering (stencil kinds first, cover strip last)
+CRH_D void item_candidates(const SceneDev& s, const DrawItem& it, uint32_t cb[8], uint32_t& first, uint32_t& last) {
+    shape_candidates(s, it.shape, cb);
+    first = (it.ops & 1u) ? 0u : cb[6];
+    last = (it.ops >> 4) ? cb[7] : cb[6];
+}
+
 // ---------------------------------------------------------------------------------------------- scans
 // Two-kernel exclusive scan over a u32 array (1024 items per block): out[i] = sum of in[0..i), out[n] = total.
 struct ScanJob {
@@ -114,6 +125,14 @@ __global__ __launch_bounds__(256) void k_shape_ncand(SceneDev s, uint32_t* shape
     if (shape >= s.n_shapes) return;
     uint32_t c[8];
     shape_ncand[shape] = shape_candidates(s, shape, c);
+}
+// the same per draw item of a recorded pass (per frame)
+__global__ __launch_bounds__(256) void k_item_ncand(SceneDev s, RasterParams r, uint32_t* item_ncand) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= r.n_items) return;
+    uint32_t cb[8], first, last;
+    item_candidates(s, r.items[i], cb, first, last);
+    item_ncand[i] = last - first;
 }
 __global__ __launch_bounds__(256) void k_scan_local(ScanJob j) {
     __shared__ uint32_t wave_sum[4];
@@ -243,13 +262,17 @@ CRH_D bool wave_tile_rect(bool valid, const PrimCoverage& cov, uint32_t& tx0, ui
 // ---------------------------------------------------------------------------------------------- k_prim_setup
 template <int S>
 __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
-    const uint32_t shape = blockIdx.x, lane = threadIdx.x;
-    const float* m = r.transforms + 16u * shape;
+    const uint32_t item = blockIdx.x, lane = threadIdx.x;
+    const DrawItem it = item_of(r, item);
+    const uint32_t shape = it.shape;
+    const float* m = r.transforms + 16u * it.instance;
     if (lane == 0 && !(m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f)) // affine instances only this round (clip.w == 1)
         raise_error(s, s.elem_path[min(s.shape_elem_begin[shape], s.n_elems - 1u)], CRH_ERR_UNSUPPORTED);
-    uint32_t cb[8];
-    const uint32_t n_candidates = shape_candidates(s, shape, cb);
-    const uint32_t prim0 = r.shape_prim_begin[shape];
+    uint32_t cb[8], first_candidate, last_candidate;
+    item_candidates(s, it, cb, first_candidate, last_candidate);
+    const uint32_t n_candidates = last_candidate - first_candidate;
+    const uint32_t prim0 = r.shape_prim_begin[item];
+    const uint32_t cover_op = (it.ops >> 4) ? (it.ops >> 4) - 1u : (uint32_t)CRH_OP_COLOR;
     if (prim0 + n_candidates > r.prim_capacity) return; // cannot happen: the capacity is an upper bound derived from the totals
     const uint32_t* b0 = s.shape_base + shape * NCH;
     const uint32_t lv0 = b0[CH_LINE_V], j0 = b0[CH_JOINT], sv0 = b0[CH_SOLID_V], iq0 = b0[CH_IQ], ic0 = b0[CH_IC_V], rq0 = b0[CH_RQ], rc0 = b0[CH_RC_V],
@@ -257,8 +280,8 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
     const uint32_t dyn0 = s.shape_dyn_begin[shape];
     const float W = (float)r.width, H = (float)r.height;
     for (uint32_t c0 = 0; c0 < n_candidates; c0 += 64u) { // all 64 lanes stay in the loop: the tile walk below is wave-wide
-        const uint32_t c = c0 + lane;
-        const bool in_range_c = c < n_candidates;
+        const uint32_t c = first_candidate + c0 + lane; // in the Shape's candidate numbering
+        const bool in_range_c = c0 + lane < n_candidates;
         float2 p[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
         float attr[3][4];
         uint32_t kind = KIND_SOLID, flat_u = 0, desc = 0;
@@ -380,7 +403,9 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
                 const float inv_det = 1.0f / det;
                 const bool front = det < 0.0f; // y-down cross < 0 == counter-clockwise on screen (FrontFace::Ccw, renderer.rs:477)
                 const float2 nv[3] = {p[0], det < 0.0f ? p[2] : p[1], det < 0.0f ? p[1] : p[2]}; // clockwise-in-y-down edge walk
-                uint32_t flags = (front ? 8u : 0u) | (kind << 4);
+                // bits 0-2 top-left, 3 front, 4-6 kind, 7-9 cover operation, 16-23 stencil reference (clip depth), 24-27 alpha layer
+                const uint32_t clip_ref = kind == KIND_COVER ? (it.refs >> 8) & 255u : it.refs & 255u;
+                uint32_t flags = (front ? 8u : 0u) | (kind << 4) | (cover_op << 7) | (clip_ref << 16) | (((it.refs >> 16) & 15u) << 24);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float2 a = nv[i], b = nv[(i + 1) % 3];
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
                     }
                 }
                 if (kind == KIND_COVER) { // color_cover: (rgb * a, a), shaders.wgsl:304-309
-                    const float* color = r.colors + 4u * shape;
+                    const float* color = r.colors + 4u * it.instance;
                     rec.frag.a0[0] = color[0] * color[3];
                     rec.frag.a0[1] = color[1] * color[3];
                     rec.frag.a0[2] = color[2] * color[3];
@@ -422,9 +447,9 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
         }
         if (in_range_c) {
             if (drawn)
-                r.prim_rec[prim0 + c] = rec;
+                r.prim_rec[prim0 + c0 + lane] = rec;
             else
-                r.prim_rec[prim0 + c].cov.box = rec.cov.box;
+                r.prim_rec[prim0 + c0 + lane].cov.box = rec.cov.box;
         }
     }
 }
@@ -529,7 +554,10 @@ __device__ __noinline__ bool stroke_dashed_joint(const crh_dynamic_stroke_descri
 //                       constants and kind dispatch are paid once per (tile, primitive) and only the per-sample arithmetic repeats;
 //   ROWS == 1 (msaa 4): four wavefronts per tile, wavefront w owns rows 4w..4w+3 — 4 samples x 1 row per lane keeps the per-lane state
 //                       (winding + colour of every sample) at the same 20 registers instead of 80.
-template <int S, int ROWS>
+//   OPS == true: the full RenderOperation set — every sample also carries the clip nesting counter and up to kMaxAlphaLayers saved
+//                alphas; OPS == false is the plain Stencil + Color pass at clip depth 0 (what the benchmark runs).
+constexpr int kMaxAlphaLayers = 4;
+template <int S, int ROWS, bool OPS>
 __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, RasterParams r) {
     __shared__ uint32_t sort_buffer[4 / ROWS][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
 
@@ -559,6 +587,16 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, Ras
 #pragma unroll
     for (int b = 0; b < ROWS; ++b) row_bit[b] = 1u << (first_row + 4u * b + rq);
     int winding[ROWS][S];
+    int clipc[OPS ? ROWS : 1][OPS ? S : 1];                        // clip nesting counter (the upper stencil bits, renderer.rs:565)
+    float saved[OPS ? ROWS : 1][OPS ? S : 1][kMaxAlphaLayers];     // alpha-context layers (renderer.rs:892-927)
+#pragma unroll
+    for (int b = 0; b < (OPS ? ROWS : 1); ++b)
+#pragma unroll
+        for (int k = 0; k < (OPS ? S : 1); ++k) {
+            clipc[OPS ? b : 0][OPS ? k : 0] = 0;
+#pragma unroll
+            for (int l = 0; l < kMaxAlphaLayers; ++l) saved[b][k][l] = 0.0f;
+        }
     float col[ROWS][S][4];
 #pragma unroll
     for (int b = 0; b < ROWS; ++b)
@@ -654,6 +692,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, Ras
             const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
             const uint32_t flags = __builtin_amdgcn_readlane(e_flags, j);
             const uint32_t kind = (flags >> 4) & 7u;
+            const int clip_ref = OPS ? (int)((flags >> 16) & 255u) : 0; // the stencil reference of this draw: its clip depth
             // the second half of the record (attribute planes / cover colour) comes through a scalar load issued up front
             PrimFragment frag;
             if (kind != KIND_SOLID) frag = load_uniform(&recs[prim].frag);
@@ -690,25 +729,62 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, Ras
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                    for (int k = 0; k < S; ++k) winding[b][k] += inside[b][k] ? delta : 0;
+                    for (int k = 0; k < S; ++k) winding[b][k] += (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref)) ? delta : 0; // LessEqual(ref <= stencil)
                 continue;
             }
-            if (kind == KIND_COVER) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
-                const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
-                const float one_minus_a = 1.0f - ca;
+            if (kind == KIND_COVER) {
+                const uint32_t cover_op = OPS ? (flags >> 7) & 7u : (uint32_t)CRH_OP_COLOR;
+                if (cover_op == CRH_OP_COLOR) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
+                    const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
+                    const float one_minus_a = 1.0f - ca;
 #pragma unroll
-                for (int b = 0; b < ROWS; ++b) {
+                    for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                    for (int k = 0; k < S; ++k) {
-                        const bool blend = inside[b][k] && (winding[b][k] & wmask) != 0;
-                        const float n0 = s0 + col[b][k][0] * one_minus_a, n1 = s1 + col[b][k][1] * one_minus_a;
-                        const float n2 = s2 + col[b][k][2] * one_minus_a, n3 = ca + col[b][k][3] * one_minus_a;
-                        col[b][k][0] = blend ? n0 : col[b][k][0];
-                        col[b][k][1] = blend ? n1 : col[b][k][1];
-                        col[b][k][2] = blend ? n2 : col[b][k][2];
-                        col[b][k][3] = blend ? n3 : col[b][k][3];
-                        winding[b][k] = inside[b][k] ? 0 : winding[b][k];
-                    }
+                        for (int k = 0; k < S; ++k) {
+                            // Less(ref < stencil) on clip | winding: a deeper clip level, or this level with a non-zero winding
+                            const bool stencil_pass = OPS ? (clipc[OPS ? b : 0][OPS ? k : 0] > clip_ref || (clipc[OPS ? b : 0][OPS ? k : 0] == clip_ref && (winding[b][k] & wmask) != 0)) : (winding[b][k] & wmask) != 0;
+                            const bool blend = inside[b][k] && stencil_pass;
+                            const float n0 = s0 + col[b][k][0] * one_minus_a, n1 = s1 + col[b][k][1] * one_minus_a;
+                            const float n2 = s2 + col[b][k][2] * one_minus_a, n3 = ca + col[b][k][3] * one_minus_a;
+                            col[b][k][0] = blend ? n0 : col[b][k][0];
+                            col[b][k][1] = blend ? n1 : col[b][k][1];
+                            col[b][k][2] = blend ? n2 : col[b][k][2];
+                            col[b][k][3] = blend ? n3 : col[b][k][3];
+                            winding[b][k] = inside[b][k] ? 0 : winding[b][k];
+                        }
+                } else if (OPS) {
+                    // Clip / UnClip / the alpha-context covers, branch-free per sample (the operation is wave uniform)
+                    const uint32_t layer = (flags >> 24) & 15u;
+                    const float ca = frag.a0[3]; // the instance colour's alpha
+                    const bool is_clip = cover_op == CRH_OP_CLIP, is_unclip = cover_op == CRH_OP_UNCLIP, is_save = cover_op == CRH_OP_SAVE_ALPHA_CONTEXT;
+                    const bool is_scale = cover_op == CRH_OP_SCALE_ALPHA_CONTEXT, is_restore = cover_op == CRH_OP_RESTORE_ALPHA_CONTEXT;
+                    const float scale_src = 1.0f - ca; // scale_alpha_context_cover: src = (0, 0, 0, 1 - a), shaders.wgsl:311-316
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const int cb_ = OPS ? b : 0, ck_ = OPS ? k : 0;
+                            const bool in = inside[b][k];
+                            const int clip_now = clipc[cb_][ck_];
+                            // Clip: NotEqual on the winding bits -> Replace(ref) (renderer.rs:703-708); UnClip: Less on the clip bits (ref < stencil)
+                            // -> Replace(ref) (renderer.rs:722-727); both rewrite clip | winding
+                            const bool replace = in && ((is_clip && (winding[b][k] & wmask) != 0) || (is_unclip && clip_ref < clip_now));
+                            clipc[cb_][ck_] = replace ? clip_ref : clip_now;
+                            winding[b][k] = replace ? 0 : winding[b][k];
+                            // alpha-context covers: LessEqual(ref <= stencil), stencil untouched (renderer.rs:761-766)
+                            const bool pass = in && clip_now >= clip_ref;
+                            const float alpha = col[b][k][3];
+                            float mine = 0.0f;
+#pragma unroll
+                            for (int l = 0; l < kMaxAlphaLayers; ++l) mine = (uint32_t)l == layer ? saved[cb_][ck_][l] : mine;
+                            const float scaled = scale_src + alpha * (1.0f - scale_src);      // alpha' = src.a * One + dst.a * (1 - src.a), renderer.rs:803-828
+                            const float restored = alpha - (1.0f - mine) * (1.0f - ca);        // alpha' = dst.a - (1 - saved)(1 - a), renderer.rs:829-861
+                            const float next = is_scale ? scaled : (is_restore ? restored : alpha);
+                            col[b][k][3] = pass ? next : alpha;
+#pragma unroll
+                            for (int l = 0; l < kMaxAlphaLayers; ++l) // save_alpha_context_cover: the layer receives the frame's alpha, shaders.wgsl:326-331
+                                saved[cb_][ck_][l] = (pass && is_save && (uint32_t)l == layer) ? alpha : saved[cb_][ck_][l];
+                        }
                 }
                 continue;
             }
@@ -735,7 +811,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, Ras
                         const float a2 = fmaf(y, frag.gy[2], hx[2][k]), a3 = fmaf(y, frag.gy[3], hx[3][k]);
                         const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
                         const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
-                        winding[b][k] += (inside[b][k] && lhs - rhs <= 0.0f) ? delta : 0;
+                        winding[b][k] += (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref) && lhs - rhs <= 0.0f) ? delta : 0;
                     }
                 }
             } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
@@ -755,7 +831,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, Ras
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
                             // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
-                            if (inside[b][k] && (winding[b][k] & wmask) == 0) {
+                            if (inside[b][k] && (winding[b][k] & wmask) == 0 && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] == clip_ref)) { // Equal(ref) on clip | winding
                                 const float y = sy0[k] + (float)(4 * b);
                                 const float a0 = fmaf(y, frag.gy[0], hx[0][k]), a1 = fmaf(y, frag.gy[1], hx[1][k]), a2 = fmaf(y, frag.gy[2], hx[2][k]);
                                 bool fill;
@@ -837,20 +913,28 @@ void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shap
     hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
     hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, unused, 0);
 }
+// per frame, for a recorded pass: candidate counts and contiguous primitive ids per draw item
+void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream) {
+    hipLaunchKernelGGL(k_item_ncand, dim3((r.n_items + 255u) / 256u), dim3(256), 0, stream, s, r, item_ncand);
+    const ScanJob j = scan_job(item_ncand, item_prim_begin, scratch, r.n_items);
+    RasterParams unused = {};
+    hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
+    hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, unused, 0);
+}
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
-    if (s.n_shapes) {
+    if (r.n_items) {
         if (samples == 4)
-            hipLaunchKernelGGL(k_prim_setup<4>, dim3(s.n_shapes), dim3(64), 0, stream, s, r);
+            hipLaunchKernelGGL(k_prim_setup<4>, dim3(r.n_items), dim3(64), 0, stream, s, r);
         else
-            hipLaunchKernelGGL(k_prim_setup<1>, dim3(s.n_shapes), dim3(64), 0, stream, s, r);
+            hipLaunchKernelGGL(k_prim_setup<1>, dim3(r.n_items), dim3(64), 0, stream, s, r);
     }
     if (mark) mark(ctx, "raster_prim_setup", 0);
-    if (s.n_shapes) {
+    if (r.n_items) {
         if (samples == 4)
-            hipLaunchKernelGGL((k_tile_walk<4, false>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+            hipLaunchKernelGGL((k_tile_walk<4, false>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
         else
-            hipLaunchKernelGGL((k_tile_walk<1, false>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+            hipLaunchKernelGGL((k_tile_walk<1, false>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
     }
     if (mark) mark(ctx, "raster_tile_count", 0);
     const ScanJob j = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles);
@@ -860,17 +944,22 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
 }
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
                    uint64_t raster_bytes) {
-    if (s.n_shapes) {
+    if (r.n_items) {
         if (samples == 4)
-            hipLaunchKernelGGL((k_tile_walk<4, true>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+            hipLaunchKernelGGL((k_tile_walk<4, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
         else
-            hipLaunchKernelGGL((k_tile_walk<1, true>), dim3(s.n_shapes), dim3(64 * kWalkWaves), 0, stream, s, r);
+            hipLaunchKernelGGL((k_tile_walk<1, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
     }
     if (mark) mark(ctx, "raster_tile_fill", 0);
     if (samples == 4)
-        hipLaunchKernelGGL((k_raster_tile<4, 1>), dim3(r.n_tiles), dim3(256), 0, stream, s, r);
+        if (r.items)
+            hipLaunchKernelGGL((k_raster_tile<4, 1, true>), dim3(r.n_tiles), dim3(256), 0, stream, s, r);
+        else
+            hipLaunchKernelGGL((k_raster_tile<4, 1, false>), dim3(r.n_tiles), dim3(256), 0, stream, s, r);
+    else if (r.items)
+        hipLaunchKernelGGL((k_raster_tile<1, 4, true>), dim3(r.n_tiles), dim3(64), 0, stream, s, r);
     else
-        hipLaunchKernelGGL((k_raster_tile<1, 4>), dim3(r.n_tiles), dim3(64), 0, stream, s, r);
+        hipLaunchKernelGGL((k_raster_tile<1, 4, false>), dim3(r.n_tiles), dim3(64), 0, stream, s, r);
     if (mark) mark(ctx, "raster_tiles", raster_bytes);
 }
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream) {

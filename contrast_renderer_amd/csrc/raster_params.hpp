@@ -7,20 +7,31 @@ namespace crh {
 
 struct PrimRec;
 
+// One Shape::render(Stencil) optionally followed by one cover operation of the same Shape and instance (the host merges adjacent
+// draws of a recorded pass); the unit the setup and binning kernels are launched over.
+struct DrawItem {
+    uint32_t shape, instance;
+    uint32_t ops;  // bit 0: stencil phase present; bits 4-6: cover operation + 1 (crh_render_op), 0 = none
+    uint32_t refs; // bits 0-7 clip depth of the stencil phase, 8-15 clip depth of the cover phase, 16-23 alpha layer
+};
+
 struct RasterParams {
     uint32_t width, height, tiles_x, tiles_y, n_tiles, n_bands; // 16x16 tiles, 4 bands (16x4 pixels) per tile: bin = tile * 4 + band
     uint32_t winding_mask;
+    uint32_t clip_mask_count; // (1 << clip_nesting_counter_bits) - 1: clip depths are compared as plain counters
+    const DrawItem* items;    // [n_items], or nullptr: item i = Shape i, instance i, Stencil + Color at clip depth 0
+    uint32_t n_items;
     uint32_t load_existing; // 0: the frame was cleared (LoadOp::Clear), 1: composite over the resolved image already there
-    const float* transforms; // [n_shapes][16] column-major
-    const float* colors;     // [n_shapes][4] straight alpha
+    const float* transforms; // [n_instances][16] column-major
+    const float* colors;     // [n_instances][4] straight alpha
     uint32_t* tile_count;    // [n_tiles], immediately followed by tile_cursor (one memset clears both)
     uint32_t* tile_cursor;   // [n_tiles]
     uint32_t* tile_offset;   // [n_tiles + 1]
-    uint32_t* tile_list;     // [pair_capacity] prim id << 8 | full-band mask << 4 | band mask
+    uint32_t* tile_list;     // [pair_capacity] prim ids, grouped by tile
     uint32_t pair_capacity;
     uint32_t* overflow;      // [0] pair capacity exceeded, [1] required pairs, [2..] tools counters
-    const uint32_t* shape_ncand;      // [n_shapes] candidate triangles per Shape (written by the hull kernel)
-    uint32_t* shape_prim_begin;       // [n_shapes + 1]
+    const uint32_t* shape_ncand;      // [n_items] candidate triangles per item
+    uint32_t* shape_prim_begin;       // [n_items + 1] contiguous primitive ids per item, ascending in draw order
     uint32_t* scan_scratch;           // block sums of the scans
     PrimRec* prim_rec;                // [prim capacity] 128-byte set-up triangles
     uint32_t prim_capacity;

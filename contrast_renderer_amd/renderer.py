@@ -167,6 +167,20 @@ class Scene:
             self.set_instances(transforms, colors)
         check(self.lib.crh_scene_render_resident(self.handle, frame.handle))
 
+    def render_draws(self, frame: Frame, transforms, colors, draws):
+        """A recorded render pass: draws = [(shape, instance, RenderOperation, clip_depth, alpha_layer), ...] — one tuple per
+        Shape::render call (renderer.rs:267-273) with the clip depth (Renderer::set_clip_depth, renderer.rs:932-938) and alpha layer
+        (save/restore_alpha_context, renderer.rs:941-985) in effect. `instance` indexes transforms / colors (instancing)."""
+        t = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 16)
+        c = np.ascontiguousarray(colors, dtype=np.float32).reshape(-1, 4)
+        assert len(t) == len(c)
+        arr = (_ffi.DrawC * max(1, len(draws)))()
+        for i, d in enumerate(draws):
+            d = tuple(d) + (0,) * (5 - len(d))
+            arr[i] = _ffi.DrawC(int(d[0]), int(d[1]), int(d[2]), int(d[3]), int(d[4]))
+        fp = C.POINTER(C.c_float)
+        check(self.lib.crh_scene_render_draws(self.handle, frame.handle, t.ctypes.data_as(fp), c.ctypes.data_as(fp), len(t), arr, len(draws)))
+
     def set_dynamic_stroke_options(self, shape_index, group_index, options):
         c = options.to_c()
         check(self.lib.crh_scene_set_dynamic_stroke_options(self.handle, shape_index, group_index, C.byref(c)))

@@ -26,8 +26,8 @@ extern "C" {
 typedef enum crh_status {
     CRH_OK = 0,
     CRH_ERR_NUMBER_OF_STENCIL_BITS_IS_UNSUPPORTED = 1,    /* renderer.rs:433-435 */
-    CRH_ERR_CLIP_STACK_OVERFLOW = 2,                      /* renderer.rs:934 (clip ops: out of scope, never raised) */
-    CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS = 3,           /* renderer.rs:948,981 (out of scope, never raised) */
+    CRH_ERR_CLIP_STACK_OVERFLOW = 2,                      /* renderer.rs:933-935 */
+    CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS = 3,           /* renderer.rs:947-949, :980-982 */
     CRH_ERR_TOO_MANY_DASH_INTERVALS = 4,                  /* renderer.rs:32-34 */
     CRH_ERR_DYNAMIC_STROKE_OPTIONS_INDEX_OUT_OF_BOUNDS = 5, /* renderer.rs:189-191, :366-368 */
     CRH_ERR_NON_FINITE = 6,        /* the reference panics: safe_float.rs:46,114 */
@@ -127,7 +127,7 @@ typedef struct crh_config {
     uint32_t msaa_sample_count;         /* 1 or 4 */
     uint32_t clip_nesting_counter_bits; /* validated as in renderer.rs:433 */
     uint32_t winding_counter_bits;      /* >= 1, sum <= 8 */
-    uint32_t alpha_layer_count;         /* accepted, unused */
+    uint32_t alpha_layer_count;         /* <= 4; layers of the alpha-context operations (renderer.rs:403-404) */
 } crh_config;
 
 typedef struct crh_renderer crh_renderer; /* Renderer, renderer.rs:408 */
@@ -206,6 +206,26 @@ crh_status crh_scene_render(crh_scene* scene, crh_frame* frame, const float* tra
 /* Same, with per-shape data already in HBM (used by bench.py so that PCIe is outside the step). */
 crh_status crh_scene_set_instances(crh_scene* scene, const float* transforms, const float* colors);
 crh_status crh_scene_render_resident(crh_scene* scene, crh_frame* frame);
+
+/* A recorded render pass. One crh_draw = one call of Shape::render(renderer, pass, instance_indices, op) (renderer.rs:267-273) together
+ * with the pass state it sees: the stencil reference set by Renderer::set_clip_depth (renderer.rs:932-938) and, for the alpha-context
+ * operations, the layer bound by Renderer::save_alpha_context / restore_alpha_context (renderer.rs:941-985). `instance` indexes
+ * `transforms` / `colors` (the instance buffers, shaders.wgsl:13-27): a Shape may be drawn any number of times.
+ *   Stencil                     the seven stencil pipelines (renderer.rs:275-337)
+ *   Clip / UnClip               increment / decrement_clip_nesting_counter pipelines (renderer.rs:692-729)
+ *   Color                       color_cover (renderer.rs:736-754, shaders.wgsl:304-309)
+ *   Save / Scale / Restore      the alpha-context covers (renderer.rs:761-861, shaders.wgsl:311-355); the saved layers live with the frame
+ * Draws execute in order. Errors as the reference: clip_depth >= 2^clip_nesting_counter_bits -> CRH_ERR_CLIP_STACK_OVERFLOW,
+ * alpha_layer >= alpha_layer_count -> CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS. At most 4 alpha layers are supported. */
+typedef struct crh_draw {
+    uint32_t shape;       /* index of the Shape in the scene */
+    uint32_t instance;    /* index into transforms / colors */
+    uint32_t op;          /* crh_render_op */
+    uint32_t clip_depth;  /* Renderer::set_clip_depth value in effect */
+    uint32_t alpha_layer; /* alpha_layer of save_alpha_context / restore_alpha_context in effect (alpha-context operations only) */
+} crh_draw;
+crh_status crh_scene_render_draws(crh_scene* scene, crh_frame* frame, const float* transforms, const float* colors, uint32_t n_instances,
+                                  const crh_draw* draws, uint32_t n_draws);
 
 /* MSAA resolve (box average, examples/showcase/main.rs:215) + copy to host, `rgba8` = width*height*4 bytes, row 0 = top. */
 crh_status crh_frame_download(crh_frame* frame, void* rgba8);

@@ -125,6 +125,28 @@ int oracle_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint3
     return CRH_OK;
 }
 
+// A recorded render pass: draws[i] = {shape, instance, op (crh_render_op), clip_depth, alpha_layer}, executed in order into a cleared frame.
+int oracle_render_draws(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
+                        const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws, uint8_t* rgba8) {
+    Scene* sc = static_cast<Scene*>(h);
+    if (!(msaa == 1 || msaa == 4) || winding_bits == 0 || winding_bits + clip_bits > 8) return CRH_ERR_INVALID_ARGUMENT;
+    Frame f;
+    f.create(width, height, msaa, winding_bits, clip_bits, alpha_layers);
+    for (uint32_t i = 0; i < n_draws; ++i) {
+        const uint32_t shape = draws[5 * i], instance = draws[5 * i + 1], op = draws[5 * i + 2], clip_depth = draws[5 * i + 3], layer = draws[5 * i + 4];
+        if (shape >= sc->shapes.size()) return CRH_ERR_INVALID_ARGUMENT;
+        if (clip_depth >= (1u << clip_bits)) return CRH_ERR_CLIP_STACK_OVERFLOW; // renderer.rs:933-935
+        if (op >= CRH_OP_SAVE_ALPHA_CONTEXT && layer >= alpha_layers) return CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS; // renderer.rs:947,980
+        f.reference = clip_depth << winding_bits;
+        if (op == CRH_OP_STENCIL)
+            render_stencil(f, sc->shapes[shape], transforms + 16 * (size_t)instance);
+        else
+            render_cover(f, sc->shapes[shape], transforms + 16 * (size_t)instance, colors + 4 * (size_t)instance, op, layer);
+    }
+    resolve_rgba8(f, rgba8);
+    return CRH_OK;
+}
+
 // cpu_baseline: wall seconds of `repeats` full tessellations (restatement of the CPU part of from_paths).
 double oracle_time_tessellate(const crh_path_batch* batch, int n_threads, int repeats) {
     const auto t0 = std::chrono::steady_clock::now();

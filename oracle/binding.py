@@ -51,6 +51,8 @@ def _load():
         lib.oracle_convert_dynamic_stroke_options.argtypes = [C.POINTER(_ffi.DynamicStrokeOptionsC), C.POINTER(_ffi.DynamicStrokeDescriptorC)]
         lib.oracle_render.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32,
                                       C.c_uint32, V]
+        lib.oracle_render_draws.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, V]
         lib.oracle_time_tessellate.restype = C.c_double
         lib.oracle_time_tessellate.argtypes = [C.POINTER(_ffi.PathBatchC), C.c_int, C.c_int]
         lib.oracle_fmath_eval.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
@@ -120,6 +122,19 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"oracle_render failed: {rc}")
         return out
+
+
+def render_draws(oracle, width, height, msaa, winding_bits, clip_bits, alpha_layers, transforms, colors, draws):
+    """A recorded render pass: draws = [(shape, instance, op, clip_depth, alpha_layer), ...] -> RGBA8 [h, w, 4] (cleared frame)."""
+    t = np.ascontiguousarray(transforms, dtype=np.float32)
+    c = np.ascontiguousarray(colors, dtype=np.float32)
+    d = np.ascontiguousarray(draws, dtype=np.uint32).reshape(-1, 5)
+    out = np.zeros((height, width, 4), dtype=np.uint8)
+    rc = oracle.lib.oracle_render_draws(oracle.handle, width, height, msaa, winding_bits, clip_bits, alpha_layers, t.ctypes.data_as(C.POINTER(C.c_float)),
+                                        c.ctypes.data_as(C.POINTER(C.c_float)), d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_draws failed: {rc}")
+    return out
 
 
 def split_shape(vo, io, vb, ib):

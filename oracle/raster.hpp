@@ -28,15 +28,21 @@ constexpr int TILE = 16;
 
 struct Frame {
     uint32_t width = 0, height = 0, samples = 1, winding_mask = 15;
-    std::vector<uint8_t> winding; // [y][x][s]
+    uint32_t clip_mask = 0;  // clip nesting counter bits, above the winding bits (renderer.rs:565)
+    uint32_t reference = 0;  // stencil reference = clip_depth << winding_counter_bits (Renderer::set_clip_depth, renderer.rs:932-938)
+    std::vector<uint8_t> winding; // [y][x][s] the whole stencil byte: clip nesting counter | winding counter
     std::vector<float> color;     // [y][x][s][4] premultiplied
-    void create(uint32_t w, uint32_t h, uint32_t s, uint32_t winding_bits) {
+    std::vector<std::vector<float>> alpha_layers; // [layer][y][x][s] saved alpha (R8 targets of renderer.rs:892-927, kept in f32 like the colour)
+    void create(uint32_t w, uint32_t h, uint32_t s, uint32_t winding_bits, uint32_t clip_bits = 0, uint32_t n_alpha_layers = 0) {
         width = w;
         height = h;
         samples = s;
         winding_mask = (1u << winding_bits) - 1u;
+        clip_mask = ((1u << clip_bits) - 1u) << winding_bits;
+        reference = 0;
         winding.assign((size_t)w * h * s, 0);
         color.assign((size_t)w * h * s * 4, 0.0f);
+        alpha_layers.assign(n_alpha_layers, std::vector<float>((size_t)w * h * s, 0.0f));
     }
     void clear() {
         std::fill(winding.begin(), winding.end(), 0);
@@ -238,11 +244,12 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
         // out-of-range reads of a storage buffer are clamped/zero in WebGPU; never happens for validated input
         return path_index < shape.stroke_buffer.size() ? shape.stroke_buffer[path_index] : zero_descriptor;
     };
-    auto stroke_stencil = [&](size_t si, bool) { // Equal(ref 0) -> IncrementWrap, both faces (renderer.rs:571-576)
-        if ((f.winding[si] & f.winding_mask) == 0) f.winding[si] = wrap_add(f.winding[si], 1, f.winding_mask);
+    const uint32_t read_mask = f.clip_mask | f.winding_mask;
+    auto stroke_stencil = [&](size_t si, bool) { // Equal(ref) -> IncrementWrap, both faces, write mask = winding (renderer.rs:571-576)
+        if ((f.winding[si] & read_mask) == (f.reference & read_mask)) f.winding[si] = wrap_add(f.winding[si], 1, f.winding_mask);
     };
-    auto fill_stencil = [&](size_t si, bool front) { // LessEqual -> front Increment / back Decrement (renderer.rs:577-582)
-        f.winding[si] = wrap_add(f.winding[si], front ? 1 : -1, f.winding_mask);
+    auto fill_stencil = [&](size_t si, bool front) { // LessEqual(ref <= stencil) -> front Increment / back Decrement (renderer.rs:577-582)
+        if ((f.reference & read_mask) <= (f.winding[si] & read_mask)) f.winding[si] = wrap_add(f.winding[si], front ? 1 : -1, f.winding_mask);
     };
     // 1. stroke line strips (renderer.rs:278-287, shaders.wgsl:268-285)
     {
@@ -377,11 +384,16 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
     }
 }
 
-// Shape::render(Color) (renderer.rs:340,345-354, pipeline :736-754, shaders.wgsl:304-309) for one instance
-inline void render_color(Frame& f, const Shape& shape, const float m[16], const float rgba[4]) {
+// The cover operations: Shape::render(Clip | UnClip | Color | SaveAlphaContext | ScaleAlphaContext | RestoreAlphaContext)
+// (renderer.rs:338-354) draw the hull strip with the fixed-function state of renderer.rs:692-754 / :761-861 and the fragment stages
+// shaders.wgsl:304-355, for one instance. `op` = crh_render_op.
+inline void render_cover(Frame& f, const Shape& shape, const float m[16], const float rgba[4], uint32_t op, uint32_t alpha_layer) {
     const float W = (float)f.width, H = (float)f.height;
     const float src[4] = {rgba[0] * rgba[3], rgba[1] * rgba[3], rgba[2] * rgba[3], rgba[3]};
     const float one_minus_a = 1.0f - src[3];
+    const uint32_t read_mask = f.clip_mask | f.winding_mask;
+    const uint32_t ref = f.reference;
+    std::vector<float>* layer = alpha_layer < f.alpha_layers.size() ? &f.alpha_layers[alpha_layer] : nullptr;
     const auto& hull = shape.convex_hull; // already in strip order
     for (size_t i = 0; i + 2 < hull.size(); ++i) {
         size_t tri[3];
@@ -391,14 +403,38 @@ inline void render_color(Frame& f, const Shape& shape, const float m[16], const 
         raster_triangle<0>(
             f, v, attr, [](const float*) { return true; },
             [&](size_t si, bool) {
-                if ((f.winding[si] & f.winding_mask) != 0) { // Less: ref 0 < stencil
-                    float* dst = &f.color[si * 4];
-                    for (int c = 0; c < 4; ++c) dst[c] = src[c] + dst[c] * one_minus_a;
+                const uint32_t st = f.winding[si];
+                float* dst = &f.color[si * 4];
+                switch (op) {
+                    case CRH_OP_COLOR: // Less(ref < stencil): blend premultiplied "over"; pass -> Zero, fail -> Zero on the winding bits (renderer.rs:747-752)
+                        if ((ref & read_mask) < (st & read_mask))
+                            for (int c = 0; c < 4; ++c) dst[c] = src[c] + dst[c] * one_minus_a;
+                        f.winding[si] = (uint8_t)(st & ~f.winding_mask);
+                        break;
+                    case CRH_OP_CLIP: // NotEqual on the winding bits -> Replace(ref) on clip | winding (renderer.rs:703-708)
+                        if ((ref & f.winding_mask) != (st & f.winding_mask)) f.winding[si] = (uint8_t)((st & ~read_mask) | (ref & read_mask));
+                        break;
+                    case CRH_OP_UNCLIP: // Less on the clip bits (ref < stencil) -> Replace(ref) on clip | winding (renderer.rs:722-727)
+                        if ((ref & f.clip_mask) < (st & f.clip_mask)) f.winding[si] = (uint8_t)((st & ~read_mask) | (ref & read_mask));
+                        break;
+                    default: // the alpha-context covers: LessEqual(ref <= stencil), stencil write mask 0 (renderer.rs:761-766)
+                        if (layer && (ref & read_mask) <= (st & read_mask)) {
+                            if (op == CRH_OP_SAVE_ALPHA_CONTEXT) { // shaders.wgsl:326-331: the layer receives the frame's alpha
+                                (*layer)[si] = dst[3];
+                            } else if (op == CRH_OP_SCALE_ALPHA_CONTEXT) { // src = (0,0,0,1-a): alpha' = src.a * One + dst.a * (1 - src.a), renderer.rs:803-828
+                                const float sa = 1.0f - rgba[3];
+                                dst[3] = sa + dst[3] * (1.0f - sa);
+                            } else { // RestoreAlphaContext: src.a = (1 - saved)(1 - a); alpha' = dst.a * One - src.a * One, renderer.rs:829-861
+                                const float sa = (1.0f - (*layer)[si]) * (1.0f - rgba[3]);
+                                dst[3] = dst[3] - sa;
+                            }
+                        }
+                        break;
                 }
-                f.winding[si] = (uint8_t)(f.winding[si] & ~f.winding_mask); // pass -> Zero, fail -> Zero
             });
     }
 }
+inline void render_color(Frame& f, const Shape& shape, const float m[16], const float rgba[4]) { render_cover(f, shape, m, rgba, CRH_OP_COLOR, 0); }
 
 // MSAA resolve (box average) + RGBA8 unorm
 inline void resolve_rgba8(const Frame& f, uint8_t* out) {

@@ -1,0 +1,151 @@
+"""RenderOperation::{Clip, UnClip, SaveAlphaContext, ScaleAlphaContext, RestoreAlphaContext} and instancing:
+the oracle's statement of renderer.rs:692-729,761-861 + shaders.wgsl:311-355 (CPU tests, hand-checkable), and the HIP tile rasterizer
+against it through crh_scene_render_draws (GPU tests, bit-exact)."""
+import numpy as np
+import pytest
+
+from contrast_renderer_amd import Path, batch_from_shapes
+from contrast_renderer_amd.renderer import RenderOperation as Op
+
+IDENTITY = np.eye(4, dtype=np.float32).reshape(-1)
+
+
+def rect(cx, cy, hx, hy):
+    return ([], [Path.from_rect((cx, cy), (hx, hy))])
+
+
+def clip_scene():
+    """Shape 0: a 24-gon used as clip; shapes 1, 2: rectangles drawn inside the clip; shape 3: a nested clip; shape 4: drawn after UnClip."""
+    shapes = [([], [Path.from_regular_polygon((0.0, 0.0), 0.6, 0.0, 24)]), rect(-0.3, 0.0, 0.5, 0.2), rect(0.3, 0.3, 0.5, 0.2),
+              rect(0.0, 0.0, 0.25, 0.9), rect(0.0, -0.6, 0.9, 0.1)]
+    colors = np.array([[1, 0, 0, 1], [0, 1, 0, 0.5], [0, 0, 1, 1], [1, 0, 1, 1], [1, 1, 0, 0.75]], dtype=np.float32)
+    transforms = np.tile(IDENTITY, (5, 1))
+    draws = [(0, 0, Op.Stencil, 0, 0), (0, 0, Op.Clip, 1, 0),            # clip_depth += 1; set_clip_depth; Clip
+             (1, 1, Op.Stencil, 1, 0), (1, 1, Op.Color, 1, 0),
+             (3, 3, Op.Stencil, 1, 0), (3, 3, Op.Clip, 2, 0),            # nested clip
+             (2, 2, Op.Stencil, 2, 0), (2, 2, Op.Color, 2, 0),
+             (3, 3, Op.UnClip, 1, 0),                                    # clip_depth -= 1; set_clip_depth; UnClip
+             (0, 0, Op.UnClip, 0, 0),
+             (4, 4, Op.Stencil, 0, 0), (4, 4, Op.Color, 0, 0)]
+    return batch_from_shapes(shapes), transforms, colors, draws
+
+
+def alpha_scene():
+    """An opacity group: save the frame's alpha under the group shape, scale it, draw the group's content, restore."""
+    shapes = [rect(0.0, 0.0, 0.9, 0.9), rect(0.0, 0.0, 0.6, 0.6), rect(-0.2, 0.1, 0.3, 0.5), rect(0.3, -0.2, 0.4, 0.2)]
+    colors = np.array([[0.2, 0.4, 0.8, 0.5], [0, 0, 0, 0.25], [1, 0, 0, 1], [0, 1, 0, 0.6]], dtype=np.float32)
+    transforms = np.tile(IDENTITY, (4, 1))
+    draws = [(0, 0, Op.Stencil, 0, 0), (0, 0, Op.Color, 0, 0),                    # background
+             (1, 1, Op.SaveAlphaContext, 0, 0), (1, 1, Op.ScaleAlphaContext, 0, 0),
+             (2, 2, Op.Stencil, 0, 0), (2, 2, Op.Color, 0, 0), (3, 3, Op.Stencil, 0, 0), (3, 3, Op.Color, 0, 0),
+             (1, 1, Op.RestoreAlphaContext, 0, 0)]
+    return batch_from_shapes(shapes), transforms, colors, draws
+
+
+def instanced_scene():
+    """One Shape, many instances (instance_indices of renderer.rs:271): the same star stroked + filled at different places / colours."""
+    from contrast_renderer_amd import scenes
+    sc = scenes.scene_mixed(3, (256, 256), seed=3)
+    rng = np.random.RandomState(9)
+    n = 12
+    transforms = scenes.place(256, 256, rng.uniform(30, 226, n), rng.uniform(30, 226, n), rng.uniform(10, 40, n))
+    colors = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0.3, 1, (n, 1))], axis=1).astype(np.float32)
+    draws = []
+    for i in range(n):
+        draws += [(i % 3, i, Op.Stencil, 0, 0), (i % 3, i, Op.Color, 0, 0)]
+    return sc["batch"], transforms, colors, draws
+
+
+def oracle_image(batch, transforms, colors, draws, size=192, msaa=1, clip_bits=4, layers=2):
+    from oracle.binding import Oracle, render_draws
+    o = Oracle(batch)
+    assert o.status() == 0
+    return render_draws(o, size, size, msaa, 4, clip_bits, layers, transforms, colors, [tuple(int(v) for v in d) for d in draws])
+
+
+def pixel(img, x, y, size=192):  # scene coordinates in [-1, 1], y up
+    return img[int((0.5 - y * 0.5) * size), int((x * 0.5 + 0.5) * size)]
+
+
+def test_oracle_clip_nesting_known_answers(oracle_lib):
+    batch, t, c, draws = clip_scene()
+    img = oracle_image(batch, t, c, draws)
+    assert tuple(pixel(img, -0.3, 0.0)) == (0, 128, 0, 128)       # green 50 %, inside the clip polygon
+    assert tuple(pixel(img, -0.75, 0.0)) == (0, 0, 0, 0)          # the same rectangle outside the polygon: clipped away
+    assert tuple(pixel(img, 0.1, 0.3)) == (0, 0, 255, 255)        # blue: inside polygon AND inside the nested clip |x| < 0.25
+    assert tuple(pixel(img, 0.4, 0.3)) == (0, 0, 0, 0)            # blue rectangle outside the nested clip
+    assert tuple(pixel(img, 0.0, 0.8)) == (0, 0, 0, 0)            # clip shapes themselves are never coloured
+    assert tuple(pixel(img, 0.8, -0.6)) == (191, 191, 0, 191)     # drawn after both UnClips, outside the polygon: not clipped
+    # without the UnClips the last shape would be confined to the clips
+    clipped = oracle_image(batch, t, c, [d for d in draws if d[2] != Op.UnClip][:-2] + [(4, 4, Op.Stencil, 2, 0), (4, 4, Op.Color, 2, 0)])
+    assert tuple(pixel(clipped, 0.8, -0.6)) == (0, 0, 0, 0)
+
+
+def test_oracle_alpha_context_known_answers(oracle_lib):
+    batch, t, c, draws = alpha_scene()
+    img = oracle_image(batch, t, c, draws)
+    base = oracle_image(batch, t, c, draws[:2])
+    assert tuple(pixel(base, 0.8, 0.8)) == tuple(pixel(img, 0.8, 0.8)) == (26, 51, 102, 128)  # outside the group: untouched
+    # inside the group, away from its content: alpha goes 0.5 -> scale: (1-a) + 0.5*a with a = 0.25 -> 0.875
+    #                                          -> restore: 0.875 - (1 - 0.5) * (1 - 0.25) = 0.5 again
+    assert tuple(pixel(img, 0.5, 0.5)) == (26, 51, 102, 128)
+    # under the opaque red content: colour = red over background, alpha: scaled 0.875 -> over with a=1 -> 1 -> restore 1 - 0.375 = 0.625
+    assert tuple(pixel(img, -0.2, 0.4)) == (255, 0, 0, 159)
+
+
+def test_oracle_draw_validation(oracle_lib):
+    from oracle.binding import Oracle, render_draws
+    batch, t, c, draws = clip_scene()
+    o = Oracle(batch)
+    with pytest.raises(RuntimeError, match="2"):  # ClipStackOverflow: depth 2 does not fit 1 clip bit
+        render_draws(o, 64, 64, 1, 4, 1, 0, t, c, [tuple(int(v) for v in d) for d in draws])
+    with pytest.raises(RuntimeError, match="3"):  # TooManyNestedOpacityGroups
+        render_draws(o, 64, 64, 1, 4, 4, 1, t, c, [(0, 0, int(Op.SaveAlphaContext), 0, 1)])
+
+
+CASES = {"clip": clip_scene, "alpha": alpha_scene, "instanced": instanced_scene}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_recorded_pass_matches_the_oracle(case, msaa, oracle_lib):
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    batch, t, c, draws = CASES[case]()
+    size = 256 if case == "instanced" else 192
+    r = R.Renderer(R.Configuration(msaa_sample_count=msaa, clip_nesting_counter_bits=4, winding_counter_bits=4, alpha_layer_count=2), device=0)
+    scene = R.Scene(r, batch)
+    assert scene.status() == 0
+    frame = R.Frame(r, size, size)
+    frame.clear()
+    scene.render_draws(frame, t, c, draws)
+    image = frame.download()
+    expect = oracle_image(batch, t, c, draws, size=size, msaa=msaa)
+    diff = (image != expect).any(axis=2)
+    assert not diff.any(), f"{case} msaa {msaa}: {diff.sum()} pixels differ"
+    assert (image[..., 3] > 0).mean() > 0.02
+    # the plain pass afterwards still works on the same frame / scene objects
+    if case != "instanced":
+        frame.clear()
+        scene.render(frame, t, c)
+        assert np.array_equal(frame.download(), oracle_lib.Oracle(batch).render(size, size, msaa, 4, t, c))
+
+
+@pytest.mark.gpu
+def test_recorded_pass_errors_match_the_reference(oracle_lib):
+    from contrast_renderer_amd import ContrastError, _ffi
+    from contrast_renderer_amd import renderer as R
+    batch, t, c, draws = clip_scene()
+    r = R.Renderer(R.Configuration(msaa_sample_count=1, clip_nesting_counter_bits=1, winding_counter_bits=4, alpha_layer_count=1), device=0)
+    scene = R.Scene(r, batch)
+    frame = R.Frame(r, 64, 64)
+    with pytest.raises(ContrastError) as e:
+        scene.render_draws(frame, t, c, draws)  # depth 2 with one clip bit (renderer.rs:933-935)
+    assert e.value.status == _ffi.ERR_CLIP_STACK_OVERFLOW
+    with pytest.raises(ContrastError) as e:
+        scene.render_draws(frame, t, c, [(0, 0, Op.SaveAlphaContext, 0, 1)])  # layer 1 of 1 (renderer.rs:947-949)
+    assert e.value.status == _ffi.ERR_TOO_MANY_NESTED_OPACITY_GROUPS
+    with pytest.raises(ContrastError):
+        scene.render_draws(frame, t, c, [(9, 0, Op.Stencil, 0, 0)])  # no such Shape
