@@ -1,0 +1,483 @@
+// contrast_renderer.hpp — header-only C++17 host mirror of the reference's public API for the hot path, over the C ABI of
+// contrast_hip.h: the same type and function names, argument order, ownership and error behaviour as the Rust crate
+// (Lichtso/contrast_renderer v0.1.4, citations relative to its tree), so that code written against
+//     contrast_renderer::path::{Path, StrokeOptions, DynamicStrokeOptions, ...}          (src/path.rs)
+//     contrast_renderer::renderer::{Configuration, Renderer, Shape, RenderOperation}     (src/renderer.rs)
+//     contrast_renderer::text::{Font, Layout, paths_of_glyph, paths_of_text}             (src/text.rs)
+// reads the same here. wgpu's Device / Queue / RenderPass become HIP-backed handles (a device ordinal, a Frame and a recorded
+// RenderPass). Errors: Result<_, Error> becomes `throw Error` with the reference's variants (error.rs:5-16) in `Error::status`; the
+// reference's panics (non-finite input, degenerate cubic) surface as status 6 / 7 instead of aborting the process.
+//
+// The Rust toolchain is absent from the build image, so this C++ mirror (and the ctypes one in contrast_renderer_amd/) is what the
+// tests drive; INTEGRATION.md shows the equivalent Rust shim.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "contrast_hip.h"
+
+namespace contrast_renderer {
+
+// ---------------------------------------------------------------------------------------------- error.rs
+struct Error : std::runtime_error {
+    crh_status status;
+    explicit Error(crh_status s) : std::runtime_error(describe(s)), status(s) {}
+    static std::string describe(crh_status s) {
+        static const char* names[] = {"Ok", "NumberOfStencilBitsIsUnsupported", "ClipStackOverflow", "TooManyNestedOpacityGroups", "TooManyDashIntervals",
+                                      "DynamicStrokeOptionsIndexOutOfBounds", "NonFinite (the reference panics: safe_float.rs:46)",
+                                      "DegenerateCubic (the reference panics: fill.rs:174,178)", "Unsupported", "Hip", "InvalidArgument"};
+        std::string text = s <= CRH_ERR_INVALID_ARGUMENT ? names[s] : "unknown";
+        const char* detail = crh_last_error();
+        if ((s == CRH_ERR_HIP || s == CRH_ERR_INVALID_ARGUMENT) && detail && *detail) text += std::string(": ") + detail;
+        return text;
+    }
+};
+inline void check(crh_status s) {
+    if (s != CRH_OK) throw Error(s);
+}
+
+// ---------------------------------------------------------------------------------------------- safe_float.rs
+// SafeFloat::from (safe_float.rs:44-52): finite or panic, -0.0 -> +0.0
+inline float safe_float(float v) {
+    if (!std::isfinite(v)) throw Error(CRH_ERR_NON_FINITE);
+    return v == 0.0f ? 0.0f : v;
+}
+using Vec2 = std::pair<float, float>;
+
+// ---------------------------------------------------------------------------------------------- path.rs
+enum class SegmentType : uint8_t { Line = 0, IntegralQuadraticCurve = 1, IntegralCubicCurve = 2, RationalQuadraticCurve = 3, RationalCubicCurve = 4 }; // :56-67
+enum class Join : uint32_t { Miter = 0, Bevel = 1, Round = 2 };                                                                                     // :71-82
+enum class Cap : uint32_t { Square = 0, Round = 1, Out = 2, In = 3, Right = 4, Left = 5, Butt = 6 };                                               // :86-101
+
+struct DashInterval { // path.rs:105-118
+    float gap_start, gap_end;
+    Cap dash_start, dash_end;
+};
+
+struct DynamicStrokeOptions { // path.rs:127-149: Dashed { join, pattern, phase } | Solid { join, start, end }
+    bool dashed = false;
+    Join join = Join::Miter;
+    std::vector<DashInterval> pattern;
+    float phase = 0.0f;
+    Cap start = Cap::Butt, end = Cap::Butt;
+    static DynamicStrokeOptions Dashed(Join join, std::vector<DashInterval> pattern, float phase) {
+        DynamicStrokeOptions o;
+        o.dashed = true;
+        o.join = join;
+        o.pattern = std::move(pattern);
+        o.phase = safe_float(phase);
+        return o;
+    }
+    static DynamicStrokeOptions Solid(Join join, Cap start, Cap end) {
+        DynamicStrokeOptions o;
+        o.join = join;
+        o.start = start;
+        o.end = end;
+        return o;
+    }
+    crh_dynamic_stroke_options to_c() const {
+        crh_dynamic_stroke_options c = {};
+        c.dashed = dashed ? 1u : 0u;
+        c.join = (uint32_t)join;
+        c.pattern_len = (uint32_t)pattern.size(); // > 4 is reported by the library as TooManyDashIntervals, like renderer.rs:32-34
+        for (size_t i = 0; i < pattern.size() && i < CRH_MAX_DASH_INTERVALS; ++i)
+            c.pattern[i] = crh_dash_interval{safe_float(pattern[i].gap_start), safe_float(pattern[i].gap_end), (uint32_t)pattern[i].dash_start, (uint32_t)pattern[i].dash_end};
+        c.phase = phase;
+        c.start = (uint32_t)start;
+        c.end = (uint32_t)end;
+        return c;
+    }
+};
+
+struct CurveApproximation { // path.rs:153-167
+    bool uniform_tangent_angle = false;
+    uint32_t steps = 1;
+    float angle = 0.0f;
+    static CurveApproximation UniformlySpacedParameters(uint32_t steps) { return CurveApproximation{false, steps, 0.0f}; }
+    static CurveApproximation UniformTangentAngle(float angle) { return CurveApproximation{true, 0u, safe_float(angle)}; }
+};
+
+struct StrokeOptions { // path.rs:171-192
+    float width = 1.0f, offset = 0.0f, miter_clip = 1.0f;
+    bool closed = false;
+    uint32_t dynamic_stroke_options_group = 0;
+    CurveApproximation curve_approximation = CurveApproximation::UniformlySpacedParameters(1);
+    void legalize() { // path.rs:196-200
+        width = std::fabs(width);
+        offset = std::fmin(std::fmax(offset, -0.5f), 0.5f);
+        miter_clip = std::fabs(miter_clip);
+    }
+    crh_stroke_options to_c() const {
+        crh_stroke_options c = {};
+        c.width = safe_float(width);
+        c.offset = safe_float(offset);
+        c.miter_clip = safe_float(miter_clip);
+        c.closed = closed ? 1u : 0u;
+        c.dynamic_stroke_options_group = dynamic_stroke_options_group;
+        c.curve_approximation = curve_approximation.uniform_tangent_angle ? CRH_CURVE_UNIFORM_TANGENT_ANGLE : CRH_CURVE_UNIFORMLY_SPACED_PARAMETERS;
+        c.steps = curve_approximation.steps;
+        c.angle_step = curve_approximation.angle;
+        return c;
+    }
+};
+
+// Path (path.rs:213-230). The five typed segment Vecs + segment_types of the reference are kept as one interleaved record list in
+// segment order, which is what the SoA batch of the C ABI wants.
+class Path {
+  public:
+    Vec2 start{0.0f, 0.0f};
+    std::optional<StrokeOptions> stroke_options;
+    std::vector<SegmentType> segment_types;
+    std::vector<float> control; // per segment {2, 4, 6, 5, 10} floats, layouts of path.rs:15-52
+
+    void push_line(Vec2 p) { // path.rs:234-237
+        segment_types.push_back(SegmentType::Line);
+        put(p);
+    }
+    void push_integral_quadratic_curve(Vec2 c0, Vec2 c1) { // path.rs:240-243
+        segment_types.push_back(SegmentType::IntegralQuadraticCurve);
+        put(c0), put(c1);
+    }
+    void push_integral_cubic_curve(Vec2 c0, Vec2 c1, Vec2 c2) { // path.rs:246-249
+        segment_types.push_back(SegmentType::IntegralCubicCurve);
+        put(c0), put(c1), put(c2);
+    }
+    void push_rational_quadratic_curve(float weight, Vec2 c0, Vec2 c1) { // path.rs:252-255
+        segment_types.push_back(SegmentType::RationalQuadraticCurve);
+        control.push_back(safe_float(weight));
+        put(c0), put(c1);
+    }
+    void push_rational_cubic_curve(const float (&weights)[4], Vec2 c0, Vec2 c1, Vec2 c2) { // path.rs:258-261
+        segment_types.push_back(SegmentType::RationalCubicCurve);
+        for (float w : weights) control.push_back(safe_float(w));
+        put(c0), put(c1), put(c2);
+    }
+    Vec2 get_end() const { return control.empty() ? start : Vec2{control[control.size() - 2], control[control.size() - 1]}; } // path.rs:266-290
+
+    static Path from_polygon(const std::vector<Vec2>& vertices) { // path.rs:711-724
+        Path path;
+        path.start = Vec2{safe_float(vertices.at(0).first), safe_float(vertices.at(0).second)};
+        for (size_t i = 1; i < vertices.size(); ++i) path.push_line(vertices[i]);
+        return path;
+    }
+    static Path from_regular_polygon(Vec2 center, float radius, float rotation, size_t vertex_count) { // path.rs:727-734
+        std::vector<Vec2> vertices;
+        for (size_t i = 0; i < vertex_count; ++i) {
+            const float angle = rotation + (float)i / (float)vertex_count * 3.14159265358979323846f * 2.0f;
+            vertices.push_back(Vec2{center.first + radius * std::cos(angle), center.second + radius * std::sin(angle)});
+        }
+        return from_polygon(vertices);
+    }
+    static Path from_rect(Vec2 center, Vec2 half_extent) { // path.rs:736-743
+        const float cx = center.first, cy = center.second, hx = half_extent.first, hy = half_extent.second;
+        return from_polygon({{cx - hx, cy - hy}, {cx - hx, cy + hy}, {cx + hx, cy + hy}, {cx + hx, cy - hy}});
+    }
+
+  private:
+    void put(Vec2 p) {
+        control.push_back(safe_float(p.first));
+        control.push_back(safe_float(p.second));
+    }
+};
+
+// Flattens the argument lists of Shape::from_paths (renderer.rs:177-183), one per Shape, into the SoA crh_path_batch.
+class PathBatch {
+  public:
+    void add_shape(const std::vector<DynamicStrokeOptions>& dynamic_stroke_options, const std::vector<Path>& paths) {
+        for (const Path& path : paths) {
+            path_start_.push_back(path.start.first);
+            path_start_.push_back(path.start.second);
+            if (path.stroke_options) {
+                path_stroke_.push_back((int32_t)stroke_options_.size());
+                stroke_options_.push_back(path.stroke_options->to_c());
+            } else {
+                path_stroke_.push_back(-1);
+            }
+            for (SegmentType t : path.segment_types) types_.push_back((uint8_t)t);
+            control_.insert(control_.end(), path.control.begin(), path.control.end());
+            path_segment_begin_.push_back((uint32_t)types_.size());
+        }
+        shape_path_begin_.push_back((uint32_t)path_stroke_.size());
+        for (const DynamicStrokeOptions& o : dynamic_stroke_options) dynamic_.push_back(o.to_c());
+        shape_dynamic_begin_.push_back((uint32_t)dynamic_.size());
+    }
+    uint32_t n_shapes() const { return (uint32_t)shape_path_begin_.size() - 1u; }
+    crh_path_batch view() const {
+        crh_path_batch b = {};
+        b.n_shapes = n_shapes();
+        b.shape_path_begin = shape_path_begin_.data();
+        b.n_paths = (uint32_t)path_stroke_.size();
+        b.path_segment_begin = path_segment_begin_.data();
+        b.path_start = path_start_.data();
+        b.path_stroke_options = path_stroke_.data();
+        b.n_segments = (uint32_t)types_.size();
+        b.segment_types = types_.data();
+        b.control_data = control_.data();
+        b.n_control_floats = (uint32_t)control_.size();
+        b.n_stroke_options = (uint32_t)stroke_options_.size();
+        b.stroke_options = stroke_options_.data();
+        b.shape_dynamic_begin = shape_dynamic_begin_.data();
+        b.n_dynamic_stroke_options = (uint32_t)dynamic_.size();
+        b.dynamic_stroke_options = dynamic_.data();
+        return b;
+    }
+
+  private:
+    std::vector<uint32_t> shape_path_begin_{0u}, path_segment_begin_{0u}, shape_dynamic_begin_{0u};
+    std::vector<float> path_start_, control_;
+    std::vector<int32_t> path_stroke_;
+    std::vector<uint8_t> types_;
+    std::vector<crh_stroke_options> stroke_options_;
+    std::vector<crh_dynamic_stroke_options> dynamic_;
+};
+
+// ---------------------------------------------------------------------------------------------- renderer.rs
+enum class RenderOperation : uint32_t { Stencil = 0, Clip = 1, UnClip = 2, Color = 3, SaveAlphaContext = 4, ScaleAlphaContext = 5, RestoreAlphaContext = 6 }; // :145-160
+
+struct Configuration { // renderer.rs:380-405, the fields that change results on this path
+    uint32_t msaa_sample_count = 1, clip_nesting_counter_bits = 4, winding_counter_bits = 4, alpha_layer_count = 0;
+};
+
+class Renderer { // renderer.rs:408-435
+  public:
+    Renderer(int device, const Configuration& config) { // Renderer::new(&device, config) -> Result<Renderer, Error>
+        const crh_config c = {config.msaa_sample_count, config.clip_nesting_counter_bits, config.winding_counter_bits, config.alpha_layer_count};
+        check(crh_renderer_create(&c, device, &handle_));
+    }
+    ~Renderer() { crh_renderer_destroy(handle_); }
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+    Configuration get_config() const { // renderer.rs:887
+        crh_config c;
+        check(crh_renderer_get_config(handle_, &c));
+        return Configuration{c.msaa_sample_count, c.clip_nesting_counter_bits, c.winding_counter_bits, c.alpha_layer_count};
+    }
+    void synchronize() { check(crh_renderer_synchronize(handle_)); }
+    crh_renderer* raw() const { return handle_; }
+
+  private:
+    crh_renderer* handle_ = nullptr;
+};
+
+// The caller-owned colour + depth/stencil attachments of the render pass (examples/showcase/main.rs:217-230).
+class Frame {
+  public:
+    Frame(Renderer& renderer, uint32_t width, uint32_t height) : width_(width), height_(height) { check(crh_frame_create(renderer.raw(), width, height, &handle_)); }
+    ~Frame() { crh_frame_destroy(handle_); }
+    Frame(const Frame&) = delete;
+    Frame& operator=(const Frame&) = delete;
+    void clear() { check(crh_frame_clear(handle_)); } // LoadOp::Clear(TRANSPARENT) + stencil clear
+    std::vector<uint8_t> download() {                 // MSAA resolve + read back: premultiplied RGBA8, row 0 = top
+        std::vector<uint8_t> out((size_t)width_ * height_ * 4);
+        check(crh_frame_download(handle_, out.data()));
+        return out;
+    }
+    uint32_t width() const { return width_; }
+    uint32_t height() const { return height_; }
+    crh_frame* raw() const { return handle_; }
+
+  private:
+    crh_frame* handle_ = nullptr;
+    uint32_t width_, height_;
+};
+
+struct ShapeBuffers { // the byte image Shape::from_paths uploads (renderer.rs:198-209)
+    uint64_t vertex_offsets[8], index_offsets[3];
+    std::vector<uint8_t> vertex_bytes, index_bytes;
+};
+
+class RenderPass;
+
+// A batch of Shapes built together (one launch tessellates all of them). Shape below is the n == 1 case with the reference's signature.
+class Scene {
+  public:
+    Scene(Renderer& renderer, const PathBatch& batch, Scene* existing = nullptr) : n_shapes_(batch.n_shapes()) {
+        const crh_path_batch view = batch.view();
+        check(crh_scene_upload(renderer.raw(), &view, existing ? existing->release() : nullptr, &handle_));
+        check(crh_scene_tessellate(handle_));
+        const crh_status st = crh_scene_status(handle_); // surfaces the reference's panics at the call site, like the reference
+        if (st != CRH_OK) {
+            crh_scene_destroy(handle_);
+            throw Error(st);
+        }
+    }
+    ~Scene() {
+        if (handle_) crh_scene_destroy(handle_);
+    }
+    Scene(Scene&& other) noexcept : handle_(other.release()), n_shapes_(other.n_shapes_) {}
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+    uint32_t n_shapes() const { return n_shapes_; }
+    ShapeBuffers buffers(uint32_t shape) const {
+        ShapeBuffers b;
+        check(crh_scene_shape_layout(handle_, shape, b.vertex_offsets, b.index_offsets));
+        b.vertex_bytes.resize(b.vertex_offsets[7]);
+        b.index_bytes.resize(b.index_offsets[2]);
+        check(crh_scene_shape_download(handle_, shape, b.vertex_bytes.data(), b.index_bytes.data()));
+        return b;
+    }
+    // Shape::set_dynamic_stroke_options (renderer.rs:360-376)
+    void set_dynamic_stroke_options(uint32_t shape, size_t dynamic_stroke_options_index, const DynamicStrokeOptions& options) {
+        const crh_dynamic_stroke_options c = options.to_c();
+        check(crh_scene_set_dynamic_stroke_options(handle_, shape, (uint32_t)dynamic_stroke_options_index, &c));
+    }
+    // Stencil + Color of every Shape in index order, instance i = Shape i (the loop of examples/showcase/main.rs:236-250)
+    void render(Frame& frame, const std::vector<float>& transforms, const std::vector<float>& colors) {
+        if (transforms.size() != (size_t)n_shapes_ * 16 || colors.size() != (size_t)n_shapes_ * 4) throw Error(CRH_ERR_INVALID_ARGUMENT);
+        check(crh_scene_render(handle_, frame.raw(), transforms.data(), colors.data()));
+    }
+    crh_scene* raw() const { return handle_; }
+    crh_scene* release() {
+        crh_scene* h = handle_;
+        handle_ = nullptr;
+        return h;
+    }
+
+  private:
+    crh_scene* handle_ = nullptr;
+    uint32_t n_shapes_ = 0;
+};
+
+// wgpu::RenderPass stand-in: records Shape::render calls with the pass state they see and submits them as one draw list.
+class RenderPass {
+  public:
+    RenderPass(Renderer& renderer, Frame& frame) : config_(renderer.get_config()), frame_(frame) {}
+    // instance data of the pass (the instance buffers bound at slot 0 / 2, renderer.rs:462-466): returns the instance index
+    uint32_t push_instance(const float (&transform)[16], const float (&color)[4]) {
+        transforms_.insert(transforms_.end(), transform, transform + 16);
+        colors_.insert(colors_.end(), color, color + 4);
+        return (uint32_t)(colors_.size() / 4 - 1);
+    }
+    // Renderer::set_clip_depth (renderer.rs:932-938)
+    void set_clip_depth(size_t clip_depth) {
+        if (clip_depth >= ((size_t)1 << config_.clip_nesting_counter_bits)) throw Error(CRH_ERR_CLIP_STACK_OVERFLOW);
+        clip_depth_ = (uint32_t)clip_depth;
+    }
+    // Renderer::save_alpha_context / restore_alpha_context (renderer.rs:941-985) select the layer of the following alpha-context draws
+    void set_alpha_layer(size_t alpha_layer) {
+        if (alpha_layer >= config_.alpha_layer_count) throw Error(CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS);
+        alpha_layer_ = (uint32_t)alpha_layer;
+    }
+    // Shape::render(&renderer, &mut render_pass, instance_indices, render_operation) (renderer.rs:267-273) for Shape `shape` of `scene`
+    void render(const Scene& scene, uint32_t shape, uint32_t first_instance, uint32_t end_instance, RenderOperation op) {
+        if (scene_ && scene_ != &scene) throw Error(CRH_ERR_UNSUPPORTED); // one Scene per pass
+        scene_ = &scene;
+        for (uint32_t i = first_instance; i < end_instance; ++i) draws_.push_back(crh_draw{shape, i, (uint32_t)op, clip_depth_, alpha_layer_});
+    }
+    // end of the pass: everything recorded executes in order
+    void submit() {
+        if (!scene_) return;
+        check(crh_scene_render_draws(scene_->raw(), frame_.raw(), transforms_.data(), colors_.data(), (uint32_t)(colors_.size() / 4), draws_.data(), (uint32_t)draws_.size()));
+        draws_.clear();
+    }
+
+  private:
+    Configuration config_;
+    Frame& frame_;
+    const Scene* scene_ = nullptr;
+    std::vector<float> transforms_, colors_;
+    std::vector<crh_draw> draws_;
+    uint32_t clip_depth_ = 0, alpha_layer_ = 0;
+};
+
+// Shape (renderer.rs:163-171): `Shape::from_paths(&device, &renderer, &dynamic_stroke_options, &paths, existing_shape)` (renderer.rs:177-183)
+class Shape : public Scene {
+  public:
+    static Shape from_paths(Renderer& renderer, const std::vector<DynamicStrokeOptions>& dynamic_stroke_options, const std::vector<Path>& paths,
+                            Shape* existing_shape = nullptr) {
+        PathBatch batch;
+        batch.add_shape(dynamic_stroke_options, paths);
+        return Shape(renderer, batch, existing_shape);
+    }
+    ShapeBuffers buffers() const { return Scene::buffers(0); }
+    void set_dynamic_stroke_options(size_t dynamic_stroke_options_index, const DynamicStrokeOptions& options) { // renderer.rs:360-376
+        Scene::set_dynamic_stroke_options(0, dynamic_stroke_options_index, options);
+    }
+    // Shape::render for one pass: see RenderPass::render(scene, 0, instances..., op)
+    void render(RenderPass& pass, uint32_t first_instance, uint32_t end_instance, RenderOperation op) const { pass.render(*this, 0, first_instance, end_instance, op); }
+
+  private:
+    Shape(Renderer& renderer, const PathBatch& batch, Shape* existing) : Scene(renderer, batch, existing) {}
+};
+
+// ---------------------------------------------------------------------------------------------- text.rs
+enum class Orientation : uint32_t { RightToLeft = 0, LeftToRight = 1, TopToBottom = 2, BottomToTop = 3 }; // :106-117
+enum class Alignment : uint32_t { Begin = 0, Baseline = 1, Center = 2, End = 3 };                       // :119-131
+struct Layout {                                                                                         // :133-143
+    float size;
+    Orientation orientation = Orientation::LeftToRight;
+    Alignment major_alignment = Alignment::Begin, minor_alignment = Alignment::Baseline;
+};
+
+class Font { // text.rs:11-38; face() of the reference returns the parsed ttf_parser::Face — here the Font is the face
+  public:
+    Font(std::string name, const std::vector<uint8_t>& font_data) : name_(std::move(name)) { check(crh_font_create(font_data.data(), font_data.size(), &handle_)); }
+    ~Font() { crh_font_destroy(handle_); }
+    Font(const Font&) = delete;
+    Font& operator=(const Font&) = delete;
+    const std::string& name() const { return name_; }
+    const Font& face() const { return *this; }
+    crh_font_metrics metrics() const {
+        crh_font_metrics m;
+        check(crh_font_get_metrics(handle_, &m));
+        return m;
+    }
+    std::optional<uint16_t> glyph_index(char32_t c) const {
+        uint16_t glyph;
+        uint32_t found;
+        check(crh_font_glyph_index(handle_, (uint32_t)c, &glyph, &found));
+        return found ? std::optional<uint16_t>(glyph) : std::nullopt;
+    }
+    crh_font* raw() const { return handle_; }
+
+  private:
+    std::string name_;
+    crh_font* handle_ = nullptr;
+};
+
+namespace detail {
+inline std::vector<Path> take_paths(crh_path_list* list) {
+    crh_path_batch view;
+    const crh_status st = crh_path_list_view(list, &view);
+    std::vector<Path> out;
+    if (st == CRH_OK) {
+        static const int floats[5] = {2, 4, 6, 5, 10};
+        size_t at = 0;
+        for (uint32_t p = 0; p < view.n_paths; ++p) {
+            Path path;
+            path.start = Vec2{view.path_start[2 * p], view.path_start[2 * p + 1]};
+            for (uint32_t s = view.path_segment_begin[p]; s < view.path_segment_begin[p + 1]; ++s) {
+                path.segment_types.push_back((SegmentType)view.segment_types[s]);
+                path.control.insert(path.control.end(), view.control_data + at, view.control_data + at + floats[view.segment_types[s]]);
+                at += floats[view.segment_types[s]];
+            }
+            out.push_back(std::move(path));
+        }
+    }
+    crh_path_list_destroy(list);
+    check(st);
+    return out;
+}
+} // namespace detail
+
+inline std::vector<Path> paths_of_glyph(const Font& face, uint16_t glyph_id) { // text.rs:97-104
+    crh_path_list* list = nullptr;
+    check(crh_paths_of_glyph(face.raw(), glyph_id, &list));
+    return detail::take_paths(list);
+}
+// text.rs:236-263; clipping_area = clockwise convex polygon of (x, y) pairs, or empty
+inline std::vector<Path> paths_of_text(const Font& face, const Layout& layout, const std::u32string& text, const std::vector<Vec2>& clipping_area = {}) {
+    const crh_text_layout c = {layout.size, (uint32_t)layout.orientation, (uint32_t)layout.major_alignment, (uint32_t)layout.minor_alignment};
+    std::vector<float> clip;
+    for (const Vec2& p : clipping_area) clip.push_back(p.first), clip.push_back(p.second);
+    crh_path_list* list = nullptr;
+    check(crh_paths_of_text(face.raw(), &c, reinterpret_cast<const uint32_t*>(text.data()), text.size(), clip.empty() ? nullptr : clip.data(), clip.size() / 2, &list));
+    return detail::take_paths(list);
+}
+
+} // namespace contrast_renderer
