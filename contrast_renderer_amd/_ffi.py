@@ -205,6 +205,16 @@ class TextLayoutC(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so. If this library (linked against the system ROCm) is loaded first and torch
+    afterwards, the process holds two HIP runtimes and the second one sees no device. Importing torch first (when it is installed) makes
+    the dynamic loader bind libcontrast_hip.so to the runtime torch uses — which bench.py needs anyway to hand frames to RCCL."""
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
 def load_library():
     """Loads the HIP library. Fails loudly when it is missing: there is no CPU fallback in the product."""
     global _lib
@@ -213,6 +223,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). contrast_renderer_amd has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(LIB_PATH)
     V = C.c_void_p
     sig = {
