@@ -19,7 +19,7 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void*
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx);
-void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes);
+void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -452,7 +452,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
-    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes);
+    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     HIP_TRY(hipGetLastError());
     f->cleared = false;
     f->last_scene = sc;

@@ -557,7 +557,9 @@ __device__ __noinline__ bool stroke_dashed_joint(const crh_dynamic_stroke_descri
 //   OPS == true: the full RenderOperation set — every sample also carries the clip nesting counter and up to kMaxAlphaLayers saved
 //                alphas; OPS == false is the plain Stencil + Color pass at clip depth 0 (what the benchmark runs).
 constexpr int kMaxAlphaLayers = 4;
-template <int S, int ROWS, bool OPS>
+//   STROKES == false: the scene has no stroked path, so the stroke fragment stages (and the registers their out-of-line dashed pattern
+//                walk reserves) are compiled out: fewer VGPRs, more waves per SIMD.
+template <int S, int ROWS, bool OPS, bool STROKES>
 __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, RasterParams r) {
     __shared__ uint32_t sort_buffer[4 / ROWS][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
 
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, Ras
                         winding[b][k] += (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref) && lhs - rhs <= 0.0f) ? delta : 0;
                     }
                 }
-            } else { // KIND_LINE / KIND_JOINT: the stroke fragment stages
+            } else if (STROKES) { // KIND_LINE / KIND_JOINT: the stroke fragment stages
                 int any_inside = 0;
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
@@ -943,7 +945,7 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
     if (mark) mark(ctx, "raster_tile_scan", 0);
 }
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
-                   uint64_t raster_bytes) {
+                   uint64_t raster_bytes, bool has_stroke) {
     if (r.n_items) {
         if (samples == 4)
             hipLaunchKernelGGL((k_tile_walk<4, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
@@ -951,15 +953,22 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
             hipLaunchKernelGGL((k_tile_walk<1, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
     }
     if (mark) mark(ctx, "raster_tile_fill", 0);
-    if (samples == 4)
-        if (r.items)
-            hipLaunchKernelGGL((k_raster_tile<4, 1, true>), dim3(r.n_tiles), dim3(256), 0, stream, s, r);
-        else
-            hipLaunchKernelGGL((k_raster_tile<4, 1, false>), dim3(r.n_tiles), dim3(256), 0, stream, s, r);
-    else if (r.items)
-        hipLaunchKernelGGL((k_raster_tile<1, 4, true>), dim3(r.n_tiles), dim3(64), 0, stream, s, r);
-    else
-        hipLaunchKernelGGL((k_raster_tile<1, 4, false>), dim3(r.n_tiles), dim3(64), 0, stream, s, r);
+    const dim3 grid(r.n_tiles);
+#define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), 0, stream, s, r)
+    if (samples == 4) {
+        if (r.items) {
+            if (has_stroke) CRH_LAUNCH_TILE(4, 1, true, true); else CRH_LAUNCH_TILE(4, 1, true, false);
+        } else {
+            if (has_stroke) CRH_LAUNCH_TILE(4, 1, false, true); else CRH_LAUNCH_TILE(4, 1, false, false);
+        }
+    } else {
+        if (r.items) {
+            if (has_stroke) CRH_LAUNCH_TILE(1, 4, true, true); else CRH_LAUNCH_TILE(1, 4, true, false);
+        } else {
+            if (has_stroke) CRH_LAUNCH_TILE(1, 4, false, true); else CRH_LAUNCH_TILE(1, 4, false, false);
+        }
+    }
+#undef CRH_LAUNCH_TILE
     if (mark) mark(ctx, "raster_tiles", raster_bytes);
 }
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream) {
