@@ -28,6 +28,13 @@
 #include "raster_params.hpp"
 #include "scene.hpp"
 
+#ifndef CRH_TILE_WAVES
+#define CRH_TILE_WAVES 7
+#endif
+#ifndef CRH_WALK_WAVES
+#define CRH_WALK_WAVES 4
+#endif
+
 namespace crh {
 
 constexpr int kTile = 16;
@@ -455,14 +462,15 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
 }
 
 // ---------------------------------------------------------------------------------------------- k_tile_walk
-// Count pass (FILL = false) and fill pass (FILL = true) of the tile lists. One workgroup of 16 wavefronts per Shape; the Shape's
-// triangles are taken 64 at a time (lane = triangle) and wavefront w walks every 16th tile ROW of the chunk's tile rectangle, so the
-// largest Shapes (hundreds of tiles) do not leave one long serial tail.
+// Count pass (FILL = false) and fill pass (FILL = true) of the tile lists. One workgroup of kWalkWaves wavefronts per draw item; its
+// triangles are taken 64 at a time (lane = triangle) and wavefront w walks every kWalkWaves-th tile ROW of the chunk's tile rectangle,
+// so the largest Shapes (hundreds of tiles) do not leave one long serial tail (1 wave: 0.92 ms tail; 16 waves: idle waves dominate;
+// 4 measured best on the 10k-path scene).
 //   count: ballot of the lanes whose triangle can touch the tile -> ONE atomic per (chunk, tile)
 //   fill : lane 0 reserves popcount(ballot) slots of the tile's list with one returning atomic (consumed one iteration later, after
 //          the next tile's test has been computed, so its latency is hidden); every hit lane writes
 //          prim id at its rank.
-constexpr uint32_t kWalkWaves = 16;
+constexpr uint32_t kWalkWaves = CRH_WALK_WAVES;
 template <int S, bool FILL>
 __global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, RasterParams r) {
     const uint32_t shape = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -560,7 +568,7 @@ constexpr int kMaxAlphaLayers = 4;
 //   STROKES == false: the scene has no stroked path, so the stroke fragment stages (and the registers their out-of-line dashed pattern
 //                walk reserves) are compiled out: fewer VGPRs, more waves per SIMD.
 template <int S, int ROWS, bool OPS, bool STROKES>
-__global__ __launch_bounds__(64 * (4 / ROWS)) void k_raster_tile(SceneDev s, RasterParams r) {
+__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((OPS || STROKES || S == 4) ? 1 : CRH_TILE_WAVES))) void k_raster_tile(SceneDev s, RasterParams r) {
     __shared__ uint32_t sort_buffer[4 / ROWS][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
 
     const uint32_t tile = blockIdx.x;
