@@ -80,7 +80,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 CRH_D f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); } // two IEEE fmas (v_pk_fma_f32)
 CRH_D f32x2 splat2(float v) { return f32x2{v, v}; }
-CRH_D float readlane_f(float v, uint32_t lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)lane)); }
 template <class T>
 CRH_D T load_uniform(const T* p) { // p must be wave uniform
     static_assert(sizeof(T) % 16 == 0, "16-byte multiples");
@@ -570,6 +569,7 @@ constexpr int kMaxAlphaLayers = 4;
 template <int S, int ROWS, bool OPS, bool STROKES>
 __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((OPS || STROKES || S == 4) ? 1 : CRH_TILE_WAVES))) void k_raster_tile(SceneDev s, RasterParams r) {
     __shared__ uint32_t sort_buffer[4 / ROWS][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
+    __shared__ float4 entry_buffer[4 / ROWS][64 * 3];        // wave-private: the set-up values of the current chunk's 64 entries
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % r.tiles_x, ty = tile / r.tiles_x;
@@ -679,8 +679,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
         if (n > 64u) my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
         const uint32_t count = min(64u, n - q0);
-        // ---- entry setup, vectorised across the chunk: lane j prepares entry j (one gathered 64-byte record per lane), so that the
-        // per-entry loop below only has to pull wave-uniform values out of these registers with v_readlane
+        // ---- entry setup, vectorised across the chunk: lane j prepares entry j (one gathered 64-byte record per lane)
         uint32_t e_bits = 0, e_flags = 0, e_desc = 0;
         float e_c[3] = {0.0f, 0.0f, 0.0f}, e_bx[3] = {0.0f, 0.0f, 0.0f}, e_nay[3] = {0.0f, 0.0f, 0.0f};
         if (lane < count) {
@@ -698,9 +697,19 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 e_nay[i] = mine.nay[i];
             }
         }
+        // staged in LDS so that the loop reads entry j with three uniform-address (broadcast) ds_read_b128 — the LDS pipe instead of a
+        // dozen v_readlane on the VALU pipe, which is what bounds this kernel
+        float4* entries = entry_buffer[wave];
+        __builtin_amdgcn_wave_barrier(); // the previous chunk's reads are done
+        entries[lane * 3u + 0u] = make_float4(e_c[0], e_c[1], e_c[2], __uint_as_float(e_bits));
+        entries[lane * 3u + 1u] = make_float4(e_bx[0], e_bx[1], e_bx[2], __uint_as_float(e_flags));
+        entries[lane * 3u + 2u] = make_float4(e_nay[0], e_nay[1], e_nay[2], __uint_as_float(e_desc));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t j = 0; j < count; ++j) {
             const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
-            const uint32_t flags = __builtin_amdgcn_readlane(e_flags, j);
+            const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
+            const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
             const uint32_t kind = (flags >> 4) & 7u;
             const int clip_ref = OPS ? (int)((flags >> 16) & 255u) : 0; // the stencil reference of this draw: its clip depth
             // the second half of the record (attribute planes / cover colour) comes through a scalar load issued up front
@@ -715,11 +724,9 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             // unit; "the pixel is inside the clamped box" is a bit lookup in (column mask, row mask).
             bool inside[ROWS][S];
             {
-                const uint32_t bits = __builtin_amdgcn_readlane(e_bits, j);
+                const uint32_t bits = __float_as_uint(ea4.w);
+                const float c0 = ea4.x, c1 = ea4.y, c2 = ea4.z, bx_0 = eb4.x, bx_1 = eb4.y, bx_2 = eb4.z, nay_0 = ec4.x, nay_1 = ec4.y, nay_2 = ec4.z;
                 const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) : 0u;
-                const float c0 = readlane_f(e_c[0], j), c1 = readlane_f(e_c[1], j), c2 = readlane_f(e_c[2], j);
-                const float bx_0 = readlane_f(e_bx[0], j), bx_1 = readlane_f(e_bx[1], j), bx_2 = readlane_f(e_bx[2], j);
-                const float nay_0 = readlane_f(e_nay[0], j), nay_1 = readlane_f(e_nay[1], j), nay_2 = readlane_f(e_nay[2], j);
                 const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
                 // the ROWS * S (row, sample) combinations are taken two at a time
 #pragma unroll
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                     for (int k = 0; k < S; ++k) any_inside |= (int)inside[b][k];
                 if (__any(any_inside)) {
-                    const crh_dynamic_stroke_descriptor* d = &s.descriptors[__builtin_amdgcn_readlane(e_desc, j)];
+                    const crh_dynamic_stroke_descriptor* d = &s.descriptors[__builtin_amdgcn_readfirstlane(__float_as_uint(ec4.w))];
                     const uint32_t caps = d->caps, count_dashed_join = d->count_dashed_join; // wave uniform
                     const uint32_t flat_u = frag.flat_u;
                     const float end_y = frag.end_y;
