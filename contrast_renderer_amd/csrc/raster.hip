@@ -742,32 +742,35 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 }
             }
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+            // Every kind only produces the change of the winding counters (dw) and, for the colour cover, which samples blend; the state
+            // itself is updated once after the dispatch. (Updating winding / colour inside the multi-way dispatch made every iteration end
+            // with ~18 register-pair copies: the SSA join of 20 state registers over all kinds.)
+            int dw[ROWS][S];
+            bool blend[ROWS][S];
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    dw[b][k] = 0;
+                    blend[b][k] = false;
+                }
+            const uint32_t cover_op = OPS ? (flags >> 7) & 7u : (uint32_t)CRH_OP_COLOR;
+            const bool color_cover = kind == KIND_COVER && cover_op == CRH_OP_COLOR;
             if (kind == KIND_SOLID) { // stencil_solid
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                    for (int k = 0; k < S; ++k) winding[b][k] += (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref)) ? delta : 0; // LessEqual(ref <= stencil)
-                continue;
-            }
-            if (kind == KIND_COVER) {
-                const uint32_t cover_op = OPS ? (flags >> 7) & 7u : (uint32_t)CRH_OP_COLOR;
-                if (cover_op == CRH_OP_COLOR) { // color_cover + stencil Less / Zero (renderer.rs:747-752, shaders.wgsl:304-309)
-                    const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
-                    const float one_minus_a = 1.0f - ca;
+                    for (int k = 0; k < S; ++k) dw[b][k] = (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref)) ? delta : 0; // LessEqual(ref <= stencil)
+            } else if (kind == KIND_COVER) {
+                if (cover_op == CRH_OP_COLOR) { // stencil Less / Zero of color_cover (renderer.rs:747-752); the blend itself follows the dispatch
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int k = 0; k < S; ++k) {
                             // Less(ref < stencil) on clip | winding: a deeper clip level, or this level with a non-zero winding
                             const bool stencil_pass = OPS ? (clipc[OPS ? b : 0][OPS ? k : 0] > clip_ref || (clipc[OPS ? b : 0][OPS ? k : 0] == clip_ref && (winding[b][k] & wmask) != 0)) : (winding[b][k] & wmask) != 0;
-                            const bool blend = inside[b][k] && stencil_pass;
-                            const float n0 = s0 + col[b][k][0] * one_minus_a, n1 = s1 + col[b][k][1] * one_minus_a;
-                            const float n2 = s2 + col[b][k][2] * one_minus_a, n3 = ca + col[b][k][3] * one_minus_a;
-                            col[b][k][0] = blend ? n0 : col[b][k][0];
-                            col[b][k][1] = blend ? n1 : col[b][k][1];
-                            col[b][k][2] = blend ? n2 : col[b][k][2];
-                            col[b][k][3] = blend ? n3 : col[b][k][3];
-                            winding[b][k] = inside[b][k] ? 0 : winding[b][k];
+                            blend[b][k] = inside[b][k] && stencil_pass;
+                            dw[b][k] = inside[b][k] ? -winding[b][k] : 0; // pass -> Zero, fail -> Zero
                         }
                 } else if (OPS) {
                     // Clip / UnClip / the alpha-context covers, branch-free per sample (the operation is wave uniform)
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                             // -> Replace(ref) (renderer.rs:722-727); both rewrite clip | winding
                             const bool replace = in && ((is_clip && (winding[b][k] & wmask) != 0) || (is_unclip && clip_ref < clip_now));
                             clipc[cb_][ck_] = replace ? clip_ref : clip_now;
-                            winding[b][k] = replace ? 0 : winding[b][k];
+                            dw[b][k] = replace ? -winding[b][k] : 0;
                             // alpha-context covers: LessEqual(ref <= stencil), stencil untouched (renderer.rs:761-766)
                             const bool pass = in && clip_now >= clip_ref;
                             const float alpha = col[b][k][3];
@@ -803,8 +806,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                                 saved[cb_][ck_][l] = (pass && is_save && (uint32_t)l == layer) ? alpha : saved[cb_][ck_][l];
                         }
                 }
-                continue;
-            }
+            } else {
             // attribute planes, tile relative: ac = (a0 + (tx0 - v0x) * gx) + (ty0 - v0y) * gy; a = fma(sy, gy, fma(sx, gx, ac))
             const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
             float hx[4][S]; // the row-independent inner fma
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         const float a2 = fmaf(y, frag.gy[2], hx[2][k]), a3 = fmaf(y, frag.gy[3], hx[3][k]);
                         const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
                         const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
-                        winding[b][k] += (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref) && lhs - rhs <= 0.0f) ? delta : 0;
+                        dw[b][k] = (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref) && lhs - rhs <= 0.0f) ? delta : 0;
                     }
                 }
             } else if (STROKES) { // KIND_LINE / KIND_JOINT: the stroke fragment stages
@@ -867,10 +869,30 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                                     fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
                                     if (fill && dashed) fill = stroke_dashed_joint(d, radius, a0, a1, a2);
                                 }
-                                winding[b][k] += fill ? 1 : 0;
+                                dw[b][k] = fill ? 1 : 0;
                             }
                         }
                 }
+            }
+            } // kinds with attribute planes
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int k = 0; k < S; ++k) winding[b][k] += dw[b][k];
+            if (color_cover) { // color_cover: premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
+                const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
+                const float one_minus_a = 1.0f - ca;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const float n0 = s0 + col[b][k][0] * one_minus_a, n1 = s1 + col[b][k][1] * one_minus_a;
+                        const float n2 = s2 + col[b][k][2] * one_minus_a, n3 = ca + col[b][k][3] * one_minus_a;
+                        col[b][k][0] = blend[b][k] ? n0 : col[b][k][0];
+                        col[b][k][1] = blend[b][k] ? n1 : col[b][k][1];
+                        col[b][k][2] = blend[b][k] ? n2 : col[b][k][2];
+                        col[b][k][3] = blend[b][k] ? n3 : col[b][k][3];
+                    }
             }
         }
     }
