@@ -116,6 +116,7 @@ struct crh_frame {
     uint32_t n_items = 0;
     bool cleared = true;
     bool pairs_known = false;
+    uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
     // last render, for the transparent re-run after a bin-capacity overflow
     crh_scene* last_scene = nullptr;
     bool check_pending = false;
@@ -381,6 +382,17 @@ void assemble_shape(const crh_scene* sc, const HostCopy& h, uint32_t s, uint8_t*
     put(ib, h.solid_i, ((size_t)a[CH_SOLID_V] + a[CH_SOLID_END]) * 2, ((size_t)(b[CH_SOLID_V] - a[CH_SOLID_V]) + (b[CH_SOLID_END] - a[CH_SOLID_END])) * 2);
 }
 
+// the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
+bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
+    if (longest_list <= f->sort_capacity) return false;
+    const uint32_t limit = 32768u / (4u * (f->renderer->config.msaa_sample_count == 4 ? 4u : 1u)); // 32 KiB of dynamic LDS per workgroup (kSortBytesMax)
+    uint32_t capacity = f->sort_capacity;
+    while (capacity < longest_list && capacity < limit) capacity <<= 1;
+    const bool grew = capacity != f->sort_capacity;
+    f->sort_capacity = capacity; // lists beyond the limit are reported by the kernel as CRH_ERR_UNSUPPORTED
+    return grew;
+}
+
 crh_status render_impl(crh_scene* sc, crh_frame* f) {
     crh_renderer* r = sc->renderer;
     const bool recorded = f->n_items != 0; // crh_scene_render_draws stored a pass in the frame
@@ -433,18 +445,24 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.scan_scratch = f->scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec.p);
     p.overflow = f->overflow.as<uint32_t>();
+    p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
     r->begin_marks();
+    // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
+    // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
+    if (!f->cleared) f->pairs_known = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         p.tile_list = f->tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(f->tile_list.cap / 4);
         launch_bin(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r);
         if (f->pairs_known) break;
-        uint32_t ov[2];
-        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 8, hipMemcpyDeviceToHost, r->stream));
+        uint32_t ov[4];
+        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 16, hipMemcpyDeviceToHost, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream));
         f->pairs_known = true;
+        grow_sort_capacity(f, ov[3]);
+        p.sort_capacity = f->sort_capacity;
         if (ov[0] == 0) break;
         HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
         r->begin_marks();
@@ -464,11 +482,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
 crh_status settle_frame(crh_frame* f) {
     if (!f->check_pending) return CRH_OK;
     crh_renderer* r = f->renderer;
-    uint32_t ov[2];
-    HIP_TRY(hipMemcpyAsync(ov, f->overflow.p, 8, hipMemcpyDeviceToHost, r->stream));
+    uint32_t ov[4];
+    HIP_TRY(hipMemcpyAsync(ov, f->overflow.p, 16, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     f->check_pending = false;
-    if (ov[0] != 0 && f->last_scene) {
+    const bool sort_overflow = grow_sort_capacity(f, ov[3]);
+    if ((ov[0] != 0 || sort_overflow) && f->last_scene) {
         HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
         f->cleared = true; // a frame rendered over existing content cannot be recovered exactly; documented in DESIGN.md
         crh_status st = render_impl(f->last_scene, f);

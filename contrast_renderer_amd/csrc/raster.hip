@@ -38,7 +38,7 @@
 namespace crh {
 
 constexpr int kTile = 16;
-constexpr uint32_t kBandListMax = 1024; // primitives per band that the in-wave sort handles
+constexpr uint32_t kSortBytesMax = 32u * 1024u; // dynamic LDS per workgroup for the tile sort: 8 192 primitives per tile at msaa 1, 2 048 at msaa 4
 
 CRH_D float2 to_framebuffer(const float* m, float w, float h, float x, float y) { // oracle/raster.hpp to_framebuffer
     const float cx = (m[0] * x + m[4] * y) + m[12];
@@ -124,6 +124,7 @@ struct ScanJob {
     uint32_t* out;
     uint32_t* block_sum;
     uint32_t n, blocks;
+    uint32_t* max_out; // optional: atomicMax of the items (the longest tile list)
 };
 // candidate counts are transform independent: one lane per Shape (runs at the end of tessellation, before the scan)
 __global__ __launch_bounds__(256) void k_shape_ncand(SceneDev s, uint32_t* shape_ncand) {
@@ -149,6 +150,12 @@ __global__ __launch_bounds__(256) void k_scan_local(ScanJob j) {
     const uint32_t mine = v[0] + v[1] + v[2] + v[3];
     uint32_t incl = mine;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (j.max_out) {
+        uint32_t longest = max(max(v[0], v[1]), max(v[2], v[3]));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
+        if (lane == 0 && longest > 0u) atomicMax(j.max_out, longest);
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up = __shfl_up(incl, d, 64);
@@ -568,13 +575,13 @@ constexpr int kMaxAlphaLayers = 4;
 //                walk reserves) are compiled out: fewer VGPRs, more waves per SIMD.
 template <int S, int ROWS, bool OPS, bool STROKES>
 __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((OPS || STROKES || S == 4) ? 1 : CRH_TILE_WAVES))) void k_raster_tile(SceneDev s, RasterParams r) {
-    __shared__ uint32_t sort_buffer[4 / ROWS][kBandListMax]; // wave-private; only used by tiles with more than 64 primitives
+    extern __shared__ uint32_t sort_buffer[]; // [waves][r.sort_capacity], wave-private; only used by tiles with more than 64 primitives
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];        // wave-private: the set-up values of the current chunk's 64 entries
 
     const uint32_t tile = blockIdx.x;
     const uint32_t tx = tile % r.tiles_x, ty = tile / r.tiles_x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* keys = sort_buffer[wave];
+    uint32_t* __restrict__ keys = sort_buffer + wave * r.sort_capacity;
     const uint32_t px = lane & 15u, rq = lane >> 4;
     const uint32_t first_row = ROWS == 4 ? 0u : 4u * wave; // local row b of this lane is pixel row first_row + 4b + rq
     const uint32_t gx = tx * kTile + px;
@@ -634,8 +641,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 
     const uint32_t list_begin = r.tile_offset[tile];
     uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
-    if (n > kBandListMax) {
-        if (lane == 0) raise_error(s, 0, CRH_ERR_UNSUPPORTED);
+    if (n > r.sort_capacity) { // the host sizes the sort buffer from overflow[3] (the longest list) and runs the frame again
+        if (lane == 0 && n > kSortBytesMax / (4u * (4u / ROWS))) raise_error(s, 0, CRH_ERR_UNSUPPORTED); // beyond what LDS can sort
         n = 0;
     }
     // ---- draw order = ascending prim id: bitonic network in registers (<= 64 entries) or in LDS
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         }
         // staged in LDS so that the loop reads entry j with three uniform-address (broadcast) ds_read_b128 — the LDS pipe instead of a
         // dozen v_readlane on the VALU pipe, which is what bounds this kernel
-        float4* entries = entry_buffer[wave];
+        float4* __restrict__ entries = entry_buffer[wave];
         __builtin_amdgcn_wave_barrier(); // the previous chunk's reads are done
         entries[lane * 3u + 0u] = make_float4(e_c[0], e_c[1], e_c[2], __uint_as_float(e_bits));
         entries[lane * 3u + 1u] = make_float4(e_bx[0], e_bx[1], e_bx[2], __uint_as_float(e_flags));
@@ -938,7 +945,9 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* const* layers,
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-static ScanJob scan_job(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uint32_t n) { return ScanJob{in, out, block_sum, n, (n + 1023u) / 1024u}; }
+static ScanJob scan_job(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uint32_t n, uint32_t* max_out = nullptr) {
+    return ScanJob{in, out, block_sum, n, (n + 1023u) / 1024u, max_out};
+}
 
 // transform independent: contiguous primitive ids per Shape (runs at the end of tessellation)
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream) {
@@ -962,6 +971,7 @@ void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item
 }
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
+    (void)hipMemsetAsync(r.overflow, 0, 16, stream);
     if (r.n_items) {
         if (samples == 4)
             hipLaunchKernelGGL(k_prim_setup<4>, dim3(r.n_items), dim3(64), 0, stream, s, r);
@@ -976,7 +986,7 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
             hipLaunchKernelGGL((k_tile_walk<1, false>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
     }
     if (mark) mark(ctx, "raster_tile_count", 0);
-    const ScanJob j = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles);
+    const ScanJob j = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles, r.overflow + 3); // overflow[3] = longest tile list
     hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
     hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, r, 1);
     if (mark) mark(ctx, "raster_tile_scan", 0);
@@ -991,7 +1001,8 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
     }
     if (mark) mark(ctx, "raster_tile_fill", 0);
     const dim3 grid(r.n_tiles);
-#define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), 0, stream, s, r)
+#define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
+    hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {
         if (r.items) {
             if (has_stroke) CRH_LAUNCH_TILE(4, 1, true, true); else CRH_LAUNCH_TILE(4, 1, true, false);
