@@ -134,7 +134,7 @@ struct crh_scene {
     // inputs
     DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
     // scan state
-    DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, status;
+    DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, hull_large, status;
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
@@ -146,7 +146,7 @@ struct crh_scene {
 
     void release_all() {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
-                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &status, &line_v, &joint_v,
+                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec};
         for (DevBuf* b : all) b->release();
@@ -633,7 +633,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     for (uint32_t s = 0; s < b->n_shapes; ++s) {
         const uint32_t p0 = b->shape_path_begin[s], p1 = b->shape_path_begin[s + 1];
         const uint64_t segs = b->path_segment_begin[p1] - b->path_segment_begin[p0];
-        if (3 * segs + (p1 - p0) > 128) sc->big_shapes = true;
+        if (3 * segs + (p1 - p0) > 64) sc->big_shapes = true; // upper bound of the hull candidates (k_hull_small handles <= 64)
     }
     SceneDev& d = sc->d;
     std::memset(&d, 0, sizeof(d));
@@ -676,7 +676,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     if (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
         !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") ||
         !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
-        !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
+        !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((2 * (size_t)b->n_shapes + 2) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
         !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 4), "hipMalloc")) {
@@ -702,6 +702,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.totals = sc->totals.as<uint32_t>();
     d.shape_base = sc->shape_base.as<uint32_t>();
     d.hull_count = sc->hull_count.as<uint32_t>();
+    d.hull_large_count = sc->hull_large.as<uint32_t>();
+    d.hull_large_list = sc->hull_large.as<uint32_t>() + 2;
     d.status = sc->status.as<uint32_t>();
     if (!hip_ok(hipMemsetAsync(d.status, 0xFF, 4, st), "hipMemset")) {
         rc = CRH_ERR_HIP;

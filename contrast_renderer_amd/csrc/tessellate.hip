@@ -4,7 +4,7 @@
 //   k_scan    one workgroup: exclusive scan of the per-workgroup totals                 -> global offsets
 //   k_emit    one lane per path element: recompute and write at the scanned offsets     (fill.rs, stroke.rs)
 //   k_stroke_lengths  one lane per stroked path: replay the f32 running length sum in reference order (stroke.rs:156,307,111)
-//   k_hull    one wavefront per Shape: sort proto_hull in LDS + monotone chain         (convex_hull.rs, vertex.rs:28-35)
+//   k_hull_*  one wavefront per Shape: sort proto_hull (registers / LDS) + monotone chain (convex_hull.rs, vertex.rs:28-35)
 //
 // Two-phase emission reproduces the sequential `start_index` bookkeeping of the reference (fill.rs:361-365,
 // stroke.rs:95,108,126-129) exactly: offsets are exclusive prefix sums in element order.
@@ -323,37 +323,154 @@ __global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_hull
-// convex_hull::andrew (convex_hull.rs:7-40) + triangle_fan_to_strip (renderer.rs:197): one wavefront per Shape.
-// The candidates are sorted with a bitonic network in LDS (SafeFloat's lexicographic Ord, safe_float.rs:163-173;
-// equal keys are bit-identical after -0 canonicalisation, so stability is moot), then lane 0 walks the chain.
-constexpr uint32_t kHullSmall = 128;  // candidates per Shape handled by the small-LDS variant (1 KiB + 2 KiB)
-constexpr uint32_t kHullMax = 2048;   // candidates per Shape that fit the large LDS sort (16 KiB + 32 KiB chain stack)
+// convex_hull::andrew (convex_hull.rs:7-40) + triangle_fan_to_strip (renderer.rs:197). The candidates are sorted in SafeFloat's
+// lexicographic order (safe_float.rs:163-173; equal keys are bit-identical after -0 canonicalisation, so stability is moot), then the
+// monotone chain is walked.
+//   k_hull_small  Shapes with <= 64 candidates (the common case), 64 Shapes per workgroup. Phase 1: a wavefront sorts one Shape at a
+//                 time (lane = candidate, bitonic network on registers) into LDS. Phase 2: lane = Shape — 64 Shapes walk their
+//                 (inherently serial) monotone chains simultaneously, the stack being a byte index per entry, its two topmost points
+//                 kept in registers. A wavefront per Shape spent ~1500 VALU issues on one serial chain. Larger Shapes are queued.
+//   k_hull_large  Shapes with 65..2048 candidates, taken from the queue by a fixed grid: bitonic sort + chain in LDS.
+constexpr uint32_t kHullSmall = 64;
+constexpr uint32_t kHullMid = 256;
+constexpr uint32_t kHullMax = 2048; // candidates per Shape that fit the large LDS sort (16 KiB + 32 KiB chain stack)
 
 CRH_D bool lex_less(float2 a, float2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
 CRH_D float turn(float2 a, float2 b, float2 c) { return triple(vec_to_point(a.x, a.y), vec_to_point(b.x, b.y), vec_to_point(c.x, c.y)); }
 
-template <uint32_t CAP, uint32_t MIN_N>
-__global__ __launch_bounds__(64) void k_hull(SceneDev s) {
+// the strip order of triangle_fan_to_strip (vertex.rs:28-35): [0, h-1, 1, h-2, ...]
+CRH_D uint32_t fan_to_strip_source(uint32_t i, uint32_t h) { return (i & 1u) == 0 ? (i >> 1) : h - 1u - (i >> 1); }
+
+constexpr uint32_t kHullBatch = 16;                 // Shapes per workgroup of k_hull_small (4 per wavefront in phase 1, one lane each in phase 2)
+constexpr uint32_t kHullRow = kHullSmall + 1;       // LDS row pitch in float2 (odd: lane-per-Shape accesses spread over the banks)
+
+__global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
+    __shared__ float2 sorted[kHullBatch][kHullRow];         // sorted candidates of the batch's Shapes
+    __shared__ uint8_t stack[kHullBatch][2 * kHullSmall];   // the monotone chain as indices into `sorted`
+    __shared__ uint32_t count[kHullBatch];                  // candidates per Shape; 0 = nothing to do here (empty, queued or rejected)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (!fits(s)) return;
+    const uint32_t first_shape = blockIdx.x * kHullBatch;
+    // ---- phase 1: every wavefront sorts kHullBatch / 4 Shapes (lane = candidate, bitonic network on registers); the dependent
+    // global loads (range, then candidates) of all its Shapes are issued together before the first sort
+    constexpr uint32_t kPerWave = kHullBatch / 4u;
+    uint32_t n_of[kPerWave], base_of[kPerWave];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerWave; ++u) {
+        const uint32_t shape = first_shape + wave + 4u * u;
+        n_of[u] = 0;
+        base_of[u] = 0;
+        if (shape < s.n_shapes) {
+            base_of[u] = s.shape_base[shape * NCH + CH_HULL];
+            n_of[u] = s.shape_base[(shape + 1) * NCH + CH_HULL] - base_of[u];
+        }
+    }
+    const float inf = __uint_as_float(0x7f800000u);
+    float2 p_of[kPerWave];
+#pragma unroll
+    for (uint32_t u = 0; u < kPerWave; ++u) {
+        p_of[u] = make_float2(inf, inf);
+        if (n_of[u] <= kHullSmall && lane < n_of[u]) p_of[u] = make_float2(s.hull_cand[base_of[u] + lane].x, s.hull_cand[base_of[u] + lane].y);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kPerWave; ++u) {
+        const uint32_t slot = wave + 4u * u, shape = first_shape + slot;
+        uint32_t n = n_of[u];
+        if (shape < s.n_shapes) {
+            if (n > kHullMax) {
+                if (lane == 0) {
+                    raise_error(s, s.elem_path[s.shape_elem_begin[shape]], CRH_ERR_UNSUPPORTED);
+                    s.hull_count[shape] = 0;
+                }
+                n = 0;
+            } else if (n > kHullSmall) { // queue 0: up to kHullMid candidates (small LDS footprint), queue 1: up to kHullMax
+                const uint32_t queue = n > kHullMid ? 1u : 0u;
+                if (lane == 0) s.hull_large_list[queue * s.n_shapes + atomicAdd(s.hull_large_count + queue, 1u)] = shape;
+                n = 0;
+            } else if (n == 0) {
+                if (lane == 0) s.hull_count[shape] = 0;
+            } else {
+                float2 p = p_of[u];
+                if (n >= 3) { // fewer are returned as they are (convex_hull.rs:9-11)
+#pragma unroll
+                    for (uint32_t k = 2; k <= 64u; k <<= 1) {
+#pragma unroll
+                        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                            const float2 q = make_float2(__shfl_xor(p.x, j, 64), __shfl_xor(p.y, j, 64));
+                            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
+                            const bool q_less = lex_less(q, p);
+                            p = (keep_min == q_less) ? q : p; // min keeps q when q < p, max keeps q when !(q < p); equal keys are identical
+                        }
+                    }
+                }
+                sorted[slot][lane] = p;
+            }
+        }
+        if (lane == 0) count[slot] = n;
+    }
+    __syncthreads();
+    // ---- phase 2: lane = Shape; every lane of wavefront 0 walks the lower then the upper chain of its own Shape (convex_hull.rs:12-39)
+    if (wave != 0 || lane >= kHullBatch) return;
+    const uint32_t n = count[lane];
+    const uint32_t shape = first_shape + lane;
+    if (n == 0) return;
+    const float2* pts = sorted[lane];
+    uint8_t* chain = stack[lane];
+    uint32_t h = n;
+    if (n < 3) {
+        for (uint32_t i = 0; i < n; ++i) chain[i] = (uint8_t)i;
+    } else {
+        uint32_t m = 0;
+        float2 a = make_float2(0.0f, 0.0f), b = a; // chain[m - 2], chain[m - 1]
+        for (uint32_t i = 0; i < n; ++i) {
+            const float2 c = pts[i];
+            while (m > 1 && turn(a, b, c) <= kErrorMargin) {
+                m -= 1;
+                b = a;
+                if (m >= 2) a = pts[chain[m - 2]];
+            }
+            chain[m++] = (uint8_t)i;
+            a = b;
+            b = c;
+        }
+        m -= 1; // the last point of the lower chain starts the upper one
+        b = a;
+        if (m >= 2) a = pts[chain[m - 2]];
+        const uint32_t t = m + 1;
+        for (uint32_t i = n; i-- > 0;) {
+            const float2 c = pts[i];
+            while (m > t && turn(a, b, c) <= kErrorMargin) {
+                m -= 1;
+                b = a;
+                if (m >= 2) a = pts[chain[m - 2]];
+            }
+            chain[m++] = (uint8_t)i;
+            a = b;
+            b = c;
+        }
+        m -= 1;
+        h = m;
+    }
+    const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
+    for (uint32_t i = 0; i < h; ++i) { // triangle_fan_to_strip order (vertex.rs:28-35)
+        const float2 q = pts[chain[fan_to_strip_source(i, h)]];
+        s.hull_v[base + i] = {q.x, q.y};
+    }
+    s.hull_count[shape] = h;
+}
+
+template <uint32_t CAP, uint32_t QUEUE>
+__global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
     __shared__ float2 pts[CAP];
     __shared__ float2 chain[2 * CAP];
     __shared__ uint32_t chain_n;
-    const uint32_t shape = blockIdx.x;
     if (!fits(s)) return;
-    const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
-    const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
     const uint32_t lane = threadIdx.x;
-    if (n < MIN_N || (CAP < kHullMax && n > CAP)) return; // the other variant owns this Shape
-    if (n > kHullMax) {
-        if (lane == 0) {
-            raise_error(s, s.elem_path[s.shape_elem_begin[shape]], CRH_ERR_UNSUPPORTED);
-            s.hull_count[shape] = 0;
-        }
-        return;
-    }
-    uint32_t h = n;
-    if (n < 3) { // returned as is (convex_hull.rs:9-11)
-        for (uint32_t i = lane; i < n; i += 64) chain[i] = make_float2(s.hull_cand[base + i].x, s.hull_cand[base + i].y);
-    } else {
+    const uint32_t queued = s.hull_large_count[QUEUE];
+    for (uint32_t q = blockIdx.x; q < queued; q += gridDim.x) {
+        const uint32_t shape = s.hull_large_list[QUEUE * s.n_shapes + q];
+        const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
+        const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
         uint32_t padded = 1;
         while (padded < n) padded <<= 1;
         const float inf = __uint_as_float(0x7f800000u);
@@ -393,15 +510,14 @@ __global__ __launch_bounds__(64) void k_hull(SceneDev s) {
             chain_n = m;
         }
         __syncthreads();
-        h = chain_n;
+        const uint32_t h = chain_n;
+        for (uint32_t i = lane; i < h; i += 64) {
+            const float2 p = chain[fan_to_strip_source(i, h)];
+            s.hull_v[base + i] = {p.x, p.y};
+        }
+        if (lane == 0) s.hull_count[shape] = h;
+        __syncthreads();
     }
-    __syncthreads();
-    for (uint32_t i = lane; i < h; i += 64) { // triangle_fan_to_strip gather (vertex.rs:29)
-        const uint32_t src = (i & 1u) == 0 ? (i >> 1) : h - 1u - (i >> 1);
-        const float2 p = chain[src];
-        s.hull_v[base + i] = {p.x, p.y};
-    }
-    if (lane == 0) s.hull_count[shape] = h;
 }
 
 // ------------------------------------------------------------------------------------------------ self test
@@ -446,10 +562,12 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
         hipLaunchKernelGGL(k_stroke_lengths, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
         if (mark) mark(ctx, "stroke_lengths", 0);
     }
-    hipLaunchKernelGGL((k_hull<kHullSmall, 0>), dim3(s.n_shapes), dim3(64), 0, stream, s);
+    (void)hipMemsetAsync(s.hull_large_count, 0, 8, stream);
+    hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(256), 0, stream, s);
     if (mark) mark(ctx, "tess_hull", bytes[3]);
-    if (has_stroke || big_shapes) {
-        hipLaunchKernelGGL((k_hull<kHullMax, kHullSmall + 1>), dim3(s.n_shapes), dim3(64), 0, stream, s);
+    if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
+        hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(s.n_shapes, 4096u)), dim3(64), 0, stream, s);
+        hipLaunchKernelGGL((k_hull_large<kHullMax, 1>), dim3(min(s.n_shapes, 1024u)), dim3(64), 0, stream, s);
         if (mark) mark(ctx, "tess_hull_large", 0);
     }
 }
