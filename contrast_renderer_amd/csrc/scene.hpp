@@ -48,12 +48,17 @@ struct Vertex4f {
     float x, y, k, l, m, n;
 };
 
-// Per-element exclusive prefix inside its 256-element workgroup (global prefix = wg_base[e >> 8] + this).
+// Per-element exclusive prefix inside its kTessBlock-element workgroup (global prefix = wg_base[e >> kTessBlockShift] + this).
 struct ElemScan {
     uint32_t v[NCH];
 };
 
-constexpr int kTessBlock = 256;
+#ifndef CRH_TESS_BLOCK
+#define CRH_TESS_BLOCK 256
+#endif
+constexpr int kTessBlock = CRH_TESS_BLOCK; // elements per workgroup of k_count / k_emit
+constexpr int kTessBlockShift = kTessBlock == 256 ? 8 : (kTessBlock == 128 ? 7 : 6);
+static_assert(kTessBlock == 256 || kTessBlock == 128 || kTessBlock == 64, "kTessBlock");
 
 struct SceneDev {
     // ---- inputs (written once by crh_scene_upload) ----
@@ -105,6 +110,6 @@ struct SceneDev {
 __device__ __forceinline__ void raise_error(const SceneDev& s, uint32_t path, uint32_t code) { atomicMin(s.status, (path << 8) | code); }
 
 // global exclusive prefix of channel ch at element e
-__device__ __forceinline__ uint32_t gscan(const SceneDev& s, uint32_t e, int ch) { return s.wg_base[(e >> 8) * NCH + ch] + s.elem_scan[e].v[ch]; }
+__device__ __forceinline__ uint32_t gscan(const SceneDev& s, uint32_t e, int ch) { return s.wg_base[(e >> kTessBlockShift) * NCH + ch] + s.elem_scan[e].v[ch]; }
 
 } // namespace crh

@@ -182,35 +182,59 @@ __global__ __launch_bounds__(kTessBlock) void k_count(SceneDev s) {
 
 // ------------------------------------------------------------------------------------------------ k_scan
 __global__ __launch_bounds__(256) void k_scan(SceneDev s) {
-    __shared__ uint32_t partial[256];
+    // one block: thread t owns a contiguous chunk of workgroup rows; all ten channels are scanned together
+    __shared__ uint32_t wave_total[4][NCH];
     const uint32_t chunk = (s.n_wg + 255u) / 256u;
-    const uint32_t begin = threadIdx.x * chunk;
+    const uint32_t begin = min(threadIdx.x * chunk, s.n_wg);
     const uint32_t end = min(begin + chunk, s.n_wg);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t sum[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) sum[c] = 0;
+    for (uint32_t w = begin; w < end; ++w)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) sum[c] += s.wg_total[w * NCH + c];
+    uint32_t excl[NCH];
+#pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        uint32_t sum = 0;
-        for (uint32_t w = begin; w < end; ++w) sum += s.wg_total[w * NCH + c];
-        partial[threadIdx.x] = sum;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const uint32_t v = threadIdx.x >= (uint32_t)d ? partial[threadIdx.x - d] : 0u;
-            __syncthreads();
-            partial[threadIdx.x] += v;
-            __syncthreads();
+        uint32_t v = sum[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += up;
         }
-        uint32_t run = partial[threadIdx.x] - sum;
-        for (uint32_t w = begin; w < end; ++w) {
-            s.wg_base[w * NCH + c] = run;
-            run += s.wg_total[w * NCH + c];
+        excl[c] = v - sum[c];
+        if (lane == 63) wave_total[wave][c] = v;
+    }
+    __syncthreads();
+    uint32_t total[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            if (w < wave) before += wave_total[w][c];
+            all += wave_total[w][c];
         }
-        if (threadIdx.x == 255) {
-            s.totals[c] = partial[255];
-            // the sentinel row, and the rows of trailing empty Shapes (they have no element to publish them)
-            for (uint32_t shape = s.n_shapes;; --shape) {
-                s.shape_base[shape * NCH + c] = partial[255];
-                if (shape == 0 || s.shape_elem_begin[shape - 1u] != s.n_elems) break;
-            }
+        excl[c] += before;
+        total[c] = all;
+    }
+    for (uint32_t w = begin; w < end; ++w)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            s.wg_base[w * NCH + c] = excl[c];
+            excl[c] += s.wg_total[w * NCH + c];
         }
-        __syncthreads();
+    if (threadIdx.x < NCH) {
+        const uint32_t c = threadIdx.x;
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) t = c == (uint32_t)k ? total[k] : t;
+        s.totals[c] = t;
+        // the sentinel row, and the rows of trailing empty Shapes (they have no element to publish them)
+        for (uint32_t shape = s.n_shapes;; --shape) {
+            s.shape_base[shape * NCH + c] = t;
+            if (shape == 0 || s.shape_elem_begin[shape - 1u] != s.n_elems) break;
+        }
     }
 }
 
