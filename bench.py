@@ -24,13 +24,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 # timing mark (HIP events inside the library) -> kernel name as rocprofv3 prints it
 MARK_TO_KERNEL = {
-    "raster_tiles": "crh::k_raster_tile<1, 4, false>",
+    "raster_tiles": "crh::k_raster_tile<1, 4, false, false>",
     "raster_tile_fill": "crh::k_tile_walk<1, true>",
     "raster_tile_count": "crh::k_tile_walk<1, false>",
     "raster_prim_setup": "crh::k_prim_setup<1>",
     "tess_emit": "crh::k_emit",
     "tess_count": "crh::k_count",
-    "tess_hull": "crh::k_hull<128u, 0u>",
+    "tess_hull": "crh::k_hull_small",
 }
 
 

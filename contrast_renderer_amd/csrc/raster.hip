@@ -29,7 +29,7 @@
 #include "scene.hpp"
 
 #ifndef CRH_TILE_WAVES
-#define CRH_TILE_WAVES 7
+#define CRH_TILE_WAVES 5
 #endif
 #ifndef CRH_WALK_WAVES
 #define CRH_WALK_WAVES 4
