@@ -268,6 +268,8 @@ def load_library():
         "crh_paths_of_text": (C.c_int, [V, C.POINTER(TextLayoutC), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_float), C.c_size_t, C.POINTER(V)]),
         "crh_text_aligned_positions": (C.c_int, [V, C.POINTER(TextLayoutC), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                                  C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "crh_path_elliptical_arc": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "crh_path_list_transform": (C.c_int, [V, C.c_float, C.POINTER(C.c_float)]),
         "crh_path_list_view": (C.c_int, [V, C.POINTER(PathBatchC)]),
         "crh_path_list_destroy": (None, [V]),

@@ -1,7 +1,8 @@
 """Host-side mirror of the reference's Path data model (src/path.rs:15-230) — same names, same meaning.
 
-Only the data model and the trivial polygon constructors live here (they are the *input layout* of the
-hot path); arcs / ellipses / reverse / convert are scene-building helpers that SURVEY.md §8(f) ranks "next".
+The data model, the constructors (polygon, rect, rounded rect, ellipse, circle, quarter ellipse, elliptical arc) and the conversions
+(reverse, integral -> rational, quadratic -> cubic, close, append, end tangents) of path.rs. f32 arithmetic in the reference's operation
+order; the elliptical arc is computed natively (csrc/path.cpp) so that this mirror and the C++ one agree to the bit.
 """
 import math
 from dataclasses import dataclass, field
@@ -144,6 +145,9 @@ class Path:  # path.rs:213-230 (the five typed Vecs + segment_types are kept as 
     segment_types: List[int] = field(default_factory=list)
     records: List[Tuple[float, ...]] = field(default_factory=list)
 
+    def __post_init__(self):
+        self.start = _vec2(self.start)  # SafeFloat<f32, 2>: finite, f32, -0 -> +0
+
     def push_line(self, control_point):  # path.rs:234-237
         self.segment_types.append(SegmentType.Line)
         self.records.append(_vec2(control_point))
@@ -169,6 +173,114 @@ class Path:  # path.rs:213-230 (the five typed Vecs + segment_types are kept as 
             return self.start
         return self.records[-1][-2:]
 
+    # ---- tangents (path.rs:296-372); Plane = (c, nx, ny), signum = multiply by 1 / sqrt(nx^2 + ny^2)
+    def get_start_tangent(self):
+        """path.rs:296-322. The reference looks at `segment_types.last()` and the last segment of that type — reproduced as written."""
+        if not self.segment_types:
+            return (0.0, 0.0, 0.0)
+        last_type = self.segment_types[-1]
+        record = [r for t, r in zip(self.segment_types, self.records) if t == last_type][-1]
+        first_point = record[1:3] if last_type == SegmentType.RationalQuadraticCurve else (record[4:6] if last_type == SegmentType.RationalCubicCurve else record[0:2])
+        return _signum(_tangent_from_points(self.start, first_point))
+
+    def get_end_tangent(self):
+        """path.rs:326-372."""
+        if not self.segment_types:
+            return (0.0, 0.0, 0.0)
+        last_type, record = self.segment_types[-1], self.records[-1]
+        if last_type == SegmentType.Line:
+            previous = self.records[-2][-2:] if len(self.records) > 1 else self.start
+            return _signum(_tangent_from_points(previous, record[0:2]))
+        return _signum(_tangent_from_points(record[-4:-2], record[-2:]))
+
+    def append(self, other: "Path"):
+        """path.rs:376-384 moves the five typed Vecs of `other` but NOT its segment_types, so the appended segments are unreachable
+        through segment_types. Reproduced: `other` is emptied, nothing reachable is added."""
+        other.records = []
+        other.segment_types = []
+
+    def reverse(self):
+        """path.rs:445-488: swaps start and end, reverses the segment order and every segment's direction."""
+        f = np.float32
+        previous = self.start
+        new_records = []
+        for t, rec in zip(self.segment_types, self.records):
+            rec = list(rec)
+            if t == SegmentType.IntegralCubicCurve:
+                rec[0:4] = rec[2:4] + rec[0:2]
+            elif t == SegmentType.RationalCubicCurve:
+                rec[0:4] = rec[0:4][::-1]
+                rec[4:8] = rec[6:8] + rec[4:6]
+            end = tuple(rec[-2:])
+            rec[-2:] = list(previous)
+            previous = end
+            new_records.append(tuple(float(f(v)) for v in rec))
+        self.start = previous
+        self.segment_types.reverse()
+        new_records.reverse()
+        self.records = new_records
+
+    def convert_integral_curves_to_rational_curves(self):
+        """path.rs:492-534: weight 1 for quadratics, weights [1, 1, 1, 1] for cubics."""
+        for i, t in enumerate(self.segment_types):
+            if t == SegmentType.IntegralQuadraticCurve:
+                self.segment_types[i] = SegmentType.RationalQuadraticCurve
+                self.records[i] = (1.0,) + tuple(self.records[i])
+            elif t == SegmentType.IntegralCubicCurve:
+                self.segment_types[i] = SegmentType.RationalCubicCurve
+                self.records[i] = (1.0, 1.0, 1.0, 1.0) + tuple(self.records[i])
+
+    def convert_quadratic_curves_to_cubic_curves(self):
+        """path.rs:538-615: degree elevation; `(a - p) * 2.0 / 3.0` is ((a - p) * 2) / 3 in f32, the rational case works on
+        homogeneous points with the f32 constant 2.0 / 3.0."""
+        f = np.float32
+        previous = (f(self.start[0]), f(self.start[1]))
+        for i, (t, rec) in enumerate(zip(self.segment_types, self.records)):
+            rec = [f(v) for v in rec]
+            if t == SegmentType.IntegralQuadraticCurve:
+                a, b = (rec[0], rec[1]), (rec[2], rec[3])
+                c0 = tuple(previous[k] + (a[k] - previous[k]) * f(2.0) / f(3.0) for k in range(2))
+                c1 = tuple(b[k] + (a[k] - b[k]) * f(2.0) / f(3.0) for k in range(2))
+                self.segment_types[i] = SegmentType.IntegralCubicCurve
+                self.records[i] = _vec2(c0) + _vec2(c1) + _vec2(b)
+            elif t == SegmentType.RationalQuadraticCurve:
+                w, a, b = rec[0], (rec[1], rec[2]), (rec[3], rec[4])
+                p0, p1, p2 = (f(1.0), previous[0], previous[1]), (w, a[0] * w, a[1] * w), (f(1.0), b[0], b[1])
+                two_thirds = f(2.0) / f(3.0)
+                n0 = tuple(p0[k] + (p1[k] - p0[k]) * two_thirds for k in range(3))
+                n1 = tuple(p2[k] + (p1[k] - p2[k]) * two_thirds for k in range(3))
+                self.segment_types[i] = SegmentType.RationalCubicCurve
+                self.records[i] = ((1.0, safe_float(n0[0]), safe_float(n1[0]), 1.0) + _vec2((n0[1] / n0[0], n0[2] / n0[0])) + _vec2((n1[1] / n1[0], n1[2] / n1[0])) + _vec2(b))
+            previous = (f(self.records[i][-2]), f(self.records[i][-1]))
+
+    def close(self):
+        """path.rs:621-628: an explicit closing line unless the end is (within ERROR_MARGIN) the start."""
+        t = _tangent_from_points(self.start, self.get_end())
+        if np.float32(t[1]) * np.float32(t[1]) + np.float32(t[2]) * np.float32(t[2]) <= np.float32(1e-4):
+            return
+        self.push_line(self.start)
+
+    def push_quarter_ellipse(self, tangent_crossing, to):  # path.rs:631-636
+        self.push_rational_quadratic_curve(np.float32(0.70710678118654752440), tangent_crossing, to)
+
+    def push_elliptical_arc(self, half_extent, rotation, large_arc, sweep, to):
+        """path.rs:639-708, the SVG "arc to" command (native: crh_path_elliptical_arc)."""
+        import ctypes as C
+        lib = _ffi.load_library()
+        fp = C.POINTER(C.c_float)
+        start = (C.c_float * 2)(*self.get_end())
+        half = (C.c_float * 2)(float(half_extent[0]), float(half_extent[1]))
+        end = (C.c_float * 2)(float(to[0]), float(to[1]))
+        records = (C.c_float * 20)()
+        n, is_line = C.c_uint32(), C.c_uint32()
+        _ffi.check(lib.crh_path_elliptical_arc(start, half, float(rotation), int(bool(large_arc)), int(bool(sweep)), end, records, 4, C.byref(n), C.byref(is_line)))
+        if is_line.value:
+            self.push_line(to)
+            return
+        for i in range(n.value):
+            r = records[5 * i:5 * i + 5]
+            self.push_rational_quadratic_curve(r[0], (r[1], r[2]), (r[3], r[4]))
+
     @staticmethod
     def from_polygon(vertices: Sequence[Sequence[float]]):  # path.rs:711-724
         path = Path(start=_vec2(vertices[0]))
@@ -190,6 +302,51 @@ class Path:  # path.rs:213-230 (the five typed Vecs + segment_types are kept as 
         f = np.float32
         cx, cy, hx, hy = f(center[0]), f(center[1]), f(half_extent[0]), f(half_extent[1])
         return Path.from_polygon([(cx - hx, cy - hy), (cx - hx, cy + hy), (cx + hx, cy + hy), (cx + hx, cy - hy)])
+
+
+def _rounded_corner_path(start, corners):
+    path = Path(start=_vec2(start))
+    for corner in corners:
+        if len(corner) == 3:
+            path.push_line(corner[0])
+            path.push_quarter_ellipse(corner[1], corner[2])
+        else:
+            path.push_quarter_ellipse(corner[0], corner[1])
+    return path
+
+
+def _from_rounded_rect(center, half_extent, radius):  # path.rs:746-780
+    f = np.float32
+    cx, cy, hx, hy, r = f(center[0]), f(center[1]), f(half_extent[0]), f(half_extent[1]), f(radius)
+    vertices = [((cx - hx + r, cy - hy), (cx - hx, cy - hy), (cx - hx, cy - hy + r)),
+                ((cx - hx, cy + hy - r), (cx - hx, cy + hy), (cx - hx + r, cy + hy)),
+                ((cx + hx - r, cy + hy), (cx + hx, cy + hy), (cx + hx, cy + hy - r)),
+                ((cx + hx, cy - hy + r), (cx + hx, cy - hy), (cx + hx - r, cy - hy))]
+    return _rounded_corner_path(vertices[3][2], vertices)
+
+
+def _from_ellipse(center, half_extent):  # path.rs:783-810
+    f = np.float32
+    cx, cy, hx, hy = f(center[0]), f(center[1]), f(half_extent[0]), f(half_extent[1])
+    vertices = [((cx - hx, cy - hy), (cx - hx, cy)), ((cx - hx, cy + hy), (cx, cy + hy)), ((cx + hx, cy + hy), (cx + hx, cy)), ((cx + hx, cy - hy), (cx, cy - hy))]
+    return _rounded_corner_path(vertices[3][1], vertices)
+
+
+Path.from_rounded_rect = staticmethod(_from_rounded_rect)
+Path.from_ellipse = staticmethod(_from_ellipse)
+Path.from_circle = staticmethod(lambda center, radius: _from_ellipse(center, (radius, radius)))  # path.rs:813-815
+
+
+def _tangent_from_points(a, b):  # path.rs:203-205: a v b = [ay bx - ax by, by - ay, ax - bx]
+    f = np.float32
+    ax, ay, bx, by = f(a[0]), f(a[1]), f(b[0]), f(b[1])
+    return (ay * bx - ax * by, by - ay, ax - bx)
+
+
+def _signum(plane):
+    f = np.float32
+    inv = f(1.0) / np.sqrt(plane[1] * plane[1] + plane[2] * plane[2], dtype=f)
+    return tuple(float(f(v) * inv) for v in plane)
 
 
 def batch_from_shapes(shapes: Sequence[Tuple[Sequence[DynamicStrokeOptions], Sequence[Path]]]) -> _ffi.PathBatch:

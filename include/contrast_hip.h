@@ -303,6 +303,12 @@ crh_status crh_paths_of_text(const crh_font* font, const crh_text_layout* layout
 crh_status crh_text_aligned_positions(const crh_font* font, const crh_text_layout* layout, const uint32_t* text, size_t n_chars, int64_t extent[2],
                                       int64_t offset[2], int64_t* positions /* [n_chars + 1][3] */, uint64_t* line_ends, uint64_t* line_lengths,
                                       uint64_t* n_lines);
+/* Path::push_elliptical_arc, path.rs:639-708 (the SVG "arc to" command): the rational quadratic segments that continue a path whose
+ * current end point is `from`. `records` receives n_segments x {weight, tangent_crossing.xy, vertex.xy} (the record layout of
+ * CRH_SEGMENT_RATIONAL_QUADRATIC); *is_line = 1 when a radius is zero and the reference pushes a plain line to `to` instead.
+ * Call with records == NULL to query *n_segments (at most 3). Host code. */
+crh_status crh_path_elliptical_arc(const float from[2], const float half_extent[2], float rotation, uint32_t large_arc, uint32_t sweep, const float to[2],
+                                   float* records, uint32_t capacity, uint32_t* n_segments, uint32_t* is_line);
 /* Path::transform(scale, &motor), path.rs:387-439, on every path of the list. motor = ppga2d::Motor [scalar, e12, e01, e02]
  * (utils.rs:122-129: rotate2d, translate2d). */
 crh_status crh_path_list_transform(crh_path_list* list, float scale, const float motor[4]);

@@ -159,6 +159,131 @@ class Path {
     }
     Vec2 get_end() const { return control.empty() ? start : Vec2{control[control.size() - 2], control[control.size() - 1]}; } // path.rs:266-290
 
+    // ---- tangents (path.rs:296-372); Plane = (c, nx, ny)
+    struct Plane {
+        float c, nx, ny;
+    };
+    Plane get_start_tangent() const { // path.rs:296-322 — looks at segment_types.last() and the last segment of that type, as written there
+        if (segment_types.empty()) return Plane{0.0f, 0.0f, 0.0f};
+        const SegmentType last_type = segment_types.back();
+        size_t at = 0, found = 0;
+        for (size_t i = 0; i < segment_types.size(); ++i) {
+            if (segment_types[i] == last_type) found = at;
+            at += floats(segment_types[i]);
+        }
+        const size_t first_point = found + (last_type == SegmentType::RationalQuadraticCurve ? 1 : (last_type == SegmentType::RationalCubicCurve ? 4 : 0));
+        return signum(tangent_from_points(start, Vec2{control[first_point], control[first_point + 1]}));
+    }
+    Plane get_end_tangent() const { // path.rs:326-372
+        if (segment_types.empty()) return Plane{0.0f, 0.0f, 0.0f};
+        const size_t n = control.size();
+        if (segment_types.back() == SegmentType::Line) {
+            const Vec2 previous = segment_types.size() > 1 ? Vec2{control[n - 4], control[n - 3]} : start;
+            return signum(tangent_from_points(previous, Vec2{control[n - 2], control[n - 1]}));
+        }
+        return signum(tangent_from_points(Vec2{control[n - 4], control[n - 3]}, Vec2{control[n - 2], control[n - 1]}));
+    }
+    // path.rs:376-384 moves the typed segment Vecs of `other` but not its segment_types: nothing reachable is added (reproduced)
+    void append(Path& other) {
+        other.segment_types.clear();
+        other.control.clear();
+    }
+    void reverse() { // path.rs:445-488
+        std::vector<SegmentType> types;
+        std::vector<std::vector<float>> records;
+        Vec2 previous = start;
+        size_t at = 0;
+        for (SegmentType t : segment_types) {
+            std::vector<float> rec(control.begin() + (long)at, control.begin() + (long)(at + floats(t)));
+            at += floats(t);
+            if (t == SegmentType::IntegralCubicCurve) {
+                std::swap(rec[0], rec[2]);
+                std::swap(rec[1], rec[3]);
+            } else if (t == SegmentType::RationalCubicCurve) {
+                std::swap(rec[0], rec[3]);
+                std::swap(rec[1], rec[2]);
+                std::swap(rec[4], rec[6]);
+                std::swap(rec[5], rec[7]);
+            }
+            const Vec2 end{rec[rec.size() - 2], rec[rec.size() - 1]};
+            rec[rec.size() - 2] = previous.first;
+            rec[rec.size() - 1] = previous.second;
+            previous = end;
+            types.push_back(t);
+            records.push_back(std::move(rec));
+        }
+        start = previous;
+        segment_types.assign(types.rbegin(), types.rend());
+        control.clear();
+        for (auto it = records.rbegin(); it != records.rend(); ++it) control.insert(control.end(), it->begin(), it->end());
+    }
+    void convert_integral_curves_to_rational_curves() { // path.rs:492-534
+        std::vector<float> out;
+        size_t at = 0;
+        for (SegmentType& t : segment_types) {
+            const size_t n = floats(t);
+            if (t == SegmentType::IntegralQuadraticCurve) {
+                out.push_back(1.0f);
+                t = SegmentType::RationalQuadraticCurve;
+            } else if (t == SegmentType::IntegralCubicCurve) {
+                out.insert(out.end(), 4, 1.0f);
+                t = SegmentType::RationalCubicCurve;
+            }
+            out.insert(out.end(), control.begin() + (long)at, control.begin() + (long)(at + n));
+            at += n;
+        }
+        control = std::move(out);
+    }
+    void convert_quadratic_curves_to_cubic_curves() { // path.rs:538-615
+        std::vector<float> out;
+        size_t at = 0;
+        Vec2 previous = start;
+        for (SegmentType& t : segment_types) {
+            const size_t n = floats(t);
+            const float* r = control.data() + at;
+            at += n;
+            if (t == SegmentType::IntegralQuadraticCurve) {
+                const float c0x = previous.first + (r[0] - previous.first) * 2.0f / 3.0f, c0y = previous.second + (r[1] - previous.second) * 2.0f / 3.0f;
+                const float c1x = r[2] + (r[0] - r[2]) * 2.0f / 3.0f, c1y = r[3] + (r[1] - r[3]) * 2.0f / 3.0f;
+                for (float v : {c0x, c0y, c1x, c1y, r[2], r[3]}) out.push_back(safe_float(v));
+                t = SegmentType::IntegralCubicCurve;
+            } else if (t == SegmentType::RationalQuadraticCurve) {
+                const float w = r[0];
+                const float p0[3] = {1.0f, previous.first, previous.second}, p1[3] = {w, r[1] * w, r[2] * w}, p2[3] = {1.0f, r[3], r[4]};
+                const float two_thirds = 2.0f / 3.0f;
+                float n0[3], n1[3];
+                for (int k = 0; k < 3; ++k) {
+                    n0[k] = p0[k] + (p1[k] - p0[k]) * two_thirds;
+                    n1[k] = p2[k] + (p1[k] - p2[k]) * two_thirds;
+                }
+                for (float v : {1.0f, n0[0], n1[0], 1.0f, n0[1] / n0[0], n0[2] / n0[0], n1[1] / n1[0], n1[2] / n1[0], r[3], r[4]}) out.push_back(safe_float(v));
+                t = SegmentType::RationalCubicCurve;
+            } else {
+                out.insert(out.end(), r, r + n);
+            }
+            previous = Vec2{out[out.size() - 2], out[out.size() - 1]};
+        }
+        control = std::move(out);
+    }
+    void close() { // path.rs:621-628
+        const Plane t = tangent_from_points(start, get_end());
+        if (t.nx * t.nx + t.ny * t.ny <= 1e-4f) return;
+        push_line(start);
+    }
+    void push_quarter_ellipse(Vec2 tangent_crossing, Vec2 to) { push_rational_quadratic_curve(0.70710678118654752440f, tangent_crossing, to); } // path.rs:631-636
+    void push_elliptical_arc(Vec2 half_extent, float rotation, bool large_arc, bool sweep, Vec2 to) { // path.rs:639-708 (native: csrc/path.cpp)
+        const Vec2 end = get_end();
+        const float from[2] = {end.first, end.second}, half[2] = {half_extent.first, half_extent.second}, target[2] = {to.first, to.second};
+        float records[20];
+        uint32_t n = 0, is_line = 0;
+        check(crh_path_elliptical_arc(from, half, rotation, large_arc, sweep, target, records, 4, &n, &is_line));
+        if (is_line) {
+            push_line(to);
+            return;
+        }
+        for (uint32_t i = 0; i < n; ++i) push_rational_quadratic_curve(records[5 * i], {records[5 * i + 1], records[5 * i + 2]}, {records[5 * i + 3], records[5 * i + 4]});
+    }
+
     static Path from_polygon(const std::vector<Vec2>& vertices) { // path.rs:711-724
         Path path;
         path.start = Vec2{safe_float(vertices.at(0).first), safe_float(vertices.at(0).second)};
@@ -178,7 +303,42 @@ class Path {
         return from_polygon({{cx - hx, cy - hy}, {cx - hx, cy + hy}, {cx + hx, cy + hy}, {cx + hx, cy - hy}});
     }
 
+    static Path from_rounded_rect(Vec2 center, Vec2 half_extent, float radius) { // path.rs:746-780
+        const float cx = center.first, cy = center.second, hx = half_extent.first, hy = half_extent.second, r = radius;
+        const Vec2 v[4][3] = {{{cx - hx + r, cy - hy}, {cx - hx, cy - hy}, {cx - hx, cy - hy + r}},
+                              {{cx - hx, cy + hy - r}, {cx - hx, cy + hy}, {cx - hx + r, cy + hy}},
+                              {{cx + hx - r, cy + hy}, {cx + hx, cy + hy}, {cx + hx, cy + hy - r}},
+                              {{cx + hx, cy - hy + r}, {cx + hx, cy - hy}, {cx + hx - r, cy - hy}}};
+        Path path;
+        path.start = Vec2{safe_float(v[3][2].first), safe_float(v[3][2].second)};
+        for (const auto& corner : v) {
+            path.push_line(corner[0]);
+            path.push_quarter_ellipse(corner[1], corner[2]);
+        }
+        return path;
+    }
+    static Path from_ellipse(Vec2 center, Vec2 half_extent) { // path.rs:783-810
+        const float cx = center.first, cy = center.second, hx = half_extent.first, hy = half_extent.second;
+        const Vec2 v[4][2] = {{{cx - hx, cy - hy}, {cx - hx, cy}}, {{cx - hx, cy + hy}, {cx, cy + hy}}, {{cx + hx, cy + hy}, {cx + hx, cy}}, {{cx + hx, cy - hy}, {cx, cy - hy}}};
+        Path path;
+        path.start = Vec2{safe_float(v[3][1].first), safe_float(v[3][1].second)};
+        for (const auto& corner : v) path.push_quarter_ellipse(corner[0], corner[1]);
+        return path;
+    }
+    static Path from_circle(Vec2 center, float radius) { return from_ellipse(center, {radius, radius}); } // path.rs:813-815
+
   private:
+    static size_t floats(SegmentType t) {
+        static const size_t n[5] = {2, 4, 6, 5, 10};
+        return n[(size_t)t];
+    }
+    static Plane tangent_from_points(Vec2 a, Vec2 b) { // path.rs:203-205: a v b
+        return Plane{a.second * b.first - a.first * b.second, b.second - a.second, a.first - b.first};
+    }
+    static Plane signum(Plane p) {
+        const float inv = 1.0f / std::sqrt(p.nx * p.nx + p.ny * p.ny);
+        return Plane{p.c * inv, p.nx * inv, p.ny * inv};
+    }
     void put(Vec2 p) {
         control.push_back(safe_float(p.first));
         control.push_back(safe_float(p.second));
