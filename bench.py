@@ -34,6 +34,24 @@ MARK_TO_KERNEL = {
 }
 
 
+def valu_issue(mark, avg_launch_ms):
+    """Secondary roofline of the dominant kernel: VALU issue utilisation = wave-level VALU instructions (SQ_INSTS_VALU of the newest committed
+    PMC summary) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x launch time). None when the counters do not cover the kernel."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))
+    if not files or mark not in MARK_TO_KERNEL or avg_launch_ms <= 0:
+        return None
+    with open(files[-1]) as f:
+        doc = json.load(f)
+    k = doc.get("per_launch", {}).get(MARK_TO_KERNEL[mark])
+    if not k or "SQ_INSTS_VALU" not in k:
+        return None
+    simds, clock_hz = 256 * 4, 2.4e9
+    return {"valu_wave_instructions": int(k["SQ_INSTS_VALU"]), "salu_wave_instructions": int(k.get("SQ_INSTS_SALU", 0)),
+            "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * avg_launch_ms * 1e-3), "source": os.path.basename(files[-1]),
+            "note": "one wave64 VALU instruction per 4 cycles per SIMD; 256 CUs x 4 SIMDs at 2.4 GHz"}
+
+
 def measured_traffic(mark):
     """HBM bytes per launch of the kernel behind `mark`, from the newest committed PMC summary (profiles/rNN_traffic.json, produced by
     tools/profile.sh: separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of the microarchitecture guide). The
@@ -210,6 +228,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_source,
             "algorithmic_bytes": dk["algorithmic_bytes"],
+            "valu_issue": valu_issue(dominant, dk["avg_ms"]) if default_workload else None,
             "avg_launch_ms": dk["avg_ms"],
             "note": "achieved = algorithmic bytes (SURVEY.md §8(d): emitted vertex/index bytes read once + 80 B per shape + W*H*4 written once) / "
                     "HIP-event launch time of the dominant kernel; traffic = HBM bytes per launch from rocprofv3 PMC passes (committed under "
