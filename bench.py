@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--paths", type=int, default=10000, help="paths per GPU (configs[1] = 10000)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="nccl = RCCL over xGMI (the real thing); gloo validates the multi-rank flow "
+                    "where RCCL cannot run (e.g. two ranks on one GPU with --same-device): layers are staged through host memory")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
+    ap.add_argument("--check", action="store_true", help="N > 1: rank 0 also renders every shard itself and compares the composite of those layers with the gathered image")
     ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed"),
                     help="cubic = BASELINE configs[1] (the metric's configuration, default); glyphs = configs[2] (50 000 glyphs @ 2048^2); "
                          "dashed = configs[4] (2 000 dashed rational-cubic strokes @ 4096^2, msaa 4). Only `cubic` is the headline line.")
@@ -91,7 +95,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
@@ -101,7 +105,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from contrast_renderer_amd import distributed as D
     from contrast_renderer_amd import scenes
@@ -172,7 +179,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_times = renderer.kernel_times()
@@ -180,6 +187,24 @@ def main():
     scene.check()
     image = frame.download()
     covered = float((image[..., 3] > 0).mean())
+    check = None
+    if args.check and world > 1:
+        gathered = step()  # one more pass outside the timed region: the gathered frame on rank 0
+        sync()
+        if rank == 0:
+            layers = []
+            for other in range(world):  # the same shards, rendered one after the other by this rank alone
+                shard = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=other * args.paths)
+                shard_scene = Scene(renderer, shard["batch"], tessellate=True)
+                shard_frame = Frame(renderer, *size)
+                shard_frame.clear()
+                shard_scene.render(shard_frame, shard["transforms"], shard["colors"])
+                layers.append(shard_frame.download())
+            expect = D.composite_over_reference(np.stack(layers))
+            got = gathered.cpu().numpy()
+            check = {"gathered_equals_ordered_composite_of_all_shards": bool(np.array_equal(got, expect)),
+                     "max_abs_difference": int(np.abs(got.astype(np.int32) - expect.astype(np.int32)).max()),
+                     "own_layer_unchanged": bool(np.array_equal(image, layers[0]))}
 
     # per-kernel averages
     agg = {}
@@ -235,6 +260,7 @@ def main():
                     "profiles/). The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
         },
         "kernels": kernels,
+        "check": check,
         # the boundary hands over host buffers once per scene (crh_scene_upload); never part of `value`
         "host_inclusive": {"upload_ms": upload_s * 1e3, "paths_per_s_first_frame": args.paths / (upload_s + elapsed / args.steps),
                            "input_bytes": int(batch.input_bytes())},

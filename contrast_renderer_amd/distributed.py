@@ -30,11 +30,21 @@ def slab_rows(height: int, world: int):
     return out
 
 
+def _transport_needs_host_staging(tensor):
+    """RCCL moves device memory directly. The gloo backend (used to validate the multi-rank flow on a single GPU) only sends host
+    memory, so device tensors are staged through the host for it."""
+    import torch.distributed as dist
+    return tensor.is_cuda and dist.get_backend() == "gloo"
+
+
 def exchange_layers(layer, rank: int, world: int, group=None):
     """layer: uint8 tensor [H, W, 4] (this rank's premultiplied layer). Returns (received [world, h_r, W, 4], (row0, row1))
     = slab `rank` of every rank's layer, in rank order."""
     import torch
     import torch.distributed as dist
+    if _transport_needs_host_staging(layer):
+        received, rows = exchange_layers(layer.cpu(), rank, world, group)
+        return received.to(layer.device), rows
     h = layer.shape[0]
     rows = slab_rows(h, world)
     r0, r1 = rows[rank]
@@ -59,6 +69,9 @@ def gather_slabs(slab, rank: int, world: int, height: int, group=None):
     """Collects the composited slabs on rank 0 -> full [H, W, 4] image (None on the other ranks)."""
     import torch
     import torch.distributed as dist
+    if _transport_needs_host_staging(slab):
+        image = gather_slabs(slab.cpu(), rank, world, height, group)
+        return image.to(slab.device) if image is not None else None
     rows = slab_rows(height, world)
     if rank == 0:
         image = torch.empty((height,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
