@@ -109,7 +109,7 @@ struct crh_renderer {
 
 struct crh_frame {
     crh_renderer* renderer;
-    uint32_t width, height, tiles_x, tiles_y, n_tiles, n_bands;
+    uint32_t width, height, tiles_x, tiles_y, n_tiles;
     DevBuf rgba8, tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
@@ -405,7 +405,6 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.tiles_x = f->tiles_x;
     p.tiles_y = f->tiles_y;
     p.n_tiles = f->n_tiles;
-    p.n_bands = f->n_bands;
     p.winding_mask = (1u << r->config.winding_counter_bits) - 1u;
     p.clip_mask_count = (1u << r->config.clip_nesting_counter_bits) - 1u;
     p.items = recorded ? f->items.as<DrawItem>() : nullptr;
@@ -832,7 +831,6 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     f->tiles_x = (width + 15) / 16;
     f->tiles_y = (height + 15) / 16;
     f->n_tiles = f->tiles_x * f->tiles_y;
-    f->n_bands = f->n_tiles * 4u;
     if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") ||
         !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") ||
         !hip_ok(f->overflow.ensure(64), "hipMalloc")) {

@@ -1,29 +1,25 @@
-// csrc/raster.hip — band-binned compute rasterizer that replaces the reference's stencil-then-cover passes
-// (Shape::render renderer.rs:267-355, stencil states renderer.rs:565-582,736-754, fragment stage shaders.wgsl:155-309).
+// csrc/raster.hip — tile-binned compute rasterizer that replaces the reference's stencil-then-cover passes
+// (Shape::render renderer.rs:267-355, stencil states renderer.rs:565-582,692-754,761-861, fragment stages shaders.wgsl:155-355).
 //
-// The frame is cut into 16x16-pixel tiles of four 16x4 BANDS; one wavefront owns one band (lane = pixel, S samples per lane), so the
-// winding counters (the reference's 8-bit stencil) and the colour of a pixel never leave the lane's registers, and no workgroup
-// barrier is needed anywhere.
+// The frame is cut into 16x16-pixel tiles; one wavefront owns one tile (msaa 1: lane = column x row group, four pixels per lane; msaa 4:
+// four wavefronts per tile, one pixel x four samples per lane), so the stencil byte of the reference (winding counter, clip nesting
+// counter), the saved alpha layers and the colour of a sample never leave the owning lane's registers, and no workgroup barrier is
+// needed anywhere in the raster kernel.
 //
-//   k_scan_*         two-kernel exclusive scan (per-Shape primitive ranges at tessellation time, tile offsets per frame)
-//   k_prim_setup<S>  one wavefront per Shape, one lane per triangle: vertex stage (shaders.wgsl:66-151), edge functions in canonical
-//                    orientation, attribute planes -> a 128-byte record, ONCE per frame. Primitive ids are contiguous per Shape and
-//                    ascend in draw order (Shape index, then line / joint / solid / IQ / IC / RQ / RC / cover = renderer.rs:275-354).
-//                    Then the wave walks the tiles of the Shape's rectangle: every lane tests ITS triangle against the tile's four
-//                    bands (exact: an edge function is monotone in x and y, so its extremes over a band sit at sample corners),
-//                    ballot + popcount -> ONE atomic per (Shape, tile) instead of one per (triangle, tile).
-//   k_prim_bin<S>    same walk; lane 0 reserves popcount slots of the tile's list with one atomic, lanes write
-//                    (prim id << 8 | full-band mask << 4 | band mask) at their rank.
-//   k_raster_band<S> one wavefront per band: sorts the tile's list by prim id (= draw order) in registers / wave-private LDS and
-//                    walks it, skipping entries whose band bit is clear (two scalar instructions). The record is fetched with
-//                    scalar loads from the constant address space (wave-uniform), the next record is prefetched while the current
-//                    one is evaluated; coverage + fragment tests run per sample in VALU; stencil semantics are integer adds on
-//                    the lane's counters; the cover blends premultiplied "over" where winding != 0.
-//   Coverage and attribute arithmetic follow oracle/raster.hpp operation by operation (tile-relative constants, explicit fmaf),
-//   so pixels are bit-identical to the CPU spec.
+//   k_scan_*           two-kernel exclusive scan (primitive ranges per Shape / draw item, tile list offsets per frame)
+//   k_prim_setup<S>    one wavefront per draw item (= Shape in the plain pass), one lane per triangle: vertex stage (shaders.wgsl:13-27,
+//                      66-151), edge functions in canonical orientation, clamped pixel box, attribute planes -> a 128-byte record, once
+//                      per frame. Primitive ids are contiguous per item and ascend in draw order (item, then line / joint / solid / IQ /
+//                      IC / RQ / RC / cover = renderer.rs:275-354).
+//   k_tile_walk<S,F>   count pass (F = false) and fill pass (F = true) of the per-tile lists: kWalkWaves wavefronts per item, lane =
+//                      triangle, exact tile test (an edge function is monotone in x and y under fmaf, so the best tile corner
+//                      decides), ballot + popcount -> ONE atomic per (64-triangle chunk, tile); the fill pass writes prim ids.
+//   k_raster_tile<..>  sorts the tile's list by prim id (= draw order) in registers / LDS and walks it; see the kernel's comment.
+//   Coverage and attribute arithmetic follow oracle/raster.hpp operation by operation (tile-relative constants, explicit fmaf), so
+//   pixels are bit-identical to the CPU spec.
 //
-// Roofline note: algorithmic traffic = emitted vertices read once + W*H*4 bytes written once; the kernels are VALU / latency
-// bound (polynomial evaluation per sample, integer bookkeeping), not HBM bound, and contain no GEMM shape for MFMA.
+// Roofline note: algorithmic traffic = emitted vertices read once + W*H*4 bytes written once; the raster kernel is VALU-issue bound
+// (edge functions per sample), the others latency bound; there is no GEMM shape for MFMA anywhere.
 #include "ga.hpp"
 #include "raster_params.hpp"
 #include "scene.hpp"
@@ -173,7 +169,7 @@ __global__ __launch_bounds__(256) void k_scan_local(ScanJob j) {
     }
     if (threadIdx.x == 255) j.block_sum[blockIdx.x] = run;
 }
-// mode 0: primitive ranges; mode 1: band offsets (also publishes the pair count and the overflow flag)
+// mode 0: primitive ranges; mode 1: tile list offsets (also publishes the pair count and the overflow flag)
 __global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int mode) {
     __shared__ uint32_t partial[256];
     uint32_t sum = 0;
@@ -199,14 +195,12 @@ __global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int
     }
 }
 
-// ---------------------------------------------------------------------------------------------- exact tile / band tests
+// ---------------------------------------------------------------------------------------------- exact tile test
 // An edge function E = fma(rx, nay, fma(ry, bx, c)) is monotone in rx and in ry (fmaf rounds monotonically), so its extremes over a
-// box of sample positions sit at the corners. Sample positions inside a tile span [s_lo, 15 + s_hi] in x; band b spans rows
-// [4b + s_lo, 4b + 3 + s_hi].
-//   tile_hit : the triangle's pixel box overlaps the tile and no edge rejects its best tile corner (count pass; a superset of
-//              "some band is hit", so the lists may hold entries whose band mask is 0 — the raster skips them)
-//   band_masks: bit b of `bands` = no edge rejects the best corner of band b and the pixel box reaches its rows;
-//              bit b of `full`  = the pixel box spans band b and every edge accepts its worst corner (no per-sample test needed)
+// box of sample positions sit at the corners. Sample positions inside a tile span [s_lo, 15 + s_hi] in x and in y.
+//   tile_hit : the triangle's pixel box overlaps the tile and no edge rejects its best tile corner — a conservative superset of "some
+//              sample of the tile is covered" (three half planes each touching the tile do not imply a common point); the raster kernel
+//              decides per sample
 template <int S>
 struct TileTest {
     float ec[3];
@@ -228,30 +222,6 @@ struct TileTest {
 #pragma unroll
         for (int i = 0; i < 3; ++i) hit = hit && accepts(cov, i, cov.nay[i] > 0.0f ? hi : lo, cov.bx[i] > 0.0f ? hi : lo);
         return hit;
-    }
-    CRH_D void band_masks(const PrimCoverage& cov, uint32_t tx, uint32_t ty, uint32_t& bands, uint32_t& full) const {
-        bands = 0;
-        full = 0;
-        if (!overlap) return;
-        const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
-        const float s_lo = S == 1 ? 0.5f : 0.125f, s_hi = S == 1 ? 0.5f : 0.875f;
-        const float x_lo = s_lo, x_hi = (float)(kTile - 1) + s_hi;
-        const bool wide = (int)cov.box.x <= tpx && (int)cov.box.y >= tpx + kTile - 1;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int row0 = tpy + 4 * b, row1 = row0 + 3;
-            if ((int)cov.box.z > row1 || (int)cov.box.w < row0) continue;
-            const float y_lo = (float)(4 * b) + s_lo, y_hi = (float)(4 * b + 3) + s_hi;
-            bool some = true, all = wide && (int)cov.box.z <= row0 && (int)cov.box.w >= row1;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const bool xp = cov.nay[i] > 0.0f, yp = cov.bx[i] > 0.0f;
-                some = some && accepts(cov, i, xp ? x_hi : x_lo, yp ? y_hi : y_lo);
-                all = all && accepts(cov, i, xp ? x_lo : x_hi, yp ? y_lo : y_hi);
-            }
-            if (some) bands |= 1u << b;
-            if (some && all) full |= 1u << b;
-        }
     }
 };
 

@@ -1,4 +1,4 @@
-// csrc/raster_params.hpp — launch parameters of the band rasterizer, shared by raster.hip and api.hip.
+// csrc/raster_params.hpp — launch parameters of the tile rasterizer, shared by raster.hip and api.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,7 +16,7 @@ struct DrawItem {
 };
 
 struct RasterParams {
-    uint32_t width, height, tiles_x, tiles_y, n_tiles, n_bands; // 16x16 tiles, 4 bands (16x4 pixels) per tile: bin = tile * 4 + band
+    uint32_t width, height, tiles_x, tiles_y, n_tiles; // 16x16-pixel tiles
     uint32_t winding_mask;
     uint32_t clip_mask_count; // (1 << clip_nesting_counter_bits) - 1: clip depths are compared as plain counters
     const DrawItem* items;    // [n_items], or nullptr: item i = Shape i, instance i, Stencil + Color at clip depth 0
