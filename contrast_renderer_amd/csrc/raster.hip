@@ -376,13 +376,12 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             float minx = fminf(p[0].x, fminf(p[1].x, p[2].x)), maxx = fmaxf(p[0].x, fmaxf(p[1].x, p[2].x));
             float miny = fminf(p[0].y, fminf(p[1].y, p[2].y)), maxy = fmaxf(p[0].y, fmaxf(p[1].y, p[2].y));
             const bool nan_free = minx == minx && maxx == maxx && miny == miny && maxy == maxy;
-            minx = fmaxf(minx, 0.0f);
-            miny = fmaxf(miny, 0.0f);
-            maxx = fminf(maxx, W - 1.0f);
-            maxy = fminf(maxy, H - 1.0f);
-            if (nan_free && minx <= maxx && miny <= maxy) {
+            // inclusive pixel range: clamp, floor, THEN compare (oracle/raster.hpp setup_triangle)
+            const int x0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), x1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
+            const int y0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), y1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
+            if (nan_free && x0 <= x1 && y0 <= y1) {
                 drawn = true;
-                rec.cov.box = make_ushort4((unsigned short)floorf(minx), (unsigned short)floorf(maxx), (unsigned short)floorf(miny), (unsigned short)floorf(maxy));
+                rec.cov.box = make_ushort4((unsigned short)x0, (unsigned short)x1, (unsigned short)y0, (unsigned short)y1);
                 const float inv_det = 1.0f / det;
                 const bool front = det < 0.0f; // y-down cross < 0 == counter-clockwise on screen (FrontFace::Ccw, renderer.rs:477)
                 const float2 nv[3] = {p[0], det < 0.0f ? p[2] : p[1], det < 0.0f ? p[1] : p[2]}; // clockwise-in-y-down edge walk

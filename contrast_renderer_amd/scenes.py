@@ -87,9 +87,10 @@ def _blob_points(rng, n, size, r_lo, r_hi, log_radius, n_seg=8):
         radius = rng.uniform(r_lo, r_hi)
     angles = np.stack([2.0 * math.pi * k / n_seg + rng.uniform(-0.2, 0.2) for k in range(n_seg)], axis=1)
     rr = np.stack([rng.uniform(0.8, 1.2) for _ in range(n_seg)], axis=1)
-    # odd paths run clockwise so both stencil faces are exercised
-    direction = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)[:, None]
-    angles = angles * direction
+    # All paths run CLOCKWISE (y up): that is the reference's convention for solid paths — from_rect / from_rounded_rect / from_ellipse
+    # (path.rs:736-810) wind clockwise and holes are made with reverse(). The cubic fill (fill.rs:116-250) is only geometrically exact for
+    # that orientation: a stand-alone counter-clockwise cubic path is filled out to its control polygon (tests/test_oracle_ground_truth.py).
+    angles = -angles
     px = rr * np.cos(angles)  # local units: centre 0, radius ~1
     py = rr * np.sin(angles)
     return cx, cy, radius, angles, px, py
@@ -154,11 +155,11 @@ def _cubic_records(rng, n, px, py, rational):
     for k in range(n_seg):
         l1, l2 = rng.uniform(0.2, 0.45), rng.uniform(0.2, 0.45)
         a1, a2 = rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3)
-        # bulge outwards: rotate the chord direction away from the centre by ~0.4 rad plus the perturbation
-        h1x = px[:, k] + l1 * (np.cos(a1 - 0.4) * dx[:, k] - np.sin(a1 - 0.4) * dy[:, k])
-        h1y = py[:, k] + l1 * (np.sin(a1 - 0.4) * dx[:, k] + np.cos(a1 - 0.4) * dy[:, k])
-        h2x = ex[:, k] - l2 * (np.cos(a2 + 0.4) * dx[:, k] - np.sin(a2 + 0.4) * dy[:, k])
-        h2y = ey[:, k] - l2 * (np.sin(a2 + 0.4) * dx[:, k] + np.cos(a2 + 0.4) * dy[:, k])
+        # bulge outwards (clockwise travel: the outside is on the LEFT): rotate the chord direction by ~+0.4 rad plus the perturbation
+        h1x = px[:, k] + l1 * (np.cos(a1 + 0.4) * dx[:, k] - np.sin(a1 + 0.4) * dy[:, k])
+        h1y = py[:, k] + l1 * (np.sin(a1 + 0.4) * dx[:, k] + np.cos(a1 + 0.4) * dy[:, k])
+        h2x = ex[:, k] - l2 * (np.cos(a2 - 0.4) * dx[:, k] - np.sin(a2 - 0.4) * dy[:, k])
+        h2y = ey[:, k] - l2 * (np.sin(a2 - 0.4) * dx[:, k] + np.cos(a2 - 0.4) * dy[:, k])
         w = [rng.uniform(0.5, 2.0) for _ in range(4)]
         is_rational = rational == "all" or (rational == "mixed" and k % 2 == 1)
         if is_rational:
@@ -166,8 +167,8 @@ def _cubic_records(rng, n, px, py, rational):
             # areas (fill.rs:141-156), so with non-uniform weights a control point inside the triangle of the other three
             # trips assert_eq!/assert_ne! (fill.rs:174,178). P1, P2 sit on the legs of a triangle over the chord.
             depth, along = rng.uniform(0.25, 0.6), rng.uniform(0.4, 0.6)
-            apex_x = px[:, k] + along * dx[:, k] + depth * dy[:, k]   # right of travel: (dy, -dx)
-            apex_y = py[:, k] + along * dy[:, k] - depth * dx[:, k]
+            apex_x = px[:, k] + along * dx[:, k] - depth * dy[:, k]   # left of travel (outside of a clockwise path): (-dy, dx)
+            apex_y = py[:, k] + along * dy[:, k] + depth * dx[:, k]
             t1, t2 = rng.uniform(0.3, 0.55), rng.uniform(0.3, 0.55)
             h1x = px[:, k] + t1 * (apex_x - px[:, k])
             h1y = py[:, k] + t1 * (apex_y - py[:, k])

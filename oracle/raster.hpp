@@ -115,16 +115,13 @@ inline TriangleSetup setup_triangle(const float v[3][2], int width, int height) 
     float minx = std::fmin(v[0][0], std::fmin(v[1][0], v[2][0])), maxx = std::fmax(v[0][0], std::fmax(v[1][0], v[2][0]));
     float miny = std::fmin(v[0][1], std::fmin(v[1][1], v[2][1])), maxy = std::fmax(v[0][1], std::fmax(v[1][1], v[2][1]));
     if (!(minx == minx && maxx == maxx && miny == miny && maxy == maxy)) return t;
-    // clamp in float first (coordinates may exceed int range), then floor
-    minx = std::fmax(minx, 0.0f);
-    miny = std::fmax(miny, 0.0f);
-    maxx = std::fmin(maxx, (float)(width - 1));
-    maxy = std::fmin(maxy, (float)(height - 1));
-    if (minx > maxx || miny > maxy) return t;
-    t.x0 = (int)std::floor(minx);
-    t.x1 = (int)std::floor(maxx);
-    t.y0 = (int)std::floor(miny);
-    t.y1 = (int)std::floor(maxy);
+    // inclusive pixel range: clamp in float first (coordinates may exceed the int range), floor, THEN compare — a sliver that begins at
+    // x = W - 0.8 still owns the last pixel column although its clamped float range is empty
+    t.x0 = (int)std::floor(std::fmin(std::fmax(minx, 0.0f), (float)width));
+    t.x1 = (int)std::floor(std::fmax(std::fmin(maxx, (float)(width - 1)), -1.0f));
+    t.y0 = (int)std::floor(std::fmin(std::fmax(miny, 0.0f), (float)height));
+    t.y1 = (int)std::floor(std::fmax(std::fmin(maxy, (float)(height - 1)), -1.0f));
+    if (t.x0 > t.x1 || t.y0 > t.y1) return t;
     t.valid = true;
     return t;
 }
