@@ -246,3 +246,27 @@ def test_dash_pattern_along_a_straight_line(oracle_lib):
     safe = (edge_distance > 0.01) & (np.abs(arc + 0.5) * width * size * 0.5 > 0.01) & (np.abs(arc - 1.8 / width - 0.5) * width * size * 0.5 > 0.01)
     assert np.array_equal(row[safe], dash[safe])
     assert dash.sum() > 100 and (on_path & ~dash).sum() > 40
+
+
+@pytest.mark.parametrize("offset", [-0.5, 0.0, 0.25, 0.5])
+def test_stroke_offset_shifts_the_band_to_the_right_of_travel(oracle_lib, offset):
+    """StrokeOptions::offset: "negative = left, positive = right of the path's forward direction" (path.rs:179): the stroke of a line
+    travelling in +x covers y in [-(offset + 0.5) w, -(offset - 0.5) w] (y up)."""
+    width = 0.2
+    path = Path(start=(-0.7, 0.1))
+    path.push_line((0.7, 0.1))
+    path.stroke_options = StrokeOptions(width, offset, 4.0, False, 0, CurveApproximation.UniformlySpacedParameters(1))
+    batch = batch_from_shapes([([DynamicStrokeOptions.Solid(Join.Miter, Cap.Butt, Cap.Butt)], [path])])
+    oracle = oracle_lib.Oracle(batch)
+    assert oracle.status() == 0
+    transform = scenes.place(SIZE, SIZE, np.array([SIZE / 2.0]), np.array([SIZE / 2.0]), np.array([SIZE * 0.5]))
+    image = oracle.render(SIZE, SIZE, 1, 4, transform, np.array([[1.0, 1.0, 1.0, 1.0]], dtype=np.float32))
+    covered = image[..., 3] > 0
+    ys, xs = np.nonzero(covered)
+    # scene y of the covered rows (pixel centre -> y up, frame centre = 0, scale SIZE / 2)
+    y_scene = (SIZE / 2.0 - (ys + 0.5)) / (SIZE * 0.5)
+    lo, hi = 0.1 - (offset + 0.5) * width, 0.1 - (offset - 0.5) * width
+    assert y_scene.min() > lo - 1.0 / SIZE and y_scene.max() < hi + 1.0 / SIZE
+    assert abs(y_scene.min() - lo) < 2.5 / SIZE and abs(y_scene.max() - hi) < 2.5 / SIZE
+    x_scene = ((xs + 0.5) - SIZE / 2.0) / (SIZE * 0.5)
+    assert x_scene.min() > -0.7 - 1.0 / SIZE and x_scene.max() < 0.7 + 1.0 / SIZE
