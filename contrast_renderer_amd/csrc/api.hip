@@ -18,8 +18,9 @@ typedef void (*MarkFn)(void*, const char*, uint64_t);
 void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke);
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
-void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx);
-void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
+void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_setup);
+void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke,
+                   hipEvent_t after_fill);
 void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -71,13 +72,16 @@ struct Mark {
     hipEvent_t event;
     std::string name;
     uint64_t bytes;
+    int lane; // 0 = raster stream, 1 = tessellation stream: durations are taken between consecutive marks of one lane
 };
 } // namespace
 
 struct crh_renderer {
     crh_config config;
     int device;
-    hipStream_t stream;
+    hipStream_t stream;       // setup, binning, raster, copies
+    hipStream_t tess_stream;  // tessellation: frame N + 1's (small, latency bound) kernels overlap frame N's binning and raster
+    bool pipeline = true;     // CRH_NO_PIPELINE=1 runs everything on `stream`
     bool timing = false;
     std::vector<hipEvent_t> event_pool;
     std::vector<Mark> marks;
@@ -92,19 +96,32 @@ struct crh_renderer {
         return event_pool[events_used++];
     }
     // marks accumulate over calls (so a benchmark can time K steps without a sync per step); kernel_times() drains them
-    void begin_marks() {
+    hipStream_t tessellation_stream() const { return pipeline ? tess_stream : stream; }
+    void begin_marks(int lane = 0) {
         if (!timing) return;
         hipEvent_t e = next_event();
-        (void)hipEventRecord(e, stream);
-        marks.push_back({e, "", 0});
+        (void)hipEventRecord(e, lane ? tessellation_stream() : stream);
+        marks.push_back({e, "", 0, lane});
     }
     static void mark_cb(void* ctx, const char* name, uint64_t bytes) {
         crh_renderer* r = static_cast<crh_renderer*>(ctx);
         hipEvent_t e = r->next_event();
         (void)hipEventRecord(e, r->stream);
-        r->marks.push_back({e, name, bytes});
+        r->marks.push_back({e, name, bytes, 0});
+    }
+    static void mark_cb_tess(void* ctx, const char* name, uint64_t bytes) {
+        crh_renderer* r = static_cast<crh_renderer*>(ctx);
+        hipEvent_t e = r->next_event();
+        (void)hipEventRecord(e, r->tessellation_stream());
+        r->marks.push_back({e, name, bytes, 1});
     }
     MarkFn mark_fn() const { return timing ? &crh_renderer::mark_cb : nullptr; }
+    MarkFn mark_fn_tess() const { return timing ? &crh_renderer::mark_cb_tess : nullptr; }
+    hipError_t sync() { // both streams
+        const hipError_t e = hipStreamSynchronize(tess_stream);
+        const hipError_t f = hipStreamSynchronize(stream);
+        return e != hipSuccess ? e : f;
+    }
 };
 
 struct crh_frame {
@@ -140,6 +157,11 @@ struct crh_scene {
     // instances + binning
     DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch, prim_rec;
     bool instances_set = false;
+    // frame pipelining: tessellation runs on its own stream; these events order it against the raster stream
+    hipEvent_t tess_done = nullptr;     // recorded on the tessellation stream after the last tessellation kernel
+    hipEvent_t vertices_free = nullptr; // recorded on the raster stream after k_prim_setup (last reader of the vertex streams and hulls)
+    hipEvent_t ranges_free = nullptr;   // recorded on the raster stream after the fill pass (last reader of the primitive ranges)
+    bool rendered_once = false;
     // host copies for the parity taps
     std::vector<uint32_t> shape_base_host, hull_count_host;
     bool layout_valid = false;
@@ -240,28 +262,34 @@ crh_status run_tessellation(crh_scene* sc) {
     crh_renderer* r = sc->renderer;
     HIP_TRY(hipSetDevice(r->device));
     SceneDev& d = sc->d;
-    r->begin_marks();
-    HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, r->stream));
+    const hipStream_t ts = r->tessellation_stream();
+    // the previous frame's k_prim_setup must have consumed the vertex streams this run overwrites; its binning and raster may still run
+    if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->vertices_free, 0));
+    r->begin_marks(1);
+    HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, ts));
     if (d.n_elems == 0) { // nothing to tessellate: every offset is zero
-        HIP_TRY(hipMemsetAsync(d.totals, 0, NCH * 4, r->stream));
-        HIP_TRY(hipMemsetAsync(d.shape_base, 0, (size_t)(d.n_shapes + 1) * NCH * 4, r->stream));
-        if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.hull_count, 0, (size_t)d.n_shapes * 4, r->stream));
+        HIP_TRY(hipMemsetAsync(d.totals, 0, NCH * 4, ts));
+        HIP_TRY(hipMemsetAsync(d.shape_base, 0, (size_t)(d.n_shapes + 1) * NCH * 4, ts));
+        if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.hull_count, 0, (size_t)d.n_shapes * 4, ts));
     }
     const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
-    launch_tessellate(d, r->stream, r->mark_fn(), r, bytes, sc->has_stroke);
+    launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke);
     if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
-        HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, ts));
+        HIP_TRY(r->sync());
         crh_status st = ensure_outputs(sc);
         if (st != CRH_OK) return st;
         sc->capacity_known = true;
     }
-    if (sc->has_stroke) HIP_TRY(hipMemsetAsync(d.line_pair_cut, 0, sc->line_pair_cut.cap, r->stream));
+    if (sc->has_stroke) HIP_TRY(hipMemsetAsync(d.line_pair_cut, 0, sc->line_pair_cut.cap, ts));
     const uint64_t bytes2[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, (uint64_t)sc->totals_host[CH_HULL] * 8};
-    launch_emit(d, r->stream, r->mark_fn(), r, bytes2, sc->has_stroke, sc->big_shapes);
-    // contiguous primitive ids per Shape, in draw order (transform independent, so it belongs to the tessellation)
-    launch_prim_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), r->stream);
-    if (r->timing) crh_renderer::mark_cb(r, "tess_prim_ranges", 0);
+    launch_emit(d, ts, r->mark_fn_tess(), r, bytes2, sc->has_stroke, sc->big_shapes);
+    // contiguous primitive ids per Shape, in draw order (transform independent, so it belongs to the tessellation); the previous
+    // frame's tile walks read the old ranges until its fill pass is through
+    if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0));
+    launch_prim_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), ts);
+    if (r->timing) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
+    HIP_TRY(hipEventRecord(sc->tess_done, ts));
     HIP_TRY(hipGetLastError());
     sc->layout_valid = false;
     return CRH_OK;
@@ -273,7 +301,7 @@ crh_status settle_tessellation(crh_scene* sc, uint32_t* status_word) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint32_t word = 0;
         HIP_TRY(hipMemcpyAsync(&word, sc->d.status, 4, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(r->sync());
         if (word != 0xFFFFFFFFu && (word & 0xFFu) >= 0x80u && attempt == 0) {
             sc->capacity_known = false;
             crh_status st = run_tessellation(sc);
@@ -297,7 +325,7 @@ crh_status fetch_layout(crh_scene* sc) {
     HIP_TRY(hipMemcpyAsync(sc->shape_base_host.data(), sc->d.shape_base, sc->shape_base_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
     if (sc->d.n_shapes) HIP_TRY(hipMemcpyAsync(sc->hull_count_host.data(), sc->d.hull_count, sc->hull_count_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipMemcpyAsync(sc->totals_host, sc->d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->sync());
     sc->layout_valid = true;
     return CRH_OK;
 }
@@ -399,6 +427,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     if (!recorded && !sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
     if (!sc->capacity_known) return CRH_ERR_INVALID_ARGUMENT; // tessellate first
     HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamWaitEvent(r->stream, sc->tess_done, 0)); // the tessellation this frame draws (a no-op when it finished long ago)
     RasterParams p;
     p.width = f->width;
     p.height = f->height;
@@ -425,7 +454,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
         launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), r->stream);
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(r->sync());
         if (total >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED;
         HIP_TRY(sc->prim_rec.ensure(((size_t)total + 64) * 128));
         HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
@@ -454,11 +483,11 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         p.tile_list = f->tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(f->tile_list.cap / 4);
-        launch_bin(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r);
+        launch_bin(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, sc->vertices_free);
         if (f->pairs_known) break;
         uint32_t ov[4];
         HIP_TRY(hipMemcpyAsync(ov, p.overflow, 16, hipMemcpyDeviceToHost, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(r->sync());
         f->pairs_known = true;
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
@@ -469,7 +498,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
-    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
+    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke, sc->ranges_free);
+    sc->rendered_once = true;
     HIP_TRY(hipGetLastError());
     f->cleared = false;
     f->last_scene = sc;
@@ -483,15 +513,16 @@ crh_status settle_frame(crh_frame* f) {
     crh_renderer* r = f->renderer;
     uint32_t ov[4];
     HIP_TRY(hipMemcpyAsync(ov, f->overflow.p, 16, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->sync());
     f->check_pending = false;
+    if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
     if ((ov[0] != 0 || sort_overflow) && f->last_scene) {
         HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
         f->cleared = true; // a frame rendered over existing content cannot be recovered exactly; documented in DESIGN.md
         crh_status st = render_impl(f->last_scene, f);
         if (st != CRH_OK) return st;
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(r->sync());
         f->check_pending = false;
     }
     return CRH_OK;
@@ -524,19 +555,22 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     crh_renderer* r = new crh_renderer;
     r->config = *config;
     r->device = device_ordinal;
-    if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+    if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipStreamCreateWithFlags(&r->tess_stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete r;
         return CRH_ERR_HIP;
     }
+    r->pipeline = getenv("CRH_NO_PIPELINE") == nullptr;
     *out = r;
     return CRH_OK;
 }
 void crh_renderer_destroy(crh_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    (void)hipStreamSynchronize(r->stream);
+    (void)r->sync();
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(r->stream);
+    (void)hipStreamDestroy(r->tess_stream);
     delete r;
 }
 crh_status crh_renderer_get_config(const crh_renderer* r, crh_config* out) {
@@ -618,6 +652,15 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     HIP_TRY(hipSetDevice(r->device));
     crh_scene* sc = existing ? existing : new crh_scene;
     sc->renderer = r;
+    if (!sc->tess_done) {
+        if (!hip_ok(hipEventCreateWithFlags(&sc->tess_done, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&sc->vertices_free, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&sc->ranges_free, hipEventDisableTiming), "hipEventCreate")) {
+            if (!existing) delete sc;
+            return CRH_ERR_HIP;
+        }
+    }
+    sc->rendered_once = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
     sc->capacity_known = false;
@@ -733,8 +776,10 @@ crh_status crh_scene_status(crh_scene* sc) {
 void crh_scene_destroy(crh_scene* sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->renderer->device);
-    (void)hipStreamSynchronize(sc->renderer->stream);
+    (void)sc->renderer->sync();
     sc->release_all();
+    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free})
+        if (e) (void)hipEventDestroy(e);
     delete sc;
 }
 crh_status crh_shape_from_paths(crh_renderer* r, const crh_path_batch* one_shape, crh_scene* existing, crh_scene** out) {
@@ -817,7 +862,7 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* sc, uint32_t shape, u
     if (st != CRH_OK) return st;
     HIP_TRY(hipSetDevice(sc->renderer->device));
     HIP_TRY(hipMemcpyAsync(sc->d.descriptors + begin + group, &d, sizeof(d), hipMemcpyHostToDevice, sc->renderer->stream));
-    HIP_TRY(hipStreamSynchronize(sc->renderer->stream));
+    HIP_TRY(sc->renderer->sync());
     return CRH_OK;
 }
 
@@ -845,7 +890,7 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
 void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->renderer->device);
-    (void)hipStreamSynchronize(f->renderer->stream);
+    (void)f->renderer->sync();
     DevBuf* all[] = {&f->rgba8, &f->tile_count_cursor, &f->tile_offset, &f->tile_list, &f->overflow, &f->scan_scratch,
                      &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
     for (DevBuf* b : all) b->release();
@@ -868,7 +913,7 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
     if (sc->d.n_shapes) {
         HIP_TRY(hipMemcpyAsync(sc->transforms.p, transforms, (size_t)sc->d.n_shapes * 64, hipMemcpyHostToDevice, r->stream));
         HIP_TRY(hipMemcpyAsync(sc->colors.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->stream));
-        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(r->sync());
     }
     sc->instances_set = true;
     return CRH_OK;
@@ -920,7 +965,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     HIP_TRY(hipMemcpyAsync(f->items.p, items.data(), items.size() * sizeof(DrawItem), hipMemcpyHostToDevice, r->stream));
     HIP_TRY(hipMemcpyAsync(f->item_transforms.p, transforms, (size_t)n_instances * 64, hipMemcpyHostToDevice, r->stream));
     HIP_TRY(hipMemcpyAsync(f->item_colors.p, colors, (size_t)n_instances * 16, hipMemcpyHostToDevice, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream)); // `items` and the caller's arrays may go away
+    HIP_TRY(r->sync()); // `items` and the caller's arrays may go away
     f->n_items = (uint32_t)items.size();
     f->pairs_known = false; // a different pass: re-learn the tile list size
     return render_impl(sc, f);
@@ -937,12 +982,12 @@ crh_status crh_frame_download(crh_frame* f, void* rgba8) {
     crh_status st = settle_frame(f);
     if (st != CRH_OK) return st;
     HIP_TRY(hipMemcpyAsync(rgba8, f->rgba8.p, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->sync());
     return CRH_OK;
 }
 extern "C" crh_status crh_debug_frame_counters(crh_frame* f, uint32_t out[8]) { // tools only (not in the public header)
     HIP_TRY(hipSetDevice(f->renderer->device));
-    HIP_TRY(hipStreamSynchronize(f->renderer->stream));
+    HIP_TRY(f->renderer->sync());
     HIP_TRY(hipMemcpy(out, f->overflow.p, 32, hipMemcpyDeviceToHost));
     return CRH_OK;
 }
@@ -961,7 +1006,7 @@ crh_status crh_composite_over(crh_renderer* r, const void* const* layers_dev, ui
     hipError_t e = hipMemcpyAsync(table, layers_dev, sizeof(void*) * n_layers, hipMemcpyHostToDevice, r->stream);
     if (e == hipSuccess) {
         launch_composite(static_cast<const uint8_t* const*>(table), n_layers, n_pixels, static_cast<uint8_t*>(dst_dev), r->stream);
-        e = hipStreamSynchronize(r->stream);
+        e = r->sync();
     }
     (void)hipFree(table);
     HIP_TRY(e);
@@ -980,7 +1025,7 @@ crh_status crh_selftest_fmath(crh_renderer* r, int fn, const float* a, const flo
             rc = CRH_ERR_HIP;
         if (rc == CRH_OK) {
             launch_fmath(fn, da.as<float>(), db.as<float>(), dout.as<float>(), n, r->stream);
-            if (!hip_ok(hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, r->stream), "memcpy") || !hip_ok(hipStreamSynchronize(r->stream), "sync")) rc = CRH_ERR_HIP;
+            if (!hip_ok(hipMemcpyAsync(out, dout.p, n * 4, hipMemcpyDeviceToHost, r->stream), "memcpy") || !hip_ok(r->sync(), "sync")) rc = CRH_ERR_HIP;
         }
     }
     da.release();
@@ -992,7 +1037,7 @@ crh_status crh_selftest_fmath(crh_renderer* r, int fn, const float* a, const flo
 crh_status crh_renderer_synchronize(crh_renderer* r) {
     if (!r) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->sync());
     return CRH_OK;
 }
 void* crh_renderer_stream(crh_renderer* r) { return r ? (void*)r->stream : nullptr; }
@@ -1006,13 +1051,16 @@ crh_status crh_renderer_enable_timing(crh_renderer* r, int enabled) {
 crh_status crh_renderer_kernel_times(crh_renderer* r, crh_kernel_time* out, uint32_t capacity, uint32_t* count) {
     if (!r || !count) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(r->sync());
     uint32_t n = 0;
-    for (size_t i = 1; i < r->marks.size(); ++i) {
-        if (r->marks[i].name.empty()) continue; // a begin mark: the gap before it is host time, not a kernel
+    size_t previous_of_lane[2] = {SIZE_MAX, SIZE_MAX};
+    for (size_t i = 0; i < r->marks.size(); ++i) {
+        const size_t before = previous_of_lane[r->marks[i].lane];
+        previous_of_lane[r->marks[i].lane] = i;
+        if (r->marks[i].name.empty() || before == SIZE_MAX) continue; // a begin mark: the gap before it is host time, not a kernel
         if (n < capacity && out) {
             float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, r->marks[i - 1].event, r->marks[i].event));
+            HIP_TRY(hipEventElapsedTime(&ms, r->marks[before].event, r->marks[i].event));
             std::snprintf(out[n].name, sizeof(out[n].name), "%s", r->marks[i].name.c_str());
             out[n].ms = ms;
             out[n].algorithmic_bytes = r->marks[i].bytes;

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     const uint32_t list_begin = r.tile_offset[tile];
     uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
     if (n > r.sort_capacity) { // the host sizes the sort buffer from overflow[3] (the longest list) and runs the frame again
-        if (lane == 0 && n > kSortBytesMax / (4u * (4u / ROWS))) raise_error(s, 0, CRH_ERR_UNSUPPORTED); // beyond what LDS can sort
+        if (lane == 0 && n > kSortBytesMax / (4u * (4u / ROWS))) atomicMax(&r.overflow[2], 1u); // beyond what LDS can sort: reported with the frame
         n = 0;
     }
     // ---- draw order = ascending prim id: bitonic network in registers (<= 64 entries) or in LDS
@@ -938,7 +938,8 @@ void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item
     hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
     hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, unused, 0);
 }
-void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
+// `after_setup` (optional) is recorded when k_prim_setup, the last reader of the tessellated vertex streams, has been enqueued
+void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_setup) {
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
     (void)hipMemsetAsync(r.overflow, 0, 16, stream);
     if (r.n_items) {
@@ -947,6 +948,7 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
         else
             hipLaunchKernelGGL(k_prim_setup<1>, dim3(r.n_items), dim3(64), 0, stream, s, r);
     }
+    if (after_setup) (void)hipEventRecord(after_setup, stream);
     if (mark) mark(ctx, "raster_prim_setup", 0);
     if (r.n_items) {
         if (samples == 4)
@@ -960,14 +962,16 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
     hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, r, 1);
     if (mark) mark(ctx, "raster_tile_scan", 0);
 }
+// `after_fill` (optional) is recorded when the fill pass, the last reader of the per-item primitive ranges, has been enqueued
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
-                   uint64_t raster_bytes, bool has_stroke) {
+                   uint64_t raster_bytes, bool has_stroke, hipEvent_t after_fill) {
     if (r.n_items) {
         if (samples == 4)
             hipLaunchKernelGGL((k_tile_walk<4, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
         else
             hipLaunchKernelGGL((k_tile_walk<1, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
     }
+    if (after_fill) (void)hipEventRecord(after_fill, stream);
     if (mark) mark(ctx, "raster_tile_fill", 0);
     const dim3 grid(r.n_tiles);
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \

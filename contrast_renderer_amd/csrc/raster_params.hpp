@@ -29,7 +29,7 @@ struct RasterParams {
     uint32_t* tile_offset;   // [n_tiles + 1]
     uint32_t* tile_list;     // [pair_capacity] prim ids, grouped by tile
     uint32_t pair_capacity;
-    uint32_t* overflow;      // [0] pair capacity exceeded, [1] required pairs, [3] longest tile list
+    uint32_t* overflow;      // [0] pair capacity exceeded, [1] required pairs, [2] a tile list is longer than LDS can sort, [3] longest tile list
     uint32_t sort_capacity;  // primitives per tile the raster kernel's LDS sort buffer holds (a power of two)
     const uint32_t* shape_ncand;      // [n_items] candidate triangles per item
     uint32_t* shape_prim_begin;       // [n_items + 1] contiguous primitive ids per item, ascending in draw order
