@@ -19,8 +19,8 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void*
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_setup);
-void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke,
-                   hipEvent_t after_fill);
+void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_fill);
+void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -72,14 +72,15 @@ struct Mark {
     hipEvent_t event;
     std::string name;
     uint64_t bytes;
-    int lane; // 0 = raster stream, 1 = tessellation stream: durations are taken between consecutive marks of one lane
+    int lane; // 0 = raster, 1 = tessellation, 2 = binning stream: durations are taken between consecutive marks of one lane
 };
 } // namespace
 
 struct crh_renderer {
     crh_config config;
     int device;
-    hipStream_t stream;       // setup, binning, raster, copies
+    hipStream_t stream;       // raster kernel, copies
+    hipStream_t bin_stream;   // primitive setup + tile binning: frame N + 1's overlap frame N's raster kernel (double-buffered records / lists)
     hipStream_t tess_stream;  // tessellation: frame N + 1's (small, latency bound) kernels overlap frame N's binning and raster
     bool pipeline = true;     // CRH_NO_PIPELINE=1 runs everything on `stream`
     bool timing = false;
@@ -97,12 +98,21 @@ struct crh_renderer {
     }
     // marks accumulate over calls (so a benchmark can time K steps without a sync per step); kernel_times() drains them
     hipStream_t tessellation_stream() const { return pipeline ? tess_stream : stream; }
+    hipStream_t binning_stream() const { return pipeline ? bin_stream : stream; }
+    hipStream_t lane_stream(int lane) const { return lane == 1 ? tessellation_stream() : (lane == 2 ? binning_stream() : stream); }
     void begin_marks(int lane = 0) {
         if (!timing) return;
         hipEvent_t e = next_event();
-        (void)hipEventRecord(e, lane ? tessellation_stream() : stream);
+        (void)hipEventRecord(e, lane_stream(lane));
         marks.push_back({e, "", 0, lane});
     }
+    static void mark_cb_bin(void* ctx, const char* name, uint64_t bytes) {
+        crh_renderer* r = static_cast<crh_renderer*>(ctx);
+        hipEvent_t e = r->next_event();
+        (void)hipEventRecord(e, r->binning_stream());
+        r->marks.push_back({e, name, bytes, 2});
+    }
+    MarkFn mark_fn_bin() const { return timing ? &crh_renderer::mark_cb_bin : nullptr; }
     static void mark_cb(void* ctx, const char* name, uint64_t bytes) {
         crh_renderer* r = static_cast<crh_renderer*>(ctx);
         hipEvent_t e = r->next_event();
@@ -119,21 +129,31 @@ struct crh_renderer {
     MarkFn mark_fn_tess() const { return timing ? &crh_renderer::mark_cb_tess : nullptr; }
     hipError_t sync() { // both streams
         const hipError_t e = hipStreamSynchronize(tess_stream);
+        const hipError_t b = hipStreamSynchronize(bin_stream);
         const hipError_t f = hipStreamSynchronize(stream);
-        return e != hipSuccess ? e : f;
+        return e != hipSuccess ? e : (b != hipSuccess ? b : f);
     }
 };
 
 struct crh_frame {
     crh_renderer* renderer;
     uint32_t width, height, tiles_x, tiles_y, n_tiles;
-    DevBuf rgba8, tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
+    DevBuf rgba8;
+    // Two sets of binning buffers, used alternately: frame N + 1 is binned while frame N's raster kernel still reads the other set.
+    struct BinSet {
+        DevBuf tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
+        hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
+        hipEvent_t raster_done = nullptr; // recorded on the raster stream after the raster kernel that read this set
+        bool used = false;
+    } sets[2];
+    int next_set = 0, last_set = 0;
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
     uint32_t n_items = 0;
     bool cleared = true;
     bool pairs_known = false;
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
+    size_t pair_capacity_bytes = 1024 * 4; // size of a set's tile list (both sets grow to it)
     // last render, for the transparent re-run after a bin-capacity overflow
     crh_scene* last_scene = nullptr;
     bool check_pending = false;
@@ -155,7 +175,11 @@ struct crh_scene {
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
-    DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch, prim_rec;
+    DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch;
+    DevBuf prim_rec[2];                 // set-up triangles, double-buffered like the frame's binning buffers
+    hipEvent_t rec_raster_done[2] = {nullptr, nullptr};
+    bool rec_used[2] = {false, false};
+    int next_rec = 0;
     bool instances_set = false;
     // frame pipelining: tessellation runs on its own stream; these events order it against the raster stream
     hipEvent_t tess_done = nullptr;     // recorded on the tessellation stream after the last tessellation kernel
@@ -170,7 +194,7 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec[0], &prim_rec[1]};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -427,7 +451,14 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     if (!recorded && !sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
     if (!sc->capacity_known) return CRH_ERR_INVALID_ARGUMENT; // tessellate first
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipStreamWaitEvent(r->stream, sc->tess_done, 0)); // the tessellation this frame draws (a no-op when it finished long ago)
+    // Three lanes: tessellation -> binning (setup, tile walks) -> raster. This frame is binned into the frame's other set of tile
+    // buffers and the scene's other record buffer while the previous frame's raster kernel may still be reading its own.
+    const hipStream_t bin = r->binning_stream();
+    crh_frame::BinSet& set = f->sets[f->next_set];
+    const int rec = sc->next_rec;
+    HIP_TRY(hipStreamWaitEvent(bin, sc->tess_done, 0)); // the tessellation this frame draws (a no-op when it finished long ago)
+    if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.raster_done, 0));
+    if (sc->rec_used[rec]) HIP_TRY(hipStreamWaitEvent(bin, sc->rec_raster_done[rec], 0));
     RasterParams p;
     p.width = f->width;
     p.height = f->height;
@@ -441,23 +472,23 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.load_existing = f->cleared ? 0u : 1u;
     p.transforms = recorded ? f->item_transforms.as<float>() : sc->transforms.as<float>();
     p.colors = recorded ? f->item_colors.as<float>() : sc->colors.as<float>();
-    p.tile_count = f->tile_count_cursor.as<uint32_t>();
-    p.tile_cursor = f->tile_count_cursor.as<uint32_t>() + f->n_tiles;
-    p.tile_offset = f->tile_offset.as<uint32_t>();
+    p.tile_count = set.tile_count_cursor.as<uint32_t>();
+    p.tile_cursor = set.tile_count_cursor.as<uint32_t>() + f->n_tiles;
+    p.tile_offset = set.tile_offset.as<uint32_t>();
     p.shape_ncand = sc->shape_ncand.as<uint32_t>();
     p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
+    HIP_TRY(set.scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
     if (recorded) {
         // primitive ranges per draw item; a Shape may be drawn many times, so the record capacity comes from the scan's total
         HIP_TRY(f->item_ncand.ensure((size_t)f->n_items * 4 + 4));
         HIP_TRY(f->item_prim_begin.ensure(((size_t)f->n_items + 1) * 4));
         HIP_TRY(f->item_scan_scratch.ensure(((size_t)(f->n_items + 1023) / 1024 + 2) * 4));
-        launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), r->stream);
+        launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), bin);
         uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, bin));
         HIP_TRY(r->sync());
         if (total >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED;
-        HIP_TRY(sc->prim_rec.ensure(((size_t)total + 64) * 128));
-        HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
+        HIP_TRY(sc->prim_rec[rec].ensure(((size_t)total + 64) * 128));
         p.prim_capacity = total + 64u;
         p.shape_ncand = f->item_ncand.as<uint32_t>();
         p.shape_prim_begin = f->item_prim_begin.as<uint32_t>();
@@ -465,42 +496,57 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
         // every candidate triangle gets a record slot: an upper bound follows from the tessellation totals
         const uint32_t* t = sc->totals_host;
         const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
-        HIP_TRY(sc->prim_rec.ensure(prim_capacity * 128));
-        if (prim_capacity == 0xFFFFFFFFu) return CRH_ERR_UNSUPPORTED; // 0xFFFFFFFF pads the tile sort
-        HIP_TRY(f->scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
+        if (prim_capacity >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED; // 0xFFFFFFFF pads the tile sort
+        HIP_TRY(sc->prim_rec[rec].ensure(prim_capacity * 128));
         p.prim_capacity = (uint32_t)prim_capacity;
     }
-    p.scan_scratch = f->scan_scratch.as<uint32_t>();
-    p.prim_rec = static_cast<PrimRec*>(sc->prim_rec.p);
-    p.overflow = f->overflow.as<uint32_t>();
+    p.scan_scratch = set.scan_scratch.as<uint32_t>();
+    p.prim_rec = static_cast<PrimRec*>(sc->prim_rec[rec].p);
+    p.overflow = set.overflow.as<uint32_t>();
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
-    r->begin_marks();
+    r->begin_marks(2);
     // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
     if (!f->cleared) f->pairs_known = false;
+    HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     for (int attempt = 0; attempt < 2; ++attempt) {
-        p.tile_list = f->tile_list.as<uint32_t>();
-        p.pair_capacity = (uint32_t)(f->tile_list.cap / 4);
-        launch_bin(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, sc->vertices_free);
+        p.tile_list = set.tile_list.as<uint32_t>();
+        p.pair_capacity = (uint32_t)(set.tile_list.cap / 4);
+        launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         if (f->pairs_known) break;
         uint32_t ov[4];
-        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 16, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 16, hipMemcpyDeviceToHost, bin));
         HIP_TRY(r->sync());
         f->pairs_known = true;
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
         if (ov[0] == 0) break;
-        HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
-        r->begin_marks();
+        f->pair_capacity_bytes = ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4;
+        HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
+        r->begin_marks(2);
     }
+    launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
+    HIP_TRY(hipEventRecord(set.bin_done, bin));
+    // ---- raster lane
+    HIP_TRY(hipStreamWaitEvent(r->stream, set.bin_done, 0));
+    r->begin_marks(0);
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
-    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke, sc->ranges_free);
+    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
+    HIP_TRY(hipEventRecord(set.raster_done, r->stream));
+    HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
+    set.used = true;
+    sc->rec_used[rec] = true;
     sc->rendered_once = true;
     HIP_TRY(hipGetLastError());
+    f->last_set = f->next_set;
+    if (r->pipeline) { // alternate the buffers; without pipelining everything is ordered on one stream anyway
+        f->next_set ^= 1;
+        sc->next_rec ^= 1;
+    }
     f->cleared = false;
     f->last_scene = sc;
     f->check_pending = true;
@@ -512,13 +558,14 @@ crh_status settle_frame(crh_frame* f) {
     if (!f->check_pending) return CRH_OK;
     crh_renderer* r = f->renderer;
     uint32_t ov[4];
-    HIP_TRY(hipMemcpyAsync(ov, f->overflow.p, 16, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r->sync());
+    HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow.p, 16, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
     if ((ov[0] != 0 || sort_overflow) && f->last_scene) {
-        HIP_TRY(f->tile_list.ensure(((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4));
+        f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4);
         f->cleared = true; // a frame rendered over existing content cannot be recovered exactly; documented in DESIGN.md
         crh_status st = render_impl(f->last_scene, f);
         if (st != CRH_OK) return st;
@@ -556,7 +603,8 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     r->config = *config;
     r->device = device_ordinal;
     if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->tess_stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        !hip_ok(hipStreamCreateWithFlags(&r->tess_stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipStreamCreateWithFlags(&r->bin_stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete r;
         return CRH_ERR_HIP;
     }
@@ -571,6 +619,7 @@ void crh_renderer_destroy(crh_renderer* r) {
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(r->stream);
     (void)hipStreamDestroy(r->tess_stream);
+    (void)hipStreamDestroy(r->bin_stream);
     delete r;
 }
 crh_status crh_renderer_get_config(const crh_renderer* r, crh_config* out) {
@@ -655,12 +704,15 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     if (!sc->tess_done) {
         if (!hip_ok(hipEventCreateWithFlags(&sc->tess_done, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&sc->vertices_free, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&sc->ranges_free, hipEventDisableTiming), "hipEventCreate")) {
+            !hip_ok(hipEventCreateWithFlags(&sc->ranges_free, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&sc->rec_raster_done[0], hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&sc->rec_raster_done[1], hipEventDisableTiming), "hipEventCreate")) {
             if (!existing) delete sc;
             return CRH_ERR_HIP;
         }
     }
     sc->rendered_once = false;
+    sc->rec_used[0] = sc->rec_used[1] = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
     sc->capacity_known = false;
@@ -778,7 +830,7 @@ void crh_scene_destroy(crh_scene* sc) {
     (void)hipSetDevice(sc->renderer->device);
     (void)sc->renderer->sync();
     sc->release_all();
-    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free})
+    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free, sc->rec_raster_done[0], sc->rec_raster_done[1]})
         if (e) (void)hipEventDestroy(e);
     delete sc;
 }
@@ -876,14 +928,19 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     f->tiles_x = (width + 15) / 16;
     f->tiles_y = (height + 15) / 16;
     f->n_tiles = f->tiles_x * f->tiles_y;
-    if (!hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame") || !hip_ok(f->tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") ||
-        !hip_ok(f->tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") || !hip_ok(f->tile_list.ensure(1024 * 4), "hipMalloc") ||
-        !hip_ok(f->overflow.ensure(64), "hipMalloc")) {
-        delete f;
+    bool ok = hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame");
+    for (crh_frame::BinSet& set : f->sets)
+        ok = ok && hip_ok(set.tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") && hip_ok(set.tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") &&
+             hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") && hip_ok(set.overflow.ensure(64), "hipMalloc") &&
+             hip_ok(hipEventCreateWithFlags(&set.bin_done, hipEventDisableTiming), "hipEventCreate") &&
+             hip_ok(hipEventCreateWithFlags(&set.raster_done, hipEventDisableTiming), "hipEventCreate");
+    if (!ok) {
+        crh_frame_destroy(f);
         return CRH_ERR_HIP;
     }
     HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)width * height * 4, r->stream));
-    HIP_TRY(hipMemsetAsync(f->overflow.p, 0, 64, r->stream));
+    for (crh_frame::BinSet& set : f->sets) HIP_TRY(hipMemsetAsync(set.overflow.p, 0, 64, r->stream));
+    HIP_TRY(r->sync());
     *out = f;
     return CRH_OK;
 }
@@ -891,9 +948,14 @@ void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->renderer->device);
     (void)f->renderer->sync();
-    DevBuf* all[] = {&f->rgba8, &f->tile_count_cursor, &f->tile_offset, &f->tile_list, &f->overflow, &f->scan_scratch,
-                     &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
+    DevBuf* all[] = {&f->rgba8, &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
     for (DevBuf* b : all) b->release();
+    for (crh_frame::BinSet& set : f->sets) {
+        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch};
+        for (DevBuf* b : bins) b->release();
+        if (set.bin_done) (void)hipEventDestroy(set.bin_done);
+        if (set.raster_done) (void)hipEventDestroy(set.raster_done);
+    }
     delete f;
 }
 crh_status crh_frame_clear(crh_frame* f) {
@@ -988,7 +1050,7 @@ crh_status crh_frame_download(crh_frame* f, void* rgba8) {
 extern "C" crh_status crh_debug_frame_counters(crh_frame* f, uint32_t out[8]) { // tools only (not in the public header)
     HIP_TRY(hipSetDevice(f->renderer->device));
     HIP_TRY(f->renderer->sync());
-    HIP_TRY(hipMemcpy(out, f->overflow.p, 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 32, hipMemcpyDeviceToHost));
     return CRH_OK;
 }
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
@@ -1053,7 +1115,7 @@ crh_status crh_renderer_kernel_times(crh_renderer* r, crh_kernel_time* out, uint
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(r->sync());
     uint32_t n = 0;
-    size_t previous_of_lane[2] = {SIZE_MAX, SIZE_MAX};
+    size_t previous_of_lane[3] = {SIZE_MAX, SIZE_MAX, SIZE_MAX};
     for (size_t i = 0; i < r->marks.size(); ++i) {
         const size_t before = previous_of_lane[r->marks[i].lane];
         previous_of_lane[r->marks[i].lane] = i;

@@ -963,8 +963,8 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
     if (mark) mark(ctx, "raster_tile_scan", 0);
 }
 // `after_fill` (optional) is recorded when the fill pass, the last reader of the per-item primitive ranges, has been enqueued
-void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
-                   uint64_t raster_bytes, bool has_stroke, hipEvent_t after_fill) {
+void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
+                 hipEvent_t after_fill) {
     if (r.n_items) {
         if (samples == 4)
             hipLaunchKernelGGL((k_tile_walk<4, true>), dim3(r.n_items), dim3(64 * kWalkWaves), 0, stream, s, r);
@@ -973,6 +973,9 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
     }
     if (after_fill) (void)hipEventRecord(after_fill, stream);
     if (mark) mark(ctx, "raster_tile_fill", 0);
+}
+void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
+                   uint64_t raster_bytes, bool has_stroke) {
     const dim3 grid(r.n_tiles);
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
     hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
