@@ -547,8 +547,14 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     extern __shared__ uint32_t sort_buffer[]; // [waves][r.sort_capacity], wave-private; only used by tiles with more than 64 primitives
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];        // wave-private: the set-up values of the current chunk's 64 entries
 
-    const uint32_t tile = blockIdx.x;
-    const uint32_t tx = tile % r.tiles_x, ty = tile / r.tiles_x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2). The frame is cut into 8x8-tile blocks dealt to the
+    // XCDs in turn (spatially interleaved, so an unevenly filled frame still loads all eight), and an XCD walks a block's 64 tiles back to
+    // back: a primitive record shared by neighbouring tiles is fetched into one L2 instead of up to eight. launch_raster pads the grid.
+    const uint32_t turn = blockIdx.x >> 3;
+    const uint32_t blocks_x = (r.tiles_x + 7u) >> 3, block = (turn >> 6) * 8u + (blockIdx.x & 7u);
+    const uint32_t tx = (block % blocks_x) * 8u + (turn & 7u), ty = (block / blocks_x) * 8u + ((turn >> 3) & 7u);
+    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* __restrict__ keys = sort_buffer + wave * r.sort_capacity;
     const uint32_t px = lane & 15u, rq = lane >> 4;
@@ -976,7 +982,9 @@ void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hip
 }
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
                    uint64_t raster_bytes, bool has_stroke) {
-    const dim3 grid(r.n_tiles);
+    // 8x8-tile blocks, an equal number per XCD (k_raster_tile's tile order)
+    const uint32_t blocks = ((r.tiles_x + 7u) / 8u) * ((r.tiles_y + 7u) / 8u);
+    const dim3 grid(((blocks + 7u) / 8u) * 64u * 8u);
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
     hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {
