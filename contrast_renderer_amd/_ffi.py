@@ -109,6 +109,9 @@ class ConfigC(C.Structure):
         ("clip_nesting_counter_bits", C.c_uint32),
         ("winding_counter_bits", C.c_uint32),
         ("alpha_layer_count", C.c_uint32),
+        ("cull_mode", C.c_uint32),
+        ("depth_compare", C.c_uint32),
+        ("depth_write_enabled", C.c_uint32),
     ]
 
 
@@ -245,6 +248,9 @@ def load_library():
         "crh_frame_create": (C.c_int, [V, C.c_uint32, C.c_uint32, C.POINTER(V)]),
         "crh_frame_destroy": (None, [V]),
         "crh_frame_clear": (C.c_int, [V]),
+        "crh_frame_clear_depth": (C.c_int, [V, C.c_float]),
+        "crh_frame_upload_depth": (C.c_int, [V, C.POINTER(C.c_float)]),
+        "crh_frame_download_depth": (C.c_int, [V, C.POINTER(C.c_float)]),
         "crh_scene_render": (C.c_int, [V, V, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "crh_scene_set_instances": (C.c_int, [V, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "crh_scene_render_resident": (C.c_int, [V, V]),

@@ -150,6 +150,8 @@ struct crh_frame {
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
     uint32_t n_items = 0;
+    bool items_projective = false; // some instance of the recorded pass is not plain (perspective, or a varying / out-of-range clip.z)
+    DevBuf depth;                  // [height][width][samples] f32, when the configuration tests or writes depth
     bool cleared = true;
     bool pairs_known = false;
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
@@ -177,6 +179,8 @@ struct crh_scene {
     // instances + binning
     DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch;
     DevBuf prim_rec[2];                 // set-up triangles, double-buffered like the frame's binning buffers
+    DevBuf prim_proj[2];                // 1/w and z/w planes of the primitives of projective instances (allocated on first use)
+    bool instances_projective = false;
     hipEvent_t rec_raster_done[2] = {nullptr, nullptr};
     bool rec_used[2] = {false, false};
     int next_rec = 0;
@@ -194,7 +198,7 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec[0], &prim_rec[1]};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec[0], &prim_rec[1], &prim_proj[0], &prim_proj[1]};
         for (DevBuf* b : all) b->release();
     }
 };
@@ -324,7 +328,8 @@ crh_status settle_tessellation(crh_scene* sc, uint32_t* status_word) {
     crh_renderer* r = sc->renderer;
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint32_t word = 0;
-        HIP_TRY(hipMemcpyAsync(&word, sc->d.status, 4, hipMemcpyDeviceToHost, r->stream));
+        // on the tessellation stream: ordered after the kernels that raise the status (the raster stream is not)
+        HIP_TRY(hipMemcpyAsync(&word, sc->d.status, 4, hipMemcpyDeviceToHost, r->tessellation_stream()));
         HIP_TRY(r->sync());
         if (word != 0xFFFFFFFFu && (word & 0xFFu) >= 0x80u && attempt == 0) {
             sc->capacity_known = false;
@@ -445,6 +450,27 @@ bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
     return grew;
 }
 
+// oracle/raster.hpp is_plain_instance, for every instance: the plain pass needs no 1/w and z/w planes
+bool all_instances_plain(const float* t, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const float* m = t + 16 * i;
+        if (!(m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f && m[2] == 0.0f && m[6] == 0.0f && m[14] >= 0.0f && m[14] <= 1.0f)) return false;
+    }
+    return true;
+}
+uint32_t depth_pass_mask(uint32_t compare) { // bit 0: fragment < stored passes, 1: ==, 2: >, 3: always
+    switch (compare) {
+        case CRH_COMPARE_NEVER: return 0u;
+        case CRH_COMPARE_LESS: return 1u;
+        case CRH_COMPARE_EQUAL: return 2u;
+        case CRH_COMPARE_LESS_EQUAL: return 3u;
+        case CRH_COMPARE_GREATER: return 4u;
+        case CRH_COMPARE_NOT_EQUAL: return 5u;
+        case CRH_COMPARE_GREATER_EQUAL: return 6u;
+        default: return 8u;
+    }
+}
+
 crh_status render_impl(crh_scene* sc, crh_frame* f) {
     crh_renderer* r = sc->renderer;
     const bool recorded = f->n_items != 0; // crh_scene_render_draws stored a pass in the frame
@@ -502,6 +528,17 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     }
     p.scan_scratch = set.scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec[rec].p);
+    const bool projective = recorded ? f->items_projective : sc->instances_projective;
+    p.prim_proj = nullptr;
+    if (projective) {
+        HIP_TRY(sc->prim_proj[rec].ensure((size_t)p.prim_capacity * 32));
+        p.prim_proj = static_cast<PrimProj*>(sc->prim_proj[rec].p);
+    }
+    p.depth = f->depth.as<float>(); // nullptr without a depth attachment
+    p.depth_pass_mask = depth_pass_mask(r->config.depth_compare);
+    p.depth_write = r->config.depth_write_enabled;
+    p.cull_mode = r->config.cull_mode;
+    p.general = (projective || p.depth) ? 1u : 0u;
     p.overflow = set.overflow.as<uint32_t>();
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
@@ -591,6 +628,7 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     // renderer.rs:433-435
     if (config->winding_counter_bits == 0 || config->clip_nesting_counter_bits + config->winding_counter_bits > 8) return CRH_ERR_NUMBER_OF_STENCIL_BITS_IS_UNSUPPORTED;
     if (!(config->msaa_sample_count == 1 || config->msaa_sample_count == 4)) return CRH_ERR_UNSUPPORTED;
+    if (config->cull_mode > CRH_CULL_BACK || config->depth_compare > CRH_COMPARE_GREATER_EQUAL || config->depth_write_enabled > 1) return CRH_ERR_INVALID_ARGUMENT;
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
     if (count <= 0) {
@@ -939,6 +977,11 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
         return CRH_ERR_HIP;
     }
     HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)width * height * 4, r->stream));
+    if (r->config.depth_compare != CRH_COMPARE_ALWAYS || r->config.depth_write_enabled) { // the depth attachment, cleared to 1.0 (main.rs:223-226)
+        const size_t n = (size_t)width * height * r->config.msaa_sample_count;
+        HIP_TRY(f->depth.ensure(n * 4));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->depth.p), 0x3f800000, n, r->stream));
+    }
     for (crh_frame::BinSet& set : f->sets) HIP_TRY(hipMemsetAsync(set.overflow.p, 0, 64, r->stream));
     HIP_TRY(r->sync());
     *out = f;
@@ -948,7 +991,7 @@ void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->renderer->device);
     (void)f->renderer->sync();
-    DevBuf* all[] = {&f->rgba8, &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
+    DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
     for (DevBuf* b : all) b->release();
     for (crh_frame::BinSet& set : f->sets) {
         DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch};
@@ -961,6 +1004,41 @@ void crh_frame_destroy(crh_frame* f) {
 crh_status crh_frame_clear(crh_frame* f) {
     if (!f) return CRH_ERR_INVALID_ARGUMENT;
     f->cleared = true; // LoadOp::Clear: the next render does not read the target, every tile is written
+    return f->depth.p ? crh_frame_clear_depth(f, 1.0f) : CRH_OK;
+}
+crh_status crh_frame_clear_depth(crh_frame* f, float value) {
+    if (!f || !f->depth.p || !std::isfinite(value)) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = f->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    uint32_t bits;
+    memcpy(&bits, &value, 4);
+    // on the raster stream: ordered after the raster kernel of the previous frame, before the next one
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->depth.p), (int)bits, (size_t)f->width * f->height * r->config.msaa_sample_count, r->stream));
+    return CRH_OK;
+}
+crh_status crh_frame_upload_depth(crh_frame* f, const float* depth) {
+    if (!f || !f->depth.p || !depth) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = f->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    const uint32_t samples = r->config.msaa_sample_count;
+    const size_t n = (size_t)f->width * f->height;
+    std::vector<float> expanded(n * samples);
+    for (size_t i = 0; i < n; ++i) {
+        if (!std::isfinite(depth[i])) return CRH_ERR_NON_FINITE;
+        for (uint32_t k = 0; k < samples; ++k) expanded[i * samples + k] = depth[i];
+    }
+    HIP_TRY(hipMemcpyAsync(f->depth.p, expanded.data(), expanded.size() * 4, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(r->sync());
+    return CRH_OK;
+}
+crh_status crh_frame_download_depth(crh_frame* f, float* depth_samples) {
+    if (!f || !f->depth.p || !depth_samples) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = f->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    crh_status st = settle_frame(f);
+    if (st != CRH_OK) return st;
+    HIP_TRY(hipMemcpyAsync(depth_samples, f->depth.p, (size_t)f->width * f->height * r->config.msaa_sample_count * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(r->sync());
     return CRH_OK;
 }
 
@@ -977,6 +1055,7 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
         HIP_TRY(hipMemcpyAsync(sc->colors.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->stream));
         HIP_TRY(r->sync());
     }
+    sc->instances_projective = !all_instances_plain(transforms, sc->d.n_shapes);
     sc->instances_set = true;
     return CRH_OK;
 }
@@ -1029,6 +1108,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     HIP_TRY(hipMemcpyAsync(f->item_colors.p, colors, (size_t)n_instances * 16, hipMemcpyHostToDevice, r->stream));
     HIP_TRY(r->sync()); // `items` and the caller's arrays may go away
     f->n_items = (uint32_t)items.size();
+    f->items_projective = !all_instances_plain(transforms, n_instances);
     f->pairs_known = false; // a different pass: re-learn the tile list size
     return render_impl(sc, f);
 }

@@ -48,13 +48,13 @@ enum : uint32_t { KIND_SOLID = 0, KIND_IQ = 1, KIND_IC = 2, KIND_RQ = 3, KIND_RC
 // Edge i evaluates, relative to a tile origin (tx0, ty0):
 //   c = bx*(ty0 - lo_y) + nay*(tx0 - lo_x);  E = fma(rx, nay, fma(ry, bx, c))   — the canonical-orientation sign is folded in.
 struct PrimCoverage { // everything the coverage test needs
-    uint32_t flags; // bits 0-2 top-left per edge, bit 3 front (ccw on screen), bits 4-6 kind
+    uint32_t flags; // bits 0-2 top-left per edge, bit 3 front (ccw on screen), bits 4-6 kind, 7-9 cover op, 16-23 clip ref, 24-27 alpha layer, 28 projective
     uint32_t desc;  // stroke: index of the 48-byte descriptor
     ushort4 box;    // inclusive pixel box x0 x1 y0 y1; x0 == 0xFFFF: nothing to draw
     float lo_x[3], lo_y[3], bx[3], nay[3];
 };
 struct PrimFragment { // what the fragment stage needs
-    float a0[4], gx[4], gy[4]; // attribute planes through vertex 0; cover: a0 = premultiplied source colour
+    float a0[4], gx[4], gy[4]; // attribute planes through vertex 0; cover: a0 = premultiplied source colour, gx[0] = depth of a plain instance
     float v0x, v0y;
     uint32_t flat_u; // stroke: provoking vertex' u32 (group | 0x10000)
     float end_y;     // stroke line: provoking vertex' texcoord.y
@@ -64,6 +64,13 @@ struct PrimRec {
     PrimFragment frag;
 };
 static_assert(sizeof(PrimCoverage) == 64 && sizeof(PrimFragment) == 64 && sizeof(PrimRec) == 128, "PrimRec");
+// Primitives of projective instances (flags bit 28) also carry the planes of 1/w and z/w (oracle/raster.hpp raster_projective), anchored
+// at (frag.v0x, frag.v0y) like the attribute planes — which then hold a/w. A side array, so the plain pass never touches it.
+struct PrimProj {
+    float q0, qgx, qgy, z0, zgx, zgy, ax, ay; // (ax, ay): the anchor, = frag.v0x / v0y (repeated: solid triangles never load their fragment half)
+};
+static_assert(sizeof(PrimProj) == 32, "PrimProj");
+constexpr uint32_t kFlagProjective = 1u << 28;
 
 // Wave-uniform loads through the constant address space become s_load_dwordx4..x16 (the records are written by an earlier kernel,
 // so the scalar cache is coherent with them). The host pass of the compiler never runs this code.
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
     const DrawItem it = item_of(r, item);
     const uint32_t shape = it.shape;
     const float* m = r.transforms + 16u * it.instance;
-    if (lane == 0 && !(m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f)) // affine instances only this round (clip.w == 1)
-        raise_error(s, s.elem_path[min(s.shape_elem_begin[shape], s.n_elems - 1u)], CRH_ERR_UNSUPPORTED);
+    // oracle/raster.hpp is_plain_instance: clip.w == 1 and clip.z a constant in [0, 1]; every other matrix takes the projective setup
+    const bool plain = m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f && m[2] == 0.0f && m[6] == 0.0f && m[14] >= 0.0f && m[14] <= 1.0f;
     uint32_t cb[8], first_candidate, last_candidate;
     item_candidates(s, it, cb, first_candidate, last_candidate);
     const uint32_t n_candidates = last_candidate - first_candidate;
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
         const uint32_t c = first_candidate + c0 + lane; // in the Shape's candidate numbering
         const bool in_range_c = c0 + lane < n_candidates;
         float2 p[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
-        float attr[3][4];
+        float attr[3][4] = {};
         uint32_t kind = KIND_SOLID, flat_u = 0, desc = 0;
         float end_y = 0.0f;
         int n_attr = 0;
@@ -284,9 +291,9 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             valid = s.line_pair_cut[(lv0 + k) >> 1] == 0;
             strip(k, lv0);
             const Vertex2f1i a = s.line_v[i0], b = s.line_v[i1], d = s.line_v[i2];
-            p[0] = to_framebuffer(m, W, H, a.x, a.y);
-            p[1] = to_framebuffer(m, W, H, b.x, b.y);
-            p[2] = to_framebuffer(m, W, H, d.x, d.y);
+            p[0] = make_float2(a.x, a.y);
+            p[1] = make_float2(b.x, b.y);
+            p[2] = make_float2(d.x, d.y);
             attr[0][0] = a.u, attr[0][1] = a.v;
             attr[1][0] = b.u, attr[1][1] = b.v;
             attr[2][0] = d.u, attr[2][1] = d.v;
@@ -299,9 +306,9 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             const uint32_t q = c - cb[0], jn = q / 3u, k = q - 3u * jn;
             strip(k, 5u * (j0 + jn));
             const Vertex3f1i a = s.joint_v[i0], b = s.joint_v[i1], d = s.joint_v[i2];
-            p[0] = to_framebuffer(m, W, H, a.x, a.y);
-            p[1] = to_framebuffer(m, W, H, b.x, b.y);
-            p[2] = to_framebuffer(m, W, H, d.x, d.y);
+            p[0] = make_float2(a.x, a.y);
+            p[1] = make_float2(b.x, b.y);
+            p[2] = make_float2(d.x, d.y);
             attr[0][0] = a.u, attr[0][1] = a.v, attr[0][2] = a.w;
             attr[1][0] = b.u, attr[1][1] = b.v, attr[1][2] = b.w;
             attr[2][0] = d.u, attr[2][1] = d.v, attr[2][2] = d.w;
@@ -318,14 +325,14 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             i1 = sv0 + (parity ? k + 2u : k + 1u);
             i2 = sv0 + (parity ? k + 1u : k + 2u);
             const Vertex0 a = s.solid_v[i0], b = s.solid_v[i1], d = s.solid_v[i2];
-            p[0] = to_framebuffer(m, W, H, a.x, a.y);
-            p[1] = to_framebuffer(m, W, H, b.x, b.y);
-            p[2] = to_framebuffer(m, W, H, d.x, d.y);
+            p[0] = make_float2(a.x, a.y);
+            p[1] = make_float2(b.x, b.y);
+            p[2] = make_float2(d.x, d.y);
         } else if (c < cb[3]) {
             const uint32_t at = 3u * (iq0 + (c - cb[2]));
             for (int v = 0; v < 3; ++v) {
                 const Vertex2f a = s.iq_v[at + v];
-                p[v] = to_framebuffer(m, W, H, a.x, a.y);
+                p[v] = make_float2(a.x, a.y);
                 attr[v][0] = a.u, attr[v][1] = a.v;
             }
             kind = KIND_IQ;
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             const uint32_t at = ic0 + 3u * (c - cb[3]);
             for (int v = 0; v < 3; ++v) {
                 const Vertex3f a = s.ic_v[at + v];
-                p[v] = to_framebuffer(m, W, H, a.x, a.y);
+                p[v] = make_float2(a.x, a.y);
                 attr[v][0] = a.u, attr[v][1] = a.v, attr[v][2] = a.w;
             }
             kind = KIND_IC;
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             const uint32_t at = 3u * (rq0 + (c - cb[4]));
             for (int v = 0; v < 3; ++v) {
                 const Vertex3f a = s.rq_v[at + v];
-                p[v] = to_framebuffer(m, W, H, a.x, a.y);
+                p[v] = make_float2(a.x, a.y);
                 attr[v][0] = a.u, attr[v][1] = a.v, attr[v][2] = a.w;
             }
             kind = KIND_RQ;
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             const uint32_t at = rc0 + 3u * (c - cb[5]);
             for (int v = 0; v < 3; ++v) {
                 const Vertex4f a = s.rc_v[at + v];
-                p[v] = to_framebuffer(m, W, H, a.x, a.y);
+                p[v] = make_float2(a.x, a.y);
                 attr[v][0] = a.k, attr[v][1] = a.l, attr[v][2] = a.m, attr[v][3] = a.n;
             }
             kind = KIND_RC;
@@ -360,15 +367,23 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
         } else { // cover: hull strip (vertex_color / color_cover)
             strip(c - cb[6], hull0);
             const Vertex0 a = s.hull_v[i0], b = s.hull_v[i1], d = s.hull_v[i2];
-            p[0] = to_framebuffer(m, W, H, a.x, a.y);
-            p[1] = to_framebuffer(m, W, H, b.x, b.y);
-            p[2] = to_framebuffer(m, W, H, d.x, d.y);
+            p[0] = make_float2(a.x, a.y);
+            p[1] = make_float2(b.x, b.y);
+            p[2] = make_float2(d.x, d.y);
             kind = KIND_COVER;
         }
         // ---- oracle/raster.hpp setup_triangle + setup_attribute
         PrimRec rec;
+        PrimProj proj = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         rec.cov.box = make_ushort4(0xFFFFu, 0, 0, 0);
         bool drawn = false;
+        const uint32_t clip_ref = kind == KIND_COVER ? (it.refs >> 8) & 255u : it.refs & 255u;
+        // bits 0-2 top-left, 3 front, 4-6 kind, 7-9 cover operation, 16-23 stencil reference (clip depth), 24-27 alpha layer, 28 projective
+        const uint32_t flags_common = (kind << 4) | (cover_op << 7) | (clip_ref << 16) | (((it.refs >> 16) & 15u) << 24);
+        const bool culled_kind = kind == KIND_COVER && cover_op == CRH_OP_COLOR && r.cull_mode != 0u; // Configuration::cull_mode: the colour cover only
+        if (plain) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) p[v] = to_framebuffer(m, W, H, p[v].x, p[v].y);
         const float d1x = p[1].x - p[0].x, d1y = p[1].y - p[0].y;
         const float d2x = p[2].x - p[0].x, d2y = p[2].y - p[0].y;
         const float det = d1x * d2y - d2x * d1y;
@@ -379,15 +394,13 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
             // inclusive pixel range: clamp, floor, THEN compare (oracle/raster.hpp setup_triangle)
             const int x0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), x1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
             const int y0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), y1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
-            if (nan_free && x0 <= x1 && y0 <= y1) {
+            if (nan_free && x0 <= x1 && y0 <= y1 && !(culled_kind && (r.cull_mode == CRH_CULL_FRONT) == (det < 0.0f))) {
                 drawn = true;
                 rec.cov.box = make_ushort4((unsigned short)x0, (unsigned short)x1, (unsigned short)y0, (unsigned short)y1);
                 const float inv_det = 1.0f / det;
                 const bool front = det < 0.0f; // y-down cross < 0 == counter-clockwise on screen (FrontFace::Ccw, renderer.rs:477)
                 const float2 nv[3] = {p[0], det < 0.0f ? p[2] : p[1], det < 0.0f ? p[1] : p[2]}; // clockwise-in-y-down edge walk
-                // bits 0-2 top-left, 3 front, 4-6 kind, 7-9 cover operation, 16-23 stencil reference (clip depth), 24-27 alpha layer
-                const uint32_t clip_ref = kind == KIND_COVER ? (it.refs >> 8) & 255u : it.refs & 255u;
-                uint32_t flags = (front ? 8u : 0u) | (kind << 4) | (cover_op << 7) | (clip_ref << 16) | (((it.refs >> 16) & 15u) << 24);
+                uint32_t flags = (front ? 8u : 0u) | flags_common;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float2 a = nv[i], b = nv[(i + 1) % 3];
@@ -418,6 +431,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
                     rec.frag.a0[1] = color[1] * color[3];
                     rec.frag.a0[2] = color[2] * color[3];
                     rec.frag.a0[3] = color[3];
+                    rec.frag.gx[0] = m[14]; // the fragment depth of a plain instance
                 }
                 rec.frag.v0x = p[0].x;
                 rec.frag.v0y = p[0].y;
@@ -427,11 +441,130 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
                 rec.cov.desc = desc;
             }
         }
+        } else {
+        // ---- oracle/raster.hpp setup_projective + setup_projective_plane, operation by operation
+        float PX[3], PY[3], PZ[3], PW[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const float cx = (m[0] * p[v].x + m[4] * p[v].y) + m[12];
+            const float cy = (m[1] * p[v].x + m[5] * p[v].y) + m[13];
+            const float cz = (m[2] * p[v].x + m[6] * p[v].y) + m[14];
+            const float cw = (m[3] * p[v].x + m[7] * p[v].y) + m[15];
+            PX[v] = (cx * 0.5f + cw * 0.5f) * W;
+            PY[v] = (cw * 0.5f - cy * 0.5f) * H;
+            PZ[v] = cz;
+            PW[v] = cw;
+        }
+        const int k = PW[0] > 0.0f ? 0 : (PW[1] > 0.0f ? 1 : (PW[2] > 0.0f ? 2 : -1)); // the first vertex in front of the eye
+        bool ok = in_range_c && valid && k >= 0;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) ok = ok && is_finite(PX[v]) && is_finite(PY[v]) && is_finite(PZ[v]) && is_finite(PW[v]);
+        const float c0 = PX[1] * PY[2] - PY[1] * PX[2], a0 = PY[1] * PW[2] - PW[1] * PY[2], b0 = PW[1] * PX[2] - PX[1] * PW[2];
+        const float det = (PX[0] * a0 + PY[0] * b0) + PW[0] * c0;
+        ok = ok && det != 0.0f && is_finite(det);
+        const bool front = det < 0.0f;
+        uint32_t flags = (front ? 8u : 0u) | flags_common | kFlagProjective;
+        const int order[3] = {0, det < 0.0f ? 2 : 1, det < 0.0f ? 1 : 2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ia = order[i], ib = order[(i + 1) % 3];
+            const float aX = PX[ia], aY = PY[ia], aW = PW[ia], bX = PX[ib], bY = PY[ib], bW = PW[ib];
+            const bool flip = !(aX < bX || (aX == bX && (aY < bY || (aY == bY && aW < bW)))); // canonical (lexicographic) endpoint order
+            const float lX = flip ? bX : aX, lY = flip ? bY : aY, lW = flip ? bW : aW, hX = flip ? aX : bX, hY = flip ? aY : bY, hW = flip ? aW : bW;
+            const float nay = lY * hW - lW * hY, bx = lW * hX - lX * hW;
+            const float sg = flip ? -1.0f : 1.0f;
+            const float A = nay * sg, B = bx * sg; // exact: the oracle negates
+            if (A > 0.0f || (A == 0.0f && B > 0.0f)) flags |= 1u << i;
+            const bool use_lo = lW > 0.0f || (!(hW > 0.0f) && lW != 0.0f);
+            const float nX = use_lo ? lX : hX, nY = use_lo ? lY : hY, nW = use_lo ? lW : hW;
+            ok = ok && nW != 0.0f;
+            const float ax = nX / nW, ay = nY / nW;
+            ok = ok && is_finite(ax) && is_finite(ay);
+            rec.cov.lo_x[i] = ax;
+            rec.cov.lo_y[i] = ay;
+            rec.cov.bx[i] = B;
+            rec.cov.nay[i] = A;
+        }
+        int x0 = 0, y0 = 0, x1 = (int)r.width - 1, y1 = (int)r.height - 1; // crossing the eye plane: every pixel is a candidate
+        if (PW[0] > 0.0f && PW[1] > 0.0f && PW[2] > 0.0f) {
+            const float q0x = PX[0] / PW[0], q1x = PX[1] / PW[1], q2x = PX[2] / PW[2], q0y = PY[0] / PW[0], q1y = PY[1] / PW[1], q2y = PY[2] / PW[2];
+            const float minx = fminf(q0x, fminf(q1x, q2x)), maxx = fmaxf(q0x, fmaxf(q1x, q2x));
+            const float miny = fminf(q0y, fminf(q1y, q2y)), maxy = fmaxf(q0y, fmaxf(q1y, q2y));
+            ok = ok && minx == minx && maxx == maxx && miny == miny && maxy == maxy;
+            x0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W));
+            x1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
+            y0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H));
+            y1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
+            ok = ok && x0 <= x1 && y0 <= y1;
+        }
+        // planes relative to the anchor = the projection of vertex k (index 0 = k, then cyclic)
+        const int kk = k < 0 ? 0 : k, ku = (kk + 1) % 3, kv = (kk + 2) % 3;
+        float KX = 0.0f, KY = 0.0f, KZ = 0.0f, KW = 1.0f, UX = 0.0f, UY = 0.0f, UZ = 0.0f, UW = 1.0f, VX = 0.0f, VY = 0.0f, VZ = 0.0f, VW = 1.0f;
+        float fk[4], fu[4], fv[4];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) { // register-only selection (no dynamic indexing)
+            if (v == kk) KX = PX[v], KY = PY[v], KZ = PZ[v], KW = PW[v];
+            if (v == ku) UX = PX[v], UY = PY[v], UZ = PZ[v], UW = PW[v];
+            if (v == kv) VX = PX[v], VY = PY[v], VZ = PZ[v], VW = PW[v];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (v == kk) fk[a] = attr[v][a];
+                if (v == ku) fu[a] = attr[v][a];
+                if (v == kv) fv[a] = attr[v][a];
+            }
+        }
+        const float ancx = KX / KW, ancy = KY / KW;
+        const float lx0 = UX - ancx * UW, ly0 = UY - ancy * UW, lx1 = VX - ancx * VW, ly1 = VY - ancy * VW;
+        const float local_det = KW * (lx0 * ly1 - ly0 * lx1);
+        ok = ok && local_det != 0.0f && is_finite(local_det);
+        ok = ok && !(culled_kind && (r.cull_mode == CRH_CULL_FRONT) == front);
+        if (ok) {
+            drawn = true;
+            rec.cov.box = make_ushort4((unsigned short)x0, (unsigned short)x1, (unsigned short)y0, (unsigned short)y1);
+            const float inv_det = 1.0f / local_det;
+            const float ak = ly0 * VW - UW * ly1, bk = UW * lx1 - lx0 * VW; // P'_u x P'_v
+            const float au = ly1 * KW, bu = -(lx1 * KW);                    // P'_v x P'_k
+            const float av = -(KW * ly0), bv = KW * lx0;                    // P'_k x P'_u
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a < n_attr) {
+                    rec.frag.a0[a] = fk[a] / KW;
+                    rec.frag.gx[a] = ((fk[a] * ak + fu[a] * au) + fv[a] * av) * inv_det;
+                    rec.frag.gy[a] = ((fk[a] * bk + fu[a] * bu) + fv[a] * bv) * inv_det;
+                } else {
+                    rec.frag.a0[a] = rec.frag.gx[a] = rec.frag.gy[a] = 0.0f;
+                }
+            }
+            proj.ax = ancx;
+            proj.ay = ancy;
+            proj.q0 = 1.0f / KW;
+            proj.qgx = ((1.0f * ak + 1.0f * au) + 1.0f * av) * inv_det;
+            proj.qgy = ((1.0f * bk + 1.0f * bu) + 1.0f * bv) * inv_det;
+            proj.z0 = KZ / KW;
+            proj.zgx = ((KZ * ak + UZ * au) + VZ * av) * inv_det;
+            proj.zgy = ((KZ * bk + UZ * bu) + VZ * bv) * inv_det;
+            if (kind == KIND_COVER) {
+                const float* color = r.colors + 4u * it.instance;
+                rec.frag.a0[0] = color[0] * color[3];
+                rec.frag.a0[1] = color[1] * color[3];
+                rec.frag.a0[2] = color[2] * color[3];
+                rec.frag.a0[3] = color[3];
+            }
+            rec.frag.v0x = ancx;
+            rec.frag.v0y = ancy;
+            rec.frag.flat_u = flat_u;
+            rec.frag.end_y = end_y;
+            rec.cov.flags = flags;
+            rec.cov.desc = desc;
+        }
+        } // projective
         if (in_range_c) {
-            if (drawn)
+            if (drawn) {
                 r.prim_rec[prim0 + c0 + lane] = rec;
-            else
+                if (!plain) r.prim_proj[prim0 + c0 + lane] = proj; // the host allocates the side array whenever an instance is not plain
+            } else {
                 r.prim_rec[prim0 + c0 + lane].cov.box = rec.cov.box;
+            }
         }
     }
 }
@@ -597,6 +730,18 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             winding[b][k] = 0;
             col[b][k][0] = col[b][k][1] = col[b][k][2] = col[b][k][3] = 0.0f;
         }
+    // the depth attachment (OPS only): tested / written by the colour cover alone (renderer.rs:743-745)
+    float depth[OPS ? ROWS : 1][OPS ? S : 1];
+    const bool has_depth = OPS && r.depth != nullptr;
+    if (OPS) {
+#pragma unroll
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
+#pragma unroll
+            for (int k = 0; k < S; ++k)
+                depth[OPS ? b : 0][OPS ? k : 0] = (has_depth && gx < r.width && gy < r.height) ? r.depth[((size_t)gy * r.width + gx) * S + k] : 0.0f;
+        }
+    }
     if (r.load_existing) {
 #pragma unroll
         for (int b = 0; b < ROWS; ++b) {
@@ -723,6 +868,33 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & row_bit[b1]) != 0u);
                 }
             }
+            // projective instances (oracle/raster.hpp raster_projective): per-sample near / far test on z/w, and 1 / (1/w) for the attributes
+            float rw[OPS ? ROWS : 1][OPS ? S : 1], zs[OPS ? ROWS : 1][OPS ? S : 1];
+            if (OPS) {
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        rw[OPS ? b : 0][OPS ? k : 0] = 1.0f;
+                        zs[OPS ? b : 0][OPS ? k : 0] = 0.0f;
+                    }
+                if (flags & kFlagProjective) { // wave uniform
+                    const PrimProj pp = load_uniform(&r.prim_proj[prim]);
+                    const float dxa = tx0 - pp.ax, dya = ty0 - pp.ay;
+                    const float zc = (pp.z0 + dxa * pp.zgx) + dya * pp.zgy, qc = (pp.q0 + dxa * pp.qgx) + dya * pp.qgy;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            const float y = sy0[k] + (float)(4 * b);
+                            const float z = fmaf(y, pp.zgy, fmaf(sx[k], pp.zgx, zc));
+                            const float q = fmaf(y, pp.qgy, fmaf(sx[k], pp.qgx, qc));
+                            inside[b][k] = inside[b][k] & (z >= 0.0f) & (z <= 1.0f); // unclipped_depth: false (renderer.rs:478)
+                            zs[OPS ? b : 0][OPS ? k : 0] = z;
+                            rw[OPS ? b : 0][OPS ? k : 0] = 1.0f / q;
+                        }
+                }
+            }
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
             // Every kind only produces the change of the winding counters (dw) and, for the colour cover, which samples blend; the state
             // itself is updated once after the dispatch. (Updating winding / colour inside the multi-way dispatch made every iteration end
@@ -751,8 +923,20 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         for (int k = 0; k < S; ++k) {
                             // Less(ref < stencil) on clip | winding: a deeper clip level, or this level with a non-zero winding
                             const bool stencil_pass = OPS ? (clipc[OPS ? b : 0][OPS ? k : 0] > clip_ref || (clipc[OPS ? b : 0][OPS ? k : 0] == clip_ref && (winding[b][k] & wmask) != 0)) : (winding[b][k] & wmask) != 0;
-                            blend[b][k] = inside[b][k] && stencil_pass;
-                            dw[b][k] = inside[b][k] ? -winding[b][k] : 0; // pass -> Zero, fail -> Zero
+                            if (OPS) {
+                                // the depth test follows the stencil test; depth_fail_op = Keep (renderer.rs:442): the winding survives a depth fail
+                                const float z = (flags & kFlagProjective) ? zs[OPS ? b : 0][OPS ? k : 0] : frag.gx[0];
+                                const float stored = depth[OPS ? b : 0][OPS ? k : 0];
+                                const uint32_t relation = (z < stored ? 1u : 0u) | (z == stored ? 2u : 0u) | (z > stored ? 4u : 0u) | 8u;
+                                const bool depth_pass = !has_depth || (relation & r.depth_pass_mask) != 0u;
+                                const bool depth_fail = inside[b][k] && stencil_pass && !depth_pass;
+                                blend[b][k] = inside[b][k] && stencil_pass && depth_pass;
+                                dw[b][k] = (inside[b][k] && !depth_fail) ? -winding[b][k] : 0;
+                                depth[OPS ? b : 0][OPS ? k : 0] = (blend[b][k] && has_depth && r.depth_write != 0u) ? z : stored;
+                            } else {
+                                blend[b][k] = inside[b][k] && stencil_pass;
+                                dw[b][k] = inside[b][k] ? -winding[b][k] : 0; // pass -> Zero, fail -> Zero
+                            }
                         }
                 } else if (OPS) {
                     // Clip / UnClip / the alpha-context covers, branch-free per sample (the operation is wave uniform)
@@ -808,8 +992,12 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                     for (int k = 0; k < S; ++k) {
                         const float y = sy0[k] + (float)(4 * b);
-                        const float a0 = fmaf(y, frag.gy[0], hx[0][k]), a1 = fmaf(y, frag.gy[1], hx[1][k]);
-                        const float a2 = fmaf(y, frag.gy[2], hx[2][k]), a3 = fmaf(y, frag.gy[3], hx[3][k]);
+                        // (x * 1.0f is exact, so the plain instances of an OPS pass keep their bits)
+                        const float w = OPS ? rw[OPS ? b : 0][OPS ? k : 0] : 1.0f;
+                        const float a0 = OPS ? fmaf(y, frag.gy[0], hx[0][k]) * w : fmaf(y, frag.gy[0], hx[0][k]);
+                        const float a1 = OPS ? fmaf(y, frag.gy[1], hx[1][k]) * w : fmaf(y, frag.gy[1], hx[1][k]);
+                        const float a2 = OPS ? fmaf(y, frag.gy[2], hx[2][k]) * w : fmaf(y, frag.gy[2], hx[2][k]);
+                        const float a3 = OPS ? fmaf(y, frag.gy[3], hx[3][k]) * w : fmaf(y, frag.gy[3], hx[3][k]);
                         const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
                         const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
                         dw[b][k] = (inside[b][k] && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] >= clip_ref) && lhs - rhs <= 0.0f) ? delta : 0;
@@ -834,7 +1022,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                             // stroke stencil: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
                             if (inside[b][k] && (winding[b][k] & wmask) == 0 && (!OPS || clipc[OPS ? b : 0][OPS ? k : 0] == clip_ref)) { // Equal(ref) on clip | winding
                                 const float y = sy0[k] + (float)(4 * b);
-                                const float a0 = fmaf(y, frag.gy[0], hx[0][k]), a1 = fmaf(y, frag.gy[1], hx[1][k]), a2 = fmaf(y, frag.gy[2], hx[2][k]);
+                                const float w = OPS ? rw[OPS ? b : 0][OPS ? k : 0] : 1.0f;
+                                const float a0 = OPS ? fmaf(y, frag.gy[0], hx[0][k]) * w : fmaf(y, frag.gy[0], hx[0][k]);
+                                const float a1 = OPS ? fmaf(y, frag.gy[1], hx[1][k]) * w : fmaf(y, frag.gy[1], hx[1][k]);
+                                const float a2 = OPS ? fmaf(y, frag.gy[2], hx[2][k]) * w : fmaf(y, frag.gy[2], hx[2][k]);
                                 bool fill;
                                 if (kind == KIND_LINE) { // stencil_stroke_line, shaders.wgsl:268-285
                                     if (dashed)
@@ -875,6 +1066,16 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         col[b][k][2] = blend[b][k] ? n2 : col[b][k][2];
                         col[b][k][3] = blend[b][k] ? n3 : col[b][k][3];
                     }
+            }
+        }
+    }
+    if (OPS && has_depth && r.depth_write != 0u) {
+#pragma unroll
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
+            if (gx < r.width && gy < r.height) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) r.depth[((size_t)gy * r.width + gx) * S + k] = depth[OPS ? b : 0][OPS ? k : 0];
             }
         }
     }
@@ -988,13 +1189,13 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
     hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {
-        if (r.items) {
+        if (r.items || r.general) {
             if (has_stroke) CRH_LAUNCH_TILE(4, 1, true, true); else CRH_LAUNCH_TILE(4, 1, true, false);
         } else {
             if (has_stroke) CRH_LAUNCH_TILE(4, 1, false, true); else CRH_LAUNCH_TILE(4, 1, false, false);
         }
     } else {
-        if (r.items) {
+        if (r.items || r.general) {
             if (has_stroke) CRH_LAUNCH_TILE(1, 4, true, true); else CRH_LAUNCH_TILE(1, 4, true, false);
         } else {
             if (has_stroke) CRH_LAUNCH_TILE(1, 4, false, true); else CRH_LAUNCH_TILE(1, 4, false, false);

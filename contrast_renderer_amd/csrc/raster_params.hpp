@@ -6,6 +6,7 @@
 namespace crh {
 
 struct PrimRec;
+struct PrimProj;
 
 // One Shape::render(Stencil) optionally followed by one cover operation of the same Shape and instance (the host merges adjacent
 // draws of a recorded pass); the unit the setup and binning kernels are launched over.
@@ -37,6 +38,13 @@ struct RasterParams {
     PrimRec* prim_rec;                // [prim capacity] 128-byte set-up triangles
     uint32_t prim_capacity;
     uint8_t* rgba8;                   // [height][width][4]
+    // ---- the general pass (perspective instances, depth test): selects the OPS variant of the raster kernel
+    uint32_t general;                 // 1: some instance is not plain (clip.w != 1 or clip.z not a constant in [0, 1]) or depth is tested / written
+    PrimProj* prim_proj;              // [prim capacity] 1/w and z/w planes of the primitives of projective instances, or nullptr
+    float* depth;                     // [height][width][samples] depth attachment, or nullptr: no depth test
+    uint32_t depth_pass_mask;         // bit 0: fragment < stored passes, bit 1: ==, bit 2: >, bit 3: Always (crh_compare as a mask)
+    uint32_t depth_write;             // Configuration::depth_write_enabled
+    uint32_t cull_mode;               // crh_cull of the colour cover
     uint32_t debug;                   // CRH_RASTER_DEBUG (tools only)
 };
 

@@ -24,12 +24,32 @@ class RenderOperation(IntEnum):  # renderer.rs:145-160
     RestoreAlphaContext = 6
 
 
+class Cull(IntEnum):  # Option<wgpu::Face> of Configuration::cull_mode (renderer.rs:383-384); front = counter-clockwise on screen
+    Disabled = 0
+    Front = 1
+    Back = 2
+
+
+class Compare(IntEnum):  # wgpu::CompareFunction of Configuration::depth_compare (renderer.rs:387-388): fragment depth OP stored depth
+    Always = 0
+    Never = 1
+    Less = 2
+    Equal = 3
+    LessEqual = 4
+    Greater = 5
+    NotEqual = 6
+    GreaterEqual = 7
+
+
 @dataclass
 class Configuration:  # renderer.rs:380-405 (fields that change results on this path)
     msaa_sample_count: int = 1
     clip_nesting_counter_bits: int = 4
     winding_counter_bits: int = 4
     alpha_layer_count: int = 0
+    cull_mode: int = Cull.Disabled          # the three depth / cull fields act on the colour cover only (renderer.rs:743-745)
+    depth_compare: int = Compare.Always
+    depth_write_enabled: bool = False
 
 
 class Renderer:
@@ -38,7 +58,8 @@ class Renderer:
     def __init__(self, config: Configuration = None, device: int = 0):
         self.lib = _ffi.load_library()
         config = config or Configuration()
-        c = _ffi.ConfigC(config.msaa_sample_count, config.clip_nesting_counter_bits, config.winding_counter_bits, config.alpha_layer_count)
+        c = _ffi.ConfigC(config.msaa_sample_count, config.clip_nesting_counter_bits, config.winding_counter_bits, config.alpha_layer_count,
+                         int(config.cull_mode), int(config.depth_compare), 1 if config.depth_write_enabled else 0)
         handle = C.c_void_p()
         check(self.lib.crh_renderer_create(C.byref(c), device, C.byref(handle)))
         self.handle = handle
@@ -89,6 +110,21 @@ class Frame:
 
     def clear(self):
         check(self.lib.crh_frame_clear(self.handle))
+
+    def clear_depth(self, value=1.0):
+        """LoadOp::Clear(value) of the depth attachment (main.rs:223-226); it exists when the configuration tests or writes depth."""
+        check(self.lib.crh_frame_clear_depth(self.handle, value))
+
+    def upload_depth(self, depth):
+        """The depth of the 3-D scene the Shapes are decals in: [height, width] floats, replicated to every sample."""
+        d = np.ascontiguousarray(depth, dtype=np.float32).reshape(self.height, self.width)
+        check(self.lib.crh_frame_upload_depth(self.handle, d.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def download_depth(self):
+        """-> [height, width, msaa_sample_count] float32."""
+        out = np.zeros((self.height, self.width, self.renderer.config.msaa_sample_count), dtype=np.float32)
+        check(self.lib.crh_frame_download_depth(self.handle, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def download(self):
         out = np.zeros((self.height, self.width, 4), dtype=np.uint8)

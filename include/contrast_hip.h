@@ -120,14 +120,30 @@ typedef struct crh_path_batch {
 
 /* ---- Renderer (renderer.rs:380-435) --------------------------------------------------------------- */
 
-/* Configuration, renderer.rs:380-405. Only the fields that change results on this path are kept:
- * blending is fixed to premultiplied "over" (One, OneMinusSrcAlpha — examples/showcase/main.rs:32-43);
- * depth / cull / alpha layers are out of scope. */
+/* Configuration, renderer.rs:380-405. The fields that change results on this path:
+ * blending is fixed to premultiplied "over" (One, OneMinusSrcAlpha — examples/showcase/main.rs:32-43), the depth attachment is
+ * f32 per sample (depth_stencil_format is a wgpu detail), color_attachment_in_stencil_pass has no meaning in a compute rasterizer.
+ * The three depth / cull fields act on the colour cover only, as in the reference (renderer.rs:743-745: every other pipeline is
+ * built with cull None, CompareFunction::Always and no depth write). Zero-initialised = no culling, Always, no write. */
+typedef enum crh_cull { CRH_CULL_NONE = 0, CRH_CULL_FRONT = 1, CRH_CULL_BACK = 2 } crh_cull; /* Option<wgpu::Face>; front = counter-clockwise on screen (renderer.rs:477) */
+typedef enum crh_compare { /* wgpu::CompareFunction of `fragment depth  OP  stored depth` */
+    CRH_COMPARE_ALWAYS = 0,
+    CRH_COMPARE_NEVER = 1,
+    CRH_COMPARE_LESS = 2,
+    CRH_COMPARE_EQUAL = 3,
+    CRH_COMPARE_LESS_EQUAL = 4,
+    CRH_COMPARE_GREATER = 5,
+    CRH_COMPARE_NOT_EQUAL = 6,
+    CRH_COMPARE_GREATER_EQUAL = 7
+} crh_compare;
 typedef struct crh_config {
     uint32_t msaa_sample_count;         /* 1 or 4 */
     uint32_t clip_nesting_counter_bits; /* validated as in renderer.rs:433 */
     uint32_t winding_counter_bits;      /* >= 1, sum <= 8 */
     uint32_t alpha_layer_count;         /* <= 4; layers of the alpha-context operations (renderer.rs:403-404) */
+    uint32_t cull_mode;                 /* crh_cull, renderer.rs:383-384 */
+    uint32_t depth_compare;             /* crh_compare, renderer.rs:387-388 */
+    uint32_t depth_write_enabled;       /* 0 / 1, renderer.rs:389-390 */
 } crh_config;
 
 typedef struct crh_renderer crh_renderer; /* Renderer, renderer.rs:408 */
@@ -194,13 +210,20 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* scene, uint32_t shape
 /* The colour target (RGBA8 unorm, premultiplied) plus the per-sample winding ("stencil") state. */
 crh_status crh_frame_create(crh_renderer* renderer, uint32_t width, uint32_t height, crh_frame** out);
 void crh_frame_destroy(crh_frame* frame);
-/* LoadOp::Clear(TRANSPARENT) + stencil clear 0 (examples/showcase/main.rs:217-230) */
+/* LoadOp::Clear(TRANSPARENT) + depth clear 1.0 + stencil clear 0 (examples/showcase/main.rs:217-230) */
 crh_status crh_frame_clear(crh_frame* frame);
+/* The depth attachment (f32 per sample, [height][width][msaa_sample_count]); it exists when the renderer's configuration tests or
+ * writes depth. clear_depth = LoadOp::Clear(value) (main.rs:223-226); upload_depth places the depth of a 3-D scene the Shapes are
+ * decals in (README.md:8-12): `depth` = [height][width] host floats, replicated to every sample; download_depth copies all samples out. */
+crh_status crh_frame_clear_depth(crh_frame* frame, float value);
+crh_status crh_frame_upload_depth(crh_frame* frame, const float* depth);
+crh_status crh_frame_download_depth(crh_frame* frame, float* depth_samples);
 
 /* For every shape i of the scene, in index order: Shape::render(Stencil) then Shape::render(Color)
  * with instance transform `transforms[i]` (column-major mat4, 64 B: shaders.wgsl:13-27) and colour
  * `colors[i]` (straight RGBA, 16 B: shaders.wgsl:304-309) — the loop of examples/showcase/main.rs:236-250.
- * Round 1 supports affine transforms (clip.w == 1, z ignored); others give CRH_ERR_UNSUPPORTED.
+ * Any 4x4 matrix is accepted: perspective instances (utils.rs:181-203, main.rs:162-202) are rasterised with homogeneous edge functions,
+ * a per-sample near / far test and perspective-correct attributes.
  * Pointers are host memory; they are copied to the device when they change. Asynchronous. */
 crh_status crh_scene_render(crh_scene* scene, crh_frame* frame, const float* transforms, const float* colors);
 /* Same, with per-shape data already in HBM (used by bench.py so that PCIe is outside the step). */

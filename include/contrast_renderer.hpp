@@ -11,6 +11,7 @@
 // The Rust toolchain is absent from the build image, so this C++ mirror (and the ctypes one in contrast_renderer_amd/) is what the
 // tests drive; INTEGRATION.md shows the equivalent Rust shim.
 #pragma once
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <optional>
@@ -401,13 +402,19 @@ enum class RenderOperation : uint32_t { Stencil = 0, Clip = 1, UnClip = 2, Color
 
 struct Configuration { // renderer.rs:380-405, the fields that change results on this path
     uint32_t msaa_sample_count = 1, clip_nesting_counter_bits = 4, winding_counter_bits = 4, alpha_layer_count = 0;
+    // of the colour cover only, as in the reference (renderer.rs:743-745)
+    crh_cull cull_mode = CRH_CULL_NONE;              // Option<wgpu::Face>
+    crh_compare depth_compare = CRH_COMPARE_ALWAYS;  // wgpu::CompareFunction
+    bool depth_write_enabled = false;
 };
 
 class Renderer { // renderer.rs:408-435
   public:
     Renderer(int device, const Configuration& config) { // Renderer::new(&device, config) -> Result<Renderer, Error>
-        const crh_config c = {config.msaa_sample_count, config.clip_nesting_counter_bits, config.winding_counter_bits, config.alpha_layer_count};
+        const crh_config c = {config.msaa_sample_count, config.clip_nesting_counter_bits, config.winding_counter_bits, config.alpha_layer_count,
+                              (uint32_t)config.cull_mode,  (uint32_t)config.depth_compare,      config.depth_write_enabled ? 1u : 0u};
         check(crh_renderer_create(&c, device, &handle_));
+        samples_ = config.msaa_sample_count;
     }
     ~Renderer() { crh_renderer_destroy(handle_); }
     Renderer(const Renderer&) = delete;
@@ -415,23 +422,40 @@ class Renderer { // renderer.rs:408-435
     Configuration get_config() const { // renderer.rs:887
         crh_config c;
         check(crh_renderer_get_config(handle_, &c));
-        return Configuration{c.msaa_sample_count, c.clip_nesting_counter_bits, c.winding_counter_bits, c.alpha_layer_count};
+        return Configuration{c.msaa_sample_count, c.clip_nesting_counter_bits, c.winding_counter_bits, c.alpha_layer_count,
+                             (crh_cull)c.cull_mode, (crh_compare)c.depth_compare, c.depth_write_enabled != 0};
     }
     void synchronize() { check(crh_renderer_synchronize(handle_)); }
     crh_renderer* raw() const { return handle_; }
+    uint32_t msaa_sample_count() const { return samples_; }
 
   private:
     crh_renderer* handle_ = nullptr;
+    uint32_t samples_ = 1;
 };
 
 // The caller-owned colour + depth/stencil attachments of the render pass (examples/showcase/main.rs:217-230).
 class Frame {
   public:
-    Frame(Renderer& renderer, uint32_t width, uint32_t height) : width_(width), height_(height) { check(crh_frame_create(renderer.raw(), width, height, &handle_)); }
+    Frame(Renderer& renderer, uint32_t width, uint32_t height) : width_(width), height_(height), samples_(renderer.msaa_sample_count()) {
+        check(crh_frame_create(renderer.raw(), width, height, &handle_));
+    }
     ~Frame() { crh_frame_destroy(handle_); }
     Frame(const Frame&) = delete;
     Frame& operator=(const Frame&) = delete;
-    void clear() { check(crh_frame_clear(handle_)); } // LoadOp::Clear(TRANSPARENT) + stencil clear
+    void clear() { check(crh_frame_clear(handle_)); } // LoadOp::Clear(TRANSPARENT) + depth clear 1.0 + stencil clear
+    // the depth attachment (present when the Configuration tests or writes depth): LoadOp::Clear(value), the depth of the 3-D scene
+    // the Shapes are decals in ([height][width], replicated to the samples), and read back of every sample
+    void clear_depth(float value) { check(crh_frame_clear_depth(handle_, value)); }
+    void upload_depth(const std::vector<float>& depth) {
+        if (depth.size() != (size_t)width_ * height_) throw Error(CRH_ERR_INVALID_ARGUMENT);
+        check(crh_frame_upload_depth(handle_, depth.data()));
+    }
+    std::vector<float> download_depth() {
+        std::vector<float> out((size_t)width_ * height_ * samples_);
+        check(crh_frame_download_depth(handle_, out.data()));
+        return out;
+    }
     std::vector<uint8_t> download() {                 // MSAA resolve + read back: premultiplied RGBA8, row 0 = top
         std::vector<uint8_t> out((size_t)width_ * height_ * 4);
         check(crh_frame_download(handle_, out.data()));
@@ -443,7 +467,7 @@ class Frame {
 
   private:
     crh_frame* handle_ = nullptr;
-    uint32_t width_, height_;
+    uint32_t width_, height_, samples_;
 };
 
 struct ShapeBuffers { // the byte image Shape::from_paths uploads (renderer.rs:198-209)
@@ -599,6 +623,35 @@ class Font { // text.rs:11-38; face() of the reference returns the parsed ttf_pa
     std::string name_;
     crh_font* handle_ = nullptr;
 };
+
+// ---- utils.rs:168-203: column-major 4x4 matrices as the instance buffer holds them (shaders.wgsl:13-27), element [4 * column + row]
+using Mat4 = std::array<float, 16>;
+inline Mat4 perspective_projection(float field_of_view_y, float aspect_ratio, float near, float far) { // utils.rs:181-192
+    const float height = 1.0f / std::tan(field_of_view_y * 0.5f), denominator = 1.0f / (near - far);
+    Mat4 m{};
+    m[0] = height / aspect_ratio;
+    m[5] = height;
+    m[10] = -far * denominator;
+    m[11] = 1.0f;
+    m[14] = near * far * denominator;
+    return m;
+}
+inline Mat4 matrix_multiplication(const Mat4& a, const Mat4& b) { // utils.rs:194-203: a * b, accumulated left to right like the reference
+    Mat4 out{};
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float acc = a[r] * b[4 * c];
+            for (int k = 1; k < 4; ++k) acc = acc + a[4 * k + r] * b[4 * c + k];
+            out[4 * c + r] = acc;
+        }
+    return out;
+}
+inline Mat4 translation_matrix(float x, float y, float z) { // what motor3d_to_mat4 (utils.rs:168-179) yields for a pure translator
+    Mat4 m{};
+    m[0] = m[5] = m[10] = m[15] = 1.0f;
+    m[12] = x, m[13] = y, m[14] = z;
+    return m;
+}
 
 namespace detail {
 inline std::vector<Path> take_paths(crh_path_list* list) {

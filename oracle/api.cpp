@@ -126,12 +126,21 @@ int oracle_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint3
 }
 
 // A recorded render pass: draws[i] = {shape, instance, op (crh_render_op), clip_depth, alpha_layer}, executed in order into a cleared frame.
-int oracle_render_draws(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
-                        const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws, uint8_t* rgba8) {
+// `depth_state` (optional) = {cull_mode, depth_compare, depth_write_enabled}; `depth` (optional, with depth_state) = the depth attachment
+// [height][width][msaa] the pass starts from and, on return, what it left there.
+int oracle_render_pass(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
+                       const uint32_t* depth_state, float* depth, const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws,
+                       uint8_t* rgba8) {
     Scene* sc = static_cast<Scene*>(h);
     if (!(msaa == 1 || msaa == 4) || winding_bits == 0 || winding_bits + clip_bits > 8) return CRH_ERR_INVALID_ARGUMENT;
     Frame f;
     f.create(width, height, msaa, winding_bits, clip_bits, alpha_layers);
+    if (depth_state) {
+        f.cull_mode = depth_state[0];
+        f.depth_compare = depth_state[1];
+        f.depth_write = depth_state[2];
+        if (depth) f.depth.assign(depth, depth + (size_t)width * height * msaa);
+    }
     for (uint32_t i = 0; i < n_draws; ++i) {
         const uint32_t shape = draws[5 * i], instance = draws[5 * i + 1], op = draws[5 * i + 2], clip_depth = draws[5 * i + 3], layer = draws[5 * i + 4];
         if (shape >= sc->shapes.size()) return CRH_ERR_INVALID_ARGUMENT;
@@ -144,7 +153,12 @@ int oracle_render_draws(void* h, uint32_t width, uint32_t height, uint32_t msaa,
             render_cover(f, sc->shapes[shape], transforms + 16 * (size_t)instance, colors + 4 * (size_t)instance, op, layer);
     }
     resolve_rgba8(f, rgba8);
+    if (depth && !f.depth.empty()) std::copy(f.depth.begin(), f.depth.end(), depth);
     return CRH_OK;
+}
+int oracle_render_draws(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
+                        const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws, uint8_t* rgba8) {
+    return oracle_render_pass(h, width, height, msaa, winding_bits, clip_bits, alpha_layers, nullptr, nullptr, transforms, colors, draws, n_draws, rgba8);
 }
 
 // cpu_baseline: wall seconds of `repeats` full tessellations (restatement of the CPU part of from_paths).

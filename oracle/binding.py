@@ -53,6 +53,8 @@ def _load():
                                       C.c_uint32, V]
         lib.oracle_render_draws.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                             C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, V]
+        lib.oracle_render_pass.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, V]
         lib.oracle_time_tessellate.restype = C.c_double
         lib.oracle_time_tessellate.argtypes = [C.POINTER(_ffi.PathBatchC), C.c_int, C.c_int]
         lib.oracle_fmath_eval.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
@@ -135,6 +137,25 @@ def render_draws(oracle, width, height, msaa, winding_bits, clip_bits, alpha_lay
     if rc != 0:
         raise RuntimeError(f"oracle_render_draws failed: {rc}")
     return out
+
+
+def render_pass(oracle, width, height, msaa, winding_bits, clip_bits, alpha_layers, transforms, colors, draws, cull_mode=0, depth_compare=0,
+                depth_write=0, depth=None):
+    """render_draws with the colour cover's depth / cull state (renderer.rs:383-390). `depth` = the depth attachment [h, w, msaa] the pass
+    starts from (None: no depth attachment) -> (RGBA8 [h, w, 4], depth after the pass or None)."""
+    t = np.ascontiguousarray(transforms, dtype=np.float32)
+    c = np.ascontiguousarray(colors, dtype=np.float32)
+    d = np.ascontiguousarray(draws, dtype=np.uint32).reshape(-1, 5)
+    out = np.zeros((height, width, 4), dtype=np.uint8)
+    state = np.array([cull_mode, depth_compare, depth_write], dtype=np.uint32)
+    z = None if depth is None else np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float32).reshape(height, width, -1), (height, width, msaa))).copy()
+    fp = C.POINTER(C.c_float)
+    rc = oracle.lib.oracle_render_pass(oracle.handle, width, height, msaa, winding_bits, clip_bits, alpha_layers, state.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                       None if z is None else z.ctypes.data_as(fp), t.ctypes.data_as(fp), c.ctypes.data_as(fp),
+                                       d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_pass failed: {rc}")
+    return out, z
 
 
 def split_shape(vo, io, vb, ib):

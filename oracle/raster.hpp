@@ -7,8 +7,15 @@
 // fmaf, no contraction) so a GPU kernel that follows the same recipe is bit-identical.
 //
 // Spec summary
-//  * framebuffer: y down, row 0 = top; fx = (ndc.x*0.5+0.5)*W, fy = (0.5-ndc.y*0.5)*H; affine instance
-//    transforms only (clip.w == 1), z ignored (no depth test on this path).
+//  * framebuffer: y down, row 0 = top; fx = (ndc.x*0.5+0.5)*W, fy = (0.5-ndc.y*0.5)*H.
+//  * instances: a "plain" instance transform (clip.w == 1 and clip.z a constant in [0, 1]: m3 = m7 = m2 = m6 = 0, m15 = 1) takes the
+//    affine path below; every other 4x4 matrix (perspective_projection of utils.rs:181-192 times a placement, main.rs:162-202) takes
+//    the projective path: homogeneous edge functions (no clipping: the part of a triangle behind the eye fails its own edge tests),
+//    per-sample near / far test 0 <= z/w <= 1 (unclipped_depth: false, renderer.rs:478), attributes interpolated perspective-correct
+//    at the sample (shaders.wgsl:35-58) as (a/w plane) * (1 / (1/w plane)).
+//  * depth: only the colour cover tests / writes depth (renderer.rs:743-745; every other pipeline is Always / no write); the depth
+//    attachment is f32 per sample here (the reference's Depth24Plus has implementation-defined precision); stencil depth_fail_op is
+//    Keep (renderer.rs:442), so a sample that passes the stencil test but fails the depth test keeps its winding.
 //  * samples: 1x = pixel centre; 4x = (6,2),(14,6),(2,10),(10,14)/16 (D3D/Vulkan standard pattern).
 //  * coverage: top-left rule on float edge functions. Every edge is evaluated from its endpoints in
 //    canonical (lexicographic) order, tile-relative (16x16 tiles), so the two triangles sharing an edge
@@ -33,6 +40,10 @@ struct Frame {
     std::vector<uint8_t> winding; // [y][x][s] the whole stencil byte: clip nesting counter | winding counter
     std::vector<float> color;     // [y][x][s][4] premultiplied
     std::vector<std::vector<float>> alpha_layers; // [layer][y][x][s] saved alpha (R8 targets of renderer.rs:892-927, kept in f32 like the colour)
+    // Configuration::{cull_mode, depth_compare, depth_write_enabled} (renderer.rs:383-390) of the colour cover; depth attachment [y][x][s]
+    uint32_t cull_mode = CRH_CULL_NONE, depth_compare = CRH_COMPARE_ALWAYS, depth_write = 0;
+    std::vector<float> depth;
+    void create_depth(float clear_value) { depth.assign((size_t)width * height * samples, clear_value); }
     void create(uint32_t w, uint32_t h, uint32_t s, uint32_t winding_bits, uint32_t clip_bits = 0, uint32_t n_alpha_layers = 0) {
         width = w;
         height = h;
@@ -142,9 +153,9 @@ inline float attribute_tile_constant(const TriangleSetup& t, const AttrPlane& p,
     return (p.a0 + (tx0 - t.v0[0]) * p.gx) + (ty0 - t.v0[1]) * p.gy;
 }
 
-// Rasterise one triangle; `frag(attr_values) -> bool keep`, `stencil(sample_index_in_frame, front)` applies the op.
+// Rasterise one triangle of a plain instance; `frag(attr_values) -> bool keep`, `stencil(sample_index_in_frame, front, depth)` applies the op.
 template <int NATTR, typename Frag, typename Stencil>
-inline void raster_triangle(Frame& f, const float v[3][2], const float attr[3][4], Frag frag, Stencil stencil) {
+inline void raster_plain(Frame& f, const float v[3][2], const float attr[3][4], float depth, Frag frag, Stencil stencil) {
     const TriangleSetup t = setup_triangle(v, (int)f.width, (int)f.height);
     if (!t.valid) return;
     AttrPlane planes[NATTR > 0 ? NATTR : 1];
@@ -174,11 +185,193 @@ inline void raster_triangle(Frame& f, const float v[3][2], const float attr[3][4
                         float values[NATTR > 0 ? NATTR : 1];
                         for (int a = 0; a < NATTR; ++a) values[a] = fmaf(ry, planes[a].gy, fmaf(rx, planes[a].gx, ac[a]));
                         if (!frag(values)) continue;
-                        stencil(((size_t)py * f.width + px) * f.samples + s, t.front);
+                        stencil(((size_t)py * f.width + px) * f.samples + s, t.front, depth);
                     }
                 }
             }
         }
+    }
+}
+
+// ---- projective instances -------------------------------------------------------------------------------------
+// clip = M * (x, y, 0, 1) (shaders.wgsl:66-74) kept homogeneous, with the viewport transform applied to x and y:
+//   X = (clip.x*0.5 + clip.w*0.5) * W,  Y = (clip.w*0.5 - clip.y*0.5) * H,  Z = clip.z,  Wc = clip.w   (screen point = (X/Wc, Y/Wc))
+struct ClipVertex {
+    float X, Y, Z, W;
+};
+inline bool is_plain_instance(const float m[16]) {
+    return m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f && m[2] == 0.0f && m[6] == 0.0f && m[14] >= 0.0f && m[14] <= 1.0f;
+}
+inline ClipVertex to_clip(const float m[16], float w, float h, const float p[2]) {
+    const float cx = (m[0] * p[0] + m[4] * p[1]) + m[12];
+    const float cy = (m[1] * p[0] + m[5] * p[1]) + m[13];
+    const float cz = (m[2] * p[0] + m[6] * p[1]) + m[14];
+    const float cw = (m[3] * p[0] + m[7] * p[1]) + m[15];
+    return ClipVertex{(cx * 0.5f + cw * 0.5f) * w, (cw * 0.5f - cy * 0.5f) * h, cz, cw};
+}
+inline bool lex_less3(const ClipVertex& a, const ClipVertex& b) {
+    return a.X < b.X || (a.X == b.X && (a.Y < b.Y || (a.Y == b.Y && a.W < b.W)));
+}
+// A screen point p = (x, y, 1) is inside the triangle iff p = sum lambda_i P_i with all lambda_i >= 0 (P_i = (X, Y, Wc)); where the
+// triangle is behind the eye the lambdas are all <= 0, so the three edge tests also reject the antipodal image: nothing is clipped.
+// lambda_0 * det = det[p, P1, P2] = A x + B y + C with (A, B, C) = P1 x P2: the same E = bx*(y - lo.y) + nay*(x - lo.x) form as the
+// plain path, nay = A, bx = B, anchored at the projection of an endpoint. Coefficients come from the endpoints in canonical order, so
+// the two triangles sharing an edge see exactly negated values (watertight).
+struct ProjectiveSetup {
+    bool valid, front;
+    EdgeSetup e[3];
+    int x0, x1, y0, y1;
+    float anchor[2];  // the projection of vertex k, origin of the attribute planes
+    int k;
+    float lx[2], ly[2], lw[3]; // the other two vertices relative to the anchor, in cyclic order after k: (X - ax*Wc, Y - ay*Wc), and Wc of k, k+1, k+2
+    float inv_det;
+};
+inline ProjectiveSetup setup_projective(const ClipVertex P[3], int width, int height) {
+    ProjectiveSetup t;
+    t.valid = false;
+    int k = -1;
+    for (int i = 2; i >= 0; --i)
+        if (P[i].W > 0.0f) k = i; // the first vertex in front of the eye
+    if (k < 0) return t;
+    for (int i = 0; i < 3; ++i)
+        if (!(std::isfinite(P[i].X) && std::isfinite(P[i].Y) && std::isfinite(P[i].Z) && std::isfinite(P[i].W))) return t;
+    // orientation: det[P0; P1; P2] = w0 w1 w2 * (screen cross product) when all w > 0
+    const float c0 = P[1].X * P[2].Y - P[1].Y * P[2].X, a0 = P[1].Y * P[2].W - P[1].W * P[2].Y, b0 = P[1].W * P[2].X - P[1].X * P[2].W;
+    const float det = (P[0].X * a0 + P[0].Y * b0) + P[0].W * c0;
+    if (!(det != 0.0f) || !std::isfinite(det)) return t;
+    t.front = det < 0.0f;
+    const ClipVertex* n[3] = {&P[0], det < 0.0f ? &P[2] : &P[1], det < 0.0f ? &P[1] : &P[2]};
+    for (int i = 0; i < 3; ++i) {
+        const ClipVertex& a = *n[i];
+        const ClipVertex& b = *n[(i + 1) % 3];
+        EdgeSetup& e = t.e[i];
+        e.flip = !lex_less3(a, b);
+        const ClipVertex& lo = e.flip ? b : a;
+        const ClipVertex& hi = e.flip ? a : b;
+        e.nay = lo.Y * hi.W - lo.W * hi.Y; // A of the canonical orientation
+        e.bx = lo.W * hi.X - lo.X * hi.W;  // B
+        const float A = e.flip ? -e.nay : e.nay, B = e.flip ? -e.bx : e.bx;
+        e.topleft = A > 0.0f || (A == 0.0f && B > 0.0f); // the plain rule (dy < 0 || (dy == 0 && dx > 0)) in terms of the half-plane normal
+        const ClipVertex& anchor = lo.W > 0.0f ? lo : (hi.W > 0.0f ? hi : (lo.W != 0.0f ? lo : hi));
+        if (anchor.W == 0.0f) return t; // an edge at infinity
+        e.lo[0] = anchor.X / anchor.W;
+        e.lo[1] = anchor.Y / anchor.W;
+        if (!(std::isfinite(e.lo[0]) && std::isfinite(e.lo[1]))) return t;
+    }
+    if (P[0].W > 0.0f && P[1].W > 0.0f && P[2].W > 0.0f) {
+        float px[3], py[3];
+        for (int i = 0; i < 3; ++i) {
+            px[i] = P[i].X / P[i].W;
+            py[i] = P[i].Y / P[i].W;
+        }
+        const float minx = std::fmin(px[0], std::fmin(px[1], px[2])), maxx = std::fmax(px[0], std::fmax(px[1], px[2]));
+        const float miny = std::fmin(py[0], std::fmin(py[1], py[2])), maxy = std::fmax(py[0], std::fmax(py[1], py[2]));
+        if (!(minx == minx && maxx == maxx && miny == miny && maxy == maxy)) return t;
+        t.x0 = (int)std::floor(std::fmin(std::fmax(minx, 0.0f), (float)width));
+        t.x1 = (int)std::floor(std::fmax(std::fmin(maxx, (float)(width - 1)), -1.0f));
+        t.y0 = (int)std::floor(std::fmin(std::fmax(miny, 0.0f), (float)height));
+        t.y1 = (int)std::floor(std::fmax(std::fmin(maxy, (float)(height - 1)), -1.0f));
+        if (t.x0 > t.x1 || t.y0 > t.y1) return t;
+    } else { // crosses the eye plane: its screen extent is unbounded, every pixel is a candidate
+        t.x0 = 0;
+        t.y0 = 0;
+        t.x1 = width - 1;
+        t.y1 = height - 1;
+    }
+    // attribute planes are set up relative to the anchor (the projection of vertex k) so that small triangles far from the frame
+    // origin do not cancel: with P'_k = (0, 0, w_k) the lambda gradients reduce to the expressions of setup_projective_plane
+    t.k = k;
+    const ClipVertex& K = P[k];
+    const ClipVertex& U = P[(k + 1) % 3];
+    const ClipVertex& V = P[(k + 2) % 3];
+    t.anchor[0] = K.X / K.W;
+    t.anchor[1] = K.Y / K.W;
+    t.lx[0] = U.X - t.anchor[0] * U.W;
+    t.ly[0] = U.Y - t.anchor[1] * U.W;
+    t.lx[1] = V.X - t.anchor[0] * V.W;
+    t.ly[1] = V.Y - t.anchor[1] * V.W;
+    t.lw[0] = K.W;
+    t.lw[1] = U.W;
+    t.lw[2] = V.W;
+    const float local_det = K.W * (t.lx[0] * t.ly[1] - t.ly[0] * t.lx[1]);
+    if (!(local_det != 0.0f) || !std::isfinite(local_det)) return t;
+    t.inv_det = 1.0f / local_det;
+    t.valid = true;
+    return t;
+}
+// The plane F(x, y) = sum_i f_i lambda_i(x, y) through the per-vertex values f (index 0 = vertex k, then cyclic): F = f/w interpolated
+// linearly on screen. f = attribute -> "a/w"; f = 1 -> "1/w"; f = clip.z -> z/w itself (NDC depth is affine on screen).
+inline AttrPlane setup_projective_plane(const ProjectiveSetup& t, float fk, float fu, float fv) {
+    const float ak = t.ly[0] * t.lw[2] - t.lw[1] * t.ly[1], bk = t.lw[1] * t.lx[1] - t.lx[0] * t.lw[2]; // P'_u x P'_v
+    const float au = t.ly[1] * t.lw[0], bu = -(t.lx[1] * t.lw[0]);                                       // P'_v x P'_k
+    const float av = -(t.lw[0] * t.ly[0]), bv = t.lw[0] * t.lx[0];                                       // P'_k x P'_u
+    AttrPlane p;
+    p.a0 = fk / t.lw[0];
+    p.gx = ((fk * ak + fu * au) + fv * av) * t.inv_det;
+    p.gy = ((fk * bk + fu * bu) + fv * bv) * t.inv_det;
+    return p;
+}
+
+template <int NATTR, typename Frag, typename Stencil>
+inline void raster_projective(Frame& f, const ClipVertex P[3], const float attr[3][4], Frag frag, Stencil stencil) {
+    const ProjectiveSetup t = setup_projective(P, (int)f.width, (int)f.height);
+    if (!t.valid) return;
+    const int k = t.k, u = (k + 1) % 3, v = (k + 2) % 3;
+    AttrPlane planes[NATTR > 0 ? NATTR : 1];
+    for (int a = 0; a < NATTR; ++a) planes[a] = setup_projective_plane(t, attr[k][a], attr[u][a], attr[v][a]);
+    const AttrPlane qp = setup_projective_plane(t, 1.0f, 1.0f, 1.0f);       // 1/w
+    const AttrPlane zp = setup_projective_plane(t, P[k].Z, P[u].Z, P[v].Z); // z/w
+    auto tile_constant = [&](const AttrPlane& p, float tx0, float ty0) { return (p.a0 + (tx0 - t.anchor[0]) * p.gx) + (ty0 - t.anchor[1]) * p.gy; };
+    for (int ty = t.y0 / TILE; ty <= t.y1 / TILE; ++ty) {
+        for (int tx = t.x0 / TILE; tx <= t.x1 / TILE; ++tx) {
+            const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+            float c[3];
+            for (int i = 0; i < 3; ++i) c[i] = t.e[i].bx * (ty0 - t.e[i].lo[1]) + t.e[i].nay * (tx0 - t.e[i].lo[0]);
+            float ac[NATTR > 0 ? NATTR : 1];
+            for (int a = 0; a < NATTR; ++a) ac[a] = tile_constant(planes[a], tx0, ty0);
+            const float qc = tile_constant(qp, tx0, ty0), zc = tile_constant(zp, tx0, ty0);
+            const int py0 = std::max(t.y0, ty * TILE), py1 = std::min(t.y1, ty * TILE + TILE - 1);
+            const int px0 = std::max(t.x0, tx * TILE), px1 = std::min(t.x1, tx * TILE + TILE - 1);
+            for (int py = py0; py <= py1; ++py) {
+                for (int px = px0; px <= px1; ++px) {
+                    for (uint32_t s = 0; s < f.samples; ++s) {
+                        float ox, oy;
+                        sample_offset(f.samples, s, ox, oy);
+                        const float rx = (float)(px - tx * TILE) + ox, ry = (float)(py - ty * TILE) + oy;
+                        bool inside = true;
+                        for (int i = 0; i < 3 && inside; ++i) {
+                            float e = fmaf(rx, t.e[i].nay, fmaf(ry, t.e[i].bx, c[i]));
+                            if (t.e[i].flip) e = -e;
+                            inside = e > 0.0f || (e == 0.0f && t.e[i].topleft);
+                        }
+                        if (!inside) continue;
+                        const float z = fmaf(ry, zp.gy, fmaf(rx, zp.gx, zc));
+                        if (!(z >= 0.0f && z <= 1.0f)) continue; // near / far clip of the fixed-function pipeline, per sample
+                        const float q = fmaf(ry, qp.gy, fmaf(rx, qp.gx, qc));
+                        const float w = 1.0f / q;
+                        float values[NATTR > 0 ? NATTR : 1];
+                        for (int a = 0; a < NATTR; ++a) values[a] = fmaf(ry, planes[a].gy, fmaf(rx, planes[a].gx, ac[a])) * w;
+                        if (!frag(values)) continue;
+                        stencil(((size_t)py * f.width + px) * f.samples + s, t.front, z);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// One triangle of an instance: `pos` are the model-space positions (the vertex attribute at location 4, shaders.wgsl:66-153).
+template <int NATTR, typename Frag, typename Stencil>
+inline void raster_triangle(Frame& f, const float m[16], const float pos[3][2], const float attr[3][4], Frag frag, Stencil stencil) {
+    const float W = (float)f.width, H = (float)f.height;
+    if (is_plain_instance(m)) {
+        float v[3][2];
+        for (int c = 0; c < 3; ++c) to_framebuffer(m, W, H, pos[c], v[c]);
+        raster_plain<NATTR>(f, v, attr, m[14], frag, stencil);
+    } else {
+        ClipVertex P[3];
+        for (int c = 0; c < 3; ++c) P[c] = to_clip(m, W, H, pos[c]);
+        raster_projective<NATTR>(f, P, attr, frag, stencil);
     }
 }
 
@@ -235,17 +428,16 @@ inline uint8_t wrap_add(uint8_t old, int delta, uint32_t mask) { return (uint8_t
 
 // Shape::render(Stencil) (renderer.rs:275-336) for one instance
 inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
-    const float W = (float)f.width, H = (float)f.height;
     static const crh_dynamic_stroke_descriptor zero_descriptor = {};
     auto descriptor = [&](uint32_t path_index) -> const crh_dynamic_stroke_descriptor& {
         // out-of-range reads of a storage buffer are clamped/zero in WebGPU; never happens for validated input
         return path_index < shape.stroke_buffer.size() ? shape.stroke_buffer[path_index] : zero_descriptor;
     };
     const uint32_t read_mask = f.clip_mask | f.winding_mask;
-    auto stroke_stencil = [&](size_t si, bool) { // Equal(ref) -> IncrementWrap, both faces, write mask = winding (renderer.rs:571-576)
+    auto stroke_stencil = [&](size_t si, bool, float) { // Equal(ref) -> IncrementWrap, both faces, write mask = winding (renderer.rs:571-576)
         if ((f.winding[si] & read_mask) == (f.reference & read_mask)) f.winding[si] = wrap_add(f.winding[si], 1, f.winding_mask);
     };
-    auto fill_stencil = [&](size_t si, bool front) { // LessEqual(ref <= stencil) -> front Increment / back Decrement (renderer.rs:577-582)
+    auto fill_stencil = [&](size_t si, bool front, float) { // LessEqual(ref <= stencil) -> front Increment / back Decrement (renderer.rs:577-582)
         if ((f.reference & read_mask) <= (f.winding[si] & read_mask)) f.winding[si] = wrap_add(f.winding[si], front ? 1 : -1, f.winding_mask);
     };
     // 1. stroke line strips (renderer.rs:278-287, shaders.wgsl:268-285)
@@ -261,7 +453,7 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                     float v[3][2], attr[3][4];
                     for (int c = 0; c < 3; ++c) {
                         const Vertex2f1i& vx = verts[idx[run_start + tri[c]]];
-                        to_framebuffer(m, W, H, vx.p, v[c]);
+                        v[c][0] = vx.p[0], v[c][1] = vx.p[1];
                         attr[c][0] = vx.t[0];
                         attr[c][1] = vx.t[1];
                     }
@@ -270,7 +462,7 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                     const float end_texcoord_y = provoking.t[1];
                     const crh_dynamic_stroke_descriptor& d = descriptor(flat_u & 65535u);
                     raster_triangle<2>(
-                        f, v, attr,
+                        f, m, v, attr,
                         [&](const float* t) {
                             if ((d.count_dashed_join & 4u) != 0u) return stroke_dashed(d, t[0], t[1]);
                             if ((flat_u & 65536u) != 0u) return cap(t[0], t[1] - end_texcoord_y, d.caps >> 4);
@@ -297,7 +489,7 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                     float v[3][2], attr[3][4];
                     for (int c = 0; c < 3; ++c) {
                         const Vertex3f1i& vx = verts[idx[run_start + tri[c]]];
-                        to_framebuffer(m, W, H, vx.p, v[c]);
+                        v[c][0] = vx.p[0], v[c][1] = vx.p[1];
                         attr[c][0] = vx.t[0];
                         attr[c][1] = vx.t[1];
                         attr[c][2] = vx.t[2];
@@ -305,7 +497,7 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                     const uint32_t flat_u = verts[idx[run_start + i]].u;
                     const crh_dynamic_stroke_descriptor& d = descriptor(flat_u & 65535u);
                     raster_triangle<3>(
-                        f, v, attr,
+                        f, m, v, attr,
                         [&](const float* t) {
                             const float radius = std::sqrt(t[0] * t[0] + t[1] * t[1]);
                             bool fill = joint(radius, (flat_u & 65536u) != 0u, d.count_dashed_join & 3u);
@@ -329,9 +521,9 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                     size_t tri[3];
                     StripWalker::triangle(i, tri);
                     float v[3][2], attr[3][4] = {};
-                    for (int c = 0; c < 3; ++c) to_framebuffer(m, W, H, verts[idx[run_start + tri[c]]].p, v[c]);
+                    for (int c = 0; c < 3; ++c) v[c][0] = verts[idx[run_start + tri[c]]].p[0], v[c][1] = verts[idx[run_start + tri[c]]].p[1];
                     raster_triangle<0>(
-                        f, v, attr, [](const float*) { return true; }, fill_stencil);
+                        f, m, v, attr, [](const float*) { return true; }, fill_stencil);
                 }
                 run_start = k + 1;
             }
@@ -342,50 +534,61 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
         float v[3][2], attr[3][4] = {};
         for (int c = 0; c < 3; ++c) {
             const Vertex2f& vx = shape.fill.integral_quadratic_vertices[i + c];
-            to_framebuffer(m, W, H, vx.p, v[c]);
+            v[c][0] = vx.p[0], v[c][1] = vx.p[1];
             attr[c][0] = vx.w[0];
             attr[c][1] = vx.w[1];
         }
         raster_triangle<2>(
-            f, v, attr, [](const float* w) { return w[0] * w[0] - w[1] <= 0.0f; }, fill_stencil);
+            f, m, v, attr, [](const float* w) { return w[0] * w[0] - w[1] <= 0.0f; }, fill_stencil);
     }
     for (size_t i = 0; i + 2 < shape.fill.integral_cubic_vertices.size(); i += 3) {
         float v[3][2], attr[3][4] = {};
         for (int c = 0; c < 3; ++c) {
             const Vertex3f& vx = shape.fill.integral_cubic_vertices[i + c];
-            to_framebuffer(m, W, H, vx.p, v[c]);
+            v[c][0] = vx.p[0], v[c][1] = vx.p[1];
             for (int a = 0; a < 3; ++a) attr[c][a] = vx.w[a];
         }
         raster_triangle<3>(
-            f, v, attr, [](const float* w) { return w[0] * w[0] * w[0] - w[1] * w[2] <= 0.0f; }, fill_stencil);
+            f, m, v, attr, [](const float* w) { return w[0] * w[0] * w[0] - w[1] * w[2] <= 0.0f; }, fill_stencil);
     }
     for (size_t i = 0; i + 2 < shape.fill.rational_quadratic_vertices.size(); i += 3) {
         float v[3][2], attr[3][4] = {};
         for (int c = 0; c < 3; ++c) {
             const Vertex3f& vx = shape.fill.rational_quadratic_vertices[i + c];
-            to_framebuffer(m, W, H, vx.p, v[c]);
+            v[c][0] = vx.p[0], v[c][1] = vx.p[1];
             for (int a = 0; a < 3; ++a) attr[c][a] = vx.w[a];
         }
         raster_triangle<3>(
-            f, v, attr, [](const float* w) { return w[0] * w[0] - w[1] * w[2] <= 0.0f; }, fill_stencil);
+            f, m, v, attr, [](const float* w) { return w[0] * w[0] - w[1] * w[2] <= 0.0f; }, fill_stencil);
     }
     for (size_t i = 0; i + 2 < shape.fill.rational_cubic_vertices.size(); i += 3) {
         float v[3][2], attr[3][4] = {};
         for (int c = 0; c < 3; ++c) {
             const Vertex4f& vx = shape.fill.rational_cubic_vertices[i + c];
-            to_framebuffer(m, W, H, vx.p, v[c]);
+            v[c][0] = vx.p[0], v[c][1] = vx.p[1];
             for (int a = 0; a < 4; ++a) attr[c][a] = vx.w[a];
         }
         raster_triangle<4>(
-            f, v, attr, [](const float* w) { return w[0] * w[0] * w[0] - w[1] * w[2] * w[3] <= 0.0f; }, fill_stencil);
+            f, m, v, attr, [](const float* w) { return w[0] * w[0] * w[0] - w[1] * w[2] * w[3] <= 0.0f; }, fill_stencil);
     }
 }
 
 // The cover operations: Shape::render(Clip | UnClip | Color | SaveAlphaContext | ScaleAlphaContext | RestoreAlphaContext)
 // (renderer.rs:338-354) draw the hull strip with the fixed-function state of renderer.rs:692-754 / :761-861 and the fragment stages
 // shaders.wgsl:304-355, for one instance. `op` = crh_render_op.
+inline bool depth_test(uint32_t compare, float fragment, float stored) { // wgpu::CompareFunction
+    switch (compare) {
+        case CRH_COMPARE_NEVER: return false;
+        case CRH_COMPARE_LESS: return fragment < stored;
+        case CRH_COMPARE_EQUAL: return fragment == stored;
+        case CRH_COMPARE_LESS_EQUAL: return fragment <= stored;
+        case CRH_COMPARE_GREATER: return fragment > stored;
+        case CRH_COMPARE_NOT_EQUAL: return fragment != stored;
+        case CRH_COMPARE_GREATER_EQUAL: return fragment >= stored;
+        default: return true;
+    }
+}
 inline void render_cover(Frame& f, const Shape& shape, const float m[16], const float rgba[4], uint32_t op, uint32_t alpha_layer) {
-    const float W = (float)f.width, H = (float)f.height;
     const float src[4] = {rgba[0] * rgba[3], rgba[1] * rgba[3], rgba[2] * rgba[3], rgba[3]};
     const float one_minus_a = 1.0f - src[3];
     const uint32_t read_mask = f.clip_mask | f.winding_mask;
@@ -396,16 +599,21 @@ inline void render_cover(Frame& f, const Shape& shape, const float m[16], const 
         size_t tri[3];
         StripWalker::triangle(i, tri);
         float v[3][2], attr[3][4] = {};
-        for (int c = 0; c < 3; ++c) to_framebuffer(m, W, H, hull[tri[c]].p, v[c]);
+        for (int c = 0; c < 3; ++c) v[c][0] = hull[tri[c]].p[0], v[c][1] = hull[tri[c]].p[1];
         raster_triangle<0>(
-            f, v, attr, [](const float*) { return true; },
-            [&](size_t si, bool) {
+            f, m, v, attr, [](const float*) { return true; },
+            [&](size_t si, bool front, float z) {
                 const uint32_t st = f.winding[si];
                 float* dst = &f.color[si * 4];
                 switch (op) {
                     case CRH_OP_COLOR: // Less(ref < stencil): blend premultiplied "over"; pass -> Zero, fail -> Zero on the winding bits (renderer.rs:747-752)
-                        if ((ref & read_mask) < (st & read_mask))
+                        if ((f.cull_mode == CRH_CULL_FRONT && front) || (f.cull_mode == CRH_CULL_BACK && !front)) break; // Configuration::cull_mode, renderer.rs:743
+                        if ((ref & read_mask) < (st & read_mask)) {
+                            // the depth test follows the stencil test; depth_fail_op = Keep (renderer.rs:442): the winding survives
+                            if (!f.depth.empty() && !depth_test(f.depth_compare, z, f.depth[si])) break;
                             for (int c = 0; c < 4; ++c) dst[c] = src[c] + dst[c] * one_minus_a;
+                            if (!f.depth.empty() && f.depth_write) f.depth[si] = z;
+                        }
                         f.winding[si] = (uint8_t)(st & ~f.winding_mask);
                         break;
                     case CRH_OP_CLIP: // NotEqual on the winding bits -> Replace(ref) on clip | winding (renderer.rs:703-708)

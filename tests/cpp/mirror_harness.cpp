@@ -116,6 +116,34 @@ int main(int argc, char** argv) {
         image = frame.download();
         put(out, image.data(), image.size());
 
+        // decals in a 3-D scene (main.rs:162-202): perspective instances, depth tested (LessEqual) and written, back faces culled (main.rs:46-49)
+        {
+            Configuration config{1, 2, 4, 0};
+            config.depth_compare = CRH_COMPARE_LESS_EQUAL;
+            config.depth_write_enabled = true;
+            config.cull_mode = CRH_CULL_BACK; // as the showcase, main.rs:46
+            Renderer renderer3d(0, config);
+            Scene scene3d(renderer3d, batch);
+            Frame frame3d(renderer3d, 160, 128);
+            const Mat4 projection = perspective_projection(1.5707964f, 160.0f / 128.0f, 1.0f, 1000.0f);
+            std::vector<float> t3d;
+            for (int i = 0; i < 5; ++i) {
+                const Mat4 m = matrix_multiplication(projection, translation_matrix(place[i][0] * 2.0f, place[i][1] * 1.5f, 1.5f + 0.75f * (float)((i * 3) % 5)));
+                t3d.insert(t3d.end(), m.begin(), m.end());
+            }
+            frame3d.clear();
+            std::vector<float> wall((size_t)160 * 128, 1.0f);
+            for (int y = 0; y < 128; ++y)
+                for (int x = 0; x < 40; ++x) wall[(size_t)y * 160 + x] = 0.25f; // something close to the eye hides the left quarter
+            frame3d.upload_depth(wall);
+            scene3d.render(frame3d, t3d, colors);
+            const std::vector<uint8_t> image3d = frame3d.download();
+            const std::vector<float> depth3d = frame3d.download_depth();
+            put(out, t3d.data(), t3d.size() * 4);
+            put(out, image3d.data(), image3d.size());
+            put(out, depth3d.data(), depth3d.size() * 4);
+        }
+
         // error behaviour: the reference's Err(..) values arrive as exceptions with the same variants
         int errors = 0;
         try {

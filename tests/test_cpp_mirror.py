@@ -102,6 +102,19 @@ def test_cpp_application_matches_the_oracle(oracle_lib):
     expect = render_draws(oracle, width, height, 4, 4, 4, 1, t2, colors, [tuple(int(v) for v in d) for d in draws])
     assert np.array_equal(recorded, expect)
     assert not np.array_equal(recorded, plain) and (recorded[..., 3] > 0).mean() > 0.05
+    # perspective instances + depth attachment + cull mode through the C++ mirror
+    from oracle.binding import render_pass
+    t3d = take(5 * 64).view(np.float32).reshape(5, 16)
+    assert (t3d[:, 11] == 1.0).all() and (t3d[:, 15] > 1.0).all()  # clip.w = view z: perspective
+    image3d = take(width * height * 4).reshape(height, width, 4)
+    depth3d = take(width * height * 4).view(np.float32).reshape(height, width, 1)
+    wall = np.ones((height, width, 1), dtype=np.float32)
+    wall[:, :40] = 0.25
+    plain_draws = [d for i in range(5) for d in ((i, i, int(Op.Stencil), 0, 0), (i, i, int(Op.Color), 0, 0))]
+    o3 = Oracle(batch)
+    expect3d, expect_depth = render_pass(o3, width, height, 1, 4, 2, 0, t3d, colors[:5], plain_draws, cull_mode=2, depth_compare=4, depth_write=1, depth=wall)
+    assert np.array_equal(image3d, expect3d) and np.array_equal(depth3d, expect_depth)
+    assert (image3d[..., 3] > 0).mean() > 0.03 and not (image3d[:, :40, 3] > 0).any() and (depth3d < 1.0).mean() > 0.25
     assert int(take(8).view(np.uint64)[0]) == 3
     n = int(take(8).view(np.uint64)[0])
     assert take(n).view(np.float32).reshape(-1, 2).tolist() == [[2, 2], [4, 2], [2, 6], [4, 6], [2, 2], [4, 2], [2, 6], [4, 6]]  # KAT-A through Shape::from_paths
