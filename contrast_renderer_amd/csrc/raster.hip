@@ -250,14 +250,15 @@ CRH_D bool wave_tile_rect(bool valid, const PrimCoverage& cov, uint32_t& tx0, ui
 }
 
 // ---------------------------------------------------------------------------------------------- k_prim_setup
-template <int S>
+// PROJ == false: every instance is plain (the host checked), the projective setup is compiled out
+template <int S, bool PROJ>
 __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
     const uint32_t item = blockIdx.x, lane = threadIdx.x;
     const DrawItem it = item_of(r, item);
     const uint32_t shape = it.shape;
     const float* m = r.transforms + 16u * it.instance;
     // oracle/raster.hpp is_plain_instance: clip.w == 1 and clip.z a constant in [0, 1]; every other matrix takes the projective setup
-    const bool plain = m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f && m[2] == 0.0f && m[6] == 0.0f && m[14] >= 0.0f && m[14] <= 1.0f;
+    const bool plain = !PROJ || (m[3] == 0.0f && m[7] == 0.0f && m[15] == 1.0f && m[2] == 0.0f && m[6] == 0.0f && m[14] >= 0.0f && m[14] <= 1.0f);
     uint32_t cb[8], first_candidate, last_candidate;
     item_candidates(s, it, cb, first_candidate, last_candidate);
     const uint32_t n_candidates = last_candidate - first_candidate;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
         // bits 0-2 top-left, 3 front, 4-6 kind, 7-9 cover operation, 16-23 stencil reference (clip depth), 24-27 alpha layer, 28 projective
         const uint32_t flags_common = (kind << 4) | (cover_op << 7) | (clip_ref << 16) | (((it.refs >> 16) & 15u) << 24);
         const bool culled_kind = kind == KIND_COVER && cover_op == CRH_OP_COLOR && r.cull_mode != 0u; // Configuration::cull_mode: the colour cover only
-        if (plain) {
+        if (!PROJ || plain) {
 #pragma unroll
         for (int v = 0; v < 3; ++v) p[v] = to_framebuffer(m, W, H, p[v].x, p[v].y);
         const float d1x = p[1].x - p[0].x, d1y = p[1].y - p[0].y;
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
                 rec.cov.desc = desc;
             }
         }
-        } else {
+        } else if (PROJ) {
         // ---- oracle/raster.hpp setup_projective + setup_projective_plane, operation by operation
         float PX[3], PY[3], PZ[3], PW[3];
 #pragma unroll
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
         if (in_range_c) {
             if (drawn) {
                 r.prim_rec[prim0 + c0 + lane] = rec;
-                if (!plain) r.prim_proj[prim0 + c0 + lane] = proj; // the host allocates the side array whenever an instance is not plain
+                if (PROJ && !plain) r.prim_proj[prim0 + c0 + lane] = proj; // the host allocates the side array whenever an instance is not plain
             } else {
                 r.prim_rec[prim0 + c0 + lane].cov.box = rec.cov.box;
             }
@@ -1150,10 +1151,17 @@ void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipS
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
     (void)hipMemsetAsync(r.overflow, 0, 16, stream);
     if (r.n_items) {
-        if (samples == 4)
-            hipLaunchKernelGGL(k_prim_setup<4>, dim3(r.n_items), dim3(64), 0, stream, s, r);
-        else
-            hipLaunchKernelGGL(k_prim_setup<1>, dim3(r.n_items), dim3(64), 0, stream, s, r);
+        if (samples == 4) {
+            if (r.prim_proj)
+                hipLaunchKernelGGL((k_prim_setup<4, true>), dim3(r.n_items), dim3(64), 0, stream, s, r);
+            else
+                hipLaunchKernelGGL((k_prim_setup<4, false>), dim3(r.n_items), dim3(64), 0, stream, s, r);
+        } else {
+            if (r.prim_proj)
+                hipLaunchKernelGGL((k_prim_setup<1, true>), dim3(r.n_items), dim3(64), 0, stream, s, r);
+            else
+                hipLaunchKernelGGL((k_prim_setup<1, false>), dim3(r.n_items), dim3(64), 0, stream, s, r);
+        }
     }
     if (after_setup) (void)hipEventRecord(after_setup, stream);
     if (mark) mark(ctx, "raster_prim_setup", 0);
