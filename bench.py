@@ -141,25 +141,47 @@ def main():
     lib = renderer.lib
     import ctypes as C
 
-    layer = slab = None
+    # N > 1: two frames, so that the framebuffer exchange of step i (RCCL + composite + gather) runs while step i + 1 is being
+    # tessellated and rasterized into the other frame
+    frames = [frame] + ([Frame(renderer, *size)] if world > 1 else [])
+    layer_views, slab = [], None
     if world > 1:
-        layer = torch.as_tensor(_DeviceArray(frame.device_pointer(), (size[1], size[0], 4)), device=f"cuda:{local_rank}")
+        layer_views = [torch.as_tensor(_DeviceArray(f.device_pointer(), (size[1], size[0], 4)), device=f"cuda:{local_rank}") for f in frames]
         r0, r1 = D.slab_rows(size[1], world)[rank]
         slab = torch.empty((r1 - r0, size[0], 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
 
-    def step():
+    def launch(i):
+        """Enqueues step i's tessellation + render (asynchronous on the renderer's streams)."""
+        f = frames[i % len(frames)]
         scene.tessellate()
-        frame.clear()
-        scene.render(frame)
-        if world > 1:
-            renderer.synchronize()  # our kernels run on the renderer's own HIP stream
-            received, _ = D.exchange_layers(layer, rank, world)
-            torch.cuda.synchronize()
-            ptrs = (C.c_void_p * world)(*[received[i].data_ptr() for i in range(world)])
-            rc = lib.crh_composite_over(renderer.handle, ptrs, world, received[0].numel() // 4, C.c_void_p(slab.data_ptr()))
-            assert rc == 0, rc
-            return D.gather_slabs(slab, rank, world, size[1])
-        return None
+        f.clear()
+        scene.render(f)
+
+    def finish(i):
+        """The exchange step of the path for step i's layer; the renderer may already be working on step i + 1."""
+        f = frames[i % len(frames)]
+        f.synchronize()  # step i's raster kernel only
+        received, _ = D.exchange_layers(layer_views[i % len(frames)], rank, world)
+        if received.is_cuda:
+            torch.cuda.current_stream().synchronize()  # the RCCL transfers (not the renderer's streams: step i + 1 keeps running)
+        ptrs = (C.c_void_p * world)(*[received[k].data_ptr() for k in range(world)])
+        rc = lib.crh_composite_over(renderer.handle, ptrs, world, received[0].numel() // 4, C.c_void_p(slab.data_ptr()))
+        assert rc == 0, rc
+        return D.gather_slabs(slab, rank, world, size[1])
+
+    def run(n):
+        """n steps; with N > 1 the exchange of step i overlaps the rendering of step i + 1. Returns the last gathered frame (rank 0)."""
+        out = None
+        for i in range(n):
+            launch(i)
+            if world > 1 and i > 0:
+                out = finish(i - 1)
+        if world > 1 and n > 0:
+            out = finish(n - 1)
+        return out
+
+    def step():
+        return run(1)
 
     def sync():
         renderer.synchronize()
@@ -167,15 +189,13 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     sync()
     scene.check()
     renderer.enable_timing(True)  # HIP events on the renderer's stream between kernels; drained once after the timed region
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -240,7 +260,7 @@ def main():
             "workload": workload + "; step = tessellate (count/scan/emit/hull) + bin + tile raster, inputs resident in HBM",
             "paths_per_gpu": args.paths,
             "segments_per_gpu": int(batch.n_segments),
-            "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} + tile-sliced RCCL all-to-all + ordered over-composite + gather",
+            "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} + tile-sliced RCCL all-to-all + ordered over-composite + gather (exchange of step i overlaps the rendering of step i + 1)",
             "covered_fraction": covered,
         },
         "roofline": {

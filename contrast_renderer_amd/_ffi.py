@@ -248,6 +248,7 @@ def load_library():
         "crh_frame_create": (C.c_int, [V, C.c_uint32, C.c_uint32, C.POINTER(V)]),
         "crh_frame_destroy": (None, [V]),
         "crh_frame_clear": (C.c_int, [V]),
+        "crh_frame_synchronize": (C.c_int, [V]),
         "crh_frame_clear_depth": (C.c_int, [V, C.c_float]),
         "crh_frame_upload_depth": (C.c_int, [V, C.POINTER(C.c_float)]),
         "crh_frame_download_depth": (C.c_int, [V, C.POINTER(C.c_float)]),

@@ -82,6 +82,9 @@ struct crh_renderer {
     hipStream_t stream;       // raster kernel, copies
     hipStream_t bin_stream;   // primitive setup + tile binning: frame N + 1's overlap frame N's raster kernel (double-buffered records / lists)
     hipStream_t tess_stream;  // tessellation: frame N + 1's (small, latency bound) kernels overlap frame N's binning and raster
+    hipStream_t aux_stream;   // crh_composite_over: the multi-GPU slab composite of frame N while frame N + 1 is being rendered
+    void* composite_table = nullptr; // device array of layer pointers (aux stream)
+    uint32_t composite_table_capacity = 0;
     bool pipeline = true;     // CRH_NO_PIPELINE=1 runs everything on `stream`
     bool timing = false;
     std::vector<hipEvent_t> event_pool;
@@ -127,11 +130,12 @@ struct crh_renderer {
     }
     MarkFn mark_fn() const { return timing ? &crh_renderer::mark_cb : nullptr; }
     MarkFn mark_fn_tess() const { return timing ? &crh_renderer::mark_cb_tess : nullptr; }
-    hipError_t sync() { // both streams
+    hipError_t sync() { // every stream
         const hipError_t e = hipStreamSynchronize(tess_stream);
         const hipError_t b = hipStreamSynchronize(bin_stream);
+        const hipError_t a = hipStreamSynchronize(aux_stream);
         const hipError_t f = hipStreamSynchronize(stream);
-        return e != hipSuccess ? e : (b != hipSuccess ? b : f);
+        return e != hipSuccess ? e : (b != hipSuccess ? b : (a != hipSuccess ? a : f));
     }
 };
 
@@ -642,7 +646,8 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     r->device = device_ordinal;
     if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(hipStreamCreateWithFlags(&r->tess_stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->bin_stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        !hip_ok(hipStreamCreateWithFlags(&r->bin_stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipStreamCreateWithFlags(&r->aux_stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete r;
         return CRH_ERR_HIP;
     }
@@ -658,6 +663,8 @@ void crh_renderer_destroy(crh_renderer* r) {
     (void)hipStreamDestroy(r->stream);
     (void)hipStreamDestroy(r->tess_stream);
     (void)hipStreamDestroy(r->bin_stream);
+    (void)hipStreamDestroy(r->aux_stream);
+    if (r->composite_table) (void)hipFree(r->composite_table);
     delete r;
 }
 crh_status crh_renderer_get_config(const crh_renderer* r, crh_config* out) {
@@ -1143,15 +1150,25 @@ crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
 crh_status crh_composite_over(crh_renderer* r, const void* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, void* dst_dev) {
     if (!r || !layers_dev || !dst_dev || n_layers == 0) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
-    void* table = nullptr;
-    HIP_TRY(hipMalloc(&table, sizeof(void*) * n_layers));
-    hipError_t e = hipMemcpyAsync(table, layers_dev, sizeof(void*) * n_layers, hipMemcpyHostToDevice, r->stream);
-    if (e == hipSuccess) {
-        launch_composite(static_cast<const uint8_t* const*>(table), n_layers, n_pixels, static_cast<uint8_t*>(dst_dev), r->stream);
-        e = r->sync();
+    // on its own stream and synchronised alone: the next frame may already be in flight on the render streams
+    if (n_layers > r->composite_table_capacity) {
+        HIP_TRY(hipStreamSynchronize(r->aux_stream));
+        if (r->composite_table) (void)hipFree(r->composite_table);
+        r->composite_table = nullptr;
+        r->composite_table_capacity = 0;
+        HIP_TRY(hipMalloc(&r->composite_table, sizeof(void*) * n_layers));
+        r->composite_table_capacity = n_layers;
     }
-    (void)hipFree(table);
-    HIP_TRY(e);
+    HIP_TRY(hipMemcpyAsync(r->composite_table, layers_dev, sizeof(void*) * n_layers, hipMemcpyHostToDevice, r->aux_stream));
+    launch_composite(static_cast<const uint8_t* const*>(r->composite_table), n_layers, n_pixels, static_cast<uint8_t*>(dst_dev), r->aux_stream);
+    HIP_TRY(hipStreamSynchronize(r->aux_stream));
+    return CRH_OK;
+}
+crh_status crh_frame_synchronize(crh_frame* f) {
+    if (!f) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    const crh_frame::BinSet& set = f->sets[f->last_set];
+    if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
     return CRH_OK;
 }
 

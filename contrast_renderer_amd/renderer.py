@@ -111,6 +111,10 @@ class Frame:
     def clear(self):
         check(self.lib.crh_frame_clear(self.handle))
 
+    def synchronize(self):
+        """Waits for the last render into this frame only (the next frame of a double-buffered loop keeps running)."""
+        check(self.lib.crh_frame_synchronize(self.handle))
+
     def clear_depth(self, value=1.0):
         """LoadOp::Clear(value) of the depth attachment (main.rs:223-226); it exists when the configuration tests or writes depth."""
         check(self.lib.crh_frame_clear_depth(self.handle, value))

@@ -203,7 +203,7 @@ def calculate_aligned_positions(face: Font, layout: Layout, text):
 
 
 @dataclass
-class TextGeometry:  # text.rs:266-304 (the cursor helpers of the UI are out of scope)
+class TextGeometry:  # text.rs:266-347
     major_axis: int
     half_extent: Tuple[float, float]
     lines: list
@@ -217,3 +217,43 @@ class TextGeometry:  # text.rs:266-304 (the cursor helpers of the UI are out of 
         half = (float(f(extent[0]) * scale * f(0.5)), float(f(extent[1]) * scale * f(0.5)))
         out = [(end, [(float(f(p[0] - offset[0]) * scale), float(f(p[1] - offset[1]) * scale)) for p, _ in glyphs]) for end, glyphs in lines]
         return TextGeometry(major_axis, half, out)
+
+    def line_index_from_char_index(self, char_index: int) -> int:  # text.rs:310-315 (panics when there is no such line: IndexError here)
+        for index, (line_range_end, _) in enumerate(self.lines):
+            if line_range_end > char_index:
+                return index
+        raise IndexError("char_index is beyond the last line")
+
+    def char_index_from_position(self, cursor) -> int:  # text.rs:318-331
+        f = np.float32
+        minor = 1 - self.major_axis
+        minor_half_extent = f(self.half_extent[minor])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            v = (minor_half_extent - f(cursor[minor])) * f(len(self.lines)) / (minor_half_extent * f(2.0))
+        v = min(max(float(v), 0.0), float(len(self.lines) - 1)) if v == v else 0.0  # f32::max / min ignore NaN; `as usize` saturates
+        line_index = int(v)
+        glyph_positions = self.lines[line_index][1]
+        found = len(glyph_positions) - 1
+        for i in range(len(glyph_positions) - 1):
+            if (f(glyph_positions[i][self.major_axis]) + f(glyph_positions[i + 1][self.major_axis])) * f(0.5) > f(cursor[self.major_axis]):
+                found = i
+                break
+        return found + (0 if line_index == 0 else self.lines[line_index - 1][0])
+
+    def advance_char_index_by_line_index(self, char_index: int, relative_line_index: int) -> int:  # text.rs:334-346
+        f = np.float32
+        line_index = self.line_index_from_char_index(char_index)
+        if relative_line_index < 0 and line_index == 0:
+            return 0
+        if relative_line_index > 0 and line_index == len(self.lines) - 1:
+            return self.lines[-1][0] - 1
+        line_range_end, glyph_positions = self.lines[line_index]
+        cursor = list(glyph_positions[char_index + len(glyph_positions) - line_range_end])
+        minor = 1 - self.major_axis
+        line_minor_extent = f(self.half_extent[minor]) * f(2.0) / f(len(self.lines))
+        cursor[minor] = float(f(cursor[minor]) - line_minor_extent * f(relative_line_index))
+        return self.char_index_from_position(cursor)
+
+
+def byte_offset_of_char_index(string: str, char_index: int) -> int:  # text.rs:350-352
+    return len(string[:char_index].encode("utf-8")) if char_index < len(string) else len(string.encode("utf-8"))

@@ -254,11 +254,15 @@ crh_status crh_scene_render_draws(crh_scene* scene, crh_frame* frame, const floa
 crh_status crh_frame_download(crh_frame* frame, void* rgba8);
 /* Device pointer of the resolved RGBA8 image (for the RCCL tile exchange); valid until the frame is destroyed. */
 crh_status crh_frame_device_pointer(crh_frame* frame, void** rgba8_dev);
-/* Ordered premultiplied "over" of n_layers RGBA8 images that live in HBM: dst = layers[0] under layers[1] .... */
+/* Ordered premultiplied "over" of n_layers RGBA8 images that live in HBM: dst = layers[0] under layers[1] ....
+ * Runs on a stream of its own and returns when dst is complete, without waiting for renders in flight. */
 crh_status crh_composite_over(crh_renderer* renderer, const void* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, void* dst_dev);
 
 /* ---- stream plumbing ------------------------------------------------------------------------------- */
 crh_status crh_renderer_synchronize(crh_renderer* renderer);
+/* Blocks the host until the last render INTO THIS FRAME has finished; work queued afterwards (the next frame of a double-buffered
+ * loop) keeps running. The resolved image behind crh_frame_device_pointer is then complete. */
+crh_status crh_frame_synchronize(crh_frame* frame);
 /* hipStream_t of the renderer, as void* (for HIP events in bench.py). */
 void* crh_renderer_stream(crh_renderer* renderer);
 /* Milliseconds spent by the last crh_scene_tessellate / crh_scene_render* on the GPU, per kernel,

@@ -13,6 +13,7 @@
 #pragma once
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <optional>
 #include <stdexcept>
@@ -691,6 +692,72 @@ inline std::vector<Path> paths_of_text(const Font& face, const Layout& layout, c
     crh_path_list* list = nullptr;
     check(crh_paths_of_text(face.raw(), &c, reinterpret_cast<const uint32_t*>(text.data()), text.size(), clip.empty() ? nullptr : clip.data(), clip.size() / 2, &list));
     return detail::take_paths(list);
+}
+
+// text.rs:266-347: bounding box of the entire text and the glyph positions of its characters, line by line
+struct TextGeometry {
+    size_t major_axis;                                           // 0 horizontal, 1 vertical
+    Vec2 half_extent;
+    std::vector<std::pair<size_t, std::vector<Vec2>>> lines;     // (line_range_end, glyph positions incl. the line break)
+
+    static TextGeometry make(const Font& face, const Layout& layout, const std::u32string& text) { // TextGeometry::new, text.rs:284-307
+        const crh_text_layout c = {layout.size, (uint32_t)layout.orientation, (uint32_t)layout.major_alignment, (uint32_t)layout.minor_alignment};
+        const uint32_t* chars = reinterpret_cast<const uint32_t*>(text.data());
+        uint64_t n_lines = 0;
+        check(crh_text_aligned_positions(face.raw(), &c, chars, text.size(), nullptr, nullptr, nullptr, nullptr, nullptr, &n_lines));
+        int64_t extent[2], offset[2];
+        std::vector<int64_t> positions((text.size() + 1) * 3);
+        std::vector<uint64_t> ends(n_lines), lengths(n_lines);
+        check(crh_text_aligned_positions(face.raw(), &c, chars, text.size(), extent, offset, positions.data(), ends.data(), lengths.data(), &n_lines));
+        TextGeometry g;
+        g.major_axis = (layout.orientation == Orientation::RightToLeft || layout.orientation == Orientation::LeftToRight) ? 0 : 1;
+        const float scale = layout.size / (float)face.metrics().height;
+        g.half_extent = {(float)extent[0] * scale * 0.5f, (float)extent[1] * scale * 0.5f};
+        size_t at = 0;
+        for (uint64_t l = 0; l < n_lines; ++l) {
+            std::vector<Vec2> line;
+            for (uint64_t i = 0; i < lengths[l]; ++i, ++at)
+                line.push_back({(float)(positions[at * 3] - offset[0]) * scale, (float)(positions[at * 3 + 1] - offset[1]) * scale});
+            g.lines.emplace_back((size_t)ends[l], std::move(line));
+        }
+        return g;
+    }
+    size_t line_index_from_char_index(size_t char_index) const { // text.rs:310-315 (the reference unwraps: out of range throws here)
+        for (size_t i = 0; i < lines.size(); ++i)
+            if (lines[i].first > char_index) return i;
+        throw Error(CRH_ERR_INVALID_ARGUMENT);
+    }
+    size_t char_index_from_position(Vec2 cursor) const { // text.rs:318-331
+        const auto axis = [](const Vec2& v, size_t a) { return a == 0 ? v.first : v.second; };
+        const float minor_half_extent = axis(half_extent, 1 - major_axis);
+        float v = (minor_half_extent - axis(cursor, 1 - major_axis)) * (float)lines.size() / (minor_half_extent * 2.0f);
+        v = std::fmin(std::fmax(v, 0.0f), (float)(lines.size() - 1)); // f32::max / min return the other operand for NaN
+        const size_t line_index = (size_t)v;
+        const std::vector<Vec2>& glyph_positions = lines[line_index].second;
+        size_t found = glyph_positions.size() - 1;
+        for (size_t i = 0; i + 1 < glyph_positions.size(); ++i)
+            if ((axis(glyph_positions[i], major_axis) + axis(glyph_positions[i + 1], major_axis)) * 0.5f > axis(cursor, major_axis)) {
+                found = i;
+                break;
+            }
+        return found + (line_index == 0 ? 0 : lines[line_index - 1].first);
+    }
+    size_t advance_char_index_by_line_index(size_t char_index, ptrdiff_t relative_line_index) const { // text.rs:334-346
+        const size_t line_index = line_index_from_char_index(char_index);
+        if (relative_line_index < 0 && line_index == 0) return 0;
+        if (relative_line_index > 0 && line_index == lines.size() - 1) return lines.back().first - 1;
+        const std::vector<Vec2>& glyph_positions = lines[line_index].second;
+        Vec2 cursor = glyph_positions[char_index + glyph_positions.size() - lines[line_index].first];
+        const float line_minor_extent = (major_axis == 0 ? half_extent.second : half_extent.first) * 2.0f / (float)lines.size();
+        (major_axis == 0 ? cursor.second : cursor.first) -= line_minor_extent * (float)relative_line_index;
+        return char_index_from_position(cursor);
+    }
+};
+inline size_t byte_offset_of_char_index(const std::string& utf8, size_t char_index) { // text.rs:350-352
+    size_t chars = 0;
+    for (size_t i = 0; i < utf8.size(); ++i)
+        if (((unsigned char)utf8[i] & 0xC0u) != 0x80u && chars++ == char_index) return i;
+    return utf8.size();
 }
 
 } // namespace contrast_renderer

@@ -170,6 +170,11 @@ int main(int argc, char** argv) {
         put_u64(out, (uint64_t)errors);
         put_u64(out, sb.vertex_offsets[7]);
         put(out, sb.vertex_bytes.data(), sb.vertex_bytes.size());
+        // TextGeometry and its cursor helpers (text.rs:266-352)
+        const TextGeometry g = TextGeometry::make(font, Layout{1.0f, Orientation::LeftToRight, Alignment::Center, Alignment::Center}, U"ab\ncd\nef");
+        std::printf("geometry %zu %zu %zu %zu %zu %zu %zu %.6f\n", g.lines.size(), g.line_index_from_char_index(4), g.char_index_from_position(g.lines[1].second[1]),
+                    g.advance_char_index_by_line_index(4, -1), g.advance_char_index_by_line_index(4, 1), g.advance_char_index_by_line_index(7, 1),
+                    byte_offset_of_char_index("a\xc3\xa9\xe2\x82\xac" "b", 2), g.half_extent.second);
         std::printf("ok %u shapes, %d reference errors reproduced\n", scene.n_shapes(), errors);
         return 0;
     } catch (const Error& e) {

@@ -72,6 +72,7 @@ def test_cpp_application_matches_the_oracle(oracle_lib):
         run = subprocess.run([exe, FONT, out], capture_output=True, text=True)
         assert run.returncode == 0, run.stderr
         assert "3 reference errors reproduced" in run.stdout
+        assert "geometry 3 1 4 1 7 8 3 1.500000" in run.stdout  # tests/test_text_cpu.py::test_text_geometry_and_its_cursor_helpers
         blob = np.fromfile(out, dtype=np.uint8)
     batch, transforms, colors = python_scene()
     oracle = Oracle(batch)

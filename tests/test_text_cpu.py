@@ -156,3 +156,33 @@ def test_malformed_fonts_are_rejected_not_crashed(fonts):
     for gid in range(cut.number_of_glyphs()):
         T.paths_of_glyph(cut, gid)
         T.paths_of_glyph(noisy, gid)
+
+
+def test_text_geometry_and_its_cursor_helpers(fonts):
+    """TextGeometry (text.rs:266-347): every line carries one more glyph position than printable characters (its line break), lines are
+    one `size` apart along the minor axis, and the three cursor helpers follow the reference's definitions."""
+    native = fonts[0]
+    layout = T.Layout(1.0, T.Orientation.LeftToRight, T.Alignment.Center, T.Alignment.Center)
+    g = T.TextGeometry.new(native, layout, "ab\ncd\nef")
+    assert g.major_axis == 0 and g.half_extent[1] == 1.5 and [end for end, _ in g.lines] == [3, 6, 9]
+    assert [len(p) for _, p in g.lines] == [3, 3, 3] and [p[0][1] for _, p in g.lines] == [1.0, 0.0, -1.0]
+    for _, positions in g.lines:  # centred (integer font units: symmetric up to one unit)
+        assert abs(positions[0][0] + positions[-1][0]) < 1e-3 and positions[0][0] < positions[1][0] < positions[2][0]
+    assert [g.line_index_from_char_index(i) for i in range(9)] == [0, 0, 0, 1, 1, 1, 2, 2, 2]
+    with pytest.raises(IndexError):
+        g.line_index_from_char_index(9)
+    # a cursor exactly on a glyph position selects that character; halfway past it the next one
+    for line, (end, positions) in enumerate(g.lines):
+        first = 0 if line == 0 else g.lines[line - 1][0]
+        for k, p in enumerate(positions):
+            assert g.char_index_from_position(p) == first + k
+        assert g.char_index_from_position((positions[0][0] * 0.49 + positions[1][0] * 0.51, positions[0][1])) == first + 1
+    assert g.char_index_from_position((-5.0, 9.0)) == 0 and g.char_index_from_position((5.0, -9.0)) == 8
+    # up / down keep the horizontal position; the first and last line clamp to the text's ends
+    assert g.advance_char_index_by_line_index(4, -1) == 1 and g.advance_char_index_by_line_index(4, 1) == 7
+    assert g.advance_char_index_by_line_index(1, -1) == 0 and g.advance_char_index_by_line_index(7, 1) == 8
+    assert g.advance_char_index_by_line_index(0, 2) == 6
+    vertical = T.TextGeometry.new(native, T.Layout(2.0, T.Orientation.TopToBottom, T.Alignment.Begin, T.Alignment.Begin), "ab\nc")
+    assert vertical.major_axis == 1 and [end for end, _ in vertical.lines] == [3, 5]
+    assert T.byte_offset_of_char_index("aé€b", 2) == 3 and T.byte_offset_of_char_index("aé€b", 3) == 6
+    assert T.byte_offset_of_char_index("aé€b", 10) == 7
