@@ -28,7 +28,7 @@
 #define CRH_TILE_WAVES 5
 #endif
 #ifndef CRH_WALK_WAVES
-#define CRH_WALK_WAVES 4
+#define CRH_WALK_WAVES 2
 #endif
 
 namespace crh {
