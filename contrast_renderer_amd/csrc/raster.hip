@@ -840,6 +840,19 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
             const uint32_t kind = (flags >> 4) & 7u;
             const int clip_ref = OPS ? (int)((flags >> 16) & 255u) : 0; // the stencil reference of this draw: its clip depth
+#ifndef CRH_NO_DEAD_COVER_SKIP
+            // A colour cover over a tile in which no sample can pass its stencil test (Less: a non-zero winding, or a deeper clip level)
+            // changes nothing: the blend needs a pass and the Zero operation leaves a winding that is already zero modulo the counter.
+            // The long thin triangles of a hull strip mostly find the tile already cleared by their predecessors.
+            if (kind == KIND_COVER && (!OPS || ((flags >> 7) & 7u) == (uint32_t)CRH_OP_COLOR)) {
+                int live = 0;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) live |= OPS ? (int)((winding[b][k] & wmask) != 0 || clipc[OPS ? b : 0][OPS ? k : 0] > clip_ref) : (winding[b][k] & wmask);
+                if (!__any(live != 0)) continue;
+            }
+#endif
             // the second half of the record (attribute planes / cover colour) comes through a scalar load issued up front
             PrimFragment frag;
             if (kind != KIND_SOLID) frag = load_uniform(&recs[prim].frag);
