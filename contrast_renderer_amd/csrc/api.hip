@@ -139,6 +139,14 @@ struct crh_renderer {
     }
 };
 
+// how many frames the binning lane may run ahead of the raster lane: that many sets of tile lists per frame and of primitive records
+// per scene (S10k@4096^2: 13 MB + 60 MB per set). Measured: 3 is no faster than 2 — the step is bound by the GPU's total throughput, not by
+// the coupling of the lanes.
+#ifndef CRH_PIPELINE_DEPTH
+#define CRH_PIPELINE_DEPTH 2
+#endif
+constexpr int kPipelineDepth = CRH_PIPELINE_DEPTH;
+
 struct crh_frame {
     crh_renderer* renderer;
     uint32_t width, height, tiles_x, tiles_y, n_tiles;
@@ -149,7 +157,7 @@ struct crh_frame {
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
         hipEvent_t raster_done = nullptr; // recorded on the raster stream after the raster kernel that read this set
         bool used = false;
-    } sets[2];
+    } sets[kPipelineDepth];
     int next_set = 0, last_set = 0;
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
@@ -182,11 +190,11 @@ struct crh_scene {
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
     DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch;
-    DevBuf prim_rec[2];                 // set-up triangles, double-buffered like the frame's binning buffers
-    DevBuf prim_proj[2];                // 1/w and z/w planes of the primitives of projective instances (allocated on first use)
+    DevBuf prim_rec[kPipelineDepth];    // set-up triangles, one buffer per frame in flight like the frame's binning buffers
+    DevBuf prim_proj[kPipelineDepth];                // 1/w and z/w planes of the primitives of projective instances (allocated on first use)
     bool instances_projective = false;
-    hipEvent_t rec_raster_done[2] = {nullptr, nullptr};
-    bool rec_used[2] = {false, false};
+    hipEvent_t rec_raster_done[kPipelineDepth] = {};
+    bool rec_used[kPipelineDepth] = {};
     int next_rec = 0;
     bool instances_set = false;
     // frame pipelining: tessellation runs on its own stream; these events order it against the raster stream
@@ -202,8 +210,10 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &prim_rec[0], &prim_rec[1], &prim_proj[0], &prim_proj[1]};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch};
         for (DevBuf* b : all) b->release();
+        for (DevBuf& b : prim_rec) b.release();
+        for (DevBuf& b : prim_proj) b.release();
     }
 };
 
@@ -585,8 +595,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     HIP_TRY(hipGetLastError());
     f->last_set = f->next_set;
     if (r->pipeline) { // alternate the buffers; without pipelining everything is ordered on one stream anyway
-        f->next_set ^= 1;
-        sc->next_rec ^= 1;
+        f->next_set = (f->next_set + 1) % kPipelineDepth;
+        sc->next_rec = (sc->next_rec + 1) % kPipelineDepth;
     }
     f->cleared = false;
     f->last_scene = sc;
@@ -749,15 +759,18 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     if (!sc->tess_done) {
         if (!hip_ok(hipEventCreateWithFlags(&sc->tess_done, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&sc->vertices_free, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&sc->ranges_free, hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&sc->rec_raster_done[0], hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&sc->rec_raster_done[1], hipEventDisableTiming), "hipEventCreate")) {
+            !hip_ok(hipEventCreateWithFlags(&sc->ranges_free, hipEventDisableTiming), "hipEventCreate")) {
             if (!existing) delete sc;
             return CRH_ERR_HIP;
         }
+        for (hipEvent_t& e : sc->rec_raster_done)
+            if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) {
+                if (!existing) delete sc;
+                return CRH_ERR_HIP;
+            }
     }
     sc->rendered_once = false;
-    sc->rec_used[0] = sc->rec_used[1] = false;
+    for (bool& used : sc->rec_used) used = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
     sc->capacity_known = false;
@@ -875,7 +888,9 @@ void crh_scene_destroy(crh_scene* sc) {
     (void)hipSetDevice(sc->renderer->device);
     (void)sc->renderer->sync();
     sc->release_all();
-    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free, sc->rec_raster_done[0], sc->rec_raster_done[1]})
+    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free})
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sc->rec_raster_done)
         if (e) (void)hipEventDestroy(e);
     delete sc;
 }
