@@ -869,15 +869,22 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 const float c0 = ea4.x, c1 = ea4.y, c2 = ea4.z, bx_0 = eb4.x, bx_1 = eb4.y, bx_2 = eb4.z, nay_0 = ec4.x, nay_1 = ec4.y, nay_2 = ec4.z;
                 const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) : 0u;
                 const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
+                // E = fma(ry, bx, fma(rx, nay, c)): the column term is shared by the rows of the lane (one fma per edge and sample position)
+                float ha[S], hb[S], hc[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    ha[k] = fmaf(sx[k], nay_0, c0);
+                    hb[k] = fmaf(sx[k], nay_1, c1);
+                    hc[k] = fmaf(sx[k], nay_2, c2);
+                }
                 // the ROWS * S (row, sample) combinations are taken two at a time
 #pragma unroll
                 for (int c = 0; c < ROWS * S; c += 2) {
                     const int b0 = c / S, k0 = c % S, b1 = (c + 1) / S, k1 = (c + 1) % S;
                     const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
-                    const f32x2 x = {sx[k0], sx[k1]};
-                    const f32x2 ea = fma2(x, splat2(nay_0), fma2(y, splat2(bx_0), splat2(c0)));
-                    const f32x2 eb = fma2(x, splat2(nay_1), fma2(y, splat2(bx_1), splat2(c1)));
-                    const f32x2 ec = fma2(x, splat2(nay_2), fma2(y, splat2(bx_2), splat2(c2)));
+                    const f32x2 ea = fma2(y, splat2(bx_0), f32x2{ha[k0], ha[k1]});
+                    const f32x2 eb = fma2(y, splat2(bx_1), f32x2{hb[k0], hb[k1]});
+                    const f32x2 ec = fma2(y, splat2(bx_2), f32x2{hc[k0], hc[k1]});
                     inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & row_bit[b0]) != 0u);
                     inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & row_bit[b1]) != 0u);
                 }

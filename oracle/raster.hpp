@@ -177,7 +177,7 @@ inline void raster_plain(Frame& f, const float v[3][2], const float attr[3][4], 
                         const float rx = (float)(px - tx * TILE) + ox, ry = (float)(py - ty * TILE) + oy;
                         bool inside = true;
                         for (int i = 0; i < 3 && inside; ++i) {
-                            float e = fmaf(rx, t.e[i].nay, fmaf(ry, t.e[i].bx, c[i]));
+                            float e = fmaf(ry, t.e[i].bx, fmaf(rx, t.e[i].nay, c[i])); // the column term first: shared by the rows of a pixel column
                             if (t.e[i].flip) e = -e;
                             inside = e > 0.0f || (e == 0.0f && t.e[i].topleft);
                         }
@@ -340,7 +340,7 @@ inline void raster_projective(Frame& f, const ClipVertex P[3], const float attr[
                         const float rx = (float)(px - tx * TILE) + ox, ry = (float)(py - ty * TILE) + oy;
                         bool inside = true;
                         for (int i = 0; i < 3 && inside; ++i) {
-                            float e = fmaf(rx, t.e[i].nay, fmaf(ry, t.e[i].bx, c[i]));
+                            float e = fmaf(ry, t.e[i].bx, fmaf(rx, t.e[i].nay, c[i])); // the column term first: shared by the rows of a pixel column
                             if (t.e[i].flip) e = -e;
                             inside = e > 0.0f || (e == 0.0f && t.e[i].topleft);
                         }
