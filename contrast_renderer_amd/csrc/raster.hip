@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 if (flags & kFlagProjective) { // wave uniform
                     const PrimProj pp = load_uniform(&r.prim_proj[prim]);
                     const float dxa = tx0 - pp.ax, dya = ty0 - pp.ay;
-                    const float zc = (pp.z0 + dxa * pp.zgx) + dya * pp.zgy, qc = (pp.q0 + dxa * pp.qgx) + dya * pp.qgy;
+                    const float zc = fmaf(dya, pp.zgy, fmaf(dxa, pp.zgx, pp.z0)), qc = fmaf(dya, pp.qgy, fmaf(dxa, pp.qgx, pp.q0));
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
@@ -994,12 +994,12 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         }
                 }
             } else {
-            // attribute planes, tile relative: ac = (a0 + (tx0 - v0x) * gx) + (ty0 - v0y) * gy; a = fma(sy, gy, fma(sx, gx, ac))
+            // attribute planes, tile relative: ac = fma(ty0 - v0y, gy, fma(tx0 - v0x, gx, a0)); a = fma(sy, gy, fma(sx, gx, ac))
             const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
             float hx[4][S]; // the row-independent inner fma
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float ac = (frag.a0[t] + dx0 * frag.gx[t]) + dy0 * frag.gy[t];
+                const float ac = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
 #pragma unroll
                 for (int k = 0; k < S; ++k) hx[t][k] = fmaf(sx[k], frag.gx[t], ac);
             }

@@ -150,7 +150,7 @@ inline AttrPlane setup_attribute(const TriangleSetup& t, float a0, float a1, flo
     return p;
 }
 inline float attribute_tile_constant(const TriangleSetup& t, const AttrPlane& p, float tx0, float ty0) {
-    return (p.a0 + (tx0 - t.v0[0]) * p.gx) + (ty0 - t.v0[1]) * p.gy;
+    return fmaf(ty0 - t.v0[1], p.gy, fmaf(tx0 - t.v0[0], p.gx, p.a0));
 }
 
 // Rasterise one triangle of a plain instance; `frag(attr_values) -> bool keep`, `stencil(sample_index_in_frame, front, depth)` applies the op.
@@ -321,7 +321,7 @@ inline void raster_projective(Frame& f, const ClipVertex P[3], const float attr[
     for (int a = 0; a < NATTR; ++a) planes[a] = setup_projective_plane(t, attr[k][a], attr[u][a], attr[v][a]);
     const AttrPlane qp = setup_projective_plane(t, 1.0f, 1.0f, 1.0f);       // 1/w
     const AttrPlane zp = setup_projective_plane(t, P[k].Z, P[u].Z, P[v].Z); // z/w
-    auto tile_constant = [&](const AttrPlane& p, float tx0, float ty0) { return (p.a0 + (tx0 - t.anchor[0]) * p.gx) + (ty0 - t.anchor[1]) * p.gy; };
+    auto tile_constant = [&](const AttrPlane& p, float tx0, float ty0) { return fmaf(ty0 - t.anchor[1], p.gy, fmaf(tx0 - t.anchor[0], p.gx, p.a0)); };
     for (int ty = t.y0 / TILE; ty <= t.y1 / TILE; ++ty) {
         for (int tx = t.x0 / TILE; tx <= t.x1 / TILE; ++tx) {
             const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
