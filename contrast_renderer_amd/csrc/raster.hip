@@ -638,30 +638,33 @@ CRH_D bool cap_test(float x, float y, uint32_t cap_type) { // shaders.wgsl:165-1
         default: return y < 0.0f;
     }
 }
-// The dashed pattern walk is the cold, long part of the stroke stages: kept out of line, and it indexes the descriptor through its
-// global pointer (a register copy indexed by `interval` would be demoted to scratch memory).
-__device__ __noinline__ bool stroke_dashed(const crh_dynamic_stroke_descriptor* d, float tx, float ty) { // shaders.wgsl:205-231
-    const uint32_t last = d->count_dashed_join >> 3;
-    const float pattern_length = d->gap_end[last & 3u];
-    uint32_t interval = 0;
-    float position = crh_wgsl_mod(ty - d->phase, pattern_length);
+// The dashed pattern walk of shaders.wgsl:205-231 with the 48-byte descriptor in scalar registers (it is wave uniform) and the interval
+// search unrolled into selects: interval = number of leading intervals that end before the position (at most `last`). No memory access
+// and no loop per sample — the loop over global-memory descriptor fields this replaces was half of the dashed workload's raster time.
+CRH_D bool stroke_dashed(const crh_dynamic_stroke_descriptor& d, float tx, float ty) {
+    const uint32_t last = d.count_dashed_join >> 3;
+    const float ge_last = last == 0u ? d.gap_end[0] : (last == 1u ? d.gap_end[1] : (last == 2u ? d.gap_end[2] : d.gap_end[3])); // wave uniform
+    const float pattern_length = ge_last;
+    float position = crh_wgsl_mod(ty - d.phase, pattern_length);
     if (position < 0.0f) position = position + pattern_length;
-    float gap_end;
-    for (;;) {
-        gap_end = d->gap_end[interval & 3u] - position;
-        if (gap_end >= 0.0f || interval >= last) break;
-        interval = interval + 1u;
-    }
-    const float gap_start = position - d->gap_start[interval & 3u];
+    // for (;;) { gap_end = gap_end[interval] - position; if (gap_end >= 0 || interval >= last) break; ++interval; }
+    const bool a0 = !(d.gap_end[0] - position >= 0.0f) && 0u < last;
+    const bool a1 = a0 && !(d.gap_end[1] - position >= 0.0f) && 1u < last;
+    const bool a2 = a1 && !(d.gap_end[2] - position >= 0.0f) && 2u < last;
+    const uint32_t interval = (uint32_t)a0 + (uint32_t)a1 + (uint32_t)a2;
+    const float ge = a2 ? d.gap_end[3] : (a1 ? d.gap_end[2] : (a0 ? d.gap_end[1] : d.gap_end[0]));
+    const float gs = a2 ? d.gap_start[3] : (a1 ? d.gap_start[2] : (a0 ? d.gap_start[1] : d.gap_start[0]));
+    const float gap_end = ge - position;
+    const float gap_start = position - gs;
     if (gap_start > 0.0f) {
-        const uint32_t caps = d->caps >> (interval * 8u);
+        const uint32_t caps = d.caps >> (interval * 8u);
         const bool start_cap = cap_test(tx, gap_start, caps >> 4);
         const bool end_cap = cap_test(tx, gap_end, caps);
         return start_cap || end_cap;
     }
     return true;
 }
-__device__ __noinline__ bool stroke_dashed_joint(const crh_dynamic_stroke_descriptor* d, float radius, float a0, float a1, float a2) { // shaders.wgsl:296-299
+CRH_D bool stroke_dashed_joint(const crh_dynamic_stroke_descriptor& d, float radius, float a0, float a1, float a2) { // shaders.wgsl:296-299
     const float tau = crh_acosf(-1.0f) * 2.0f;
     return stroke_dashed(d, radius, a2 + crh_atan2f(a1, a0) / tau);
 }
@@ -1031,8 +1034,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                     for (int k = 0; k < S; ++k) any_inside |= (int)inside[b][k];
                 if (__any(any_inside)) {
-                    const crh_dynamic_stroke_descriptor* d = &s.descriptors[__builtin_amdgcn_readfirstlane(__float_as_uint(ec4.w))];
-                    const uint32_t caps = d->caps, count_dashed_join = d->count_dashed_join; // wave uniform
+                    const crh_dynamic_stroke_descriptor d = load_uniform(&s.descriptors[__builtin_amdgcn_readfirstlane(__float_as_uint(ec4.w))]); // 48 B, scalar loads
+                    const uint32_t caps = d.caps, count_dashed_join = d.count_dashed_join; // wave uniform
                     const uint32_t flat_u = frag.flat_u;
                     const float end_y = frag.end_y;
                     const bool dashed = (count_dashed_join & 4u) != 0u;

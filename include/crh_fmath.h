@@ -273,7 +273,7 @@ CRH_HD float crh_powf(float b, float e) { return (float)crh_d_pow((double)b, (do
 /* WGSL `%` on f32: e1 - e2 * trunc(e1 / e2) (shaders.wgsl:211) — NOT libm fmod. */
 CRH_HD float crh_wgsl_mod(float a, float b) {
     const float q = a / b;
-    const float t = (float)(int64_t)q; /* trunc; |q| < 2^63 on the call site */
+    const float t = truncf(q); /* exact in f32 */
     return a - b * t;
 }
 
