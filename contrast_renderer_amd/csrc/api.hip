@@ -185,7 +185,7 @@ struct crh_scene {
     // inputs
     DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
     // scan state
-    DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, hull_large, status;
+    DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status;
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
@@ -208,7 +208,7 @@ struct crh_scene {
 
     void release_all() {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
-                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &status, &line_v, &joint_v,
+                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch};
         for (DevBuf* b : all) b->release();
@@ -277,6 +277,10 @@ crh_status ensure_outputs(crh_scene* sc) {
     HIP_TRY(sc->rc_v.ensure((size_t)t[CH_RC_V] * 24));
     HIP_TRY(sc->hull_cand.ensure((size_t)t[CH_HULL] * 8));
     HIP_TRY(sc->hull_v.ensure((size_t)t[CH_HULL] * 8));
+    if (sc->big_shapes) { // only Shapes beyond the LDS hull kernels (> 2048 candidates) use these; sized so that any Shape may
+        HIP_TRY(sc->hull_sort.ensure((size_t)t[CH_HULL] * 16 + 16));
+        HIP_TRY(sc->hull_chain.ensure((size_t)t[CH_HULL] * 16 + 16));
+    }
     for (int c = 0; c < NCH; ++c) d.capacity[c] = t[c];
     d.line_v = sc->line_v.as<Vertex2f1i>();
     d.joint_v = sc->joint_v.as<Vertex3f1i>();
@@ -287,6 +291,8 @@ crh_status ensure_outputs(crh_scene* sc) {
     d.rc_v = sc->rc_v.as<Vertex4f>();
     d.hull_cand = sc->hull_cand.as<Vertex0>();
     d.hull_v = sc->hull_v.as<Vertex0>();
+    d.hull_sort = sc->hull_sort.as<float2>();
+    d.hull_chain = sc->hull_chain.as<float2>();
     d.line_i = sc->line_i.as<uint16_t>();
     d.joint_i = sc->joint_i.as<uint16_t>();
     d.solid_i = sc->solid_i.as<uint16_t>();
@@ -828,7 +834,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     if (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
         !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") ||
         !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
-        !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((2 * (size_t)b->n_shapes + 2) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
+        !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((3 * (size_t)b->n_shapes + 4) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
         !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 4), "hipMalloc")) {
@@ -855,7 +861,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.shape_base = sc->shape_base.as<uint32_t>();
     d.hull_count = sc->hull_count.as<uint32_t>();
     d.hull_large_count = sc->hull_large.as<uint32_t>();
-    d.hull_large_list = sc->hull_large.as<uint32_t>() + 2;
+    d.hull_large_list = sc->hull_large.as<uint32_t>() + 4;
     d.status = sc->status.as<uint32_t>();
     if (!hip_ok(hipMemsetAsync(d.status, 0xFF, 4, st), "hipMemset")) {
         rc = CRH_ERR_HIP;

@@ -95,8 +95,10 @@ struct SceneDev {
     Vertex0* hull_cand; // proto_hull, in reference order
     Vertex0* hull_v;    // per shape at hull_cand offset: andrew() output in strip order
     uint32_t* hull_count; // [n_shapes]
-    uint32_t* hull_large_list;  // [2][n_shapes] Shapes with 65..256 / 257..2048 hull candidates, queued by k_hull_small for k_hull_large
-    uint32_t* hull_large_count; // [2]
+    uint32_t* hull_large_list;  // [3][n_shapes] Shapes with 65..256 / 257..2048 / more hull candidates, queued by k_hull_small for k_hull_large / k_hull_huge
+    uint32_t* hull_large_count; // [3] (+1 pad)
+    float2* hull_sort;          // [2 * hull candidates] global-memory sort buffer of k_hull_huge: a Shape with candidates [b, b + n) owns [2b, 2b + 2n)
+    float2* hull_chain;         // [2 * hull candidates] its monotone chain
     uint16_t* line_i;   // line_v + line_cut entries
     uint16_t* joint_i;  // 6 per join
     uint16_t* solid_i;  // solid_v + solid_end entries

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
 //                 (inherently serial) monotone chains simultaneously, the stack being a byte index per entry, its two topmost points
 //                 kept in registers. A wavefront per Shape spent ~1500 VALU issues on one serial chain. Larger Shapes are queued.
 //   k_hull_large  Shapes with 65..2048 candidates, taken from the queue by a fixed grid: bitonic sort + chain in LDS.
+//   k_hull_huge   Shapes beyond that: the same in global memory, one workgroup per Shape.
 constexpr uint32_t kHullSmall = 64;
 constexpr uint32_t kHullMid = 256;
 constexpr uint32_t kHullMax = 2048; // candidates per Shape that fit the large LDS sort (16 KiB + 32 KiB chain stack)
@@ -401,14 +402,8 @@ __global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
         const uint32_t slot = wave + 4u * u, shape = first_shape + slot;
         uint32_t n = n_of[u];
         if (shape < s.n_shapes) {
-            if (n > kHullMax) {
-                if (lane == 0) {
-                    raise_error(s, s.elem_path[s.shape_elem_begin[shape]], CRH_ERR_UNSUPPORTED);
-                    s.hull_count[shape] = 0;
-                }
-                n = 0;
-            } else if (n > kHullSmall) { // queue 0: up to kHullMid candidates (small LDS footprint), queue 1: up to kHullMax
-                const uint32_t queue = n > kHullMid ? 1u : 0u;
+            if (n > kHullSmall) { // queue 0: up to kHullMid candidates (small LDS footprint), queue 1: up to kHullMax, queue 2: global memory
+                const uint32_t queue = n > kHullMax ? 2u : (n > kHullMid ? 1u : 0u);
                 if (lane == 0) s.hull_large_list[queue * s.n_shapes + atomicAdd(s.hull_large_count + queue, 1u)] = shape;
                 n = 0;
             } else if (n == 0) {
@@ -544,6 +539,72 @@ __global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
     }
 }
 
+// Shapes with more hull candidates than the LDS kernels hold (a paragraph of text as one Shape, a long dashed stroke): the same algorithm
+// with the sort buffer and the chain in global memory, one 256-thread workgroup per Shape. Rare, so simple: O(n log^2 n) bitonic passes
+// separated by workgroup barriers, then the serial chain on one lane.
+__global__ __launch_bounds__(256) void k_hull_huge(SceneDev s) {
+    __shared__ uint32_t chain_n;
+    if (!fits(s)) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t queued = s.hull_large_count[2];
+    for (uint32_t q = blockIdx.x; q < queued; q += gridDim.x) {
+        const uint32_t shape = s.hull_large_list[2u * s.n_shapes + q];
+        const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
+        const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
+        float2* pts = s.hull_sort + 2u * (size_t)base;   // next_pow2(n) <= 2n slots
+        float2* chain = s.hull_chain + 2u * (size_t)base; // the chain never holds more than 2n points
+        uint32_t padded = 1;
+        while (padded < n) padded <<= 1;
+        const float inf = __uint_as_float(0x7f800000u);
+        for (uint32_t i = tid; i < padded; i += 256u) pts[i] = i < n ? make_float2(s.hull_cand[base + i].x, s.hull_cand[base + i].y) : make_float2(inf, inf);
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t k = 2; k <= padded; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < padded; i += 256u) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const float2 a = pts[i], b = pts[partner];
+                        const bool ascending = (i & k) == 0;
+                        if (ascending ? lex_less(b, a) : lex_less(a, b)) {
+                            pts[i] = b;
+                            pts[partner] = a;
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                const float2 p = pts[i];
+                while (m > 1 && turn(chain[m - 2], chain[m - 1], p) <= kErrorMargin) m -= 1;
+                chain[m++] = p;
+            }
+            m -= 1;
+            const uint32_t t = m + 1;
+            for (uint32_t i = n; i-- > 0;) {
+                const float2 p = pts[i];
+                while (m > t && turn(chain[m - 2], chain[m - 1], p) <= kErrorMargin) m -= 1;
+                chain[m++] = p;
+            }
+            m -= 1;
+            chain_n = m;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t h = chain_n;
+        for (uint32_t i = tid; i < h; i += 256u) {
+            const float2 p = chain[fan_to_strip_source(i, h)];
+            s.hull_v[base + i] = {p.x, p.y};
+        }
+        if (tid == 0) s.hull_count[shape] = h;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ self test
 __global__ void k_fmath(int fn, const float* a, const float* b, float* out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,12 +647,13 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
         hipLaunchKernelGGL(k_stroke_lengths, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
         if (mark) mark(ctx, "stroke_lengths", 0);
     }
-    (void)hipMemsetAsync(s.hull_large_count, 0, 8, stream);
+    (void)hipMemsetAsync(s.hull_large_count, 0, 16, stream);
     hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(256), 0, stream, s);
     if (mark) mark(ctx, "tess_hull", bytes[3]);
     if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
         hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(s.n_shapes, 4096u)), dim3(64), 0, stream, s);
         hipLaunchKernelGGL((k_hull_large<kHullMax, 1>), dim3(min(s.n_shapes, 1024u)), dim3(64), 0, stream, s);
+        hipLaunchKernelGGL(k_hull_huge, dim3(min(s.n_shapes, 256u)), dim3(256), 0, stream, s);
         if (mark) mark(ctx, "tess_hull_large", 0);
     }
 }

@@ -25,6 +25,10 @@
 //  * stencil: stroke passes = Equal(0) -> IncrementWrap (set-once); fill passes = front(ccw on screen)
 //    IncrementWrap / back DecrementWrap, modulo 2^winding_counter_bits; cover = where winding != 0 blend
 //    premultiplied "over", and zero the winding of every sample inside the hull strip.
+//  * strips are walked by POSITION (vertex n of a strip is the n-th vertex the builder appended to it), not through the u16 index
+//    values: identical as long as a sub-buffer holds at most 65 535 vertices; beyond that the reference's indices wrap (`as u16`,
+//    fill.rs:363, stroke.rs:108,128) and a hardware rasterizer would draw whatever the wrapped values point at (and cut strips at a
+//    legitimate 65 535). The emitted index BYTES keep the wrap (they are compared bit for bit); the pixels show the intended geometry.
 //  * colour: f32 per sample, one quantisation to RGBA8 at resolve (box average).
 #pragma once
 #include "tessellate.hpp"
@@ -444,20 +448,21 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
     {
         const auto& verts = shape.stroke.line_vertices;
         const auto& idx = shape.stroke.line_indices;
-        size_t run_start = 0;
+        const auto& restarts = shape.stroke.line_restarts;
+        size_t run_start = 0, vertex_base = 0, next_restart = 0;
         for (size_t k = 0; k <= idx.size(); ++k) {
-            if (k == idx.size() || idx[k] == 0xFFFF) {
+            if (k == idx.size() || (next_restart < restarts.size() && restarts[next_restart] == k)) {
                 for (size_t i = 0; run_start + i + 2 < k; ++i) {
                     size_t tri[3];
                     StripWalker::triangle(i, tri);
                     float v[3][2], attr[3][4];
                     for (int c = 0; c < 3; ++c) {
-                        const Vertex2f1i& vx = verts[idx[run_start + tri[c]]];
+                        const Vertex2f1i& vx = verts[vertex_base + tri[c]];
                         v[c][0] = vx.p[0], v[c][1] = vx.p[1];
                         attr[c][0] = vx.t[0];
                         attr[c][1] = vx.t[1];
                     }
-                    const Vertex2f1i& provoking = verts[idx[run_start + i]];
+                    const Vertex2f1i& provoking = verts[vertex_base + i];
                     const uint32_t flat_u = provoking.u;
                     const float end_texcoord_y = provoking.t[1];
                     const crh_dynamic_stroke_descriptor& d = descriptor(flat_u & 65535u);
@@ -471,7 +476,9 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                         },
                         stroke_stencil);
                 }
+                vertex_base += k - run_start;
                 run_start = k + 1;
+                ++next_restart;
             }
         }
     }
@@ -479,22 +486,23 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
     {
         const auto& verts = shape.stroke.joint_vertices;
         const auto& idx = shape.stroke.joint_indices;
+        const auto& restarts = shape.stroke.joint_restarts;
         const float TAU = crh_acosf(-1.0f) * 2.0f;
-        size_t run_start = 0;
+        size_t run_start = 0, vertex_base = 0, next_restart = 0;
         for (size_t k = 0; k <= idx.size(); ++k) {
-            if (k == idx.size() || idx[k] == 0xFFFF) {
+            if (k == idx.size() || (next_restart < restarts.size() && restarts[next_restart] == k)) {
                 for (size_t i = 0; run_start + i + 2 < k; ++i) {
                     size_t tri[3];
                     StripWalker::triangle(i, tri);
                     float v[3][2], attr[3][4];
                     for (int c = 0; c < 3; ++c) {
-                        const Vertex3f1i& vx = verts[idx[run_start + tri[c]]];
+                        const Vertex3f1i& vx = verts[vertex_base + tri[c]];
                         v[c][0] = vx.p[0], v[c][1] = vx.p[1];
                         attr[c][0] = vx.t[0];
                         attr[c][1] = vx.t[1];
                         attr[c][2] = vx.t[2];
                     }
-                    const uint32_t flat_u = verts[idx[run_start + i]].u;
+                    const uint32_t flat_u = verts[vertex_base + i].u;
                     const crh_dynamic_stroke_descriptor& d = descriptor(flat_u & 65535u);
                     raster_triangle<3>(
                         f, m, v, attr,
@@ -506,7 +514,9 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
                         },
                         stroke_stencil);
                 }
+                vertex_base += k - run_start;
                 run_start = k + 1;
+                ++next_restart;
             }
         }
     }
@@ -514,18 +524,21 @@ inline void render_stencil(Frame& f, const Shape& shape, const float m[16]) {
     {
         const auto& verts = shape.fill.solid_vertices;
         const auto& idx = shape.fill.solid_indices;
-        size_t run_start = 0;
+        const auto& restarts = shape.fill.solid_restarts;
+        size_t run_start = 0, vertex_base = 0, next_restart = 0;
         for (size_t k = 0; k <= idx.size(); ++k) {
-            if (k == idx.size() || idx[k] == 0xFFFF) {
+            if (k == idx.size() || (next_restart < restarts.size() && restarts[next_restart] == k)) {
                 for (size_t i = 0; run_start + i + 2 < k; ++i) {
                     size_t tri[3];
                     StripWalker::triangle(i, tri);
                     float v[3][2], attr[3][4] = {};
-                    for (int c = 0; c < 3; ++c) v[c][0] = verts[idx[run_start + tri[c]]].p[0], v[c][1] = verts[idx[run_start + tri[c]]].p[1];
+                    for (int c = 0; c < 3; ++c) v[c][0] = verts[vertex_base + tri[c]].p[0], v[c][1] = verts[vertex_base + tri[c]].p[1];
                     raster_triangle<0>(
                         f, m, v, attr, [](const float*) { return true; }, fill_stencil);
                 }
+                vertex_base += k - run_start;
                 run_start = k + 1;
+                ++next_restart;
             }
         }
     }

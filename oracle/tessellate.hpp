@@ -125,6 +125,7 @@ constexpr int SEGMENT_FLOATS[5] = {2, 4, 6, 5, 10};
 // ---- fill.rs -----------------------------------------------------------------------------------------------
 struct FillBuilder { // fill.rs:252-260
     std::vector<uint16_t> solid_indices;
+    std::vector<uint32_t> solid_restarts; // positions of the restart entries in solid_indices (not emitted; the rasterizer walks strips by position)
     std::vector<Vertex0> solid_vertices;
     std::vector<Vertex2f> integral_quadratic_vertices;
     std::vector<Vertex3f> integral_cubic_vertices;
@@ -403,12 +404,14 @@ inline void fill_add_path(FillBuilder& self, std::vector<Safe2>& proto_hull, con
     self.solid_vertices.insert(self.solid_vertices.end(), strip.begin(), strip.end());
     for (size_t i = start_index; i < self.solid_vertices.size() + 1; ++i) self.solid_indices.push_back((uint16_t)i);
     self.solid_indices.back() = 0xFFFF;
+    self.solid_restarts.push_back((uint32_t)self.solid_indices.size() - 1u);
 }
 
 // ---- stroke.rs ----------------------------------------------------------------------------------------------
 struct StrokeBuilder { // stroke.rs:170-177
     std::vector<uint16_t> line_indices;
     std::vector<uint16_t> joint_indices;
+    std::vector<uint32_t> line_restarts, joint_restarts; // positions of the restart entries (not emitted)
     std::vector<Vertex2f1i> line_vertices;
     std::vector<Vertex3f1i> joint_vertices;
     std::vector<Vertex2f1i> path_line_vertices;
@@ -447,6 +450,7 @@ inline void cut_stroke_polygon(StrokeBuilder& builder, std::vector<Safe2>& proto
         builder.path_line_vertices.clear();
         for (size_t i = start_index; i < builder.line_vertices.size() + 1; ++i) builder.line_indices.push_back((uint16_t)i);
         builder.line_indices.back() = 0xFFFF;
+        builder.line_restarts.push_back((uint32_t)builder.line_indices.size() - 1u);
     }
 }
 // stroke.rs:53-121
@@ -489,6 +493,7 @@ inline void emit_stroke_join(StrokeBuilder& builder, std::vector<Safe2>& proto_h
     }
     for (size_t i = start_index; i < builder.joint_vertices.size() + 1; ++i) builder.joint_indices.push_back((uint16_t)i);
     builder.joint_indices.back() = 0xFFFF;
+    builder.joint_restarts.push_back((uint32_t)builder.joint_indices.size() - 1u);
     length_accumulator += crh_acosf(tangets_dot_product) / (3.14159265358979323846f * 2.0f) * so.width;
     cut_stroke_polygon(builder, proto_hull, err);
     emit_stroke_vertices(builder, so, so.dynamic_stroke_options_group, length_accumulator, control_point, next_tangent);
