@@ -765,13 +765,49 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 
     const uint32_t list_begin = r.tile_offset[tile];
     uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
-    if (n > r.sort_capacity) { // the host sizes the sort buffer from overflow[3] (the longest list) and runs the frame again
-        if (lane == 0 && n > kSortBytesMax / (4u * (4u / ROWS))) atomicMax(&r.overflow[2], 1u); // beyond what LDS can sort: reported with the frame
-        n = 0;
-    }
-    // ---- draw order = ascending prim id: bitonic network in registers (<= 64 entries) or in LDS
+    constexpr uint32_t kLdsSortMax = kSortBytesMax / (4u * (4u / ROWS));
+    if (n > r.sort_capacity && n <= kLdsSortMax) n = 0; // the host sizes the sort buffer from overflow[3] (the longest list) and runs the frame again
+    // ---- draw order = ascending prim id: bitonic network in registers (<= 64 entries), in LDS, or — a list longer than LDS holds — in
+    //      place in global memory
     uint32_t my_key = 0xFFFFFFFFu;
-    if (n <= 64u) {
+    const bool sorted_in_place = n > kLdsSortMax;
+    uint32_t* const segment = r.tile_list + list_begin;
+    if (sorted_in_place) {
+        // Thousands of primitives over one tile (one Shape with 10^4 slivers through a point, hundreds of Shapes stacked): rare, so simple.
+        // A normalised bitonic network — every compare-exchange leaves the smaller key at the lower index — sorts any length: positions
+        // beyond n behave as +inf and are skipped. All wavefronts of the tile's workgroup take part; keys move through L2 (agent-scope
+        // atomics) so that every lane sees what the others wrote.
+        const uint32_t tid = threadIdx.x, n_threads = 64u * (4u / ROWS);
+        uint32_t padded = 1;
+        while (padded < n) padded <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t partner) {
+            if (partner < n) {
+                const uint32_t a = __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b = __hip_atomic_load(segment + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a > b) {
+                    __hip_atomic_store(segment + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(segment + partner, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        for (uint32_t k = 2; k <= padded; k <<= 1) {
+            const uint32_t half = k >> 1;
+            for (uint32_t p = tid; p < (padded >> 1); p += n_threads) { // the mirror step of the block of k
+                const uint32_t block = p / half, t = p - block * half;
+                exchange(block * k + t, block * k + k - 1u - t);
+            }
+            __threadfence();
+            __syncthreads();
+            for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+                for (uint32_t p = tid; p < (padded >> 1); p += n_threads) {
+                    const uint32_t i = 2u * j * (p / j) + (p % j);
+                    exchange(i, i + j);
+                }
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    } else if (n <= 64u) {
         if (lane < n) my_key = r.tile_list[list_begin + lane];
 #pragma unroll
         for (uint32_t k = 2; k <= 64u; k <<= 1) {
@@ -808,7 +844,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     const PrimRec* recs = r.prim_rec;
     const int wmask = (int)r.winding_mask;
     for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
-        if (n > 64u) my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
+        if (sorted_in_place)
+            my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        else if (n > 64u)
+            my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
         const uint32_t count = min(64u, n - q0);
         // ---- entry setup, vectorised across the chunk: lane j prepares entry j (one gathered 64-byte record per lane)
         uint32_t e_bits = 0, e_flags = 0, e_desc = 0;
