@@ -20,9 +20,12 @@ def random_case(seed):
     base = scenes.scene_mixed(n_shapes, (max(width, 96), max(height, 96)), seed=seed)
     batch, colors = base["batch"], base["colors"]
     n = batch.n_shapes
-    kind = seed % 4
-    if kind == 0:  # plain instances, placed over the (smaller) frame so that shapes hang over every border
+    kind = seed % 6
+    if kind == 0 or kind == 4:  # plain instances, placed over the (smaller) frame so that shapes hang over every border
         t = scenes.place(width, height, rng.uniform(-10, width + 10, n), rng.uniform(-10, height + 10, n), rng.uniform(8, 0.5 * min(width, height), n))
+    elif kind == 5:  # extreme placements: tiny and enormous scales, centres far outside the frame (slivers, clamped boxes, huge coordinates)
+        t = scenes.place(width, height, rng.uniform(-3 * width, 4 * width, n), rng.uniform(-3 * height, 4 * height, n),
+                         np.exp(rng.uniform(math.log(0.05), math.log(40.0 * max(width, height)), n)))
     else:  # perspective: tilted decals at random depths, some reaching through the near plane
         projection = utils.perspective_projection(math.pi * 0.5, width / height, 1.0, 100.0)
         t = np.stack([utils.matrix_multiplication(projection, utils.matrix_multiplication(
@@ -41,6 +44,14 @@ def random_case(seed):
         for i in range(1, n // 2):
             draws += [(i, i, Op.Stencil, 0, 0), (i, i, Op.Color, 0, 0)]
         draws += [(0, n - 1, Op.Stencil, 0, 0), (0, n - 1, Op.Color, 0, 0)]
+    elif kind == 4:  # an opacity group (Save / Scale / content / Restore) over a background, twice nested
+        draws += [(0, 0, Op.Stencil, 0, 0), (0, 0, Op.Color, 0, 0), (1, 1, Op.SaveAlphaContext, 0, 0), (1, 1, Op.ScaleAlphaContext, 0, 0)]
+        for i in range(2, n // 2):
+            draws += [(i, i, Op.Stencil, 0, 0), (i, i, Op.Color, 0, 0)]
+        draws += [(2, 2, Op.SaveAlphaContext, 0, 1), (2, 2, Op.ScaleAlphaContext, 0, 1)]
+        for i in range(n // 2, n):
+            draws += [(i, i, Op.Stencil, 0, 0), (i, i, Op.Color, 0, 0)]
+        draws += [(2, 2, Op.RestoreAlphaContext, 0, 1), (1, 1, Op.RestoreAlphaContext, 0, 0)]
     else:
         for i in range(n):
             draws += [(i, i, Op.Stencil, 0, 0), (i, i, Op.Color, 0, 0)]
@@ -60,7 +71,7 @@ def test_random_scene_matches_the_oracle(seed, oracle_lib):
     from oracle.binding import Oracle, render_pass
     c = random_case(seed)
     o = Oracle(c["batch"])
-    config = R.Configuration(msaa_sample_count=c["msaa"], clip_nesting_counter_bits=2, winding_counter_bits=c["winding_bits"], alpha_layer_count=0,
+    config = R.Configuration(msaa_sample_count=c["msaa"], clip_nesting_counter_bits=2, winding_counter_bits=c["winding_bits"], alpha_layer_count=2,
                              cull_mode=c["state"].get("cull_mode", 0), depth_compare=c["state"].get("depth_compare", 0),
                              depth_write_enabled=bool(c["state"].get("depth_write", 0)))
     r = R.Renderer(config, device=0)
@@ -82,5 +93,5 @@ def test_random_scene_matches_the_oracle(seed, oracle_lib):
 
 def render_pass_rect(o, c, render_pass):
     """oracle.binding.render_pass takes (width, height); kept in one place so that the argument order cannot drift from the GPU call."""
-    return render_pass(o, c["width"], c["height"], c["msaa"], c["winding_bits"], 2, 0, c["transforms"], c["colors"], [tuple(int(v) for v in d) for d in c["draws"]],
+    return render_pass(o, c["width"], c["height"], c["msaa"], c["winding_bits"], 2, 2, c["transforms"], c["colors"], [tuple(int(v) for v in d) for d in c["draws"]],
                        depth=c["depth"], **c["state"])
