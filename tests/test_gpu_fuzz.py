@@ -95,3 +95,89 @@ def render_pass_rect(o, c, render_pass):
     """oracle.binding.render_pass takes (width, height); kept in one place so that the argument order cannot drift from the GPU call."""
     return render_pass(o, c["width"], c["height"], c["msaa"], c["winding_bits"], 2, 2, c["transforms"], c["colors"], [tuple(int(v) for v in d) for d in c["draws"]],
                        depth=c["depth"], **c["state"])
+
+
+def random_paths(n_shapes, seed):
+    """Unstructured geometry: random control points (self-intersecting outlines, loops, cusps, coincident and collinear points, weights
+    from 0.2 to 5), one to three paths per Shape, filled or stroked with random widths / offsets / joins / caps / approximations."""
+    from contrast_renderer_amd import Cap, CurveApproximation, DashInterval, DynamicStrokeOptions, Join, Path, StrokeOptions
+    rng = np.random.RandomState(seed)
+    caps = list(Cap)
+    shapes = []
+    for s in range(n_shapes):
+        paths, dynamic = [], []
+        for _ in range(rng.randint(1, 4)):
+            scale = float(np.exp(rng.uniform(math.log(0.05), math.log(3.0))))
+
+            def pt():
+                if rng.uniform() < 0.08 and paths:  # reuse an earlier point: coincident vertices
+                    return paths[-1].start
+                return (float(np.float32(rng.normal(0, scale))), float(np.float32(rng.normal(0, scale))))
+            pen = pt()
+            p = Path(start=pen)
+            for _ in range(rng.randint(1, 10)):
+                kind = rng.randint(0, 5)
+                end = pen if rng.uniform() < 0.05 else pt()
+                if kind == 0:
+                    p.push_line(end)
+                elif kind == 1:
+                    p.push_integral_quadratic_curve(pt(), end)
+                elif kind == 2:
+                    p.push_integral_cubic_curve(pt(), pt(), end)
+                elif kind == 3:
+                    p.push_rational_quadratic_curve(float(np.exp(rng.uniform(-1.6, 1.6))), pt(), end)
+                else:
+                    p.push_rational_cubic_curve(np.exp(rng.uniform(-1.6, 1.6, 4)), pt(), pt(), end)
+                pen = end
+            if rng.uniform() < 0.5:
+                approx = CurveApproximation.UniformTangentAngle(float(rng.uniform(0.05, 0.8))) if rng.uniform() < 0.5 else CurveApproximation.UniformlySpacedParameters(int(rng.randint(1, 12)))
+                p.stroke_options = StrokeOptions(float(rng.uniform(0.001, 0.5)), float(rng.uniform(-0.5, 0.5)), float(rng.uniform(1.0, 8.0)), bool(rng.randint(0, 2)),
+                                                 len(dynamic), approx)
+                join = (Join.Miter, Join.Bevel, Join.Round)[rng.randint(0, 3)]
+                if rng.uniform() < 0.5:
+                    dynamic.append(DynamicStrokeOptions.Solid(join, caps[rng.randint(0, len(caps))], caps[rng.randint(0, len(caps))]))
+                else:
+                    a, b = sorted(rng.uniform(0.0, 4.0, 2))
+                    dynamic.append(DynamicStrokeOptions.Dashed(join, [DashInterval(float(a), float(b), caps[rng.randint(0, len(caps))], caps[rng.randint(0, len(caps))])],
+                                                               float(rng.uniform(0.0, 2.0))))
+            paths.append(p)
+        shapes.append((dynamic, paths))
+    return shapes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CRH_FUZZ_PATH_SEEDS", "4"))))
+def test_random_paths_tessellate_to_the_same_bytes_or_fail_the_same_way(seed, oracle_lib):
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import batch_from_shapes
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle
+    shapes = random_paths(1500, 77 + seed)
+    batch = batch_from_shapes(shapes)
+    oracle = Oracle(batch, 8)
+    status = [oracle.shape_status(s) for s in range(len(shapes))]
+    good = [s for s in range(len(shapes)) if status[s] == 0]
+    assert len(good) > 0.5 * len(shapes)
+    r = R.Renderer(R.Configuration(1, 4, 4), device=0)
+    clean = batch_from_shapes([shapes[s] for s in good])
+    scene = R.Scene(r, clean)
+    assert scene.status() == 0
+    layout, vb, ib = scene.all_shapes()
+    olayout, ovb, oib = Oracle(clean, 8).all_shapes()
+    assert np.array_equal(layout, olayout) and np.array_equal(ib, oib)
+    assert np.array_equal(vb, ovb), f"{np.flatnonzero(vb != ovb).size} vertex bytes differ, first at {np.flatnonzero(vb != ovb)[0]}"
+    assert vb.size > 1_000_000
+    for s in [s for s in range(len(shapes)) if status[s] != 0][:8]:  # what the reference cannot tessellate fails with the same code
+        assert R.Scene(r, batch.slice_shapes(s, s + 1)).status() == status[s]
+    # and the pixels of a frame over them
+    n = clean.n_shapes
+    rng = np.random.RandomState(seed)
+    t = scenes.place(256, 256, rng.uniform(0, 256, n), rng.uniform(0, 256, n), rng.uniform(5, 60, n))
+    c = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0.2, 1, (n, 1))], axis=1).astype(np.float32)
+    frame = R.Frame(r, 256, 256)
+    frame.clear()
+    scene.render(frame, t, c)
+    image = frame.download()
+    expect = Oracle(clean, 8).render(256, 256, 1, 4, t, c)
+    assert np.array_equal(image, expect), f"{(image != expect).any(axis=2).sum()} pixels differ"
