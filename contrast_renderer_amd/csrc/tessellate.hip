@@ -512,18 +512,30 @@ __global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
             }
         }
         if (lane == 0) {
+            // the serial monotone chain; its two top points stay in registers, so LDS is read only when a point is popped
             uint32_t m = 0;
+            float2 below = make_float2(0.0f, 0.0f), top = make_float2(0.0f, 0.0f); // chain[m - 2], chain[m - 1]
+            auto push = [&](float2 p) {
+                chain[m++] = p;
+                below = top;
+                top = p;
+            };
+            auto pop = [&]() {
+                m -= 1;
+                top = below;
+                if (m > 1) below = chain[m - 2];
+            };
             for (uint32_t i = 0; i < n; ++i) {
                 const float2 p = pts[i];
-                while (m > 1 && turn(chain[m - 2], chain[m - 1], p) <= kErrorMargin) m -= 1;
-                chain[m++] = p;
+                while (m > 1 && turn(below, top, p) <= kErrorMargin) pop();
+                push(p);
             }
-            m -= 1;
+            pop();
             const uint32_t t = m + 1;
             for (uint32_t i = n; i-- > 0;) {
                 const float2 p = pts[i];
-                while (m > t && turn(chain[m - 2], chain[m - 1], p) <= kErrorMargin) m -= 1;
-                chain[m++] = p;
+                while (m > t && turn(below, top, p) <= kErrorMargin) pop();
+                push(p);
             }
             m -= 1;
             chain_n = m;
