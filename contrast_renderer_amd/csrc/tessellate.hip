@@ -481,8 +481,8 @@ __global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
 template <uint32_t CAP, uint32_t QUEUE>
 __global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
     __shared__ float2 pts[CAP];
-    __shared__ float2 chain[2 * CAP];
-    __shared__ uint32_t chain_n;
+    __shared__ float2 chain[2 * CAP]; // [0, CAP): lower chain, [CAP, 2 CAP): upper chain
+    __shared__ uint32_t chain_m[2];
     if (!fits(s)) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t queued = s.hull_large_count[QUEUE];
@@ -511,39 +511,31 @@ __global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
                 __syncthreads();
             }
         }
-        if (lane == 0) {
-            // the serial monotone chain; its two top points stay in registers, so LDS is read only when a point is popped
+        if (lane < 2) {
+            // The two monotone chains of Andrew's scan are independent — the upper one starts from the last point on a stack floor of its
+            // own (convex_hull.rs:24-33) — so lane 0 builds the lower and lane 1 the upper chain at the same time, each with its two top
+            // points in registers (LDS is read only when a point is popped). The hull is lower[0 .. ml-1) ++ upper[0 .. mu-1).
+            float2* mine = chain + lane * CAP;
             uint32_t m = 0;
-            float2 below = make_float2(0.0f, 0.0f), top = make_float2(0.0f, 0.0f); // chain[m - 2], chain[m - 1]
-            auto push = [&](float2 p) {
-                chain[m++] = p;
+            float2 below = make_float2(0.0f, 0.0f), top = make_float2(0.0f, 0.0f); // mine[m - 2], mine[m - 1]
+            for (uint32_t i = 0; i < n; ++i) {
+                const float2 p = pts[lane == 0 ? i : n - 1u - i];
+                while (m > 1 && turn(below, top, p) <= kErrorMargin) {
+                    m -= 1;
+                    top = below;
+                    if (m > 1) below = mine[m - 2];
+                }
+                mine[m++] = p;
                 below = top;
                 top = p;
-            };
-            auto pop = [&]() {
-                m -= 1;
-                top = below;
-                if (m > 1) below = chain[m - 2];
-            };
-            for (uint32_t i = 0; i < n; ++i) {
-                const float2 p = pts[i];
-                while (m > 1 && turn(below, top, p) <= kErrorMargin) pop();
-                push(p);
             }
-            pop();
-            const uint32_t t = m + 1;
-            for (uint32_t i = n; i-- > 0;) {
-                const float2 p = pts[i];
-                while (m > t && turn(below, top, p) <= kErrorMargin) pop();
-                push(p);
-            }
-            m -= 1;
-            chain_n = m;
+            chain_m[lane] = m - 1; // without the last point, which opens the other chain
         }
         __syncthreads();
-        const uint32_t h = chain_n;
+        const uint32_t ml = chain_m[0], h = ml + chain_m[1];
         for (uint32_t i = lane; i < h; i += 64) {
-            const float2 p = chain[fan_to_strip_source(i, h)];
+            const uint32_t c = fan_to_strip_source(i, h);
+            const float2 p = c < ml ? chain[c] : chain[CAP + (c - ml)];
             s.hull_v[base + i] = {p.x, p.y};
         }
         if (lane == 0) s.hull_count[shape] = h;
