@@ -428,20 +428,24 @@ __global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
         if (lane == 0) count[slot] = n;
     }
     __syncthreads();
-    // ---- phase 2: lane = Shape; every lane of wavefront 0 walks the lower then the upper chain of its own Shape (convex_hull.rs:12-39)
-    if (wave != 0 || lane >= kHullBatch) return;
-    const uint32_t n = count[lane];
-    const uint32_t shape = first_shape + lane;
-    if (n == 0) return;
-    const float2* pts = sorted[lane];
-    uint8_t* chain = stack[lane];
-    uint32_t h = n;
+    // ---- phase 2: two lanes per Shape; the lower and the upper chain of Andrew's scan are independent (the upper one starts from the last
+    //      point on a stack floor of its own, convex_hull.rs:24-33), so the even lane walks the lower and the odd lane the upper chain
+    if (wave != 0 || lane >= 2u * kHullBatch) return;
+    const uint32_t slot = lane >> 1, upper = lane & 1u;
+    const uint32_t n = count[slot];
+    const uint32_t shape = first_shape + slot;
+    if (n == 0) return; // both lanes of the pair
+    const float2* pts = sorted[slot];
+    uint8_t* chain = stack[slot] + upper * kHullSmall;
+    uint32_t m = 0;
     if (n < 3) {
-        for (uint32_t i = 0; i < n; ++i) chain[i] = (uint8_t)i;
+        if (!upper)
+            for (uint32_t i = 0; i < n; ++i) chain[i] = (uint8_t)i;
+        m = upper ? 1u : n + 1u; // so that the hull below is pts[0 .. n)
     } else {
-        uint32_t m = 0;
         float2 a = make_float2(0.0f, 0.0f), b = a; // chain[m - 2], chain[m - 1]
-        for (uint32_t i = 0; i < n; ++i) {
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t i = upper ? n - 1u - k : k;
             const float2 c = pts[i];
             while (m > 1 && turn(a, b, c) <= kErrorMargin) {
                 m -= 1;
@@ -452,30 +456,19 @@ __global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
             a = b;
             b = c;
         }
-        m -= 1; // the last point of the lower chain starts the upper one
-        b = a;
-        if (m >= 2) a = pts[chain[m - 2]];
-        const uint32_t t = m + 1;
-        for (uint32_t i = n; i-- > 0;) {
-            const float2 c = pts[i];
-            while (m > t && turn(a, b, c) <= kErrorMargin) {
-                m -= 1;
-                b = a;
-                if (m >= 2) a = pts[chain[m - 2]];
-            }
-            chain[m++] = (uint8_t)i;
-            a = b;
-            b = c;
-        }
-        m -= 1;
-        h = m;
     }
+    // the hull: lower[0 .. ml - 1) ++ upper[0 .. mu - 1) — each chain without its last point, which opens the other one
+    const uint32_t ml = (uint32_t)__shfl((int)m, (int)(lane & ~1u), 64) - 1u, mu = (uint32_t)__shfl((int)m, (int)(lane | 1u), 64) - 1u;
+    const uint32_t h = ml + mu;
+    const uint8_t* lower_chain = stack[slot];
+    const uint8_t* upper_chain = stack[slot] + kHullSmall;
     const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
-    for (uint32_t i = 0; i < h; ++i) { // triangle_fan_to_strip order (vertex.rs:28-35)
-        const float2 q = pts[chain[fan_to_strip_source(i, h)]];
+    for (uint32_t i = upper; i < h; i += 2u) { // triangle_fan_to_strip order (vertex.rs:28-35); the pair shares the writes
+        const uint32_t c = fan_to_strip_source(i, h);
+        const float2 q = pts[c < ml ? lower_chain[c] : upper_chain[c - ml]];
         s.hull_v[base + i] = {q.x, q.y};
     }
-    s.hull_count[shape] = h;
+    if (!upper) s.hull_count[shape] = h;
 }
 
 template <uint32_t CAP, uint32_t QUEUE>
