@@ -86,6 +86,9 @@ struct crh_renderer {
     void* composite_table = nullptr; // device array of layer pointers (aux stream)
     uint32_t composite_table_capacity = 0;
     bool pipeline = true;     // CRH_NO_PIPELINE=1 runs everything on `stream`
+    std::vector<crh_scene*> scenes; // live scenes and frames: orphaned (renderer = nullptr) when the renderer goes first, so that their own
+                                    // destruction — host bindings finalise in any order — never touches a freed renderer
+    std::vector<crh_frame*> frames; // live frames: a frame whose overflow check is still pending is settled before the scene it shows changes
     bool timing = false;
     std::vector<hipEvent_t> event_pool;
     std::vector<Mark> marks;
@@ -148,7 +151,8 @@ struct crh_renderer {
 constexpr int kPipelineDepth = CRH_PIPELINE_DEPTH;
 
 struct crh_frame {
-    crh_renderer* renderer;
+    crh_renderer* renderer; // nullptr once the renderer has been destroyed (only crh_frame_destroy is valid then)
+    int device = 0;
     uint32_t width, height, tiles_x, tiles_y, n_tiles;
     DevBuf rgba8;
     // Two sets of binning buffers, used alternately: frame N + 1 is binned while frame N's raster kernel still reads the other set.
@@ -174,7 +178,8 @@ struct crh_frame {
 };
 
 struct crh_scene {
-    crh_renderer* renderer;
+    crh_renderer* renderer; // nullptr once the renderer has been destroyed (only crh_scene_destroy is valid then)
+    int device = 0;
     SceneDev d;
     uint32_t n_segments = 0;
     bool has_stroke = false, big_shapes = false;
@@ -491,8 +496,29 @@ uint32_t depth_pass_mask(uint32_t compare) { // bit 0: fragment < stored passes,
     }
 }
 
+crh_status settle_frame(crh_frame* f);
+// The check whether a frame's optimistic tile-list capacity sufficed is deferred to the next call that synchronises; its remedy renders
+// the frame again FROM THE SCENE, so the scene must still hold what the frame shows: everything that changes a scene (new geometry,
+// instance data, stroke descriptors, destruction) first settles the frames that were rendered from it.
+crh_status settle_frames_of(crh_scene* sc, bool forget) {
+    crh_status result = CRH_OK;
+    for (crh_frame* f : sc->renderer->frames) {
+        if (f->last_scene != sc) continue;
+        if (f->check_pending) {
+            const crh_status st = settle_frame(f);
+            if (st != CRH_OK && result == CRH_OK) result = st;
+        }
+        if (forget) f->last_scene = nullptr;
+    }
+    return result;
+}
+
 crh_status render_impl(crh_scene* sc, crh_frame* f) {
     crh_renderer* r = sc->renderer;
+    if (!f->cleared && f->check_pending) { // rendering over existing content: that content has to be final
+        const crh_status st = settle_frame(f);
+        if (st != CRH_OK) return st;
+    }
     const bool recorded = f->n_items != 0; // crh_scene_render_draws stored a pass in the frame
     if (!recorded && !sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
     if (!sc->capacity_known) return CRH_ERR_INVALID_ARGUMENT; // tessellate first
@@ -675,6 +701,12 @@ void crh_renderer_destroy(crh_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
     (void)r->sync();
+    for (crh_frame* f : r->frames) {
+        f->renderer = nullptr;
+        f->last_scene = nullptr;
+        f->check_pending = false;
+    }
+    for (crh_scene* sc : r->scenes) sc->renderer = nullptr;
     for (hipEvent_t e : r->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(r->stream);
     (void)hipStreamDestroy(r->tess_stream);
@@ -760,8 +792,13 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     shape_elem_begin[b->n_shapes] = e;
 
     HIP_TRY(hipSetDevice(r->device));
+    if (existing) {
+        const crh_status st = settle_frames_of(existing, false);
+        if (st != CRH_OK) return st;
+    }
     crh_scene* sc = existing ? existing : new crh_scene;
     sc->renderer = r;
+    sc->device = r->device;
     if (!sc->tess_done) {
         if (!hip_ok(hipEventCreateWithFlags(&sc->tess_done, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&sc->vertices_free, hipEventDisableTiming), "hipEventCreate") ||
@@ -867,6 +904,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         rc = CRH_ERR_HIP;
         goto fail;
     }
+    if (!existing) r->scenes.push_back(sc);
     *out = sc;
     return CRH_OK;
 fail:
@@ -891,8 +929,17 @@ crh_status crh_scene_status(crh_scene* sc) {
 }
 void crh_scene_destroy(crh_scene* sc) {
     if (!sc) return;
-    (void)hipSetDevice(sc->renderer->device);
-    (void)sc->renderer->sync();
+    (void)hipSetDevice(sc->device);
+    if (sc->renderer) {
+        (void)settle_frames_of(sc, true);
+        (void)sc->renderer->sync();
+        std::vector<crh_scene*>& live = sc->renderer->scenes;
+        for (size_t i = 0; i < live.size(); ++i)
+            if (live[i] == sc) {
+                live.erase(live.begin() + (long)i);
+                break;
+            }
+    }
     sc->release_all();
     for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free})
         if (e) (void)hipEventDestroy(e);
@@ -979,6 +1026,10 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* sc, uint32_t shape, u
     const crh_status st = convert_options(*o, d);
     if (st != CRH_OK) return st;
     HIP_TRY(hipSetDevice(sc->renderer->device));
+    {
+        const crh_status pending = settle_frames_of(sc, false);
+        if (pending != CRH_OK) return pending;
+    }
     HIP_TRY(hipMemcpyAsync(sc->d.descriptors + begin + group, &d, sizeof(d), hipMemcpyHostToDevice, sc->renderer->stream));
     HIP_TRY(sc->renderer->sync());
     return CRH_OK;
@@ -989,6 +1040,7 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     HIP_TRY(hipSetDevice(r->device));
     crh_frame* f = new crh_frame;
     f->renderer = r;
+    f->device = r->device;
     f->width = width;
     f->height = height;
     f->tiles_x = (width + 15) / 16;
@@ -1012,13 +1064,21 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     }
     for (crh_frame::BinSet& set : f->sets) HIP_TRY(hipMemsetAsync(set.overflow.p, 0, 64, r->stream));
     HIP_TRY(r->sync());
+    r->frames.push_back(f);
     *out = f;
     return CRH_OK;
 }
 void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
-    (void)hipSetDevice(f->renderer->device);
-    (void)f->renderer->sync();
+    (void)hipSetDevice(f->device);
+    if (f->renderer) {
+        (void)f->renderer->sync();
+        for (size_t i = 0; i < f->renderer->frames.size(); ++i)
+            if (f->renderer->frames[i] == f) {
+                f->renderer->frames.erase(f->renderer->frames.begin() + (long)i);
+                break;
+            }
+    }
     DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
     for (DevBuf* b : all) b->release();
     for (crh_frame::BinSet& set : f->sets) {
@@ -1078,6 +1138,10 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
         if (!std::isfinite(transforms[i])) return CRH_ERR_NON_FINITE;
     for (size_t i = 0; i < (size_t)sc->d.n_shapes * 4; ++i)
         if (!std::isfinite(colors[i])) return CRH_ERR_NON_FINITE; // Color = SafeFloat<f32, 4> (renderer.rs:16)
+    {
+        const crh_status pending = settle_frames_of(sc, false);
+        if (pending != CRH_OK) return pending;
+    }
     if (sc->d.n_shapes) {
         HIP_TRY(hipMemcpyAsync(sc->transforms.p, transforms, (size_t)sc->d.n_shapes * 64, hipMemcpyHostToDevice, r->stream));
         HIP_TRY(hipMemcpyAsync(sc->colors.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->stream));
@@ -1098,6 +1162,10 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     crh_renderer* r = sc->renderer;
     HIP_TRY(hipSetDevice(r->device));
     if (r->config.alpha_layer_count > 4) return CRH_ERR_UNSUPPORTED;
+    if (f->check_pending) { // the frame's recorded pass (its remedy for an overflowed tile list) is about to be replaced
+        const crh_status st = settle_frame(f);
+        if (st != CRH_OK) return st;
+    }
     for (size_t i = 0; i < (size_t)n_instances * 16; ++i)
         if (!std::isfinite(transforms[i])) return CRH_ERR_NON_FINITE;
     for (size_t i = 0; i < (size_t)n_instances * 4; ++i)

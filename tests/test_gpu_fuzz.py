@@ -181,3 +181,69 @@ def test_random_paths_tessellate_to_the_same_bytes_or_fail_the_same_way(seed, or
     image = frame.download()
     expect = Oracle(clean, 8).render(256, 256, 1, 4, t, c)
     assert np.array_equal(image, expect), f"{(image != expect).any(axis=2).sum()} pixels differ"
+
+
+@pytest.mark.gpu
+def test_two_renderers_and_reused_scenes_interleaved(oracle_lib):
+    """Two Renderers on the same GPU (each with its own streams) driven alternately without synchronisation in between, each re-uploading
+    scenes of changing size into the same Scene object (`existing_shape`, renderer.rs:216-221) and rendering into two frames of its own:
+    every download matches the oracle."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle
+    renderers = [R.Renderer(R.Configuration(1, 4, 4), device=0), R.Renderer(R.Configuration(4, 2, 4), device=0)]
+    frames = [[R.Frame(r, 200 + 56 * k, 150 + 40 * k) for k in range(2)] for r in renderers]
+    held = [None, None]
+    pending = []
+    for step in range(12):
+        which = step % 2
+        r = renderers[which]
+        sc = scenes.scene_mixed(4 + (step * 7) % 23, (256, 256), seed=100 + step)
+        if Oracle(sc["batch"]).status() != 0:
+            continue
+        held[which] = R.Scene(r, sc["batch"], existing=held[which])
+        frame = frames[which][(step // 2) % 2]
+        frame.clear()
+        held[which].render(frame, sc["transforms"], sc["colors"])
+        pending = [q for q in pending if q[0] is not frame] + [(frame, sc, r.config.msaa_sample_count)]  # the last render into each frame
+    checked = 0
+    for f, s, msaa in pending:
+        expect = Oracle(s["batch"]).render(f.width, f.height, msaa, 4, s["transforms"], s["colors"])
+        assert np.array_equal(f.download(), expect)
+        checked += 1
+    assert checked == 4
+
+
+@pytest.mark.gpu
+def test_objects_may_be_destroyed_in_any_order(oracle_lib):
+    """Host bindings finalise in any order (a garbage collector, a scope exit): a Renderer destroyed before its Scenes and Frames orphans
+    them, and a Scene destroyed while a Frame still refers to it (deferred tile-list check) settles that Frame first."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle
+    sc = scenes.scene_mixed(9, (128, 128), seed=1)
+    expect = Oracle(sc["batch"]).render(128, 128, 1, 4, sc["transforms"], sc["colors"])
+    for order in ("renderer_first", "scene_first", "frame_first"):
+        r = R.Renderer(R.Configuration(1, 4, 4), device=0)
+        scene = R.Scene(r, sc["batch"])
+        frame = R.Frame(r, 128, 128)
+        frame.clear()
+        scene.render(frame, sc["transforms"], sc["colors"])
+        lib = r.lib
+        if order == "renderer_first":
+            lib.crh_renderer_destroy(r.handle)
+            r.handle = None
+            lib.crh_scene_destroy(scene.handle)
+            scene.handle = None
+            lib.crh_frame_destroy(frame.handle)
+            frame.handle = None
+        elif order == "scene_first":
+            lib.crh_scene_destroy(scene.handle)  # the frame's render is still pending: it is settled here
+            scene.handle = None
+            assert np.array_equal(frame.download(), expect)
+        else:
+            lib.crh_frame_destroy(frame.handle)
+            frame.handle = None
+            assert scene.status() == 0
