@@ -1254,10 +1254,22 @@ crh_status crh_composite_over(crh_renderer* r, const void* const* layers_dev, ui
     return CRH_OK;
 }
 crh_status crh_frame_synchronize(crh_frame* f) {
-    if (!f) return CRH_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipSetDevice(f->renderer->device));
+    if (!f || !f->renderer) return CRH_ERR_INVALID_ARGUMENT;
+    crh_renderer* r = f->renderer;
+    HIP_TRY(hipSetDevice(r->device));
     const crh_frame::BinSet& set = f->sets[f->last_set];
     if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
+    if (f->check_pending) {
+        // the frame's own flags, read on the side stream: only a frame that really ran out of tile-list or sort capacity pays for the
+        // full settle (which waits for everything in flight and renders the frame again)
+        uint32_t ov[4];
+        HIP_TRY(hipMemcpyAsync(ov, set.overflow.p, 16, hipMemcpyDeviceToHost, r->aux_stream));
+        HIP_TRY(hipStreamSynchronize(r->aux_stream));
+        const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
+        const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
+        if (ov[0] != 0 || ov[2] != 0 || sort_too_small) return settle_frame(f);
+        f->check_pending = false;
+    }
     return CRH_OK;
 }
 

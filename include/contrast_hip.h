@@ -261,7 +261,8 @@ crh_status crh_composite_over(crh_renderer* renderer, const void* const* layers_
 /* ---- stream plumbing ------------------------------------------------------------------------------- */
 crh_status crh_renderer_synchronize(crh_renderer* renderer);
 /* Blocks the host until the last render INTO THIS FRAME has finished; work queued afterwards (the next frame of a double-buffered
- * loop) keeps running. The resolved image behind crh_frame_device_pointer is then complete. */
+ * loop) keeps running. The resolved image behind crh_frame_device_pointer is then complete (a frame whose tile lists turned out too
+ * small is rendered again here, which waits for everything in flight — once, while the capacities are being learned). */
 crh_status crh_frame_synchronize(crh_frame* frame);
 /* hipStream_t of the renderer, as void* (for HIP events in bench.py). */
 void* crh_renderer_stream(crh_renderer* renderer);
