@@ -647,13 +647,16 @@ crh_status settle_frame(crh_frame* f) {
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
-    if ((ov[0] != 0 || sort_overflow) && f->last_scene) {
-        f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4);
-        f->cleared = true; // a frame rendered over existing content cannot be recovered exactly; documented in DESIGN.md
-        crh_status st = render_impl(f->last_scene, f);
-        if (st != CRH_OK) return st;
-        HIP_TRY(r->sync());
-        f->check_pending = false;
+    if (ov[0] != 0 || sort_overflow) {
+        f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4); // learned either way
+        // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
+        if (f->last_scene && !f->cleared) {
+            f->cleared = true; // the pass is drawn again from scratch (only cleared frames take the optimistic path, see render_impl)
+            crh_status st = render_impl(f->last_scene, f);
+            if (st != CRH_OK) return st;
+            HIP_TRY(r->sync());
+            f->check_pending = false;
+        }
     }
     return CRH_OK;
 }
@@ -1153,6 +1156,11 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
 }
 crh_status crh_scene_render_resident(crh_scene* sc, crh_frame* f) {
     if (!sc || !f || f->renderer != sc->renderer) return CRH_ERR_INVALID_ARGUMENT;
+    if (f->check_pending && !f->cleared) { // what the frame shows has to be final before the pass that produced it is forgotten
+        HIP_TRY(hipSetDevice(sc->renderer->device));
+        const crh_status st = settle_frame(f);
+        if (st != CRH_OK) return st;
+    }
     f->n_items = 0; // the plain pass: Stencil + Color of every Shape
     return render_impl(sc, f);
 }
@@ -1219,6 +1227,10 @@ crh_status crh_frame_download(crh_frame* f, void* rgba8) {
     HIP_TRY(hipSetDevice(r->device));
     crh_status st = settle_frame(f);
     if (st != CRH_OK) return st;
+    if (f->cleared) { // LoadOp::Clear without a pass since: transparent
+        memset(rgba8, 0, (size_t)f->width * f->height * 4);
+        return CRH_OK;
+    }
     HIP_TRY(hipMemcpyAsync(rgba8, f->rgba8.p, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
     return CRH_OK;

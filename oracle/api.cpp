@@ -128,13 +128,26 @@ int oracle_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint3
 // A recorded render pass: draws[i] = {shape, instance, op (crh_render_op), clip_depth, alpha_layer}, executed in order into a cleared frame.
 // `depth_state` (optional) = {cull_mode, depth_compare, depth_write_enabled}; `depth` (optional, with depth_state) = the depth attachment
 // [height][width][msaa] the pass starts from and, on return, what it left there.
+// `load_rgba8` (optional): LoadOp::Load — the pass starts from this resolved image (every sample of a pixel = its RGBA8 value / 255).
+int oracle_render_pass_over(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
+                            const uint32_t* depth_state, float* depth, const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws,
+                            const uint8_t* load_rgba8, uint8_t* rgba8);
 int oracle_render_pass(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
                        const uint32_t* depth_state, float* depth, const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws,
                        uint8_t* rgba8) {
+    return oracle_render_pass_over(h, width, height, msaa, winding_bits, clip_bits, alpha_layers, depth_state, depth, transforms, colors, draws, n_draws, nullptr, rgba8);
+}
+int oracle_render_pass_over(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, uint32_t clip_bits, uint32_t alpha_layers,
+                            const uint32_t* depth_state, float* depth, const float* transforms, const float* colors, const uint32_t* draws, uint32_t n_draws,
+                            const uint8_t* load_rgba8, uint8_t* rgba8) {
     Scene* sc = static_cast<Scene*>(h);
     if (!(msaa == 1 || msaa == 4) || winding_bits == 0 || winding_bits + clip_bits > 8) return CRH_ERR_INVALID_ARGUMENT;
     Frame f;
     f.create(width, height, msaa, winding_bits, clip_bits, alpha_layers);
+    if (load_rgba8)
+        for (size_t p = 0; p < (size_t)width * height; ++p)
+            for (uint32_t s = 0; s < msaa; ++s)
+                for (int c = 0; c < 4; ++c) f.color[(p * msaa + s) * 4 + c] = (float)load_rgba8[p * 4 + c] * (1.0f / 255.0f);
     if (depth_state) {
         f.cull_mode = depth_state[0];
         f.depth_compare = depth_state[1];

