@@ -298,6 +298,7 @@ def test_random_api_sequences_against_a_host_model(seed, oracle_lib):
             if rng.uniform() < 0.6:
                 frames[j].clear()
                 cleared[j] = True
+                model[j] = np.zeros_like(model[j])
             n = host[k]["batch"].n_shapes
             draws = [d for i in range(n) for d in ((i, i, int(Op.Stencil), 0, 0), (i, i, int(Op.Color), 0, 0))]
             if op == 4 and n >= 3:  # recorded: shape 0 clips the rest
@@ -312,12 +313,16 @@ def test_random_api_sequences_against_a_host_model(seed, oracle_lib):
                     gpu_scenes[k].render(frames[j])
             model[j], _ = render_pass(host[k]["oracle"], w, h, msaa, 4, 2, 2, host[k]["transforms"], host[k]["colors"], draws, load=None if cleared[j] else model[j])
             cleared[j] = False
-        elif op == 5:  # a dynamic stroke option update (no re-tessellation, renderer.rs:360-376); the oracle keeps descriptors per Shape
-            pass  # covered by test_set_dynamic_stroke_options_rerenders_without_retessellation; the host model here has no descriptor hook
-        else:  # a late download
+        elif op == 5:  # tessellate again (same geometry: the frames in flight must not notice), or clear a frame without drawing
+            if rng.uniform() < 0.5:
+                gpu_scenes[k].tessellate()
+            else:
+                j = int(rng.randint(0, 2))
+                frames[j].clear()
+                cleared[j] = True
+                model[j] = np.zeros_like(model[j])
+        else:  # a late download (a cleared frame is transparent)
             j = int(rng.randint(0, 2))
-            if not cleared[j]:
-                assert np.array_equal(frames[j].download(), model[j]), f"seed {seed} step {step}: frame {j} differs"
+            assert np.array_equal(frames[j].download(), model[j]), f"seed {seed} step {step}: frame {j} differs"
     for j in range(2):
-        if not cleared[j]:
-            assert np.array_equal(frames[j].download(), model[j]), f"seed {seed}: final frame {j} differs"
+        assert np.array_equal(frames[j].download(), model[j]), f"seed {seed}: final frame {j} differs"
