@@ -166,6 +166,7 @@ struct crh_frame {
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
     uint32_t n_items = 0;
+    int last_instances = 0;        // which of the scene's two instance buffers the last plain pass read
     bool items_projective = false; // some instance of the recorded pass is not plain (perspective, or a varying / out-of-range clip.z)
     DevBuf depth;                  // [height][width][samples] f32, when the configuration tests or writes depth
     bool cleared = true;
@@ -197,7 +198,12 @@ struct crh_scene {
     DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch;
     DevBuf prim_rec[kPipelineDepth];    // set-up triangles, one buffer per frame in flight like the frame's binning buffers
     DevBuf prim_proj[kPipelineDepth];                // 1/w and z/w planes of the primitives of projective instances (allocated on first use)
-    bool instances_projective = false;
+    bool instances_projective = false;  // of the current instance buffer
+    // Instance data is double-buffered: crh_scene_set_instances writes the buffer the latest frame did NOT use, so that frame — whose
+    // deferred tile-list check may still ask for it to be drawn again — needs no wait; only a frame two updates old is settled first.
+    DevBuf transforms_b, colors_b;
+    int instances_cur = 0;
+    bool instances_projective_of[2] = {false, false};
     hipEvent_t rec_raster_done[kPipelineDepth] = {};
     bool rec_used[kPipelineDepth] = {};
     int next_rec = 0;
@@ -215,7 +221,7 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &shape_ncand, &shape_prim_begin, &prim_scan_scratch};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch};
         for (DevBuf* b : all) b->release();
         for (DevBuf& b : prim_rec) b.release();
         for (DevBuf& b : prim_proj) b.release();
@@ -497,6 +503,7 @@ uint32_t depth_pass_mask(uint32_t compare) { // bit 0: fragment < stored passes,
 }
 
 crh_status settle_frame(crh_frame* f);
+crh_status settle_frame_cheaply(crh_frame* f);
 // The check whether a frame's optimistic tile-list capacity sufficed is deferred to the next call that synchronises; its remedy renders
 // the frame again FROM THE SCENE, so the scene must still hold what the frame shows: everything that changes a scene (new geometry,
 // instance data, stroke descriptors, destruction) first settles the frames that were rendered from it.
@@ -513,7 +520,8 @@ crh_status settle_frames_of(crh_scene* sc, bool forget) {
     return result;
 }
 
-crh_status render_impl(crh_scene* sc, crh_frame* f) {
+// `again`: the remedy of settle_frame — the frame's last pass once more, from the instance buffer it used
+crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     crh_renderer* r = sc->renderer;
     if (!f->cleared && f->check_pending) { // rendering over existing content: that content has to be final
         const crh_status st = settle_frame(f);
@@ -542,8 +550,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     p.items = recorded ? f->items.as<DrawItem>() : nullptr;
     p.n_items = recorded ? f->n_items : sc->d.n_shapes;
     p.load_existing = f->cleared ? 0u : 1u;
-    p.transforms = recorded ? f->item_transforms.as<float>() : sc->transforms.as<float>();
-    p.colors = recorded ? f->item_colors.as<float>() : sc->colors.as<float>();
+    const int inst = again ? f->last_instances : sc->instances_cur;
+    if (!recorded) f->last_instances = inst;
+    p.transforms = recorded ? f->item_transforms.as<float>() : (inst ? sc->transforms_b : sc->transforms).as<float>();
+    p.colors = recorded ? f->item_colors.as<float>() : (inst ? sc->colors_b : sc->colors).as<float>();
     p.tile_count = set.tile_count_cursor.as<uint32_t>();
     p.tile_cursor = set.tile_count_cursor.as<uint32_t>() + f->n_tiles;
     p.tile_offset = set.tile_offset.as<uint32_t>();
@@ -574,7 +584,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f) {
     }
     p.scan_scratch = set.scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec[rec].p);
-    const bool projective = recorded ? f->items_projective : sc->instances_projective;
+    const bool projective = recorded ? f->items_projective : sc->instances_projective_of[inst];
     p.prim_proj = nullptr;
     if (projective) {
         HIP_TRY(sc->prim_proj[rec].ensure((size_t)p.prim_capacity * 32));
@@ -652,12 +662,28 @@ crh_status settle_frame(crh_frame* f) {
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
             f->cleared = true; // the pass is drawn again from scratch (only cleared frames take the optimistic path, see render_impl)
-            crh_status st = render_impl(f->last_scene, f);
+            crh_status st = render_impl(f->last_scene, f, true);
             if (st != CRH_OK) return st;
             HIP_TRY(r->sync());
             f->check_pending = false;
         }
     }
+    return CRH_OK;
+}
+// Waits for the last render into this frame only, reads the frame's own flags on the side stream, and pays for the full settle (which
+// waits for everything in flight and draws the frame again) only when the frame really ran out of tile-list or sort capacity.
+crh_status settle_frame_cheaply(crh_frame* f) {
+    crh_renderer* r = f->renderer;
+    const crh_frame::BinSet& set = f->sets[f->last_set];
+    if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
+    if (!f->check_pending) return CRH_OK;
+    uint32_t ov[4];
+    HIP_TRY(hipMemcpyAsync(ov, set.overflow.p, 16, hipMemcpyDeviceToHost, r->aux_stream));
+    HIP_TRY(hipStreamSynchronize(r->aux_stream));
+    const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
+    const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
+    if (ov[0] != 0 || ov[2] != 0 || sort_too_small) return settle_frame(f);
+    f->check_pending = false;
     return CRH_OK;
 }
 } // namespace
@@ -1141,16 +1167,25 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
         if (!std::isfinite(transforms[i])) return CRH_ERR_NON_FINITE;
     for (size_t i = 0; i < (size_t)sc->d.n_shapes * 4; ++i)
         if (!std::isfinite(colors[i])) return CRH_ERR_NON_FINITE; // Color = SafeFloat<f32, 4> (renderer.rs:16)
-    {
-        const crh_status pending = settle_frames_of(sc, false);
-        if (pending != CRH_OK) return pending;
-    }
+    const int next = sc->instances_set ? sc->instances_cur ^ 1 : sc->instances_cur;
+    for (crh_frame* f : r->frames) // a frame that would be drawn again from the buffer about to be overwritten (two updates old: long done)
+        if (f->last_scene == sc && f->check_pending && f->n_items == 0 && f->last_instances == next) {
+            const crh_status st = settle_frame_cheaply(f);
+            if (st != CRH_OK) return st;
+        }
+    DevBuf& tb = next ? sc->transforms_b : sc->transforms;
+    DevBuf& cb = next ? sc->colors_b : sc->colors;
     if (sc->d.n_shapes) {
-        HIP_TRY(hipMemcpyAsync(sc->transforms.p, transforms, (size_t)sc->d.n_shapes * 64, hipMemcpyHostToDevice, r->stream));
-        HIP_TRY(hipMemcpyAsync(sc->colors.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->stream));
-        HIP_TRY(r->sync());
+        HIP_TRY(tb.ensure((size_t)sc->d.n_shapes * 64));
+        HIP_TRY(cb.ensure((size_t)sc->d.n_shapes * 16));
+        // on the binning stream, whose k_prim_setup is the only reader: ordered after the setup of the frame that last read this buffer and
+        // before the next one, with no host synchronisation (the host arrays are consumed before the calls return: pageable memory)
+        HIP_TRY(hipMemcpyAsync(tb.p, transforms, (size_t)sc->d.n_shapes * 64, hipMemcpyHostToDevice, r->binning_stream()));
+        HIP_TRY(hipMemcpyAsync(cb.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->binning_stream()));
     }
-    sc->instances_projective = !all_instances_plain(transforms, sc->d.n_shapes);
+    sc->instances_cur = next;
+    sc->instances_projective_of[next] = !all_instances_plain(transforms, sc->d.n_shapes);
+    sc->instances_projective = sc->instances_projective_of[next];
     sc->instances_set = true;
     return CRH_OK;
 }
@@ -1269,20 +1304,7 @@ crh_status crh_frame_synchronize(crh_frame* f) {
     if (!f || !f->renderer) return CRH_ERR_INVALID_ARGUMENT;
     crh_renderer* r = f->renderer;
     HIP_TRY(hipSetDevice(r->device));
-    const crh_frame::BinSet& set = f->sets[f->last_set];
-    if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
-    if (f->check_pending) {
-        // the frame's own flags, read on the side stream: only a frame that really ran out of tile-list or sort capacity pays for the
-        // full settle (which waits for everything in flight and renders the frame again)
-        uint32_t ov[4];
-        HIP_TRY(hipMemcpyAsync(ov, set.overflow.p, 16, hipMemcpyDeviceToHost, r->aux_stream));
-        HIP_TRY(hipStreamSynchronize(r->aux_stream));
-        const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
-        const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
-        if (ov[0] != 0 || ov[2] != 0 || sort_too_small) return settle_frame(f);
-        f->check_pending = false;
-    }
-    return CRH_OK;
+    return settle_frame_cheaply(f);
 }
 
 crh_status crh_selftest_fmath(crh_renderer* r, int fn, const float* a, const float* b, float* out, uint64_t n) {
