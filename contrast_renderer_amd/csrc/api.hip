@@ -756,6 +756,26 @@ crh_status crh_convert_dynamic_stroke_options(const crh_dynamic_stroke_options* 
 
 crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene* existing, crh_scene** out) {
     if (!r || !b || !out) return CRH_ERR_INVALID_ARGUMENT;
+    // ---- structure of the batch: a C ABI cannot trust its index arrays (the Rust types make these states unrepresentable)
+    {
+        auto prefix_ok = [](const uint32_t* a, uint32_t n, uint32_t total) {
+            if (!a || a[0] != 0u || a[n] != total) return false;
+            for (uint32_t i = 0; i < n; ++i)
+                if (a[i] > a[i + 1]) return false;
+            return true;
+        };
+        if (!prefix_ok(b->shape_path_begin, b->n_shapes, b->n_paths) || !prefix_ok(b->path_segment_begin, b->n_paths, b->n_segments)) return CRH_ERR_INVALID_ARGUMENT;
+        if (b->shape_dynamic_begin ? !prefix_ok(b->shape_dynamic_begin, b->n_shapes, b->n_dynamic_stroke_options) : b->n_dynamic_stroke_options != 0u) return CRH_ERR_INVALID_ARGUMENT;
+        if ((b->n_paths && (!b->path_start || !b->path_stroke_options)) || (b->n_segments && !b->segment_types) || (b->n_control_floats && !b->control_data) ||
+            (b->n_stroke_options && !b->stroke_options) || (b->n_dynamic_stroke_options && !b->dynamic_stroke_options))
+            return CRH_ERR_INVALID_ARGUMENT;
+        uint64_t floats = 0;
+        for (uint32_t g = 0; g < b->n_segments; ++g) {
+            if (b->segment_types[g] > 4) return CRH_ERR_INVALID_ARGUMENT;
+            floats += (uint64_t)kSegmentFloats[b->segment_types[g]];
+        }
+        if (floats != b->n_control_floats) return CRH_ERR_INVALID_ARGUMENT;
+    }
     // ---- validation: what the reference rejects with Err(..) before any arithmetic (renderer.rs:188-191, :210-215)
     std::vector<crh_dynamic_stroke_descriptor> descriptors(b->n_dynamic_stroke_options);
     for (uint32_t i = 0; i < b->n_dynamic_stroke_options; ++i) {

@@ -326,3 +326,61 @@ def test_random_api_sequences_against_a_host_model(seed, oracle_lib):
             assert np.array_equal(frames[j].download(), model[j]), f"seed {seed} step {step}: frame {j} differs"
     for j in range(2):
         assert np.array_equal(frames[j].download(), model[j]), f"seed {seed}: final frame {j} differs"
+
+
+@pytest.mark.gpu
+def test_malformed_batches_are_rejected_not_read_out_of_bounds(oracle_lib):
+    """The C ABI cannot trust the index arrays of a crh_path_batch (the Rust types make these states unrepresentable): prefix arrays that
+    do not start at 0, decrease or end beyond the element counts, segment types out of range, a float count that does not match the
+    segment types, missing arrays — each is CRH_ERR_INVALID_ARGUMENT, and the valid batch still uploads afterwards."""
+    import copy
+    import ctypes as C
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import _ffi
+    from contrast_renderer_amd import renderer as R
+    sc = scenes.scene_mixed(6, (128, 128), seed=3)
+    batch = sc["batch"]
+    r = R.Renderer(R.Configuration(1, 4, 4), device=0)
+    lib = r.lib
+
+    def upload(c_struct):
+        handle = C.c_void_p()
+        status = lib.crh_scene_upload(r.handle, C.byref(c_struct), None, C.byref(handle))
+        if status == 0:
+            lib.crh_scene_destroy(handle)
+        return status
+
+    assert upload(batch.c) == 0
+    keep = []  # numpy arrays behind the patched pointers
+
+    def variant(edit):
+        c = _ffi.PathBatchC()
+        C.memmove(C.byref(c), C.byref(batch.c), C.sizeof(c))
+        edit(c)
+        return c
+
+    def patched(field, ctype, values):
+        arr = np.ascontiguousarray(values)
+        keep.append(arr)
+        return lambda c: setattr(c, field, arr.ctypes.data_as(C.POINTER(ctype)))
+
+    spb, psb = batch.shape_path_begin.copy(), batch.path_segment_begin.copy()
+    cases = {
+        "shape prefix does not start at 0": patched("shape_path_begin", C.c_uint32, spb + 1),
+        "shape prefix decreases": patched("shape_path_begin", C.c_uint32, np.concatenate([spb[:2][::-1], spb[2:]]) if spb[1] > 0 else spb[::-1]),
+        "shape prefix ends beyond the paths": patched("shape_path_begin", C.c_uint32, np.concatenate([spb[:-1], [spb[-1] + 5]]).astype(np.uint32)),
+        "path prefix ends beyond the segments": patched("path_segment_begin", C.c_uint32, np.concatenate([psb[:-1], [psb[-1] + 1000]]).astype(np.uint32)),
+        "path prefix decreases": patched("path_segment_begin", C.c_uint32, np.concatenate([[0, psb[-1]], psb[2:]]).astype(np.uint32)),
+        "segment type out of range": patched("segment_types", C.c_uint8, np.where(np.arange(len(batch.segment_types)) == 3, 9, batch.segment_types).astype(np.uint8)),
+        "float count too large": lambda c: setattr(c, "n_control_floats", c.n_control_floats + 7),
+        "float count too small": lambda c: setattr(c, "n_control_floats", c.n_control_floats - 2),
+        "segment count too large": lambda c: setattr(c, "n_segments", c.n_segments + 1),
+        "no control data": lambda c: setattr(c, "control_data", C.POINTER(C.c_float)()),
+        "no start points": lambda c: setattr(c, "path_start", C.POINTER(C.c_float)()),
+        "dynamic options without a prefix": lambda c: setattr(c, "shape_dynamic_begin", C.POINTER(C.c_uint32)()),
+        "stroke options index out of range": patched("path_stroke_options", C.c_int32, np.where(batch.path_stroke_options >= 0, 10 ** 6, batch.path_stroke_options).astype(np.int32)),
+    }
+    for name, edit in cases.items():
+        assert upload(variant(edit)) == _ffi.ERR_INVALID_ARGUMENT, name
+    assert upload(batch.c) == 0
