@@ -1085,7 +1085,8 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* sc, uint32_t shape, u
 }
 
 crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, crh_frame** out) {
-    if (!r || !out || width == 0 || height == 0 || width > 65535u * 16u || height > 65535u * 16u) return CRH_ERR_INVALID_ARGUMENT;
+    // pixel boxes are 16-bit (0xFFFF = nothing to draw), so a frame is at most 65 535 pixels wide and high
+    if (!r || !out || width == 0 || height == 0 || width > 65535u || height > 65535u) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     crh_frame* f = new crh_frame;
     f->renderer = r;
