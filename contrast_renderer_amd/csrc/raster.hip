@@ -203,34 +203,11 @@ __global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int
 }
 
 // ---------------------------------------------------------------------------------------------- exact tile test
-// An edge function E = fma(rx, nay, fma(ry, bx, c)) is monotone in rx and in ry (fmaf rounds monotonically), so its extremes over a
-// box of sample positions sit at the corners. Sample positions inside a tile span [s_lo, 15 + s_hi] in x and in y.
-//   tile_hit : the triangle's pixel box overlaps the tile and no edge rejects its best tile corner — a conservative superset of "some
-//              sample of the tile is covered" (three half planes each touching the tile do not imply a common point); the raster kernel
-//              decides per sample
-template <int S>
-struct TileTest {
-    float ec[3];
-    bool overlap;
-    CRH_D TileTest(const PrimCoverage& cov, uint32_t tx, uint32_t ty) {
-        const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
-        overlap = (int)cov.box.x <= tpx + kTile - 1 && (int)cov.box.y >= tpx && (int)cov.box.z <= tpy + kTile - 1 && (int)cov.box.w >= tpy;
-        const float tx0 = (float)tpx, ty0 = (float)tpy;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ec[i] = cov.bx[i] * (ty0 - cov.lo_y[i]) + cov.nay[i] * (tx0 - cov.lo_x[i]);
-    }
-    CRH_D bool accepts(const PrimCoverage& cov, int i, float x, float y) const {
-        const float e = fmaf(x, cov.nay[i], fmaf(y, cov.bx[i], ec[i]));
-        return e > 0.0f || (e == 0.0f && ((cov.flags >> i) & 1u));
-    }
-    CRH_D bool tile_hit(const PrimCoverage& cov) const {
-        const float lo = S == 1 ? 0.5f : 0.125f, hi = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f);
-        bool hit = overlap;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) hit = hit && accepts(cov, i, cov.nay[i] > 0.0f ? hi : lo, cov.bx[i] > 0.0f ? hi : lo);
-        return hit;
-    }
-};
+// An edge function E = fma(ry, bx, fma(rx, nay, c)) is monotone in rx and in ry (fmaf rounds monotonically), so its extremes over a
+// box of sample positions sit at the corners. Sample positions inside a tile span [s_lo, 15 + s_hi] in x and in y. A tile is a hit of
+// a triangle when the triangle's pixel box overlaps it and no edge rejects its best tile corner — a conservative superset of "some
+// sample of the tile is covered" (three half planes each touching the tile do not imply a common point); the raster kernel decides per
+// sample. The test itself is written out in k_tile_walk, with the tile-invariant parts hoisted.
 
 // tile rectangle that bounds the pixel boxes of the wave's (up to 64) triangles; false when no lane draws anything
 CRH_D bool wave_tile_rect(bool valid, const PrimCoverage& cov, uint32_t& tx0, uint32_t& tx1, uint32_t& ty0, uint32_t& ty1) {
@@ -604,10 +581,33 @@ __global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, Raste
             const uint32_t base = __shfl(pending_base, 0, 64);
             if ((pending_ballot >> lane) & 1ull) r.tile_list[base + (uint32_t)__popcll(pending_ballot & ((1ull << lane) - 1ull))] = pending_entry;
         };
-        for (uint32_t ty = ty_a + wave; ty <= ty_b; ty += kWalkWaves)
+        // TileTest with everything that does not depend on the tile hoisted out of the loops (the same operations in the same order: the
+        // result is bit-identical): the best corner of every edge, the row term of the edge constants, the row half of the box test
+        float best_x[3], best_y[3];
+        {
+            const float lo = S == 1 ? 0.5f : 0.125f, hi = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                best_x[i] = cov.nay[i] > 0.0f ? hi : lo;
+                best_y[i] = cov.bx[i] > 0.0f ? hi : lo;
+            }
+        }
+        const int tl0 = (int)(cov.flags & 1u), tl1 = (int)((cov.flags >> 1) & 1u), tl2 = (int)((cov.flags >> 2) & 1u);
+        for (uint32_t ty = ty_a + wave; ty <= ty_b; ty += kWalkWaves) {
+            const int tpy = (int)(ty * kTile);
+            const bool row_overlap = drawn && (int)cov.box.z <= tpy + kTile - 1 && (int)cov.box.w >= tpy;
+            const float ty0 = (float)tpy;
+            float row_term[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) row_term[i] = cov.bx[i] * (ty0 - cov.lo_y[i]);
             for (uint32_t tx = tx_a; tx <= tx_b; ++tx) {
-                const TileTest<S> test(cov, tx, ty);
-                const bool hit = drawn && test.tile_hit(cov);
+                const int tpx = (int)(tx * kTile);
+                const float tx0 = (float)tpx;
+                bool hit = row_overlap && (int)cov.box.x <= tpx + kTile - 1 && (int)cov.box.y >= tpx;
+                const float e0 = fmaf(best_y[0], cov.bx[0], fmaf(best_x[0], cov.nay[0], row_term[0] + cov.nay[0] * (tx0 - cov.lo_x[0])));
+                const float e1 = fmaf(best_y[1], cov.bx[1], fmaf(best_x[1], cov.nay[1], row_term[1] + cov.nay[1] * (tx0 - cov.lo_x[1])));
+                const float e2 = fmaf(best_y[2], cov.bx[2], fmaf(best_x[2], cov.nay[2], row_term[2] + cov.nay[2] * (tx0 - cov.lo_x[2])));
+                hit = hit && (e0 > 0.0f || (e0 == 0.0f && tl0)) && (e1 > 0.0f || (e1 == 0.0f && tl1)) && (e2 > 0.0f || (e2 == 0.0f && tl2));
                 const unsigned long long ballot = __ballot(hit);
                 if (!ballot) continue;
                 const uint32_t tile = ty * r.tiles_x + tx;
@@ -622,6 +622,7 @@ __global__ __launch_bounds__(64 * kWalkWaves) void k_tile_walk(SceneDev s, Raste
                     pending_base = base;
                 }
             }
+        }
         if (FILL) flush();
     }
 }
