@@ -25,7 +25,7 @@
 #include "scene.hpp"
 
 #ifndef CRH_TILE_WAVES
-#define CRH_TILE_WAVES 5
+#define CRH_TILE_WAVES 6
 #endif
 #ifndef CRH_WALK_WAVES
 #define CRH_WALK_WAVES 2
@@ -713,9 +713,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             sy0[k] = (float)(first_row + rq) + oy[k & 3];
         }
     }
-    uint32_t row_bit[ROWS]; // bit of the lane's row b in a 16-bit row mask
-#pragma unroll
-    for (int b = 0; b < ROWS; ++b) row_bit[b] = 1u << (first_row + 4u * b + rq);
+    const uint32_t row_shift = first_row + rq; // the lane's row b is bit row_shift + 4b of a 16-bit row mask
     int winding[ROWS][S];
     int clipc[OPS ? ROWS : 1][OPS ? S : 1];                        // clip nesting counter (the upper stencil bits, renderer.rs:565)
     float saved[OPS ? ROWS : 1][OPS ? S : 1][kMaxAlphaLayers];     // alpha-context layers (renderer.rs:892-927)
@@ -910,7 +908,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             {
                 const uint32_t bits = __float_as_uint(ea4.w);
                 const float c0 = ea4.x, c1 = ea4.y, c2 = ea4.z, bx_0 = eb4.x, bx_1 = eb4.y, bx_2 = eb4.z, nay_0 = ec4.x, nay_1 = ec4.y, nay_2 = ec4.z;
-                const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) : 0u;
+                const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) >> row_shift : 0u; // bit 4b: the lane's row b is inside the box
                 const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
                 // E = fma(ry, bx, fma(rx, nay, c)): the column term is shared by the rows of the lane (one fma per edge and sample position)
                 float ha[S], hb[S], hc[S];
@@ -928,8 +926,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     const f32x2 ea = fma2(y, splat2(bx_0), f32x2{ha[k0], ha[k1]});
                     const f32x2 eb = fma2(y, splat2(bx_1), f32x2{hb[k0], hb[k1]});
                     const f32x2 ec = fma2(y, splat2(bx_2), f32x2{hc[k0], hc[k1]});
-                    inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & row_bit[b0]) != 0u);
-                    inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & row_bit[b1]) != 0u);
+                    inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & (1u << (4 * b0))) != 0u);
+                    inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & (1u << (4 * b1))) != 0u);
                 }
             }
             // projective instances (oracle/raster.hpp raster_projective): per-sample near / far test on z/w, and 1 / (1/w) for the attributes
