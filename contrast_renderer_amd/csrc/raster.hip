@@ -27,6 +27,9 @@
 #ifndef CRH_TILE_WAVES
 #define CRH_TILE_WAVES 6
 #endif
+#ifndef CRH_XCD_BLOCK_LOG2
+#define CRH_XCD_BLOCK_LOG2 3 // the raster kernel's XCD blocks are 8x8 tiles
+#endif
 #ifndef CRH_WALK_WAVES
 #define CRH_WALK_WAVES 2
 #endif
@@ -688,9 +691,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2). The frame is cut into 8x8-tile blocks dealt to the
     // XCDs in turn (spatially interleaved, so an unevenly filled frame still loads all eight), and an XCD walks a block's 64 tiles back to
     // back: a primitive record shared by neighbouring tiles is fetched into one L2 instead of up to eight. launch_raster pads the grid.
+    constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
     const uint32_t turn = blockIdx.x >> 3;
-    const uint32_t blocks_x = (r.tiles_x + 7u) >> 3, block = (turn >> 6) * 8u + (blockIdx.x & 7u);
-    const uint32_t tx = (block % blocks_x) * 8u + (turn & 7u), ty = (block / blocks_x) * 8u + ((turn >> 3) & 7u);
+    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
+    const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
     if (tx >= r.tiles_x || ty >= r.tiles_y) return;
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1253,8 +1257,9 @@ void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hip
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
                    uint64_t raster_bytes, bool has_stroke) {
     // 8x8-tile blocks, an equal number per XCD (k_raster_tile's tile order)
-    const uint32_t blocks = ((r.tiles_x + 7u) / 8u) * ((r.tiles_y + 7u) / 8u);
-    const dim3 grid(((blocks + 7u) / 8u) * 64u * 8u);
+    constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
+    const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
+    const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
     hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {
