@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* __restrict__ keys = sort_buffer + wave * r.sort_capacity;
     const uint32_t px = lane & 15u, rq = lane >> 4;
-    const uint32_t first_row = ROWS == 4 ? 0u : 4u * wave; // local row b of this lane is pixel row first_row + 4b + rq
+    const uint32_t first_row = 4u * ROWS * wave; // local row b of this lane is pixel row first_row + 4b + rq (ROWS == 4: one wavefront, wave == 0)
     const uint32_t gx = tx * kTile + px;
     const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
     const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
