@@ -4,17 +4,18 @@
 // The frame is cut into 16x16-pixel tiles; one wavefront owns one tile (msaa 1: lane = column x row group, four pixels per lane; msaa 4:
 // four wavefronts per tile, one pixel x four samples per lane), so the stencil byte of the reference (winding counter, clip nesting
 // counter), the saved alpha layers and the colour of a sample never leave the owning lane's registers, and no workgroup barrier is
-// needed anywhere in the raster kernel.
+// needed anywhere in the raster kernel (except in the rare tile whose list is too long for LDS and is sorted in global memory).
 //
 //   k_scan_*           two-kernel exclusive scan (primitive ranges per Shape / draw item, tile list offsets per frame)
-//   k_prim_setup<S>    one wavefront per draw item (= Shape in the plain pass), one lane per triangle: vertex stage (shaders.wgsl:13-27,
+//   k_prim_setup<S,P>  one wavefront per draw item (= Shape in the plain pass), one lane per triangle: vertex stage (shaders.wgsl:13-27,
 //                      66-151), edge functions in canonical orientation, clamped pixel box, attribute planes -> a 128-byte record, once
 //                      per frame. Primitive ids are contiguous per item and ascend in draw order (item, then line / joint / solid / IQ /
 //                      IC / RQ / RC / cover = renderer.rs:275-354).
 //   k_tile_walk<S,F>   count pass (F = false) and fill pass (F = true) of the per-tile lists: kWalkWaves wavefronts per item, lane =
 //                      triangle, exact tile test (an edge function is monotone in x and y under fmaf, so the best tile corner
 //                      decides), ballot + popcount -> ONE atomic per (64-triangle chunk, tile); the fill pass writes prim ids.
-//   k_raster_tile<..>  sorts the tile's list by prim id (= draw order) in registers / LDS and walks it; see the kernel's comment.
+//   k_raster_tile<..>  sorts the tile's list by prim id (= draw order) in registers / LDS / global memory and walks it; see the kernel's
+//                      comment. Workgroup b runs on XCD b % 8: tiles are dealt to the XCDs in 8x8 blocks (L2 locality of the records).
 //   Coverage and attribute arithmetic follow oracle/raster.hpp operation by operation (tile-relative constants, explicit fmaf), so
 //   pixels are bit-identical to the CPU spec.
 //
@@ -553,8 +554,9 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
 // ---------------------------------------------------------------------------------------------- k_tile_walk
 // Count pass (FILL = false) and fill pass (FILL = true) of the tile lists. One workgroup of kWalkWaves wavefronts per draw item; its
 // triangles are taken 64 at a time (lane = triangle) and wavefront w walks every kWalkWaves-th tile ROW of the chunk's tile rectangle,
-// so the largest Shapes (hundreds of tiles) do not leave one long serial tail (1 wave: 0.92 ms tail; 16 waves: idle waves dominate;
-// 4 measured best on the 10k-path scene).
+// so the largest Shapes (hundreds of tiles) do not leave one long serial tail. Stand-alone four wavefronts per item are fastest
+// (1: 0.92 ms tail; 16: idle waves dominate); with frames overlapping two are, because the walks then share the CUs
+// with the raster kernel and total work counts, not the tail.
 //   count: ballot of the lanes whose triangle can touch the tile -> ONE atomic per (chunk, tile)
 //   fill : lane 0 reserves popcount(ballot) slots of the tile's list with one returning atomic (consumed one iteration later, after
 //          the next tile's test has been computed, so its latency is hidden); every hit lane writes
