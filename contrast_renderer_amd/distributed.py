@@ -76,18 +76,14 @@ def gather_slabs(slab, rank: int, world: int, height: int, group=None):
     if rank == 0:
         image = torch.empty((height,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
         image[rows[0][0]:rows[0][1]].copy_(slab)
-        ops, parts = [], []
+        ops = []
         for peer in range(1, world):
             p0, p1 = rows[peer]
             if p1 > p0:
-                part = torch.empty((p1 - p0,) + tuple(slab.shape[1:]), dtype=slab.dtype, device=slab.device)
-                parts.append((p0, p1, part))
-                ops.append(dist.P2POp(dist.irecv, part, peer, group))
+                ops.append(dist.P2POp(dist.irecv, image[p0:p1], peer, group))  # a row range of a contiguous image is contiguous: received in place
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for p0, p1, part in parts:
-            image[p0:p1].copy_(part)
         return image
     if slab.shape[0] > 0:
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, slab.contiguous(), 0, group)]):
