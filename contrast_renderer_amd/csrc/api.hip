@@ -167,6 +167,14 @@ struct crh_frame {
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
     uint32_t n_items = 0;
     int last_instances = 0;        // which of the scene's two instance buffers the last plain pass read
+    // the recorded pass the frame holds: when the next crh_scene_render_draws records the same items over the same geometry, their upload,
+    // the per-item primitive ranges and the read-back of the primitive total are skipped (only the instance data is refreshed)
+    std::vector<DrawItem> items_host;
+    crh_scene* items_scene = nullptr;
+    uint64_t items_generation = 0;
+    uint32_t items_total = 0;
+    bool items_ranges_valid = false;
+    bool items_need_ops = false;   // the pass uses more than Stencil / Color at clip depth 0 (otherwise the plain raster kernel serves it)
     bool items_projective = false; // some instance of the recorded pass is not plain (perspective, or a varying / out-of-range clip.z)
     DevBuf depth;                  // [height][width][samples] f32, when the configuration tests or writes depth
     bool cleared = true;
@@ -203,6 +211,7 @@ struct crh_scene {
     // deferred tile-list check may still ask for it to be drawn again — needs no wait; only a frame two updates old is settled first.
     DevBuf transforms_b, colors_b;
     int instances_cur = 0;
+    uint64_t generation = 0;            // bumped by every upload: what a frame's cached recorded pass was built against
     bool instances_projective_of[2] = {false, false};
     hipEvent_t rec_raster_done[kPipelineDepth] = {};
     bool rec_used[kPipelineDepth] = {};
@@ -565,10 +574,14 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(f->item_ncand.ensure((size_t)f->n_items * 4 + 4));
         HIP_TRY(f->item_prim_begin.ensure(((size_t)f->n_items + 1) * 4));
         HIP_TRY(f->item_scan_scratch.ensure(((size_t)(f->n_items + 1023) / 1024 + 2) * 4));
-        launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), bin);
-        uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, bin));
-        HIP_TRY(r->sync());
+        uint32_t total = f->items_total;
+        if (!f->items_ranges_valid) {
+            launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), bin);
+            HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, bin));
+            HIP_TRY(r->sync());
+            f->items_total = total;
+            f->items_ranges_valid = true;
+        }
         if (total >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED;
         HIP_TRY(sc->prim_rec[rec].ensure(((size_t)total + 64) * 128));
         p.prim_capacity = total + 64u;
@@ -594,7 +607,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.depth_pass_mask = depth_pass_mask(r->config.depth_compare);
     p.depth_write = r->config.depth_write_enabled;
     p.cull_mode = r->config.cull_mode;
-    p.general = (projective || p.depth) ? 1u : 0u;
+    p.general = (projective || p.depth || (recorded && f->items_need_ops)) ? 1u : 0u;
     p.overflow = set.overflow.as<uint32_t>();
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
@@ -848,6 +861,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     crh_scene* sc = existing ? existing : new crh_scene;
     sc->renderer = r;
     sc->device = r->device;
+    static uint64_t next_generation = 1; // unique across scenes: a new Scene at a recycled address is not mistaken for the old one
+    sc->generation = next_generation++;
     if (!sc->tess_done) {
         if (!hip_ok(hipEventCreateWithFlags(&sc->tess_done, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&sc->vertices_free, hipEventDisableTiming), "hipEventCreate") ||
@@ -1227,7 +1242,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     HIP_TRY(hipSetDevice(r->device));
     if (r->config.alpha_layer_count > 4) return CRH_ERR_UNSUPPORTED;
     if (f->check_pending) { // the frame's recorded pass (its remedy for an overflowed tile list) is about to be replaced
-        const crh_status st = settle_frame(f);
+        const crh_status st = settle_frame_cheaply(f);
         if (st != CRH_OK) return st;
     }
     for (size_t i = 0; i < (size_t)n_instances * 16; ++i)
@@ -1236,8 +1251,10 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
         if (!std::isfinite(colors[i])) return CRH_ERR_NON_FINITE;
     // validation in recording order, as the reference's calls would fail (renderer.rs:933-935, :947-949, :980-982)
     std::vector<DrawItem> items;
+    bool need_ops = false;
     for (uint32_t i = 0; i < n_draws; ++i) {
         const crh_draw& d = draws[i];
+        need_ops = need_ops || !(d.op == CRH_OP_STENCIL || d.op == CRH_OP_COLOR) || d.clip_depth != 0u;
         if (d.shape >= sc->d.n_shapes || d.instance >= n_instances || d.op > CRH_OP_RESTORE_ALPHA_CONTEXT) return CRH_ERR_INVALID_ARGUMENT;
         if (d.clip_depth >= (1u << r->config.clip_nesting_counter_bits)) return CRH_ERR_CLIP_STACK_OVERFLOW;
         if (d.op >= CRH_OP_SAVE_ALPHA_CONTEXT && d.alpha_layer >= r->config.alpha_layer_count) return CRH_ERR_TOO_MANY_NESTED_OPACITY_GROUPS;
@@ -1260,6 +1277,20 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
         f->cleared = false;
         return CRH_OK;
     }
+    f->items_need_ops = need_ops;
+    const bool same_pass = f->items_ranges_valid && f->items_scene == sc && f->items_generation == sc->generation && f->n_items == items.size() &&
+                           f->items_host.size() == items.size() && memcmp(f->items_host.data(), items.data(), items.size() * sizeof(DrawItem)) == 0 &&
+                           f->item_transforms.cap >= (size_t)n_instances * 64 && f->item_colors.cap >= (size_t)n_instances * 16;
+    if (same_pass) {
+        // the same items over the same geometry (an animation: only the instance data moves): refresh the instance data on the binning
+        // stream — k_prim_setup, its only reader, runs there, so the copy is ordered behind the previous frame's setup — and render
+        // without a host synchronisation
+        HIP_TRY(hipMemcpyAsync(f->item_transforms.p, transforms, (size_t)n_instances * 64, hipMemcpyHostToDevice, r->binning_stream()));
+        HIP_TRY(hipMemcpyAsync(f->item_colors.p, colors, (size_t)n_instances * 16, hipMemcpyHostToDevice, r->binning_stream()));
+        f->items_projective = !all_instances_plain(transforms, n_instances);
+        return render_impl(sc, f);
+    }
+    HIP_TRY(r->sync()); // the buffers below may still be read by a frame in flight
     HIP_TRY(f->items.ensure(items.size() * sizeof(DrawItem)));
     HIP_TRY(f->item_transforms.ensure((size_t)n_instances * 64 + 64));
     HIP_TRY(f->item_colors.ensure((size_t)n_instances * 16 + 16));
@@ -1268,6 +1299,10 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     HIP_TRY(hipMemcpyAsync(f->item_colors.p, colors, (size_t)n_instances * 16, hipMemcpyHostToDevice, r->stream));
     HIP_TRY(r->sync()); // `items` and the caller's arrays may go away
     f->n_items = (uint32_t)items.size();
+    f->items_host = std::move(items);
+    f->items_scene = sc;
+    f->items_generation = sc->generation;
+    f->items_ranges_valid = false; // computed by render_impl together with the primitive total
     f->items_projective = !all_instances_plain(transforms, n_instances);
     f->pairs_known = false; // a different pass: re-learn the tile list size
     return render_impl(sc, f);

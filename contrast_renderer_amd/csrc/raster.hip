@@ -1265,13 +1265,13 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
     hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {
-        if (r.items || r.general) {
+        if (r.general) { // clip nesting / alpha contexts / depth / projective instances: the OPS variant
             if (has_stroke) CRH_LAUNCH_TILE(4, 1, true, true); else CRH_LAUNCH_TILE(4, 1, true, false);
         } else {
             if (has_stroke) CRH_LAUNCH_TILE(4, 1, false, true); else CRH_LAUNCH_TILE(4, 1, false, false);
         }
     } else {
-        if (r.items || r.general) {
+        if (r.general) { // clip nesting / alpha contexts / depth / projective instances: the OPS variant
             if (has_stroke) CRH_LAUNCH_TILE(1, 4, true, true); else CRH_LAUNCH_TILE(1, 4, true, false);
         } else {
             if (has_stroke) CRH_LAUNCH_TILE(1, 4, false, true); else CRH_LAUNCH_TILE(1, 4, false, false);

@@ -214,12 +214,15 @@ class Scene:
         t = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 16)
         c = np.ascontiguousarray(colors, dtype=np.float32).reshape(-1, 4)
         assert len(t) == len(c)
-        arr = (_ffi.DrawC * max(1, len(draws)))()
-        for i, d in enumerate(draws):
-            d = tuple(d) + (0,) * (5 - len(d))
-            arr[i] = _ffi.DrawC(int(d[0]), int(d[1]), int(d[2]), int(d[3]), int(d[4]))
+        if isinstance(draws, np.ndarray):  # [n, 5] uint32 = crh_draw records: passed as they are (an animation re-submits the same array)
+            table = np.ascontiguousarray(draws, dtype=np.uint32).reshape(-1, 5)
+        else:
+            table = np.zeros((len(draws), 5), dtype=np.uint32)
+            for i, d in enumerate(draws):
+                table[i, :len(d)] = [int(v) for v in d]
         fp = C.POINTER(C.c_float)
-        check(self.lib.crh_scene_render_draws(self.handle, frame.handle, t.ctypes.data_as(fp), c.ctypes.data_as(fp), len(t), arr, len(draws)))
+        check(self.lib.crh_scene_render_draws(self.handle, frame.handle, t.ctypes.data_as(fp), c.ctypes.data_as(fp), len(t),
+                                              table.ctypes.data_as(C.POINTER(_ffi.DrawC)), len(table)))
 
     def set_dynamic_stroke_options(self, shape_index, group_index, options):
         c = options.to_c()
