@@ -68,6 +68,46 @@ struct DevBuf {
     }
 };
 
+// Host -> device copies that must not stall the host: pageable memory makes hipMemcpyAsync wait for the stream, so the bytes are first
+// copied into one of two pinned staging buffers (the previous use of that buffer — two uploads ago — is waited for, normally long done)
+// and sent from there.
+struct PinnedUpload {
+    void* host[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    hipEvent_t sent[2] = {nullptr, nullptr};
+    int next = 0;
+    hipError_t copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+        if (bytes == 0) return hipSuccess;
+        const int k = next;
+        next ^= 1;
+        hipError_t e;
+        if (!sent[k] && (e = hipEventCreateWithFlags(&sent[k], hipEventDisableTiming)) != hipSuccess) return e;
+        if (cap[k] && (e = hipEventSynchronize(sent[k])) != hipSuccess) return e;
+        if (cap[k] < bytes) {
+            if (host[k]) (void)hipHostFree(host[k]);
+            host[k] = nullptr;
+            cap[k] = 0;
+            if ((e = hipHostMalloc(&host[k], bytes, hipHostMallocDefault)) != hipSuccess) return e;
+            cap[k] = bytes;
+        }
+        memcpy(host[k], src, bytes);
+        if ((e = hipMemcpyAsync(dst, host[k], bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        return hipEventRecord(sent[k], stream);
+    }
+    void release() {
+        for (int k = 0; k < 2; ++k) {
+            if (sent[k]) {
+                (void)hipEventSynchronize(sent[k]);
+                (void)hipEventDestroy(sent[k]);
+            }
+            if (host[k]) (void)hipHostFree(host[k]);
+            host[k] = nullptr;
+            sent[k] = nullptr;
+            cap[k] = 0;
+        }
+    }
+};
+
 struct Mark {
     hipEvent_t event;
     std::string name;
@@ -82,6 +122,7 @@ struct crh_renderer {
     hipStream_t stream;       // raster kernel, copies
     hipStream_t bin_stream;   // primitive setup + tile binning: frame N + 1's overlap frame N's raster kernel (double-buffered records / lists)
     hipStream_t tess_stream;  // tessellation: frame N + 1's (small, latency bound) kernels overlap frame N's binning and raster
+    hipStream_t upload_stream; // instance data of the next frame, copied while the current one is being binned
     hipStream_t aux_stream;   // crh_composite_over: the multi-GPU slab composite of frame N while frame N + 1 is being rendered
     void* composite_table = nullptr; // device array of layer pointers (aux stream)
     uint32_t composite_table_capacity = 0;
@@ -137,8 +178,27 @@ struct crh_renderer {
         const hipError_t e = hipStreamSynchronize(tess_stream);
         const hipError_t b = hipStreamSynchronize(bin_stream);
         const hipError_t a = hipStreamSynchronize(aux_stream);
+        (void)hipStreamSynchronize(upload_stream);
         const hipError_t f = hipStreamSynchronize(stream);
         return e != hipSuccess ? e : (b != hipSuccess ? b : (a != hipSuccess ? a : f));
+    }
+};
+
+// One of two sets of instance data (transforms + colours). Its copy runs on the upload stream, behind the k_prim_setup that last read
+// the set (read_done) and ahead of the one that reads it next (ready), so it overlaps the binning of the frame in between.
+struct InstanceSlot {
+    hipEvent_t read_done = nullptr, ready = nullptr;
+    bool was_read = false, was_written = false;
+    hipError_t init() {
+        if (read_done) return hipSuccess;
+        hipError_t e = hipEventCreateWithFlags(&read_done, hipEventDisableTiming);
+        return e != hipSuccess ? e : hipEventCreateWithFlags(&ready, hipEventDisableTiming);
+    }
+    void release() {
+        if (read_done) (void)hipEventDestroy(read_done);
+        if (ready) (void)hipEventDestroy(ready);
+        read_done = ready = nullptr;
+        was_read = was_written = false;
     }
 };
 
@@ -165,6 +225,10 @@ struct crh_frame {
     int next_set = 0, last_set = 0;
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
+    DevBuf item_transforms_b, item_colors_b; // second set of instance data: a re-submitted pass writes the set its predecessor did not read
+    int item_inst_cur = 0, item_inst_last = 0, item_projective_of[2] = {0, 0};
+    PinnedUpload item_upload_t, item_upload_c;
+    InstanceSlot item_slot[2];
     uint32_t n_items = 0;
     int last_instances = 0;        // which of the scene's two instance buffers the last plain pass read
     // the recorded pass the frame holds: when the next crh_scene_render_draws records the same items over the same geometry, their upload,
@@ -175,7 +239,6 @@ struct crh_frame {
     uint32_t items_total = 0;
     bool items_ranges_valid = false;
     bool items_need_ops = false;   // the pass uses more than Stencil / Color at clip depth 0 (otherwise the plain raster kernel serves it)
-    bool items_projective = false; // some instance of the recorded pass is not plain (perspective, or a varying / out-of-range clip.z)
     DevBuf depth;                  // [height][width][samples] f32, when the configuration tests or writes depth
     bool cleared = true;
     bool pairs_known = false;
@@ -210,6 +273,8 @@ struct crh_scene {
     // Instance data is double-buffered: crh_scene_set_instances writes the buffer the latest frame did NOT use, so that frame — whose
     // deferred tile-list check may still ask for it to be drawn again — needs no wait; only a frame two updates old is settled first.
     DevBuf transforms_b, colors_b;
+    PinnedUpload upload_t, upload_c;
+    InstanceSlot slot[2];
     int instances_cur = 0;
     uint64_t generation = 0;            // bumped by every upload: what a frame's cached recorded pass was built against
     bool instances_projective_of[2] = {false, false};
@@ -234,6 +299,9 @@ struct crh_scene {
         for (DevBuf* b : all) b->release();
         for (DevBuf& b : prim_rec) b.release();
         for (DevBuf& b : prim_proj) b.release();
+        upload_t.release();
+        upload_c.release();
+        for (InstanceSlot& k : slot) k.release();
     }
 };
 
@@ -561,8 +629,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.load_existing = f->cleared ? 0u : 1u;
     const int inst = again ? f->last_instances : sc->instances_cur;
     if (!recorded) f->last_instances = inst;
-    p.transforms = recorded ? f->item_transforms.as<float>() : (inst ? sc->transforms_b : sc->transforms).as<float>();
-    p.colors = recorded ? f->item_colors.as<float>() : (inst ? sc->colors_b : sc->colors).as<float>();
+    const int item_inst = again ? f->item_inst_last : f->item_inst_cur;
+    if (recorded) f->item_inst_last = item_inst;
+    p.transforms = recorded ? (item_inst ? f->item_transforms_b : f->item_transforms).as<float>() : (inst ? sc->transforms_b : sc->transforms).as<float>();
+    p.colors = recorded ? (item_inst ? f->item_colors_b : f->item_colors).as<float>() : (inst ? sc->colors_b : sc->colors).as<float>();
     p.tile_count = set.tile_count_cursor.as<uint32_t>();
     p.tile_cursor = set.tile_count_cursor.as<uint32_t>() + f->n_tiles;
     p.tile_offset = set.tile_offset.as<uint32_t>();
@@ -597,7 +667,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     }
     p.scan_scratch = set.scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec[rec].p);
-    const bool projective = recorded ? f->items_projective : sc->instances_projective_of[inst];
+    InstanceSlot& slot = recorded ? f->item_slot[item_inst] : sc->slot[inst];
+    if (slot.was_written) HIP_TRY(hipStreamWaitEvent(bin, slot.ready, 0)); // the copy of this set on the upload stream
+    const bool projective = recorded ? f->item_projective_of[item_inst] != 0 : sc->instances_projective_of[inst];
     p.prim_proj = nullptr;
     if (projective) {
         HIP_TRY(sc->prim_proj[rec].ensure((size_t)p.prim_capacity * 32));
@@ -632,6 +704,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         f->pair_capacity_bytes = ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4;
         HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
         r->begin_marks(2);
+    }
+    if (slot.read_done) { // k_prim_setup, the only reader of the instance data, is behind us on this stream
+        HIP_TRY(hipEventRecord(slot.read_done, bin));
+        slot.was_read = true;
     }
     launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
     HIP_TRY(hipEventRecord(set.bin_done, bin));
@@ -731,7 +807,8 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(hipStreamCreateWithFlags(&r->tess_stream, hipStreamNonBlocking), "hipStreamCreate") ||
         !hip_ok(hipStreamCreateWithFlags(&r->bin_stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->aux_stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        !hip_ok(hipStreamCreateWithFlags(&r->aux_stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipStreamCreateWithFlags(&r->upload_stream, hipStreamNonBlocking), "hipStreamCreate")) {
         delete r;
         return CRH_ERR_HIP;
     }
@@ -754,6 +831,7 @@ void crh_renderer_destroy(crh_renderer* r) {
     (void)hipStreamDestroy(r->tess_stream);
     (void)hipStreamDestroy(r->bin_stream);
     (void)hipStreamDestroy(r->aux_stream);
+    (void)hipStreamDestroy(r->upload_stream);
     if (r->composite_table) (void)hipFree(r->composite_table);
     delete r;
 }
@@ -1144,8 +1222,11 @@ void crh_frame_destroy(crh_frame* f) {
                 break;
             }
     }
-    DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
+    DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
     for (DevBuf* b : all) b->release();
+    f->item_upload_t.release();
+    f->item_upload_c.release();
+    for (InstanceSlot& k : f->item_slot) k.release();
     for (crh_frame::BinSet& set : f->sets) {
         DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch};
         for (DevBuf* b : bins) b->release();
@@ -1214,10 +1295,16 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
     if (sc->d.n_shapes) {
         HIP_TRY(tb.ensure((size_t)sc->d.n_shapes * 64));
         HIP_TRY(cb.ensure((size_t)sc->d.n_shapes * 16));
-        // on the binning stream, whose k_prim_setup is the only reader: ordered after the setup of the frame that last read this buffer and
-        // before the next one, with no host synchronisation (the host arrays are consumed before the calls return: pageable memory)
-        HIP_TRY(hipMemcpyAsync(tb.p, transforms, (size_t)sc->d.n_shapes * 64, hipMemcpyHostToDevice, r->binning_stream()));
-        HIP_TRY(hipMemcpyAsync(cb.p, colors, (size_t)sc->d.n_shapes * 16, hipMemcpyHostToDevice, r->binning_stream()));
+        // on the upload stream: behind the k_prim_setup that last read this set, ahead of the next one (events), overlapping the binning of
+        // the frame in between; no host synchronisation (the host arrays are copied to pinned staging memory before the calls return)
+        InstanceSlot& slot = sc->slot[next];
+        HIP_TRY(slot.init());
+        const hipStream_t up = r->pipeline ? r->upload_stream : r->stream;
+        if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_done, 0)); // the setup that read this set two updates ago
+        HIP_TRY(sc->upload_t.copy(tb.p, transforms, (size_t)sc->d.n_shapes * 64, up));
+        HIP_TRY(sc->upload_c.copy(cb.p, colors, (size_t)sc->d.n_shapes * 16, up));
+        HIP_TRY(hipEventRecord(slot.ready, up));
+        slot.was_written = true;
     }
     sc->instances_cur = next;
     sc->instances_projective_of[next] = !all_instances_plain(transforms, sc->d.n_shapes);
@@ -1241,10 +1328,6 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     crh_renderer* r = sc->renderer;
     HIP_TRY(hipSetDevice(r->device));
     if (r->config.alpha_layer_count > 4) return CRH_ERR_UNSUPPORTED;
-    if (f->check_pending) { // the frame's recorded pass (its remedy for an overflowed tile list) is about to be replaced
-        const crh_status st = settle_frame_cheaply(f);
-        if (st != CRH_OK) return st;
-    }
     for (size_t i = 0; i < (size_t)n_instances * 16; ++i)
         if (!std::isfinite(transforms[i])) return CRH_ERR_NON_FINITE;
     for (size_t i = 0; i < (size_t)n_instances * 4; ++i)
@@ -1282,15 +1365,32 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
                            f->items_host.size() == items.size() && memcmp(f->items_host.data(), items.data(), items.size() * sizeof(DrawItem)) == 0 &&
                            f->item_transforms.cap >= (size_t)n_instances * 64 && f->item_colors.cap >= (size_t)n_instances * 16;
     if (same_pass) {
-        // the same items over the same geometry (an animation: only the instance data moves): refresh the instance data on the binning
-        // stream — k_prim_setup, its only reader, runs there, so the copy is ordered behind the previous frame's setup — and render
-        // without a host synchronisation
-        HIP_TRY(hipMemcpyAsync(f->item_transforms.p, transforms, (size_t)n_instances * 64, hipMemcpyHostToDevice, r->binning_stream()));
-        HIP_TRY(hipMemcpyAsync(f->item_colors.p, colors, (size_t)n_instances * 16, hipMemcpyHostToDevice, r->binning_stream()));
-        f->items_projective = !all_instances_plain(transforms, n_instances);
+        // the same items over the same geometry (an animation: only the instance data moves): the new instance data goes to the set the
+        // previous submission did not read — its deferred remedy may still want that one — on the binning stream, where k_prim_setup,
+        // the only reader, runs: ordered behind the setup that read this set two submissions ago, no host synchronisation
+        const int next = f->item_inst_cur ^ 1;
+        DevBuf& tb = next ? f->item_transforms_b : f->item_transforms;
+        DevBuf& cb = next ? f->item_colors_b : f->item_colors;
+        HIP_TRY(tb.ensure((size_t)n_instances * 64 + 64));
+        HIP_TRY(cb.ensure((size_t)n_instances * 16 + 16));
+        InstanceSlot& slot = f->item_slot[next];
+        HIP_TRY(slot.init());
+        const hipStream_t up = r->pipeline ? r->upload_stream : r->stream;
+        if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_done, 0));
+        HIP_TRY(f->item_upload_t.copy(tb.p, transforms, (size_t)n_instances * 64, up));
+        HIP_TRY(f->item_upload_c.copy(cb.p, colors, (size_t)n_instances * 16, up));
+        HIP_TRY(hipEventRecord(slot.ready, up));
+        slot.was_written = true;
+        f->item_inst_cur = next;
+        f->item_projective_of[next] = all_instances_plain(transforms, n_instances) ? 0 : 1;
         return render_impl(sc, f);
     }
+    if (f->check_pending) { // the frame's recorded pass (its remedy for an overflowed tile list) is about to be replaced
+        const crh_status st = settle_frame(f);
+        if (st != CRH_OK) return st;
+    }
     HIP_TRY(r->sync()); // the buffers below may still be read by a frame in flight
+    f->item_inst_cur = 0;
     HIP_TRY(f->items.ensure(items.size() * sizeof(DrawItem)));
     HIP_TRY(f->item_transforms.ensure((size_t)n_instances * 64 + 64));
     HIP_TRY(f->item_colors.ensure((size_t)n_instances * 16 + 16));
@@ -1303,7 +1403,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     f->items_scene = sc;
     f->items_generation = sc->generation;
     f->items_ranges_valid = false; // computed by render_impl together with the primitive total
-    f->items_projective = !all_instances_plain(transforms, n_instances);
+    f->item_projective_of[0] = all_instances_plain(transforms, n_instances) ? 0 : 1;
     f->pairs_known = false; // a different pass: re-learn the tile list size
     return render_impl(sc, f);
 }
