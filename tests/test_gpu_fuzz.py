@@ -384,3 +384,45 @@ def test_malformed_batches_are_rejected_not_read_out_of_bounds(oracle_lib):
     for name, edit in cases.items():
         assert upload(variant(edit)) == _ffi.ERR_INVALID_ARGUMENT, name
     assert upload(batch.c) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_resubmitted_passes_with_moving_instances(msaa, oracle_lib):
+    """An animation: the same recorded pass (clip nesting) and the same plain pass submitted frame after frame with new instance data,
+    no host synchronisation in between, two frames alternating — the cached pass, the double-buffered instance sets and the upload
+    stream. Every frame is downloaded only at the end and must equal the oracle's rendering of ITS instance data."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle, render_pass
+    sc = scenes.scene_mixed(14, (160, 160), seed=21)
+    o = Oracle(sc["batch"])
+    assert o.status() == 0
+    n = sc["batch"].n_shapes
+    inner = [d for i in range(1, n) for d in ((i, i, int(Op.Stencil), 1, 0), (i, i, int(Op.Color), 1, 0))]
+    recorded = np.array([(0, 0, int(Op.Stencil), 0, 0), (0, 0, int(Op.Clip), 1, 0)] + inner + [(0, 0, int(Op.UnClip), 0, 0)], dtype=np.uint32)
+    plain = [d for i in range(n) for d in ((i, i, int(Op.Stencil), 0, 0), (i, i, int(Op.Color), 0, 0))]
+    r = R.Renderer(R.Configuration(msaa, 2, 4, 0), device=0)
+    scene = R.Scene(r, sc["batch"])
+    rng = np.random.RandomState(5)
+    for mode in ("recorded", "plain"):
+        frames = [R.Frame(r, 160, 160) for _ in range(2)]
+        shown = [None, None]
+        for step in range(14):
+            t = scenes.place(160, 160, rng.uniform(20, 140, n), rng.uniform(20, 140, n), rng.uniform(10, 60, n))
+            c = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0.3, 1, (n, 1))], axis=1).astype(np.float32)
+            f = frames[step & 1]
+            f.clear()
+            if mode == "recorded":
+                scene.render_draws(f, t, c, recorded)
+            else:
+                scene.render(f, t, c)
+            shown[step & 1] = (t, c)
+            if step == 7:  # one download in the middle of the animation
+                expect, _ = render_pass(o, 160, 160, msaa, 4, 2, 0, t, c, recorded.tolist() if mode == "recorded" else plain)
+                assert np.array_equal(f.download(), expect)
+        for k in range(2):
+            t, c = shown[k]
+            expect, _ = render_pass(o, 160, 160, msaa, 4, 2, 0, t, c, recorded.tolist() if mode == "recorded" else plain)
+            assert np.array_equal(frames[k].download(), expect), f"{mode}: frame {k}"
