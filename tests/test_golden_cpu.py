@@ -87,3 +87,19 @@ def test_descriptor_conversion_matches_oracle(oracle_lib):
         assert ra == rb
         if ra == 0:
             assert bytes(a) == bytes(b)
+
+
+def test_header_is_plain_c():
+    """include/contrast_hip.h is the FFI boundary: it must compile as C99 / C11 (what bindgen, cgo or a JNI shim would feed on), with
+    warnings as errors."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "abi.c")
+        with open(src, "w") as f:
+            f.write('#include "contrast_hip.h"\nint main(void) { crh_config c = {1, 4, 4, 0, 0, 0, 0}; crh_draw d = {0, 0, CRH_OP_STENCIL, 0, 0}; (void)c; (void)d; return 0; }\n')
+        for std in ("c99", "c11"):
+            run = subprocess.run(["gcc", f"-std={std}", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", src],
+                                 capture_output=True, text=True)
+            assert run.returncode == 0, run.stderr
