@@ -1,0 +1,200 @@
+// tools/proto_edges.cpp — DEVELOPMENT TOOL (CPU): the boundary-edge + backdrop formulation of the solid fill and of the hull cover,
+// written the way csrc/raster_edges.hip evaluates it (tile-relative f32 arithmetic, per-tile backdrop at q0, path q0 -> q_k -> p), checked
+// bit for bit against the triangle-strip specification of oracle/raster.hpp. Not shipped, not used by tests; it exists so that the sign
+// conventions and tie rules can be verified without a GPU. Build + run: tools/proto_edges.py
+#include "../oracle/api.cpp"
+
+namespace proto {
+using namespace oracle;
+
+struct Edge { // canonical endpoints lo < hi (lexicographic), directed flag
+    float lo[2], hi[2], bx, nay;
+    int sigma; // -1: the chain runs lo -> hi, +1: hi -> lo
+    bool tl;   // top-left flag of the canonical direction
+    bool down; // canonical dy > 0
+};
+
+static bool make_edge(const float a[2], const float b[2], Edge& e) { // the chain runs a -> b
+    if (a[0] == b[0] && a[1] == b[1]) return false;
+    if (!(a[0] == a[0] && a[1] == a[1] && b[0] == b[0] && b[1] == b[1])) return false;
+    const bool flip = !lex_less(a, b);
+    const float* lo = flip ? b : a;
+    const float* hi = flip ? a : b;
+    e.lo[0] = lo[0], e.lo[1] = lo[1], e.hi[0] = hi[0], e.hi[1] = hi[1];
+    e.bx = hi[0] - lo[0];
+    e.nay = -(hi[1] - lo[1]);
+    e.sigma = flip ? 1 : -1;
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1];
+    e.tl = dy < 0.0f || (dy == 0.0f && dx > 0.0f);
+    e.down = dy > 0.0f;
+    return true;
+}
+// chain of a strip with n positions: see DESIGN.md (boundary of the zig-zag strip)
+static void strip_chain(const std::vector<const float*>& pos, std::vector<Edge>& out) {
+    const size_t n = pos.size();
+    if (n < 3) return;
+    for (size_t i = 0; i < n; ++i) {
+        size_t j;
+        if (i == 0) j = 1;
+        else if ((i & 1) == 0) j = i - 2;
+        else if (i + 2 <= n - 1) j = i + 2;
+        else j = (i == n - 1) ? n - 2 : n - 1;
+        Edge e;
+        if (make_edge(pos[i], pos[j], e)) out.push_back(e);
+    }
+}
+static inline bool g_of(float E, bool tl) { return E > 0.0f || (E == 0.0f && tl); }
+
+struct TileEval {
+    float tx0, ty0;
+    float c;
+    const Edge* e;
+    void set(const Edge& ed, int tx, int ty) {
+        e = &ed;
+        tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+        c = ed.bx * (ty0 - ed.lo[1]) + ed.nay * (tx0 - ed.lo[0]);
+    }
+    bool g(float rx, float ry) const { return g_of(fmaf(ry, e->bx, fmaf(rx, e->nay, c)), e->tl); }
+};
+
+// winding of the chain `edges` at every sample of the frame, accumulated into acc[y][x][s] (int), the GPU way
+static void chain_winding(const Frame& f, const std::vector<Edge>& edges, std::vector<int>& acc, int& tiles_touched, long& pairs) {
+    if (edges.empty()) return;
+    const int W = (int)f.width, H = (int)f.height;
+    float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+    for (const Edge& e : edges) {
+        minx = std::fmin(minx, e.lo[0]), maxx = std::fmax(maxx, e.hi[0]);
+        miny = std::fmin(miny, std::fmin(e.lo[1], e.hi[1])), maxy = std::fmax(maxy, std::fmax(e.lo[1], e.hi[1]));
+    }
+    const int x0 = (int)std::floor(std::fmin(std::fmax(minx, 0.0f), (float)W)), x1 = (int)std::floor(std::fmax(std::fmin(maxx, (float)(W - 1)), -1.0f));
+    const int y0 = (int)std::floor(std::fmin(std::fmax(miny, 0.0f), (float)H)), y1 = (int)std::floor(std::fmax(std::fmin(maxy, (float)(H - 1)), -1.0f));
+    if (x0 > x1 || y0 > y1) return;
+    const uint32_t S = f.samples;
+    float sox[4], soy[4];
+    for (uint32_t s = 0; s < S; ++s) sample_offset(S, s, sox[s], soy[s]);
+    float ry_first = soy[0], ry_last = 15.0f + soy[S - 1], rx_last = 0.0f;
+    for (uint32_t s = 0; s < S; ++s) rx_last = std::fmax(rx_last, 15.0f + sox[s]);
+    for (int ty = y0 / TILE; ty <= y1 / TILE; ++ty)
+        for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) {
+            ++tiles_touched;
+            const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+            // ---- backdrop: the ray formula at q0 = (tx0, ty0 + ry_first), every edge
+            int bd = 0;
+            std::vector<const Edge*> touching;
+            for (const Edge& e : edges) {
+                TileEval t;
+                t.set(e, tx, ty);
+                const float ymin = std::fmin(e.lo[1], e.hi[1]), ymax = std::fmax(e.lo[1], e.hi[1]);
+                const float q0y = ty0 + ry_first;
+                const bool Y0 = ymin <= q0y && q0y < ymax;
+                if (Y0) bd += e.sigma * ((t.g(0.0f, ry_first) ? 1 : 0) - (e.down ? 1 : 0));
+                // ---- does the edge matter inside the tile? g not constant over the tile's evaluation points and the boxes overlap
+                const float rx_hi = e.nay > 0.0f ? rx_last : 0.0f, rx_lo = e.nay > 0.0f ? 0.0f : rx_last;
+                const bool gmax = t.g(rx_hi, ry_last), gmin = t.g(rx_lo, ry_first); // bx >= 0: E grows with ry
+                const bool box = e.lo[0] <= tx0 + rx_last && e.hi[0] >= tx0 && ymin <= ty0 + ry_last && ymax >= ty0 + ry_first;
+                if (gmax != gmin && box) touching.push_back(&e);
+            }
+            pairs += (long)touching.size();
+            // ---- per sample: w = bd + sum over touching edges of sigma * [xr (g(qk) - g(q0)) + Yk (g(p) - g(qk))]
+            for (int py = std::max(0, ty * TILE); py < std::min(H, ty * TILE + TILE); ++py)
+                for (int px = std::max(0, tx * TILE); px < std::min(W, tx * TILE + TILE); ++px)
+                    for (uint32_t s = 0; s < S; ++s) {
+                        const float rx = (float)(px - tx * TILE) + sox[s], ry = (float)(py - ty * TILE) + soy[s];
+                        int w = bd;
+                        for (const Edge* ep : touching) {
+                            const Edge& e = *ep;
+                            TileEval t;
+                            t.set(e, tx, ty);
+                            const float ymin = std::fmin(e.lo[1], e.hi[1]), ymax = std::fmax(e.lo[1], e.hi[1]);
+                            const float sy = ty0 + ry;
+                            const bool Yk = ymin <= sy && sy < ymax;
+                            const bool xr = e.lo[0] <= tx0 && tx0 < e.hi[0];
+                            const int gq0 = t.g(0.0f, ry_first), gqk = t.g(0.0f, ry), gp = t.g(rx, ry);
+                            w += e.sigma * ((xr ? gqk - gq0 : 0) + (Yk ? gp - gqk : 0));
+                        }
+                        acc[((size_t)py * f.width + px) * S + s] += w;
+                    }
+        }
+}
+
+static void transform_points(const Frame& f, const float m[16], const std::vector<Vertex0>& v, std::vector<float>& out) {
+    out.resize(v.size() * 2);
+    for (size_t i = 0; i < v.size(); ++i) to_framebuffer(m, (float)f.width, (float)f.height, v[i].p, &out[2 * i]);
+}
+
+// Shape::render(Stencil) with the solid strips replaced by their boundary chain
+static void render_stencil_edges(Frame& f, const Shape& shape, const float m[16], int& tiles, long& pairs) {
+    // strokes and curves: the oracle's own code, on a copy of the shape without solid strips
+    Shape rest = shape;
+    rest.fill.solid_vertices.clear();
+    rest.fill.solid_indices.clear();
+    rest.fill.solid_restarts.clear();
+    render_stencil(f, rest, m);
+    // NOTE: order differs from the reference (solid after curves) — integer adds commute, and strokes stay first
+    std::vector<float> pts;
+    transform_points(f, m, shape.fill.solid_vertices, pts);
+    const auto& idx = shape.fill.solid_indices;
+    const auto& restarts = shape.fill.solid_restarts;
+    std::vector<Edge> edges;
+    size_t run_start = 0, vertex_base = 0, next_restart = 0;
+    for (size_t k = 0; k <= idx.size(); ++k) {
+        if (k == idx.size() || (next_restart < restarts.size() && restarts[next_restart] == k)) {
+            std::vector<const float*> pos;
+            for (size_t i = 0; run_start + i < k; ++i) pos.push_back(&pts[2 * (vertex_base + i)]);
+            strip_chain(pos, edges);
+            vertex_base += k - run_start;
+            run_start = k + 1;
+            ++next_restart;
+        }
+    }
+    std::vector<int> acc((size_t)f.width * f.height * f.samples, 0);
+    chain_winding(f, edges, acc, tiles, pairs);
+    for (size_t i = 0; i < acc.size(); ++i)
+        if (acc[i]) f.winding[i] = wrap_add(f.winding[i], acc[i], f.winding_mask);
+}
+static void render_color_edges(Frame& f, const Shape& shape, const float m[16], const float rgba[4], int& tiles, long& pairs) {
+    const float src[4] = {rgba[0] * rgba[3], rgba[1] * rgba[3], rgba[2] * rgba[3], rgba[3]};
+    const float one_minus_a = 1.0f - src[3];
+    std::vector<float> pts;
+    transform_points(f, m, shape.convex_hull, pts);
+    std::vector<const float*> pos;
+    for (size_t i = 0; i < shape.convex_hull.size(); ++i) pos.push_back(&pts[2 * i]);
+    std::vector<Edge> edges;
+    strip_chain(pos, edges);
+    std::vector<int> acc((size_t)f.width * f.height * f.samples, 0);
+    chain_winding(f, edges, acc, tiles, pairs);
+    for (size_t si = 0; si < acc.size(); ++si) {
+        if (!acc[si]) continue;
+        const uint32_t st = f.winding[si];
+        float* dst = &f.color[si * 4];
+        if ((st & f.winding_mask) != 0)
+            for (int c = 0; c < 4; ++c) dst[c] = src[c] + dst[c] * one_minus_a;
+        f.winding[si] = (uint8_t)(st & ~f.winding_mask);
+    }
+}
+} // namespace proto
+
+extern "C" {
+// mode 0: oracle (triangle strips), 1: edge formulation. Outputs RGBA8 and the final stencil bytes [h][w][msaa].
+int proto_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, const float* transforms, const float* colors,
+                 uint32_t shape_begin, uint32_t shape_end, int mode, uint8_t* rgba8, uint8_t* winding_out, long* stats) {
+    Scene* sc = static_cast<Scene*>(h);
+    Frame f;
+    f.create(width, height, msaa, winding_bits);
+    int tiles = 0;
+    long pairs = 0;
+    for (uint32_t s = shape_begin; s < shape_end && s < sc->shapes.size(); ++s) {
+        if (mode == 0) {
+            render_stencil(f, sc->shapes[s], transforms + 16 * (size_t)s);
+            render_color(f, sc->shapes[s], transforms + 16 * (size_t)s, colors + 4 * (size_t)s);
+        } else {
+            proto::render_stencil_edges(f, sc->shapes[s], transforms + 16 * (size_t)s, tiles, pairs);
+            proto::render_color_edges(f, sc->shapes[s], transforms + 16 * (size_t)s, colors + 4 * (size_t)s, tiles, pairs);
+        }
+    }
+    resolve_rgba8(f, rgba8);
+    if (winding_out) std::copy(f.winding.begin(), f.winding.end(), winding_out);
+    if (stats) stats[0] = tiles, stats[1] = pairs;
+    return 0;
+}
+}
