@@ -23,6 +23,11 @@ void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hip
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
+// raster_edges.hip: the plain Stencil + Color pass as boundary edges + backdrop, binned in one traversal
+void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_items, uint32_t* item_nslots, uint32_t* slot_begin, uint32_t* scratch, hipStream_t stream);
+void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_bin);
+void launch_scatter(const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
+void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
 } // namespace crh
 
@@ -218,6 +223,7 @@ struct crh_frame {
     // Two sets of binning buffers, used alternately: frame N + 1 is binned while frame N's raster kernel still reads the other set.
     struct BinSet {
         DevBuf tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
+        DevBuf pair_tile, pair_pos, pair_key;       // the edge pass: (tile, key) pairs as the binning waves produced them (same capacity as tile_list)
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
         hipEvent_t raster_done = nullptr; // recorded on the raster stream after the raster kernel that read this set
         bool used = false;
@@ -225,6 +231,8 @@ struct crh_frame {
     int next_set = 0, last_set = 0;
     // a recorded pass (crh_scene_render_draws): merged draw items, their instance data and primitive ranges
     DevBuf items, item_transforms, item_colors, item_ncand, item_prim_begin, item_scan_scratch;
+    DevBuf item_nslots, item_slot_begin; // the edge pass: slots of the primitive heap per item
+    uint32_t items_total_slots = 0;
     DevBuf item_transforms_b, item_colors_b; // second set of instance data: a re-submitted pass writes the set its predecessor did not read
     int item_inst_cur = 0, item_inst_last = 0, item_projective_of[2] = {0, 0};
     PinnedUpload item_upload_t, item_upload_c;
@@ -267,6 +275,7 @@ struct crh_scene {
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
     DevBuf transforms, colors, shape_ncand, shape_prim_begin, prim_scan_scratch;
+    DevBuf shape_nslots, shape_slot_begin; // the edge pass: slots of the primitive heap per Shape (transform independent, like shape_prim_begin)
     DevBuf prim_rec[kPipelineDepth];    // set-up triangles, one buffer per frame in flight like the frame's binning buffers
     DevBuf prim_proj[kPipelineDepth];                // 1/w and z/w planes of the primitives of projective instances (allocated on first use)
     bool instances_projective = false;  // of the current instance buffer
@@ -295,7 +304,7 @@ struct crh_scene {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
-                         &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch};
+                         &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
         for (DevBuf* b : all) b->release();
         for (DevBuf& b : prim_rec) b.release();
         for (DevBuf& b : prim_proj) b.release();
@@ -365,7 +374,8 @@ crh_status ensure_outputs(crh_scene* sc) {
     HIP_TRY(sc->rc_v.ensure((size_t)t[CH_RC_V] * 24));
     HIP_TRY(sc->hull_cand.ensure((size_t)t[CH_HULL] * 8));
     HIP_TRY(sc->hull_v.ensure((size_t)t[CH_HULL] * 8));
-    if (sc->big_shapes) { // only Shapes beyond the LDS hull kernels (> 2048 candidates) use these; sized so that any Shape may
+    if (sc->big_shapes || sc->has_stroke) { // only Shapes beyond the LDS hull kernels (> 2048 candidates) use these — a stroked Shape reaches that with few
+                                            // segments (every emitted line vertex is a hull candidate, stroke.rs:125); sized so that any Shape may
         HIP_TRY(sc->hull_sort.ensure((size_t)t[CH_HULL] * 16 + 16));
         HIP_TRY(sc->hull_chain.ensure((size_t)t[CH_HULL] * 16 + 16));
     }
@@ -424,6 +434,10 @@ crh_status run_tessellation(crh_scene* sc) {
     // frame's tile walks read the old ranges until its fill pass is through
     if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0));
     launch_prim_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), ts);
+    {
+        RasterParams plain = {}; // items == nullptr: item i is Shape i, Stencil + Color
+        launch_slot_ranges(d, plain, d.n_shapes, sc->shape_nslots.as<uint32_t>(), sc->shape_slot_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), ts);
+    }
     if (r->timing) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
     HIP_TRY(hipEventRecord(sc->tess_done, ts));
     HIP_TRY(hipGetLastError());
@@ -644,26 +658,38 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(f->item_ncand.ensure((size_t)f->n_items * 4 + 4));
         HIP_TRY(f->item_prim_begin.ensure(((size_t)f->n_items + 1) * 4));
         HIP_TRY(f->item_scan_scratch.ensure(((size_t)(f->n_items + 1023) / 1024 + 2) * 4));
-        uint32_t total = f->items_total;
+        HIP_TRY(f->item_nslots.ensure((size_t)f->n_items * 4 + 4));
+        HIP_TRY(f->item_slot_begin.ensure(((size_t)f->n_items + 1) * 4));
+        uint32_t total = f->items_total, total_slots = f->items_total_slots;
         if (!f->items_ranges_valid) {
             launch_item_ranges(sc->d, p, f->item_ncand.as<uint32_t>(), f->item_prim_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), bin);
             HIP_TRY(hipMemcpyAsync(&total, f->item_prim_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, bin));
+            launch_slot_ranges(sc->d, p, f->n_items, f->item_nslots.as<uint32_t>(), f->item_slot_begin.as<uint32_t>(), f->item_scan_scratch.as<uint32_t>(), bin);
+            HIP_TRY(hipMemcpyAsync(&total_slots, f->item_slot_begin.as<uint32_t>() + f->n_items, 4, hipMemcpyDeviceToHost, bin));
             HIP_TRY(r->sync());
             f->items_total = total;
+            f->items_total_slots = total_slots;
             f->items_ranges_valid = true;
         }
-        if (total >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED;
-        HIP_TRY(sc->prim_rec[rec].ensure(((size_t)total + 64) * 128));
+        if (total >= 0xFFFFFFF0u || total_slots >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED;
+        HIP_TRY(sc->prim_rec[rec].ensure(std::max(((size_t)total + 64) * 128, ((size_t)total_slots + 64) * 32)));
         p.prim_capacity = total + 64u;
+        p.slot_capacity = total_slots + 64u;
+        p.slot_begin = f->item_slot_begin.as<uint32_t>();
         p.shape_ncand = f->item_ncand.as<uint32_t>();
         p.shape_prim_begin = f->item_prim_begin.as<uint32_t>();
     } else {
         // every candidate triangle gets a record slot: an upper bound follows from the tessellation totals
         const uint32_t* t = sc->totals_host;
         const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
-        if (prim_capacity >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED; // 0xFFFFFFFF pads the tile sort
-        HIP_TRY(sc->prim_rec[rec].ensure(prim_capacity * 128));
+        // the edge pass: four slots per stroke / curve triangle, one per polygon vertex and hull vertex, the per-Shape cover slots
+        const size_t slot_capacity = 4u * ((size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u) + t[CH_SOLID_V] + 4u * (size_t)t[CH_HULL] +
+                                     24u * (size_t)sc->d.n_shapes + 64; // item_slots(): the hull region is sized for cover triangles (hull vertices <= candidates)
+        if (prim_capacity >= 0xFFFFFFF0u || slot_capacity >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED; // 0xFFFFFFFF pads the tile sort
+        HIP_TRY(sc->prim_rec[rec].ensure(std::max(prim_capacity * 128, slot_capacity * 32)));
         p.prim_capacity = (uint32_t)prim_capacity;
+        p.slot_capacity = (uint32_t)slot_capacity;
+        p.slot_begin = sc->shape_slot_begin.as<uint32_t>();
     }
     p.scan_scratch = set.scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec[rec].p);
@@ -679,8 +705,13 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.depth_pass_mask = depth_pass_mask(r->config.depth_compare);
     p.depth_write = r->config.depth_write_enabled;
     p.cull_mode = r->config.cull_mode;
-    p.general = (projective || p.depth || (recorded && f->items_need_ops)) ? 1u : 0u;
+    // The general pass keeps the reference's triangle strips (raster.hip): clip nesting / alpha contexts, perspective, depth, and face
+    // culling (a cull decision is per strip triangle). Everything else is the edge pass (raster_edges.hip).
+    p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops) || getenv("CRH_TRIANGLE_PASS")) ? 1u : 0u;
+    const bool edges = p.general == 0u;
+    p.slots = static_cast<uint8_t*>(sc->prim_rec[rec].p);
     p.overflow = set.overflow.as<uint32_t>();
+    p.pair_cursor = set.overflow.as<uint32_t>() + 4;
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
@@ -692,6 +723,15 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         p.tile_list = set.tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(set.tile_list.cap / 4);
+        if (edges) {
+            HIP_TRY(set.pair_tile.ensure(set.tile_list.cap));
+            HIP_TRY(set.pair_key.ensure(set.tile_list.cap));
+            HIP_TRY(set.pair_pos.ensure(set.tile_list.cap));
+            p.pair_pos = set.pair_pos.as<uint32_t>();
+            p.pair_tile = set.pair_tile.as<uint32_t>();
+            p.pair_key = set.pair_key.as<uint32_t>();
+            launch_bin_edges(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
+        } else
         launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         if (f->pairs_known) break;
         uint32_t ov[4];
@@ -709,7 +749,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(hipEventRecord(slot.read_done, bin));
         slot.was_read = true;
     }
-    launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
+    if (edges) {
+        HIP_TRY(hipEventRecord(sc->ranges_free, bin)); // k_bin_edges, the only reader of the slot ranges, is behind us
+        launch_scatter(p, bin, r->mark_fn_bin(), r);
+    } else {
+        launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
+    }
     HIP_TRY(hipEventRecord(set.bin_done, bin));
     // ---- raster lane
     HIP_TRY(hipStreamWaitEvent(r->stream, set.bin_done, 0));
@@ -717,7 +762,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
-    launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
+    if (edges)
+        launch_raster_edges(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
+    else
+        launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
     set.used = true;
@@ -1016,6 +1064,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((3 * (size_t)b->n_shapes + 4) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
+        !hip_ok(sc->shape_nslots.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_slot_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
         !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 4), "hipMalloc")) {
         rc = CRH_ERR_HIP;
         goto fail;
@@ -1222,13 +1271,14 @@ void crh_frame_destroy(crh_frame* f) {
                 break;
             }
     }
-    DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch};
+    DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
+                     &f->item_nslots, &f->item_slot_begin};
     for (DevBuf* b : all) b->release();
     f->item_upload_t.release();
     f->item_upload_c.release();
     for (InstanceSlot& k : f->item_slot) k.release();
     for (crh_frame::BinSet& set : f->sets) {
-        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch};
+        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key};
         for (DevBuf* b : bins) b->release();
         if (set.bin_done) (void)hipEventDestroy(set.bin_done);
         if (set.raster_done) (void)hipEventDestroy(set.raster_done);

@@ -1,0 +1,1086 @@
+// csrc/raster_edges.hip — the plain Stencil + Color pass (Shape::render renderer.rs:267-355 with the stencil states renderer.rs:565-582,
+// 736-754 and the fragment stages shaders.wgsl:233-309) as boundary edges + backdrop.
+//
+// The reference draws the interior of a filled path as a triangle strip (triangle_fan_to_strip, vertex.rs:28-35; renderer.rs:304-318) and
+// covers the Shape with the strip of its convex hull (renderer.rs:340-354). Both strips are long thin triangles across the whole Shape —
+// five of six (tile, triangle) pairs of the benchmark scene. Their sum is the winding number of the strip's BOUNDARY chain (interior strip
+// edges are shared by two triangles that see exactly negated edge functions under the top-left rule, so they cancel sample by sample), and
+// that is what this file evaluates, with the same canonical-orientation edge function  E = fma(ry, bx, fma(rx, nay, c))  per boundary edge:
+//
+//   g_e(p) = E_e(p) > 0 || (E_e(p) == 0 && top-left of the canonical direction)          (what a strip triangle on that side would accept)
+//   w(p)   = sum_e sigma_e * Y_e(p.y) * (g_e(p) - down_e)                                 ray to -x; Y = half-open y range, sigma = chain direction
+//
+// per 16x16 tile T with q_k = (left tile boundary, y of sample row k):
+//   w(p)   = BD(T) + sum_{e touching T} sigma_e * [ xr_e * (g_e(q_k) - g_e(q_0)) + Y_e(k) * (g_e(p) - g_e(q_k)) ]
+//   BD(T)  = w(q_0), the backdrop, summed over ALL edges of the chain by the binning kernel (one lane per edge, ballots);
+//   the bracket is the crossing count of the path q_0 -> q_k -> p with e, non-zero only for edges whose g is not constant over the tile.
+// Every term is an evaluation of the same f32 expression the triangle path uses, at sample positions or at q_k, so the result equals the
+// strip's sample for sample (tools/proto_edges.cpp checks this formulation against oracle/raster.hpp on the CPU, bit for bit; the GPU
+// parity tests check this file). Curve and stroke triangles stay triangles.
+//
+//   k_bin_edges<S>     ONE traversal per draw item: waves 0-1 set up and walk the triangles, waves 2-3 the boundary edges (fill chain +
+//                      hull chain) over the item's tile rectangle; per tile they count entries (one atomic) and append (tile, key) pairs
+//                      to a wave-private LDS stage that is flushed to the pair stream in blocks (one atomic per block).
+//   k_scatter          pair -> its slot in the tile's list (offsets from the scan of the counts).
+//   k_raster_edges<..> one wavefront per tile as in raster.hip; entries are triangles, edges and one COVER entry per (item, tile).
+// Keys are slot numbers of a 32-byte primitive heap (a triangle owns four slots = its 128-byte record); they ascend in draw order.
+#include "raster_common.hpp"
+
+namespace crh {
+
+void launch_scan_tiles(const RasterParams& r, hipStream_t stream); // raster.hip: exclusive scan of tile_count -> tile_offset, pair total, longest list
+
+constexpr uint32_t EK_EDGE = 0, EK_SYNTH = 7, EK_COVER_TRI = 8; // kinds 1..6 = KIND_IQ .. KIND_JOINT as in raster_common.hpp (flags bits 4-7)
+constexpr uint32_t kEdgeTl = 1u, kEdgeSigmaPos = 2u, kEdgeHull = 4u;
+// Synthetic slots of an item (flags bits 8-11 = code): 0 BD+1, 1 BD-1 (fill winding of the whole tile), 2 HBD+1, 3 HBD-1 (hull winding of the
+// whole tile); 4 + (bd + 1) + 3 * (hbd + 1): COVER with one unit of both backdrops folded in (bd, hbd in -1..1).
+// Slot layout of an item, in key (= draw) order, every region a multiple of 4 slots:
+//   triangles (stroke lines, joints, the four curve lists; 4 slots each) | fill chain edges | BD / HBD slots (4) |
+//   hull region: the hull chain's edges (1 slot each) or — a hull strip whose triangles do not all face the same way — its triangles as
+//   cover triangles (4 slots each; the region is sized for those) | the 9 COVER slots (12)
+struct EdgeRec {
+    uint32_t flags, pad0;
+    float lo_x, lo_y, hi_x, hi_y, bx, nay;
+};
+struct SynthRec {
+    uint32_t flags, pad0;
+    float r, g, b, a, pad1, pad2;
+};
+static_assert(sizeof(EdgeRec) == 32 && sizeof(SynthRec) == 32, "slots");
+
+struct ItemSlots {
+    uint32_t n_tri, n_fe, n_hull; // triangles, fill chain edges (= polygon vertices), hull vertices (0: no cover)
+    uint32_t fe0, synth_a, hull0, synth_b, total; // region offsets from the item's first slot
+    uint32_t cb[8];
+};
+CRH_D ItemSlots item_slots(const SceneDev& s, const DrawItem& it) {
+    ItemSlots k;
+    shape_candidates(s, it.shape, k.cb);
+    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    const bool stencil = (it.ops & 1u) != 0u, cover = (it.ops >> 4) != 0u;
+    const uint32_t hn = s.hull_count[it.shape];
+    k.n_tri = stencil ? k.cb[1] + (k.cb[6] - k.cb[2]) : 0u; // stroke line + joint triangles, then the four curve lists
+    k.n_fe = stencil ? b0[NCH + CH_SOLID_V] - b0[CH_SOLID_V] : 0u; // one boundary edge per polygon vertex
+    k.n_hull = (cover && hn >= 3u) ? hn : 0u;
+    k.fe0 = 4u * k.n_tri;
+    k.synth_a = k.fe0 + ((k.n_fe + 3u) & ~3u);
+    k.hull0 = k.synth_a + 4u;
+    k.synth_b = k.hull0 + (k.n_hull ? 4u * (k.n_hull - 2u) : 0u);
+    k.total = k.synth_b + 12u;
+    return k;
+}
+__global__ __launch_bounds__(256) void k_item_nslots(SceneDev s, RasterParams r, uint32_t n_items, uint32_t* out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_items) return;
+    out[i] = item_slots(s, item_of(r, i)).total;
+}
+
+// ---------------------------------------------------------------------------------------------- triangle setup (plain instances)
+// oracle/raster.hpp setup_triangle + setup_attribute for candidate c of the Shape (lines, joints, curve lists); false: nothing to draw
+CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const DrawItem& it, const uint32_t cb[8], uint32_t c, const float* m, PrimRec& rec) {
+    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    const uint32_t dyn0 = s.shape_dyn_begin[it.shape];
+    const float W = (float)r.width, H = (float)r.height;
+    float2 p[3];
+    float attr[3][4] = {};
+    uint32_t kind, flat_u = 0, desc = 0;
+    float end_y = 0.0f;
+    int n_attr;
+    bool valid = true;
+    if (c < cb[0]) { // stroke line strips
+        const uint32_t lv0 = b0[CH_LINE_V], k = c;
+        valid = s.line_pair_cut[(lv0 + k) >> 1] == 0;
+        const uint32_t i0 = lv0 + k, i1 = lv0 + ((k & 1u) ? k + 2u : k + 1u), i2 = lv0 + ((k & 1u) ? k + 1u : k + 2u);
+        const Vertex2f1i a = s.line_v[i0], b = s.line_v[i1], d = s.line_v[i2];
+        p[0] = make_float2(a.x, a.y), p[1] = make_float2(b.x, b.y), p[2] = make_float2(d.x, d.y);
+        attr[0][0] = a.u, attr[0][1] = a.v, attr[1][0] = b.u, attr[1][1] = b.v, attr[2][0] = d.u, attr[2][1] = d.v;
+        flat_u = a.i;
+        end_y = a.v;
+        desc = dyn0 + (a.i & 65535u);
+        kind = KIND_LINE;
+        n_attr = 2;
+    } else if (c < cb[1]) { // joint strips: 5 vertices, 3 triangles per join
+        const uint32_t q = c - cb[0], jn = q / 3u, k = q - 3u * jn, base = 5u * (b0[CH_JOINT] + jn);
+        const uint32_t i0 = base + k, i1 = base + ((k & 1u) ? k + 2u : k + 1u), i2 = base + ((k & 1u) ? k + 1u : k + 2u);
+        const Vertex3f1i a = s.joint_v[i0], b = s.joint_v[i1], d = s.joint_v[i2];
+        p[0] = make_float2(a.x, a.y), p[1] = make_float2(b.x, b.y), p[2] = make_float2(d.x, d.y);
+        attr[0][0] = a.u, attr[0][1] = a.v, attr[0][2] = a.w, attr[1][0] = b.u, attr[1][1] = b.v, attr[1][2] = b.w, attr[2][0] = d.u, attr[2][1] = d.v, attr[2][2] = d.w;
+        flat_u = a.i;
+        desc = dyn0 + (flat_u & 65535u);
+        kind = KIND_JOINT;
+        n_attr = 3;
+    } else if (c < cb[3]) {
+        const uint32_t at = 3u * (b0[CH_IQ] + (c - cb[2]));
+        for (int v = 0; v < 3; ++v) {
+            const Vertex2f a = s.iq_v[at + v];
+            p[v] = make_float2(a.x, a.y);
+            attr[v][0] = a.u, attr[v][1] = a.v;
+        }
+        kind = KIND_IQ;
+        n_attr = 2;
+    } else if (c < cb[4]) {
+        const uint32_t at = b0[CH_IC_V] + 3u * (c - cb[3]);
+        for (int v = 0; v < 3; ++v) {
+            const Vertex3f a = s.ic_v[at + v];
+            p[v] = make_float2(a.x, a.y);
+            attr[v][0] = a.u, attr[v][1] = a.v, attr[v][2] = a.w;
+        }
+        kind = KIND_IC;
+        n_attr = 3;
+    } else if (c < cb[5]) {
+        const uint32_t at = 3u * (b0[CH_RQ] + (c - cb[4]));
+        for (int v = 0; v < 3; ++v) {
+            const Vertex3f a = s.rq_v[at + v];
+            p[v] = make_float2(a.x, a.y);
+            attr[v][0] = a.u, attr[v][1] = a.v, attr[v][2] = a.w;
+        }
+        kind = KIND_RQ;
+        n_attr = 3;
+    } else if (c < cb[6]) {
+        const uint32_t at = b0[CH_RC_V] + 3u * (c - cb[5]);
+        for (int v = 0; v < 3; ++v) {
+            const Vertex4f a = s.rc_v[at + v];
+            p[v] = make_float2(a.x, a.y);
+            attr[v][0] = a.k, attr[v][1] = a.l, attr[v][2] = a.m, attr[v][3] = a.n;
+        }
+        kind = KIND_RC;
+        n_attr = 4;
+    } else { // a triangle of the hull strip as a cover triangle (hull strips whose triangles face both ways)
+        const uint32_t k = c - cb[6], hull0 = b0[CH_HULL];
+        const Vertex0 a = s.hull_v[hull0 + k], b = s.hull_v[hull0 + ((k & 1u) ? k + 2u : k + 1u)], d = s.hull_v[hull0 + ((k & 1u) ? k + 1u : k + 2u)];
+        p[0] = make_float2(a.x, a.y), p[1] = make_float2(b.x, b.y), p[2] = make_float2(d.x, d.y);
+        kind = EK_COVER_TRI;
+        n_attr = 0;
+    }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) p[v] = to_framebuffer(m, W, H, p[v].x, p[v].y);
+    const float d1x = p[1].x - p[0].x, d1y = p[1].y - p[0].y;
+    const float d2x = p[2].x - p[0].x, d2y = p[2].y - p[0].y;
+    const float det = d1x * d2y - d2x * d1y;
+    if (!(valid && det != 0.0f && det == det && is_finite(det))) return false;
+    const float minx = fminf(p[0].x, fminf(p[1].x, p[2].x)), maxx = fmaxf(p[0].x, fmaxf(p[1].x, p[2].x));
+    const float miny = fminf(p[0].y, fminf(p[1].y, p[2].y)), maxy = fmaxf(p[0].y, fmaxf(p[1].y, p[2].y));
+    const bool nan_free = minx == minx && maxx == maxx && miny == miny && maxy == maxy;
+    const int x0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), x1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
+    const int y0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), y1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
+    if (!(nan_free && x0 <= x1 && y0 <= y1)) return false;
+    rec.cov.box = make_ushort4((unsigned short)x0, (unsigned short)x1, (unsigned short)y0, (unsigned short)y1);
+    const float inv_det = 1.0f / det;
+    const bool front = det < 0.0f;
+    const float2 nv[3] = {p[0], det < 0.0f ? p[2] : p[1], det < 0.0f ? p[1] : p[2]};
+    uint32_t flags = (front ? 8u : 0u) | (kind << 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float2 a = nv[i], b = nv[(i + 1) % 3];
+        const float dx = b.x - a.x, dy = b.y - a.y;
+        if (dy < 0.0f || (dy == 0.0f && dx > 0.0f)) flags |= 1u << i;
+        const bool flip = !(a.x < b.x || (a.x == b.x && a.y < b.y));
+        const float2 el = flip ? b : a, eh = flip ? a : b;
+        const float sg = flip ? -1.0f : 1.0f;
+        rec.cov.lo_x[i] = el.x;
+        rec.cov.lo_y[i] = el.y;
+        rec.cov.bx[i] = (eh.x - el.x) * sg;
+        rec.cov.nay[i] = -(eh.y - el.y) * sg;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (a < n_attr) {
+            const float da1 = attr[1][a] - attr[0][a], da2 = attr[2][a] - attr[0][a];
+            rec.frag.a0[a] = attr[0][a];
+            rec.frag.gx[a] = (da1 * d2y - da2 * d1y) * inv_det;
+            rec.frag.gy[a] = (da2 * d1x - da1 * d2x) * inv_det;
+        } else {
+            rec.frag.a0[a] = rec.frag.gx[a] = rec.frag.gy[a] = 0.0f;
+        }
+    }
+    if (kind == EK_COVER_TRI) { // color_cover: (rgb * a, a), shaders.wgsl:304-309
+        const float* color = r.colors + 4u * it.instance;
+        rec.frag.a0[0] = color[0] * color[3], rec.frag.a0[1] = color[1] * color[3], rec.frag.a0[2] = color[2] * color[3], rec.frag.a0[3] = color[3];
+    }
+    rec.frag.v0x = p[0].x;
+    rec.frag.v0y = p[0].y;
+    rec.frag.flat_u = flat_u;
+    rec.frag.end_y = end_y;
+    rec.cov.flags = flags;
+    rec.cov.desc = desc;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- pair stage
+// (tile, position in the tile's list, key) triples of one wavefront, staged in LDS and written out in blocks: one atomic on the stream
+// cursor per block, coalesced stores. The position comes from the returning atomic on the tile's counter, so k_scatter needs none.
+constexpr uint32_t kStage = 512;
+struct Stage {
+    uint32_t* tile;
+    uint32_t* pos;
+    uint32_t* key;
+    uint32_t used;
+};
+CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
+    if (st.used == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t base = 0;
+    if (lane == 0u) base = atomicAdd(r.pair_cursor, st.used);
+    base = __shfl(base, 0, 64);
+    for (uint32_t i = lane; i < st.used; i += 64u)
+        if (base + i < r.pair_capacity) { // beyond the capacity only the counts matter: the host grows the stream and runs the pass again
+            r.pair_tile[base + i] = st.tile[i];
+            r.pair_pos[base + i] = st.pos[i];
+            r.pair_key[base + i] = st.key[i];
+        }
+    __builtin_amdgcn_wave_barrier();
+    st.used = 0u;
+}
+CRH_D uint32_t lanes_below(unsigned long long ballot, uint32_t lane) { return (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull)); }
+// the lanes of `ballot` append one entry each
+CRH_D void stage_append(Stage& st, const RasterParams& r, uint32_t lane, unsigned long long ballot, uint32_t tile, uint32_t pos, uint32_t key) {
+    if ((ballot >> lane) & 1ull) {
+        const uint32_t at = st.used + lanes_below(ballot, lane);
+        st.tile[at] = tile;
+        st.pos[at] = pos;
+        st.key[at] = key;
+    }
+    st.used += (uint32_t)__popcll(ballot);
+    if (st.used > kStage - 64u) stage_flush(st, r, lane);
+}
+
+CRH_D bool accepts(float e, uint32_t tl) { return e > 0.0f || (e == 0.0f && tl != 0u); }
+
+// ---------------------------------------------------------------------------------------------- k_bin_edges
+struct BinEdge { // one boundary edge of the item, canonical orientation
+    float lo_x, lo_y, hi_x, hi_y, bx, nay, ymin, ymax;
+    uint32_t tl, hull;
+    int sigma, down;
+    bool valid;
+};
+// boundary chain of a zig-zag strip (vertex.rs:28-35): the edge owned by strip position `pos` runs to position `target`
+//   pos 0 -> 1;  even pos >= 2 -> pos - 2;  odd pos -> pos + 2, or — at the end of the strip — to the other one of the last two positions
+// Edge i of an item: i < n_fe the fill chain(s), then the hull chain (n_hull_chain edges: 0 when the hull is drawn as triangles).
+CRH_D BinEdge load_edge(const SceneDev& s, const RasterParams& r, const DrawItem& it, const ItemSlots& k, uint32_t n_hull_chain, uint32_t i, const float* m) {
+    BinEdge e = {};
+    e.valid = false;
+    if (i >= k.n_fe + n_hull_chain) return e;
+    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    float2 a, b;
+    if (i < k.n_fe) {
+        const uint32_t sv0 = b0[CH_SOLID_V], g = sv0 + i;
+        const uint32_t f = s.solid_flag[g];
+        const bool odd = (f & 1u) != 0u, last = (f & 2u) != 0u;
+        const bool first = !odd && (i == 0u || (s.solid_flag[g - 1u] & 2u) != 0u);
+        uint32_t target;
+        if (first) {
+            if (last) return e; // a strip of one vertex
+            target = g + 1u;
+        } else if (!odd) {
+            target = g - 2u;
+        } else {
+            target = last ? g - 1u : ((s.solid_flag[g + 1u] & 2u) ? g + 1u : g + 2u);
+        }
+        const Vertex0 va = s.solid_v[g], vb = s.solid_v[target];
+        a = make_float2(va.x, va.y), b = make_float2(vb.x, vb.y);
+    } else {
+        const uint32_t pos = i - k.n_fe, n = n_hull_chain, hull0 = b0[CH_HULL];
+        uint32_t target;
+        if (pos == 0u)
+            target = 1u;
+        else if ((pos & 1u) == 0u)
+            target = pos - 2u;
+        else
+            target = pos + 1u == n ? pos - 1u : (pos + 2u == n ? pos + 1u : pos + 2u);
+        const Vertex0 va = s.hull_v[hull0 + pos], vb = s.hull_v[hull0 + target];
+        a = make_float2(va.x, va.y), b = make_float2(vb.x, vb.y);
+        e.hull = 1u;
+    }
+    const float W = (float)r.width, H = (float)r.height;
+    a = to_framebuffer(m, W, H, a.x, a.y);
+    b = to_framebuffer(m, W, H, b.x, b.y);
+    if (!(is_finite(a.x) && is_finite(a.y) && is_finite(b.x) && is_finite(b.y))) return e;
+    if (a.x == b.x && a.y == b.y) return e;
+    const bool flip = !(a.x < b.x || (a.x == b.x && a.y < b.y)); // canonical (lexicographic) endpoint order
+    const float2 lo = flip ? b : a, hi = flip ? a : b;
+    e.lo_x = lo.x, e.lo_y = lo.y, e.hi_x = hi.x, e.hi_y = hi.y;
+    e.bx = hi.x - lo.x;
+    e.nay = -(hi.y - lo.y);
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y;
+    e.tl = (dy < 0.0f || (dy == 0.0f && dx > 0.0f)) ? 1u : 0u;
+    e.down = dy > 0.0f ? 1 : 0;
+    e.sigma = flip ? 1 : -1; // -1: the chain runs in the canonical direction
+    e.ymin = fminf(lo.y, hi.y), e.ymax = fmaxf(lo.y, hi.y);
+    e.valid = true;
+    return e;
+}
+CRH_D float wave_min(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+CRH_D float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+CRH_D uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    return v;
+}
+
+// The exact tile test of a set-up triangle: its best tile corner per edge decides (an edge function is monotone in x and y under fmaf).
+// A conservative superset of "some sample of the tile is covered"; the raster kernel decides per sample.
+struct TileTest {
+    float bx[3], nay[3], lo_x[3], lo_y[3], best_x[3], best_y[3];
+    uint32_t tl[3];
+    CRH_D void set(const PrimCoverage& cov, float lo, float hi) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bx[i] = cov.bx[i], nay[i] = cov.nay[i], lo_x[i] = cov.lo_x[i], lo_y[i] = cov.lo_y[i];
+            best_x[i] = cov.nay[i] > 0.0f ? hi : lo;
+            best_y[i] = cov.bx[i] > 0.0f ? hi : lo;
+            tl[i] = (cov.flags >> i) & 1u;
+        }
+    }
+    CRH_D bool hit(uint32_t tx, uint32_t ty) const {
+        const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float e = fmaf(best_y[i], bx[i], fmaf(best_x[i], nay[i], bx[i] * (ty0 - lo_y[i]) + nay[i] * (tx0 - lo_x[i])));
+            ok = ok && accepts(e, tl[i]);
+        }
+        return ok;
+    }
+};
+// Bins up to 64 set-up triangles (lane = triangle): every lane walks the tiles of ITS OWN pixel box — a few for a curve or stroke
+// triangle; a triangle over more than kBigRect tiles is walked by the whole wavefront instead (lane = tile), one such triangle at a time.
+constexpr uint32_t kBigRect = 32;
+CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool drawn, const PrimCoverage& cov, uint32_t key, float s_lo, float s_hi) {
+    TileTest test;
+    test.set(cov, s_lo, s_hi);
+    const uint32_t bx0 = cov.box.x / kTile, bx1 = cov.box.y / kTile, by0 = cov.box.z / kTile, by1 = cov.box.w / kTile;
+    const uint32_t nx = bx1 - bx0 + 1u, nt = drawn ? nx * (by1 - by0 + 1u) : 0u;
+    const bool big = nt > kBigRect || (nt != 0u && (r.debug & 2u) != 0u); // debug bit 1 (tests): every triangle takes the wide path
+    const uint32_t mine = big ? 0u : nt, longest = wave_max_u32(mine);
+    uint32_t tx = bx0, ty = by0;
+    for (uint32_t i = 0; i < longest; ++i) {
+        const bool hit = i < mine && test.hit(tx, ty);
+        const unsigned long long ballot = __ballot(hit);
+        if (ballot) {
+            const uint32_t tile = ty * r.tiles_x + tx;
+            uint32_t pos = 0;
+            if (hit) pos = atomicAdd(&r.tile_count[tile], 1u);
+            stage_append(st, r, lane, ballot, tile, pos, key);
+        }
+        if (++tx > bx1) tx = bx0, ++ty;
+    }
+    unsigned long long todo = __ballot(big);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        TileTest wide;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            wide.bx[i] = __shfl(test.bx[i], src, 64), wide.nay[i] = __shfl(test.nay[i], src, 64), wide.lo_x[i] = __shfl(test.lo_x[i], src, 64);
+            wide.lo_y[i] = __shfl(test.lo_y[i], src, 64), wide.best_x[i] = __shfl(test.best_x[i], src, 64), wide.best_y[i] = __shfl(test.best_y[i], src, 64);
+            wide.tl[i] = (uint32_t)__shfl((int)test.tl[i], src, 64);
+        }
+        const uint32_t wx0 = (uint32_t)__shfl((int)bx0, src, 64), wy0 = (uint32_t)__shfl((int)by0, src, 64), wnx = (uint32_t)__shfl((int)nx, src, 64);
+        const uint32_t wnt = (uint32_t)__shfl((int)nt, src, 64), wkey = (uint32_t)__shfl((int)key, src, 64);
+        for (uint32_t base = 0; base < wnt; base += 64u) {
+            const uint32_t q = base + lane, qy = q / wnx, qx = q - qy * wnx;
+            const bool hit = q < wnt && wide.hit(wx0 + qx, wy0 + qy);
+            const unsigned long long ballot = __ballot(hit);
+            if (!ballot) continue;
+            const uint32_t tile = (wy0 + qy) * r.tiles_x + (wx0 + qx);
+            uint32_t pos = 0;
+            if (hit) pos = atomicAdd(&r.tile_count[tile], 1u);
+            stage_append(st, r, lane, ballot, tile, pos, wkey);
+        }
+    }
+}
+
+// One workgroup per draw item. Wavefront 0: the stroke and curve triangles (bin_triangles). Wavefront 1: the boundary edges, transposed —
+// lane = tile of the item's rectangle (64 per pass), uniform loop over the edges (staged in LDS): every lane accumulates the backdrops of
+// its tile and the bit mask of the edges that matter inside it, then emits its entries.
+template <int S>
+__global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
+    __shared__ uint32_t stage_tile[2][kStage], stage_pos[2][kStage], stage_key[2][kStage];
+    __shared__ float4 edge_a[64], edge_b[64];
+    const uint32_t item = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const DrawItem it = item_of(r, item);
+    const float* m = r.transforms + 16u * it.instance;
+    const ItemSlots k = item_slots(s, it);
+    const uint32_t slot0 = r.slot_begin[item];
+    if (slot0 + k.total > r.slot_capacity) return; // cannot happen: the capacity is the scan's total
+    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u};
+    const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
+    if (wave == 0u) {
+        // ---------------- triangles: 64 at a time, lane = triangle
+        for (uint32_t t0 = 0; t0 < k.n_tri; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            PrimRec rec = {};
+            bool drawn = false;
+            if (t < k.n_tri) {
+                const uint32_t c = t < k.cb[1] ? t : t - k.cb[1] + k.cb[2]; // the Shape's candidate numbering without the solid strips
+                drawn = setup_plain_triangle(s, r, it, k.cb, c, m, rec);
+                if (drawn) *reinterpret_cast<PrimRec*>(r.slots + (size_t)(slot0 + 4u * t) * 32u) = rec;
+            }
+            bin_triangles(st, r, lane, drawn, rec.cov, slot0 + 4u * t, ry_first, r_last);
+        }
+    } else {
+        // ---------------- boundary edges: fill chain(s) then hull chain
+        const uint32_t fe_slot0 = slot0 + k.fe0, synth_a = slot0 + k.synth_a, hull_slot0 = slot0 + k.hull0, synth_b = slot0 + k.synth_b;
+        if (lane < 13u) { // the item's synthetic slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
+            SynthRec sr = {};
+            sr.flags = (EK_SYNTH << 4) | (lane << 8);
+            if (lane >= 4u) {
+                const float* color = r.colors + 4u * it.instance;
+                sr.r = color[0] * color[3], sr.g = color[1] * color[3], sr.b = color[2] * color[3], sr.a = color[3];
+            }
+            *reinterpret_cast<SynthRec*>(r.slots + (size_t)(lane < 4u ? synth_a + lane : synth_b + lane - 4u) * 32u) = sr;
+        }
+        // Do all triangles of the hull strip face the same way? Then the cover — the UNION of those triangles (renderer.rs:340-354) — is
+        // where the winding number of the strip's boundary chain is not zero, and the chain is binned. A strip that folds over itself
+        // (andrew() decides turns with an absolute margin, convex_hull.rs:17-20: under f32 cancellation its output is not always convex)
+        // is drawn as the reference draws it, triangle by triangle.
+        bool hull_as_triangles = false;
+        if (k.n_hull) {
+            const uint32_t* b0 = s.shape_base + it.shape * NCH;
+            const uint32_t hull0 = b0[CH_HULL];
+            const float W = (float)r.width, H = (float)r.height;
+            unsigned long long front = 0, back = 0;
+            for (uint32_t t0 = 0; t0 + 2u < k.n_hull; t0 += 64u) {
+                const uint32_t t = t0 + lane;
+                float det = 0.0f;
+                if (t + 2u < k.n_hull) {
+                    const Vertex0 va = s.hull_v[hull0 + t], vb = s.hull_v[hull0 + ((t & 1u) ? t + 2u : t + 1u)], vc = s.hull_v[hull0 + ((t & 1u) ? t + 1u : t + 2u)];
+                    const float2 p0 = to_framebuffer(m, W, H, va.x, va.y), p1 = to_framebuffer(m, W, H, vb.x, vb.y), p2 = to_framebuffer(m, W, H, vc.x, vc.y);
+                    const float d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
+                    det = d1x * d2y - d2x * d1y; // setup_plain_triangle's det
+                    if (!(det == det && is_finite(det))) det = 0.0f;
+                }
+                front |= __ballot(det < 0.0f);
+                back |= __ballot(det > 0.0f);
+            }
+            hull_as_triangles = (front != 0ull && back != 0ull) || (r.debug & 4u) != 0u; // debug bit 2 (tests): always
+        }
+        const uint32_t n_hull_chain = hull_as_triangles ? 0u : k.n_hull;
+        const uint32_t n_edges = k.n_fe + n_hull_chain;
+        // one chunk of (up to 64) edges -> LDS table (+ the heap records the first time)
+        float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+        auto stage_chunk = [&](uint32_t i0, bool write_records) {
+            const uint32_t i = i0 + lane;
+            const BinEdge e = load_edge(s, r, it, k, n_hull_chain, i, m);
+            const uint32_t flags = (EK_EDGE << 4) | (e.tl ? kEdgeTl : 0u) | (e.sigma > 0 ? kEdgeSigmaPos : 0u) | (e.hull ? kEdgeHull : 0u);
+            if (e.valid && write_records) {
+                EdgeRec er;
+                er.flags = flags, er.pad0 = 0u;
+                er.lo_x = e.lo_x, er.lo_y = e.lo_y, er.hi_x = e.hi_x, er.hi_y = e.hi_y, er.bx = e.bx, er.nay = e.nay;
+                *reinterpret_cast<EdgeRec*>(r.slots + (size_t)(i < k.n_fe ? fe_slot0 + i : hull_slot0 + (i - k.n_fe)) * 32u) = er;
+            }
+            __builtin_amdgcn_wave_barrier(); // the previous chunk's readers are done
+            edge_a[lane] = make_float4(e.lo_x, e.lo_y, e.bx, e.nay);
+            edge_b[lane] = make_float4(e.ymin, e.ymax, e.hi_x, __uint_as_float(flags | (e.down ? 8u : 0u) | (e.valid ? 0x100u : 0u)));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (e.valid) {
+                minx = fminf(minx, e.lo_x), maxx = fmaxf(maxx, e.hi_x);
+                miny = fminf(miny, e.ymin), maxy = fmaxf(maxy, e.ymax);
+            }
+        };
+        const bool single = n_edges <= 64u && (r.debug & 1u) == 0u; // debug bit 0 (tests): the chunked path even for short chains
+        for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) stage_chunk(i0, true); // records + the box of every vertex (single: the table stays)
+        minx = wave_min(minx), maxx = wave_max(maxx), miny = wave_min(miny), maxy = wave_max(maxy);
+        const float W = (float)r.width, H = (float)r.height;
+        const int px0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), px1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
+        const int py0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), py1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
+        if (n_edges != 0u && minx <= maxx && px0 <= px1 && py0 <= py1) {
+            const uint32_t tx_a = (uint32_t)px0 / kTile, tx_b = (uint32_t)px1 / kTile, ty_a = (uint32_t)py0 / kTile, ty_b = (uint32_t)py1 / kTile;
+            const uint32_t nx = tx_b - tx_a + 1u, n_rect = nx * (ty_b - ty_a + 1u);
+            for (uint32_t base = 0; base < n_rect; base += 64u) {
+                const uint32_t q = base + lane, qy = q / nx, qx = q - qy * nx;
+                const bool active = q < n_rect;
+                const uint32_t tx = tx_a + qx, ty = ty_a + qy, tile = ty * r.tiles_x + tx;
+                const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+                int bd = 0, hbd = 0;
+                bool hull_touch = false;
+                for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) {
+                    if (!single) stage_chunk(i0, false);
+                    const uint32_t count = min(64u, n_edges - i0);
+                    unsigned long long mask = 0;
+                    for (uint32_t j = 0; j < count; ++j) {
+                        const float4 A = edge_a[j], B = edge_b[j];
+                        const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(B.w));
+                        if (!(flags & 0x100u)) continue;
+                        const uint32_t tl = flags & kEdgeTl;
+                        const float c = A.z * (ty0 - A.y) + A.w * (tx0 - A.x);
+                        const bool gq0 = accepts(fmaf(ry_first, A.z, fmaf(0.0f, A.w, c)), tl);
+                        const bool y0_in = B.x <= q0y && q0y < B.y; // Y_e at the backdrop row
+                        const int sigma = (flags & kEdgeSigmaPos) ? 1 : -1, down = (flags >> 3) & 1;
+                        const int term = y0_in ? sigma * ((gq0 ? 1 : 0) - down) : 0; // sigma * Y(q0) * (g(q0) - down)
+                        const bool up = A.w > 0.0f; // E grows with ry (bx >= 0) and with rx iff nay > 0
+                        const bool gmax = accepts(fmaf(r_last, A.z, fmaf(up ? r_last : 0.0f, A.w, c)), tl), gmin = accepts(fmaf(ry_first, A.z, fmaf(up ? 0.0f : r_last, A.w, c)), tl);
+                        const bool touch = active && gmax != gmin && B.x <= ty0 + r_last && B.y >= q0y && A.x <= tx0 + r_last && B.z >= tx0;
+                        if (flags & kEdgeHull) {
+                            hbd += term;
+                            hull_touch = hull_touch || touch;
+                        } else {
+                            bd += term;
+                        }
+                        mask |= touch ? (1ull << j) : 0ull;
+                    }
+                    // ---- this chunk's entries; the last chunk's go together with the item's synthetic entries
+                    const bool last_chunk = i0 + 64u >= n_edges;
+                    const uint32_t abd = (uint32_t)(bd < 0 ? -bd : bd), ahbd = (uint32_t)(hbd < 0 ? -hbd : hbd);
+                    uint32_t n_cover = 0, n_bd = 0, n_hbd = 0, cover_key = 0;
+                    if (last_chunk && active) {
+                        n_cover = (n_hull_chain != 0u && (hbd != 0 || hull_touch)) ? 1u : 0u; // the tile is inside the hull or its boundary crosses it
+                        const int cbd = bd > 0 ? 1 : (bd < 0 ? -1 : 0), chbd = hbd > 0 ? 1 : (hbd < 0 ? -1 : 0);
+                        cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1);
+                        n_bd = n_cover ? (abd ? abd - 1u : 0u) : abd; // the COVER entry carries one unit of either backdrop
+                        n_hbd = n_cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
+                    }
+                    const uint32_t bd_key = synth_a + (bd > 0 ? 0u : 1u), hbd_key = synth_a + (hbd > 0 ? 2u : 3u);
+                    const uint32_t n_mine = (uint32_t)__popcll(mask) + n_cover + n_bd + n_hbd;
+                    uint32_t pos = 0;
+                    if (n_mine) pos = atomicAdd(&r.tile_count[tile], n_mine);
+                    uint32_t left = n_mine;
+                    for (;;) {
+                        const unsigned long long ballot = __ballot(left != 0u);
+                        if (!ballot) break;
+                        uint32_t key = 0;
+                        if (left) {
+                            if (mask) {
+                                const uint32_t i = i0 + (uint32_t)(__ffsll((long long)mask) - 1);
+                                mask &= mask - 1ull;
+                                key = i < k.n_fe ? fe_slot0 + i : hull_slot0 + (i - k.n_fe);
+                            } else if (n_cover) {
+                                n_cover = 0, key = cover_key;
+                            } else if (n_bd) {
+                                --n_bd, key = bd_key;
+                            } else {
+                                --n_hbd, key = hbd_key;
+                            }
+                        }
+                        stage_append(st, r, lane, ballot, tile, pos, key);
+                        if (left) ++pos, --left;
+                    }
+                }
+            }
+        }
+        if (hull_as_triangles) { // the hull strip, triangle by triangle, as cover triangles (keys behind the fill chain and the backdrop slots)
+            for (uint32_t t0 = 0; t0 + 2u < k.n_hull; t0 += 64u) {
+                const uint32_t t = t0 + lane;
+                PrimRec rec = {};
+                bool drawn = false;
+                if (t + 2u < k.n_hull) {
+                    drawn = setup_plain_triangle(s, r, it, k.cb, k.cb[6] + t, m, rec);
+                    if (drawn) *reinterpret_cast<PrimRec*>(r.slots + (size_t)(hull_slot0 + 4u * t) * 32u) = rec;
+                }
+                bin_triangles(st, r, lane, drawn, rec.cov, hull_slot0 + 4u * t, ry_first, r_last);
+            }
+        }
+    }
+    stage_flush(st, r, lane);
+}
+
+__global__ __launch_bounds__(256) void k_scatter(RasterParams r) {
+    if (r.overflow[0]) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = min(*r.pair_cursor, r.pair_capacity);
+    if (i >= total) return;
+    r.tile_list[r.tile_offset[r.pair_tile[i]] + r.pair_pos[i]] = r.pair_key[i];
+}
+
+// ---------------------------------------------------------------------------------------------- k_raster_edges
+// One workgroup per 16x16 tile, laid out exactly as k_raster_tile (raster.hip): msaa 1 = one wavefront, four pixel rows per lane;
+// msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
+// the item being drawn and the colour; entries are walked in key order (= draw order).
+template <int S, int ROWS, bool STROKES>
+__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? 1 : CRH_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
+    extern __shared__ uint32_t sort_buffer[];
+    __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
+    constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
+    const uint32_t turn = blockIdx.x >> 3;
+    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
+    const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    const uint32_t tile = ty * r.tiles_x + tx;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* __restrict__ keys = sort_buffer + wave * r.sort_capacity;
+    const uint32_t px = lane & 15u, rq = lane >> 4;
+    const uint32_t first_row = 4u * ROWS * wave;
+    const uint32_t gx = tx * kTile + px;
+    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+    const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
+    float sx[S], sy0[S];
+    if (S == 1) {
+        sx[0] = (float)px + 0.5f;
+        sy0[0] = (float)(first_row + rq) + 0.5f;
+    } else {
+        const float ox[4] = {0.375f, 0.875f, 0.125f, 0.625f}, oy[4] = {0.125f, 0.375f, 0.625f, 0.875f};
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            sx[q] = (float)px + ox[q & 3];
+            sy0[q] = (float)(first_row + rq) + oy[q & 3];
+        }
+    }
+    const uint32_t row_shift = first_row + rq; // triangles: bit row_shift + 4b of a 16-bit pixel-row mask
+    // edges: the wave's 16 sample rows are numbered j = pixel row (msaa 1) or 4 * local row + sample (msaa 4); sample (b, q) of this lane is
+    // bit  bit_of(b, q)  of a 16-bit mask shifted right by edge_shift
+    const uint32_t edge_shift = S == 1 ? rq : 4u * rq;
+    int winding[ROWS][S], hullw[ROWS][S];
+    float col[ROWS][S][4];
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            winding[b][q] = 0;
+            hullw[b][q] = 0;
+            col[b][q][0] = col[b][q][1] = col[b][q][2] = col[b][q][3] = 0.0f;
+        }
+    if (r.load_existing) {
+#pragma unroll
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
+            if (gx < r.width && gy < r.height) {
+                const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[(size_t)gy * r.width + gx];
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    col[b][q][0] = (float)d.x * (1.0f / 255.0f);
+                    col[b][q][1] = (float)d.y * (1.0f / 255.0f);
+                    col[b][q][2] = (float)d.z * (1.0f / 255.0f);
+                    col[b][q][3] = (float)d.w * (1.0f / 255.0f);
+                }
+            }
+        }
+    }
+    const uint32_t list_begin = r.tile_offset[tile];
+    uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
+    constexpr uint32_t kLdsSortMax = kSortBytesMax / (4u * (4u / ROWS));
+    if (n > r.sort_capacity && n <= kLdsSortMax) n = 0; // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
+    uint32_t my_key = 0xFFFFFFFFu;
+    const bool sorted_in_place = n > kLdsSortMax;
+    uint32_t* const segment = r.tile_list + list_begin;
+    if (sorted_in_place) { // as raster.hip: a normalised bitonic network over the tile's segment of the list, in global memory
+        const uint32_t tid = threadIdx.x, n_threads = 64u * (4u / ROWS);
+        uint32_t padded = 1;
+        while (padded < n) padded <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t partner) {
+            if (partner < n) {
+                const uint32_t a = __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b = __hip_atomic_load(segment + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a > b) {
+                    __hip_atomic_store(segment + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(segment + partner, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        for (uint32_t kk = 2; kk <= padded; kk <<= 1) {
+            const uint32_t half = kk >> 1;
+            for (uint32_t p = tid; p < (padded >> 1); p += n_threads) {
+                const uint32_t blk = p / half, t = p - blk * half;
+                exchange(blk * kk + t, blk * kk + kk - 1u - t);
+            }
+            __threadfence();
+            __syncthreads();
+            for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+                for (uint32_t p = tid; p < (padded >> 1); p += n_threads) {
+                    const uint32_t i = 2u * j * (p / j) + (p % j);
+                    exchange(i, i + j);
+                }
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    } else if (n <= 64u) {
+        if (lane < n) my_key = r.tile_list[list_begin + lane];
+#pragma unroll
+        for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
+#pragma unroll
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                const uint32_t other = __shfl_xor(my_key, j, 64);
+                const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                my_key = keep_min ? min(my_key, other) : max(my_key, other);
+            }
+        }
+    } else {
+        uint32_t padded = 128;
+        while (padded < n) padded <<= 1;
+        for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < n ? r.tile_list[list_begin + i] : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t kk = 2; kk <= padded; kk <<= 1)
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = lane; i < padded; i += 64u) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const uint32_t a = keys[i], b = keys[partner];
+                        if (((i & kk) == 0) ? (a > b) : (a < b)) {
+                            keys[i] = b;
+                            keys[partner] = a;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+
+    const uint8_t* slots = r.slots;
+    const int wmask = (int)r.winding_mask;
+    const float ry_q0 = S == 1 ? 0.5f : 0.125f; // the backdrop row of the tile (k_bin_edges)
+    for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+        if (sorted_in_place)
+            my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        else if (n > 64u)
+            my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
+        const uint32_t count = min(64u, n - q0);
+        // ---- entry setup, vectorised across the chunk: lane j prepares entry j
+        float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0;
+        if (lane < count) {
+            const uint8_t* slot = slots + (size_t)my_key * 32u;
+            const uint32_t flags = *reinterpret_cast<const uint32_t*>(slot);
+            const uint32_t kind = (flags >> 4) & 15u;
+            if (kind == EK_EDGE) {
+                const EdgeRec er = *reinterpret_cast<const EdgeRec*>(slot);
+                const float c = er.bx * (ty0 - er.lo_y) + er.nay * (tx0 - er.lo_x);
+                const float h0 = fmaf(0.0f, er.nay, c); // the column term at the left tile boundary
+                const uint32_t tl = flags & kEdgeTl;
+                const float ymin = fminf(er.lo_y, er.hi_y), ymax = fmaxf(er.lo_y, er.hi_y);
+                const bool xr = er.lo_x <= tx0 && tx0 < er.hi_x; // the edge crosses the line of the left tile boundary
+                const int gq0 = accepts(fmaf(ry_q0, er.bx, h0), tl) ? 1 : 0;
+                uint32_t ymask = 0, kp = 0, kn = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { // the wave's sample rows
+                    const float ry = S == 1 ? (float)j + 0.5f : (float)(first_row + (uint32_t)(j >> 2)) + ((float)(j & 3) * 0.25f + 0.125f); // = the lane's sy0 (exact)
+                    const float sy = ty0 + ry;
+                    const int yk = (ymin <= sy && sy < ymax) ? 1 : 0;
+                    const int gqk = accepts(fmaf(ry, er.bx, h0), tl) ? 1 : 0;
+                    const int a = (xr ? gqk - gq0 : 0) - yk * gqk; // the row constant of  xr (g(qk) - g(q0)) + Y (g(p) - g(qk))
+                    ymask |= (uint32_t)yk << j;
+                    kp |= (uint32_t)(a > 0) << j;
+                    kn |= (uint32_t)(a < 0) << j;
+                }
+                const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma = +1; otherwise every term changes sign
+                e0 = make_float4(c, er.bx, er.nay, __uint_as_float(ymask | ((positive ? kp : kn) << 16)));
+                e1 = make_float4(__uint_as_float(positive ? kn : kp), 0.0f, 0.0f, __uint_as_float(flags));
+            } else if (kind == EK_SYNTH) {
+                const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
+                e0 = make_float4(sr.r, sr.g, sr.b, sr.a);
+                e1.w = __uint_as_float(flags);
+            } else {
+                const PrimCoverage mine = *reinterpret_cast<const PrimCoverage*>(slot);
+                const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
+                const int by0 = max((int)mine.box.z, tpy) - tpy, by1 = min((int)mine.box.w, tpy + kTile - 1) - tpy;
+                const uint32_t col_bits = bx1 >= bx0 ? (2u << bx1) - (1u << bx0) : 0u, row_bits = by1 >= by0 ? (2u << by1) - (1u << by0) : 0u;
+                float cc[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cc[i] = mine.bx[i] * (ty0 - mine.lo_y[i]) + mine.nay[i] * (tx0 - mine.lo_x[i]);
+                e0 = make_float4(cc[0], cc[1], cc[2], __uint_as_float(col_bits | (row_bits << 16)));
+                e1 = make_float4(mine.bx[0], mine.bx[1], mine.bx[2], __uint_as_float(flags));
+                e2 = make_float4(mine.nay[0], mine.nay[1], mine.nay[2], __uint_as_float(mine.desc));
+            }
+        }
+        float4* __restrict__ entries = entry_buffer[wave];
+        __builtin_amdgcn_wave_barrier();
+        entries[lane * 3u + 0u] = e0;
+        entries[lane * 3u + 1u] = e1;
+        entries[lane * 3u + 2u] = e2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = 0; j < count; ++j) {
+            const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
+            const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
+            const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
+            const uint32_t kind = (flags >> 4) & 15u;
+            if (kind == EK_EDGE) {
+                // d = sigma * (Y & g(p)) + row constants, for the lane's ROWS x S samples
+                const uint32_t masks = __builtin_amdgcn_readfirstlane(__float_as_uint(ea4.w)), kneg = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.x));
+                const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z;
+                const int thr = 1 - (int)(flags & kEdgeTl);
+                const int unit = (flags & kEdgeSigmaPos) ? 1 : -1;
+                const uint32_t ysh = (masks & 0xFFFFu) >> edge_shift;
+                int d[ROWS][S];
+                float h[S];
+#pragma unroll
+                for (int q = 0; q < S; ++q) h[q] = fmaf(sx[q], enay, c0);
+#pragma unroll
+                for (int cmb = 0; cmb < ROWS * S; cmb += 2) {
+                    const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
+                    const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
+                    const f32x2 ev = fma2(y, splat2(ebx), f32x2{h[k0], h[k1]});
+                    const int p0 = S == 1 ? 4 * b0 : k0, p1 = S == 1 ? 4 * b1 : k1;
+                    d[b0][k0] = ((__float_as_int(ev[0]) >= thr) & (((ysh >> p0) & 1u) != 0u)) ? unit : 0;
+                    d[b1][k1] = ((__float_as_int(ev[1]) >= thr) & (((ysh >> p1) & 1u) != 0u)) ? unit : 0;
+                }
+                if ((masks >> 16) | kneg) { // the edge crosses the left tile boundary (or runs left of it): row constants
+                    const uint32_t psh = (masks >> 16) >> edge_shift, nsh = kneg >> edge_shift;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) {
+                            const int p = S == 1 ? 4 * b : q;
+                            d[b][q] += (int)((psh >> p) & 1u) - (int)((nsh >> p) & 1u);
+                        }
+                }
+                if (flags & kEdgeHull) {
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) hullw[b][q] += d[b][q];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) winding[b][q] += d[b][q];
+                }
+                continue;
+            }
+            if (kind == EK_SYNTH) {
+                const uint32_t code = (flags >> 8) & 15u;
+                if (code < 4u) { // a whole-tile backdrop of the fill (0, 1) or hull (2, 3) winding
+                    const int v = (code & 1u) ? -1 : 1;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) {
+                            if (code < 2u)
+                                winding[b][q] += v;
+                            else
+                                hullw[b][q] += v;
+                        }
+                    continue;
+                }
+                // COVER: color_cover over the samples inside the hull (renderer.rs:340-354, 736-754): blend where winding != 0, zero the winding
+                const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
+                bool blend[ROWS][S];
+                int any_blend = 0;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        const int w = winding[b][q] + bd;
+                        const bool in_hull = hullw[b][q] + hbd != 0;
+                        blend[b][q] = in_hull && (w & wmask) != 0;
+                        any_blend |= (int)blend[b][q];
+                        winding[b][q] = in_hull ? 0 : w;
+                        hullw[b][q] = 0;
+                    }
+                if (__any(any_blend)) {
+                    const float s0 = ea4.x, s1 = ea4.y, s2 = ea4.z, ca = ea4.w;
+                    const float one_minus_a = 1.0f - ca;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) {
+                            const float n0 = s0 + col[b][q][0] * one_minus_a, n1 = s1 + col[b][q][1] * one_minus_a;
+                            const float n2 = s2 + col[b][q][2] * one_minus_a, n3 = ca + col[b][q][3] * one_minus_a;
+                            col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
+                            col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
+                            col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
+                            col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                        }
+                }
+                continue;
+            }
+            // ---- curve and stroke triangles: as k_raster_tile
+            const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
+            bool inside[ROWS][S];
+            {
+                const uint32_t bits = __float_as_uint(ea4.w);
+                const float c0 = ea4.x, c1 = ea4.y, c2 = ea4.z, bx_0 = eb4.x, bx_1 = eb4.y, bx_2 = eb4.z, nay_0 = ec4.x, nay_1 = ec4.y, nay_2 = ec4.z;
+                const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) >> row_shift : 0u;
+                const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
+                float ha[S], hb[S], hc[S];
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    ha[q] = fmaf(sx[q], nay_0, c0);
+                    hb[q] = fmaf(sx[q], nay_1, c1);
+                    hc[q] = fmaf(sx[q], nay_2, c2);
+                }
+#pragma unroll
+                for (int cmb = 0; cmb < ROWS * S; cmb += 2) {
+                    const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
+                    const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
+                    const f32x2 ea = fma2(y, splat2(bx_0), f32x2{ha[k0], ha[k1]});
+                    const f32x2 eb = fma2(y, splat2(bx_1), f32x2{hb[k0], hb[k1]});
+                    const f32x2 ec = fma2(y, splat2(bx_2), f32x2{hc[k0], hc[k1]});
+                    inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & (1u << (4 * b0))) != 0u);
+                    inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & (1u << (4 * b1))) != 0u);
+                }
+            }
+            if (kind == EK_COVER_TRI) { // a triangle of a hull strip drawn as the reference draws it: color_cover inside the triangle
+                bool blend[ROWS][S];
+                int any_blend = 0;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        blend[b][q] = inside[b][q] && (winding[b][q] & wmask) != 0;
+                        any_blend |= (int)blend[b][q];
+                        winding[b][q] = inside[b][q] ? 0 : winding[b][q];
+                    }
+                if (__any(any_blend)) {
+                    const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
+                    const float one_minus_a = 1.0f - ca;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) {
+                            const float n0 = s0 + col[b][q][0] * one_minus_a, n1 = s1 + col[b][q][1] * one_minus_a;
+                            const float n2 = s2 + col[b][q][2] * one_minus_a, n3 = ca + col[b][q][3] * one_minus_a;
+                            col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
+                            col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
+                            col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
+                            col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                        }
+                }
+                continue;
+            }
+            const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+            int dw[ROWS][S];
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < S; ++q) dw[b][q] = 0;
+            const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
+            float hx[4][S];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float ac = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
+#pragma unroll
+                for (int q = 0; q < S; ++q) hx[t][q] = fmaf(sx[q], frag.gx[t], ac);
+            }
+            if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) {
+                    bool row_touched = false;
+#pragma unroll
+                    for (int q = 0; q < S; ++q) row_touched = row_touched | inside[b][q];
+                    if (!__any(row_touched)) continue;
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        const float y = sy0[q] + (float)(4 * b);
+                        const float a0 = fmaf(y, frag.gy[0], hx[0][q]), a1 = fmaf(y, frag.gy[1], hx[1][q]);
+                        const float a2 = fmaf(y, frag.gy[2], hx[2][q]), a3 = fmaf(y, frag.gy[3], hx[3][q]);
+                        const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
+                        const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
+                        dw[b][q] = (inside[b][q] && lhs - rhs <= 0.0f) ? delta : 0;
+                    }
+                }
+            } else if (STROKES) { // KIND_LINE / KIND_JOINT: the stroke fragment stages (shaders.wgsl:268-300)
+                int any_inside = 0;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) any_inside |= (int)inside[b][q];
+                if (__any(any_inside)) {
+                    const crh_dynamic_stroke_descriptor dsc = load_uniform(&s.descriptors[__builtin_amdgcn_readfirstlane(__float_as_uint(ec4.w))]);
+                    const uint32_t caps = dsc.caps, count_dashed_join = dsc.count_dashed_join;
+                    const uint32_t flat_u = frag.flat_u;
+                    const float end_y = frag.end_y;
+                    const bool dashed = (count_dashed_join & 4u) != 0u;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) {
+                            if (inside[b][q] && (winding[b][q] & wmask) == 0) { // Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
+                                const float y = sy0[q] + (float)(4 * b);
+                                const float a0 = fmaf(y, frag.gy[0], hx[0][q]), a1 = fmaf(y, frag.gy[1], hx[1][q]), a2 = fmaf(y, frag.gy[2], hx[2][q]);
+                                bool fill;
+                                if (kind == KIND_LINE) {
+                                    if (dashed)
+                                        fill = stroke_dashed(dsc, a0, a1);
+                                    else if ((flat_u & 65536u) != 0u)
+                                        fill = cap_test(a0, a1 - end_y, caps >> 4);
+                                    else if (a1 < 0.0f)
+                                        fill = cap_test(a0, -a1, caps);
+                                    else
+                                        fill = true;
+                                } else {
+                                    const float radius = sqrtf(a0 * a0 + a1 * a1);
+                                    const uint32_t join = count_dashed_join & 3u;
+                                    fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
+                                    if (fill && dashed) fill = stroke_dashed_joint(dsc, radius, a0, a1, a2);
+                                }
+                                dw[b][q] = fill ? 1 : 0;
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < S; ++q) winding[b][q] += dw[b][q];
+        }
+    }
+    // ---- MSAA resolve (box average) + RGBA8 unorm store
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b) {
+        const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
+        if (gx < r.width && gy < r.height) {
+            const float inv = 1.0f / (float)S;
+            uint32_t packed_px = 0;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < S; ++q) sum = sum + col[b][q][ch];
+                float x = sum * inv;
+                x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+                if (!(x == x)) x = 0.0f;
+                packed_px |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+            }
+            reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed_px;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- launchers
+void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uint32_t n, hipStream_t stream); // raster.hip
+
+// slots per draw item (shapes in the plain pass) and their exclusive scan: slot_begin[n_items + 1]
+void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_items, uint32_t* item_nslots, uint32_t* slot_begin, uint32_t* scratch, hipStream_t stream) {
+    if (n_items == 0) {
+        (void)hipMemsetAsync(slot_begin, 0, 4, stream);
+        return;
+    }
+    hipLaunchKernelGGL(k_item_nslots, dim3((n_items + 255u) / 256u), dim3(256), 0, stream, s, r, n_items, item_nslots);
+    launch_scan_u32(item_nslots, slot_begin, scratch, n_items, stream);
+}
+void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
+    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
+    (void)hipMemsetAsync(r.overflow, 0, 32, stream);                                   // overflow[4] is the pair cursor
+    if (r.n_items) {
+        if (samples == 4)
+            hipLaunchKernelGGL((k_bin_edges<4>), dim3(r.n_items), dim3(128), 0, stream, s, r);
+        else
+            hipLaunchKernelGGL((k_bin_edges<1>), dim3(r.n_items), dim3(128), 0, stream, s, r);
+    }
+    if (after_bin) (void)hipEventRecord(after_bin, stream);
+    if (mark) mark(ctx, "raster_bin", 0);
+    launch_scan_tiles(r, stream);
+    if (mark) mark(ctx, "raster_tile_scan", 0);
+}
+void launch_scatter(const RasterParams& r, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
+    if (r.pair_capacity) hipLaunchKernelGGL(k_scatter, dim3((r.pair_capacity + 255u) / 256u), dim3(256), 0, stream, r);
+    if (mark) mark(ctx, "raster_scatter", 0);
+}
+void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
+                         uint64_t raster_bytes, bool has_stroke) {
+    constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
+    const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
+    const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
+#define CRH_LAUNCH_EDGES(S_, ROWS_, STROKES_) \
+    hipLaunchKernelGGL((k_raster_edges<S_, ROWS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
+    if (samples == 4) {
+        if (has_stroke) CRH_LAUNCH_EDGES(4, 1, true); else CRH_LAUNCH_EDGES(4, 1, false);
+    } else {
+        if (has_stroke) CRH_LAUNCH_EDGES(1, 4, true); else CRH_LAUNCH_EDGES(1, 4, false);
+    }
+#undef CRH_LAUNCH_EDGES
+    if (mark) mark(ctx, "raster_tiles", raster_bytes);
+}
+
+} // namespace crh

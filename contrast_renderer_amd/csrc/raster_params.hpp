@@ -46,6 +46,14 @@ struct RasterParams {
     uint32_t depth_write;             // Configuration::depth_write_enabled
     uint32_t cull_mode;               // crh_cull of the colour cover
     uint32_t debug;                   // CRH_RASTER_DEBUG (tools only)
+    // ---- the edge pass (raster_edges.hip): the plain Stencil + Color pass binned in ONE traversal
+    uint8_t* slots;                   // [slot_capacity][32 B] primitive heap: set-up triangles (4 slots), boundary edges and per-item cover slots (1 slot)
+    uint32_t slot_capacity;
+    const uint32_t* slot_begin;       // [n_items + 1] first slot of every item (a multiple of 4); slot numbers ascend in draw order and are the sort keys
+    uint32_t* pair_tile;              // [pair_capacity] (tile, position in the tile's list, key) in the order the binning waves produced them ...
+    uint32_t* pair_pos;
+    uint32_t* pair_key;               // ... scattered into tile_list by k_scatter once the tile offsets are known
+    uint32_t* pair_cursor;            // pairs written so far (one atomic per flushed block of a wave)
 };
 
 } // namespace crh

@@ -2,6 +2,8 @@
 // written the way csrc/raster_edges.hip evaluates it (tile-relative f32 arithmetic, per-tile backdrop at q0, path q0 -> q_k -> p), checked
 // bit for bit against the triangle-strip specification of oracle/raster.hpp. Not shipped, not used by tests; it exists so that the sign
 // conventions and tie rules can be verified without a GPU. Build + run: tools/proto_edges.py
+#include <cstdio>
+
 #include "../oracle/api.cpp"
 
 namespace proto {
@@ -197,4 +199,78 @@ int proto_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32
     if (stats) stats[0] = tiles, stats[1] = pairs;
     return 0;
 }
+}
+
+// debug: for shape s and pixel (px, py), sample 0 of msaa 1: every solid strip triangle that contains the sample, and every chain edge
+// with its terms
+extern "C" void proto_probe(void* h, uint32_t width, uint32_t height, const float* transforms, uint32_t s, int px, int py, int hull) {
+    using namespace oracle;
+    using namespace proto;
+    Scene* sc = static_cast<Scene*>(h);
+    const Shape& shape = sc->shapes[s];
+    const float* m = transforms + 16 * (size_t)s;
+    Frame f;
+    f.create(width, height, 1, 4);
+    std::vector<float> pts;
+    transform_points(f, m, hull ? shape.convex_hull : shape.fill.solid_vertices, pts);
+    std::vector<uint16_t> hull_idx(shape.convex_hull.size(), 0);
+    std::vector<uint32_t> hull_restarts;
+    const auto& idx = hull ? hull_idx : shape.fill.solid_indices;
+    const auto& restarts = hull ? hull_restarts : shape.fill.solid_restarts;
+    const int tx = px / TILE, ty = py / TILE;
+    const float rx = (float)(px - tx * TILE) + 0.5f, ry = (float)(py - ty * TILE) + 0.5f;
+    size_t run_start = 0, vertex_base = 0, next_restart = 0;
+    int strip = 0;
+    for (size_t k = 0; k <= idx.size(); ++k) {
+        if (k == idx.size() || (next_restart < restarts.size() && restarts[next_restart] == k)) {
+            const size_t n = k - run_start;
+            printf("strip %d: %zu vertices\n", strip, n);
+            for (size_t i = 0; i + 2 < n; ++i) {
+                size_t tri[3];
+                StripWalker::triangle(i, tri);
+                float v[3][2];
+                for (int c = 0; c < 3; ++c) v[c][0] = pts[2 * (vertex_base + tri[c])], v[c][1] = pts[2 * (vertex_base + tri[c]) + 1];
+                const TriangleSetup t = setup_triangle(v, (int)width, (int)height);
+                const float d1x = v[1][0] - v[0][0], d1y = v[1][1] - v[0][1], d2x = v[2][0] - v[0][0], d2y = v[2][1] - v[0][1];
+                const float det = d1x * d2y - d2x * d1y;
+                if (!t.valid) {
+                    printf("  tri %zu INVALID det %.9g  (%.9g,%.9g) (%.9g,%.9g) (%.9g,%.9g)\n", i, det, v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1]);
+                    continue;
+                }
+                if (px < t.x0 || px > t.x1 || py < t.y0 || py > t.y1) continue;
+                const float tx0 = (float)(tx * TILE), ty0 = (float)(ty * TILE);
+                bool inside = true;
+                float ev[3];
+                for (int e = 0; e < 3; ++e) {
+                    const float c = t.e[e].bx * (ty0 - t.e[e].lo[1]) + t.e[e].nay * (tx0 - t.e[e].lo[0]);
+                    float E = fmaf(ry, t.e[e].bx, fmaf(rx, t.e[e].nay, c));
+                    if (t.e[e].flip) E = -E;
+                    ev[e] = E;
+                    inside = inside && (E > 0.0f || (E == 0.0f && t.e[e].topleft));
+                }
+                printf("  tri %zu det %.9g front %d inside %d  E = %.9g %.9g %.9g\n", i, det, (int)t.front, (int)inside, ev[0], ev[1], ev[2]);
+            }
+            std::vector<const float*> pos;
+            for (size_t i = 0; i < n; ++i) pos.push_back(&pts[2 * (vertex_base + i)]);
+            std::vector<Edge> edges;
+            strip_chain(pos, edges);
+            int w = 0;
+            for (const Edge& e : edges) {
+                TileEval t;
+                t.set(e, tx, ty);
+                const float ymin = std::fmin(e.lo[1], e.hi[1]), ymax = std::fmax(e.lo[1], e.hi[1]);
+                const float sy = (float)(ty * TILE) + ry;
+                const bool Y = ymin <= sy && sy < ymax;
+                const float E = fmaf(ry, e.bx, fmaf(rx, e.nay, t.c));
+                const int term = Y ? e.sigma * ((g_of(E, e.tl) ? 1 : 0) - (e.down ? 1 : 0)) : 0;
+                w += term;
+                if (Y) printf("  edge (%.9g,%.9g)-(%.9g,%.9g) sigma %d E %.9g term %d\n", e.lo[0], e.lo[1], e.hi[0], e.hi[1], e.sigma, E, term);
+            }
+            printf("  ray winding of this strip: %d\n", w);
+            vertex_base += n;
+            run_start = k + 1;
+            ++next_restart;
+            ++strip;
+        }
+    }
 }

@@ -90,3 +90,9 @@ def main():
 
 if __name__ == "__main__":
     sys.exit(main())
+
+
+def glyphs(n=600):
+    lib = build()
+    sc = scenes.scene_glyphs(n, (2048, 2048))
+    return run(lib, sc["batch"], 2048, 2048, 1, 4, sc["transforms"], sc["colors"], f"glyphs {n}")
