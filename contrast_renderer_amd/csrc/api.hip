@@ -561,6 +561,13 @@ void assemble_shape(const crh_scene* sc, const HostCopy& h, uint32_t s, uint8_t*
     put(ib, h.solid_i, ((size_t)a[CH_SOLID_V] + a[CH_SOLID_END]) * 2, ((size_t)(b[CH_SOLID_V] - a[CH_SOLID_V]) + (b[CH_SOLID_END] - a[CH_SOLID_END])) * 2);
 }
 
+// Tile-list capacity after an overflow: ov[1] = the pairs the pass needs, ov[5] = a region of the edge pass' pair stream filled up although
+// the total fits (the stream is cut into 64 regions that fill unevenly): half as much again, so that the regions have headroom.
+size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
+    size_t pairs = (size_t)ov[1] + (ov[1] >> 1) + 65536;
+    if (ov[5] != 0) pairs = std::max(pairs, f->pair_capacity_bytes / 4 + f->pair_capacity_bytes / 8);
+    return pairs * 4;
+}
 // the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
 bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
     if (longest_list <= f->sort_capacity) return false;
@@ -711,7 +718,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     const bool edges = p.general == 0u;
     p.slots = static_cast<uint8_t*>(sc->prim_rec[rec].p);
     p.overflow = set.overflow.as<uint32_t>();
-    p.pair_cursor = set.overflow.as<uint32_t>() + 4;
+    p.pair_cursor = set.overflow.as<uint32_t>() + 8; // 64 sub-stream cursors
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
@@ -734,14 +741,14 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         } else
         launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         if (f->pairs_known) break;
-        uint32_t ov[4];
-        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 16, hipMemcpyDeviceToHost, bin));
+        uint32_t ov[8];
+        HIP_TRY(hipMemcpyAsync(ov, p.overflow, 32, hipMemcpyDeviceToHost, bin));
         HIP_TRY(r->sync());
         f->pairs_known = true;
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
-        if (ov[0] == 0) break;
-        f->pair_capacity_bytes = ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4;
+        if (ov[0] == 0 && ov[5] == 0) break;
+        f->pair_capacity_bytes = grown_pair_bytes(f, ov);
         HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
         r->begin_marks(2);
     }
@@ -787,15 +794,15 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
 crh_status settle_frame(crh_frame* f) {
     if (!f->check_pending) return CRH_OK;
     crh_renderer* r = f->renderer;
-    uint32_t ov[4];
+    uint32_t ov[8];
     HIP_TRY(r->sync());
-    HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow.p, 16, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow.p, 32, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
-    if (ov[0] != 0 || sort_overflow) {
-        f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, ((size_t)ov[1] + (ov[1] >> 2) + 1024) * 4); // learned either way
+    if (ov[0] != 0 || ov[5] != 0 || sort_overflow) {
+        f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
             f->cleared = true; // the pass is drawn again from scratch (only cleared frames take the optimistic path, see render_impl)
@@ -814,12 +821,12 @@ crh_status settle_frame_cheaply(crh_frame* f) {
     const crh_frame::BinSet& set = f->sets[f->last_set];
     if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
     if (!f->check_pending) return CRH_OK;
-    uint32_t ov[4];
-    HIP_TRY(hipMemcpyAsync(ov, set.overflow.p, 16, hipMemcpyDeviceToHost, r->aux_stream));
+    uint32_t ov[8];
+    HIP_TRY(hipMemcpyAsync(ov, set.overflow.p, 32, hipMemcpyDeviceToHost, r->aux_stream));
     HIP_TRY(hipStreamSynchronize(r->aux_stream));
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
-    if (ov[0] != 0 || ov[2] != 0 || sort_too_small) return settle_frame(f);
+    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || sort_too_small) return settle_frame(f);
     f->check_pending = false;
     return CRH_OK;
 }
@@ -1241,7 +1248,7 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
     bool ok = hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame");
     for (crh_frame::BinSet& set : f->sets)
         ok = ok && hip_ok(set.tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") && hip_ok(set.tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") &&
-             hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") && hip_ok(set.overflow.ensure(64), "hipMalloc") &&
+             hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") && hip_ok(set.overflow.ensure(512), "hipMalloc") &&
              hip_ok(hipEventCreateWithFlags(&set.bin_done, hipEventDisableTiming), "hipEventCreate") &&
              hip_ok(hipEventCreateWithFlags(&set.raster_done, hipEventDisableTiming), "hipEventCreate");
     if (!ok) {
@@ -1254,7 +1261,7 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
         HIP_TRY(f->depth.ensure(n * 4));
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->depth.p), 0x3f800000, n, r->stream));
     }
-    for (crh_frame::BinSet& set : f->sets) HIP_TRY(hipMemsetAsync(set.overflow.p, 0, 64, r->stream));
+    for (crh_frame::BinSet& set : f->sets) HIP_TRY(hipMemsetAsync(set.overflow.p, 0, 512, r->stream));
     HIP_TRY(r->sync());
     r->frames.push_back(f);
     *out = f;
@@ -1480,6 +1487,13 @@ extern "C" crh_status crh_debug_frame_counters(crh_frame* f, uint32_t out[8]) { 
     HIP_TRY(hipSetDevice(f->renderer->device));
     HIP_TRY(f->renderer->sync());
     HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 32, hipMemcpyDeviceToHost));
+    return CRH_OK;
+}
+extern "C" crh_status crh_debug_frame_counters16(crh_frame* f, uint32_t out[16]) { // tools only: + the per-class entry counts of an ablation build
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    HIP_TRY(f->renderer->sync());
+    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow.p) + 32, 0, 32));
     return CRH_OK;
 }
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {

@@ -207,27 +207,36 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
 }
 
 // ---------------------------------------------------------------------------------------------- pair stage
-// (tile, position in the tile's list, key) triples of one wavefront, staged in LDS and written out in blocks: one atomic on the stream
-// cursor per block, coalesced stores. The position comes from the returning atomic on the tile's counter, so k_scatter needs none.
+// (tile, position in the tile's list, key) triples of one wavefront, staged in LDS and written out in blocks with coalesced stores. The
+// position comes from the returning atomic on the tile's counter (addresses spread over the frame), so k_scatter needs no atomics. The
+// pair stream is cut into kSubStreams regions with a cursor each — a workgroup appends to region blockIdx % kSubStreams: ONE cursor for
+// the whole frame serialises ~10^4 same-address atomics in L2 and was measured to cost more than all the binning arithmetic.
 constexpr uint32_t kStage = 512;
+constexpr uint32_t kSubStreams = 64;
 struct Stage {
     uint32_t* tile;
     uint32_t* pos;
     uint32_t* key;
     uint32_t used;
+    uint32_t sub; // the workgroup's sub-stream
 };
 CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
     if (st.used == 0u) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    const uint32_t region = r.pair_capacity / kSubStreams;
     uint32_t base = 0;
-    if (lane == 0u) base = atomicAdd(r.pair_cursor, st.used);
+    if (lane == 0u) {
+        base = atomicAdd(&r.pair_cursor[st.sub], st.used);
+        if (base + st.used > region) r.overflow[5] = 1u; // this region is full: the host grows the stream and runs the pass again
+    }
     base = __shfl(base, 0, 64);
+    const uint32_t first = st.sub * region;
     for (uint32_t i = lane; i < st.used; i += 64u)
-        if (base + i < r.pair_capacity) { // beyond the capacity only the counts matter: the host grows the stream and runs the pass again
-            r.pair_tile[base + i] = st.tile[i];
-            r.pair_pos[base + i] = st.pos[i];
-            r.pair_key[base + i] = st.key[i];
+        if (base + i < region) {
+            r.pair_tile[first + base + i] = st.tile[i];
+            r.pair_pos[first + base + i] = st.pos[i];
+            r.pair_key[first + base + i] = st.key[i];
         }
     __builtin_amdgcn_wave_barrier();
     st.used = 0u;
@@ -253,6 +262,7 @@ struct BinEdge { // one boundary edge of the item, canonical orientation
     uint32_t tl, hull;
     int sigma, down;
     bool valid;
+    float strip_det; // hull chain: det of the strip triangle that starts at this position (0: none, degenerate or not finite)
 };
 // boundary chain of a zig-zag strip (vertex.rs:28-35): the edge owned by strip position `pos` runs to position `target`
 //   pos 0 -> 1;  even pos >= 2 -> pos - 2;  odd pos -> pos + 2, or — at the end of the strip — to the other one of the last two positions
@@ -291,6 +301,14 @@ CRH_D BinEdge load_edge(const SceneDev& s, const RasterParams& r, const DrawItem
         const Vertex0 va = s.hull_v[hull0 + pos], vb = s.hull_v[hull0 + target];
         a = make_float2(va.x, va.y), b = make_float2(vb.x, vb.y);
         e.hull = 1u;
+        if (pos + 2u < n) { // strip triangle `pos` = (pos, pos + 1, pos + 2), odd ones with the last two swapped: which way does it face?
+            const float W = (float)r.width, H = (float)r.height;
+            const Vertex0 v1 = s.hull_v[hull0 + ((pos & 1u) ? pos + 2u : pos + 1u)], v2 = s.hull_v[hull0 + ((pos & 1u) ? pos + 1u : pos + 2u)];
+            const float2 p0 = to_framebuffer(m, W, H, va.x, va.y), p1 = to_framebuffer(m, W, H, v1.x, v1.y), p2 = to_framebuffer(m, W, H, v2.x, v2.y);
+            const float d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
+            const float det = d1x * d2y - d2x * d1y; // setup_plain_triangle's det
+            e.strip_det = (det == det && is_finite(det)) ? det : 0.0f;
+        }
     }
     const float W = (float)r.width, H = (float)r.height;
     a = to_framebuffer(m, W, H, a.x, a.y);
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
     const ItemSlots k = item_slots(s, it);
     const uint32_t slot0 = r.slot_begin[item];
     if (slot0 + k.total > r.slot_capacity) return; // cannot happen: the capacity is the scan's total
-    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u};
+    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, blockIdx.x % kSubStreams};
     const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
     if (wave == 0u) {
         // ---------------- triangles: 64 at a time, lane = triangle
@@ -443,29 +461,8 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
         // where the winding number of the strip's boundary chain is not zero, and the chain is binned. A strip that folds over itself
         // (andrew() decides turns with an absolute margin, convex_hull.rs:17-20: under f32 cancellation its output is not always convex)
         // is drawn as the reference draws it, triangle by triangle.
-        bool hull_as_triangles = false;
-        if (k.n_hull) {
-            const uint32_t* b0 = s.shape_base + it.shape * NCH;
-            const uint32_t hull0 = b0[CH_HULL];
-            const float W = (float)r.width, H = (float)r.height;
-            unsigned long long front = 0, back = 0;
-            for (uint32_t t0 = 0; t0 + 2u < k.n_hull; t0 += 64u) {
-                const uint32_t t = t0 + lane;
-                float det = 0.0f;
-                if (t + 2u < k.n_hull) {
-                    const Vertex0 va = s.hull_v[hull0 + t], vb = s.hull_v[hull0 + ((t & 1u) ? t + 2u : t + 1u)], vc = s.hull_v[hull0 + ((t & 1u) ? t + 1u : t + 2u)];
-                    const float2 p0 = to_framebuffer(m, W, H, va.x, va.y), p1 = to_framebuffer(m, W, H, vb.x, vb.y), p2 = to_framebuffer(m, W, H, vc.x, vc.y);
-                    const float d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
-                    det = d1x * d2y - d2x * d1y; // setup_plain_triangle's det
-                    if (!(det == det && is_finite(det))) det = 0.0f;
-                }
-                front |= __ballot(det < 0.0f);
-                back |= __ballot(det > 0.0f);
-            }
-            hull_as_triangles = (front != 0ull && back != 0ull) || (r.debug & 4u) != 0u; // debug bit 2 (tests): always
-        }
-        const uint32_t n_hull_chain = hull_as_triangles ? 0u : k.n_hull;
-        const uint32_t n_edges = k.n_fe + n_hull_chain;
+        uint32_t n_hull_chain = k.n_hull, n_edges = k.n_fe + n_hull_chain;
+        unsigned long long faces_front = 0, faces_back = 0;
         // one chunk of (up to 64) edges -> LDS table (+ the heap records the first time)
         float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
         auto stage_chunk = [&](uint32_t i0, bool write_records) {
@@ -487,9 +484,19 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
                 minx = fminf(minx, e.lo_x), maxx = fmaxf(maxx, e.hi_x);
                 miny = fminf(miny, e.ymin), maxy = fmaxf(maxy, e.ymax);
             }
+            if (write_records) { // (a strip triangle is judged at its first position whether or not that position's chain edge is valid)
+                faces_front |= __ballot(e.strip_det < 0.0f);
+                faces_back |= __ballot(e.strip_det > 0.0f);
+            }
         };
+        for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) stage_chunk(i0, true); // records + the box of every vertex (one chunk: the table stays)
+        const bool hull_as_triangles = k.n_hull != 0u && ((faces_front != 0ull && faces_back != 0ull) || (r.debug & 4u) != 0u); // debug bit 2 (tests): always
+        if (hull_as_triangles) { // the fill chain alone (rare: the staging is simply done again)
+            n_hull_chain = 0u, n_edges = k.n_fe;
+            minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+            for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) stage_chunk(i0, false);
+        }
         const bool single = n_edges <= 64u && (r.debug & 1u) == 0u; // debug bit 0 (tests): the chunked path even for short chains
-        for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) stage_chunk(i0, true); // records + the box of every vertex (single: the table stays)
         minx = wave_min(minx), maxx = wave_max(maxx), miny = wave_min(miny), maxy = wave_max(maxy);
         const float W = (float)r.width, H = (float)r.height;
         const int px0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), px1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
@@ -585,14 +592,60 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
 }
 
 __global__ __launch_bounds__(256) void k_scatter(RasterParams r) {
-    if (r.overflow[0]) return;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t total = min(*r.pair_cursor, r.pair_capacity);
-    if (i >= total) return;
+    if (r.overflow[0] | r.overflow[5]) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, region = r.pair_capacity / kSubStreams;
+    const uint32_t sub = i / region, at = i - sub * region;
+    if (sub >= kSubStreams || at >= r.pair_cursor[sub]) return;
     r.tile_list[r.tile_offset[r.pair_tile[i]] + r.pair_pos[i]] = r.pair_key[i];
 }
 
 // ---------------------------------------------------------------------------------------------- k_raster_edges
+// w += 1 / w -= 1 where the lane's bit of a 64-bit lane mask (an SGPR pair) is set: ONE VALU instruction (add / subtract with carry-in)
+CRH_D void add_where(int& w, unsigned long long mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(w), "=s"(carry_out) : "s"(mask));
+#else
+    (void)w, (void)mask;
+#endif
+}
+CRH_D void sub_where(int& w, unsigned long long mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long carry_out;
+    asm("v_subb_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(w), "=s"(carry_out) : "s"(mask));
+#else
+    (void)w, (void)mask;
+#endif
+}
+
+// A 16-bit row mask -> the lane masks of the lane's sample slots. Lane (px, rq) owns row bit rq + 4b in slot b (msaa 1) or 4 rq + q in
+// slot q (msaa 4); a slot's lane mask repeats each of its four row bits over a 16-lane group. Scalar unit only: s_bitreplicate doubles
+// every bit of its 32-bit operand, a tree of 8 of them turns 16 bits into 4 x 64.
+struct SlotMasks {
+    unsigned long long m[4];
+};
+CRH_D unsigned long long bit_double(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long out;
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(out) : "s"(v));
+    return out;
+#else
+    return v;
+#endif
+}
+template <int S>
+CRH_D SlotMasks slot_masks(uint32_t rows16) {
+    if (S == 4) { // gather every sample's four row bits: bit 4 q + rq <- bit 4 rq + q (a 4 x 4 bit transpose)
+        const uint32_t t = rows16;
+        rows16 = (t & 0x8421u) | ((t & 0x0842u) << 3) | ((t & 0x0084u) << 6) | ((t & 0x0008u) << 9) | ((t >> 3) & 0x0842u) | ((t >> 6) & 0x0084u) | ((t >> 9) & 0x0008u);
+    }
+    const unsigned long long x2 = bit_double(rows16 & 0xFFFFu), x4 = bit_double((uint32_t)x2);
+    const unsigned long long lo = bit_double((uint32_t)x4), hi = bit_double((uint32_t)(x4 >> 32));
+    SlotMasks k;
+    k.m[0] = bit_double((uint32_t)lo), k.m[1] = bit_double((uint32_t)(lo >> 32)), k.m[2] = bit_double((uint32_t)hi), k.m[3] = bit_double((uint32_t)(hi >> 32));
+    return k;
+}
+
 // One workgroup per 16x16 tile, laid out exactly as k_raster_tile (raster.hip): msaa 1 = one wavefront, four pixel rows per lane;
 // msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
 // the item being drawn and the colour; entries are walked in key order (= draw order).
@@ -626,9 +679,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         }
     }
     const uint32_t row_shift = first_row + rq; // triangles: bit row_shift + 4b of a 16-bit pixel-row mask
-    // edges: the wave's 16 sample rows are numbered j = pixel row (msaa 1) or 4 * local row + sample (msaa 4); sample (b, q) of this lane is
+
     // bit  bit_of(b, q)  of a 16-bit mask shifted right by edge_shift
-    const uint32_t edge_shift = S == 1 ? rq : 4u * rq;
     int winding[ROWS][S], hullw[ROWS][S];
     float col[ROWS][S][4];
 #pragma unroll
@@ -656,9 +708,12 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         }
     }
     const uint32_t list_begin = r.tile_offset[tile];
-    uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
+    uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : r.tile_offset[tile + 1] - list_begin;
     constexpr uint32_t kLdsSortMax = kSortBytesMax / (4u * (4u / ROWS));
     if (n > r.sort_capacity && n <= kLdsSortMax) n = 0; // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
+#ifdef CRH_ABLATE
+    if (r.debug & 64u) n = 0;
+#endif
     uint32_t my_key = 0xFFFFFFFFu;
     const bool sorted_in_place = n > kLdsSortMax;
     uint32_t* const segment = r.tile_list + list_begin;
@@ -729,7 +784,12 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 
     const uint8_t* slots = r.slots;
     const int wmask = (int)r.winding_mask;
-    const float ry_q0 = S == 1 ? 0.5f : 0.125f; // the backdrop row of the tile (k_bin_edges)
+    // Cooperative row evaluation of an edge entry: lane j < 16 evaluates the wave's sample row j (msaa 1: pixel row j; msaa 4: local
+    // row j / 4, sample j % 4) at the left tile boundary, lane 16 the backdrop row q0 of the tile (k_bin_edges); one ballot per question.
+    const uint32_t row_j = lane & 15u;
+    const float ry_row = lane == 16u ? (S == 1 ? 0.5f : 0.125f)
+                                     : (S == 1 ? (float)row_j + 0.5f : (float)(first_row + (row_j >> 2)) + ((float)(row_j & 3u) * 0.25f + 0.125f));
+    const float sy_row = ty0 + ry_row;
     for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
         if (sorted_in_place)
             my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
@@ -745,26 +805,9 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             if (kind == EK_EDGE) {
                 const EdgeRec er = *reinterpret_cast<const EdgeRec*>(slot);
                 const float c = er.bx * (ty0 - er.lo_y) + er.nay * (tx0 - er.lo_x);
-                const float h0 = fmaf(0.0f, er.nay, c); // the column term at the left tile boundary
-                const uint32_t tl = flags & kEdgeTl;
-                const float ymin = fminf(er.lo_y, er.hi_y), ymax = fmaxf(er.lo_y, er.hi_y);
                 const bool xr = er.lo_x <= tx0 && tx0 < er.hi_x; // the edge crosses the line of the left tile boundary
-                const int gq0 = accepts(fmaf(ry_q0, er.bx, h0), tl) ? 1 : 0;
-                uint32_t ymask = 0, kp = 0, kn = 0;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) { // the wave's sample rows
-                    const float ry = S == 1 ? (float)j + 0.5f : (float)(first_row + (uint32_t)(j >> 2)) + ((float)(j & 3) * 0.25f + 0.125f); // = the lane's sy0 (exact)
-                    const float sy = ty0 + ry;
-                    const int yk = (ymin <= sy && sy < ymax) ? 1 : 0;
-                    const int gqk = accepts(fmaf(ry, er.bx, h0), tl) ? 1 : 0;
-                    const int a = (xr ? gqk - gq0 : 0) - yk * gqk; // the row constant of  xr (g(qk) - g(q0)) + Y (g(p) - g(qk))
-                    ymask |= (uint32_t)yk << j;
-                    kp |= (uint32_t)(a > 0) << j;
-                    kn |= (uint32_t)(a < 0) << j;
-                }
-                const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma = +1; otherwise every term changes sign
-                e0 = make_float4(c, er.bx, er.nay, __uint_as_float(ymask | ((positive ? kp : kn) << 16)));
-                e1 = make_float4(__uint_as_float(positive ? kn : kp), 0.0f, 0.0f, __uint_as_float(flags));
+                e0 = make_float4(c, er.bx, er.nay, 0.0f);
+                e1 = make_float4(fminf(er.lo_y, er.hi_y), fmaxf(er.lo_y, er.hi_y), 0.0f, __uint_as_float(flags | (xr ? 0x1000u : 0u)));
             } else if (kind == EK_SYNTH) {
                 const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
                 e0 = make_float4(sr.r, sr.g, sr.b, sr.a);
@@ -789,55 +832,108 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         entries[lane * 3u + 2u] = e2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#ifdef CRH_ABLATE
+        if (r.debug & 128u) continue;
+#endif
         for (uint32_t j = 0; j < count; ++j) {
             const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
             const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
             const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
             const uint32_t kind = (flags >> 4) & 15u;
+#ifdef CRH_ABLATE // tools/ablate_edges.sh: what does each class of entries cost?
+            if ((r.debug & 256u) && lane == 0u) atomicAdd(&r.overflow[8 + (kind == EK_EDGE ? ((flags & kEdgeHull) ? 1 : 0) : (kind == EK_SYNTH ? 2 : 3))], 1u);
+            if ((r.debug & 8u) && kind == EK_EDGE) continue;
+            if ((r.debug & 16u) && kind == EK_SYNTH) continue;
+            if ((r.debug & 32u) && kind != EK_EDGE && kind != EK_SYNTH) continue;
+#endif
+            // Every kind only produces the change of the winding counters (dw), of the hull winding (dh) and, for the covers, which samples
+            // blend; the state is updated once behind the dispatch. (Updating it inside the branches makes every iteration end with the
+            // SSA join of all state registers: a dozen register-pair copies per entry.)
+            int dw[ROWS][S], dh[ROWS][S];
+            bool blend[ROWS][S];
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < S; ++q) {
+                    dw[b][q] = 0;
+                    dh[b][q] = 0;
+                    blend[b][q] = false;
+                }
+            float cs0 = 0.0f, cs1 = 0.0f, cs2 = 0.0f, cs3 = 0.0f; // the premultiplied source colour of a cover
+            bool is_cover = false;
             if (kind == EK_EDGE) {
-                // d = sigma * (Y & g(p)) + row constants, for the lane's ROWS x S samples
-                const uint32_t masks = __builtin_amdgcn_readfirstlane(__float_as_uint(ea4.w)), kneg = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.x));
-                const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z;
+                // w(p) += sigma * [ Y_k g(p) + A_k ],  A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k)   (see the header of this file)
+                const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z, ymin = eb4.x, ymax = eb4.y;
                 const int thr = 1 - (int)(flags & kEdgeTl);
-                const int unit = (flags & kEdgeSigmaPos) ? 1 : -1;
-                const uint32_t ysh = (masks & 0xFFFFu) >> edge_shift;
-                int d[ROWS][S];
+                // the 16 sample rows of the wave + q0, one row per lane: g at the left tile boundary and the half-open y range
+                const float eq = fmaf(ry_row, ebx, fmaf(0.0f, enay, c0));
+                const unsigned long long gq_all = __builtin_amdgcn_ballot_w64(__float_as_int(eq) >= thr);
+                const unsigned long long y_all = __builtin_amdgcn_ballot_w64((ymin <= sy_row) & (sy_row < ymax));
+                const uint32_t gq = (uint32_t)gq_all & 0xFFFFu, ym = (uint32_t)y_all & 0xFFFFu;
+                const uint32_t g0 = ((uint32_t)gq_all >> 16) & 1u ? 0xFFFFu : 0u, xr = (flags & 0x1000u) ? 0xFFFFu : 0u;
+                uint32_t kp = xr & gq & ~g0 & ~ym;                               // A = +1
+                uint32_t kn = (xr & ~gq & g0) | (ym & gq & (~xr | g0));          // A = -1
+                const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma = +1; otherwise every term changes sign
+                if (!positive) {
+                    const uint32_t t = kp;
+                    kp = kn, kn = t;
+                }
+                const bool to_hull = (flags & kEdgeHull) != 0u;
+                const SlotMasks ys = slot_masks<S>(ym);
                 float h[S];
 #pragma unroll
                 for (int q = 0; q < S; ++q) h[q] = fmaf(sx[q], enay, c0);
+                unsigned long long hit[ROWS][S];
 #pragma unroll
                 for (int cmb = 0; cmb < ROWS * S; cmb += 2) {
                     const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
                     const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
                     const f32x2 ev = fma2(y, splat2(ebx), f32x2{h[k0], h[k1]});
-                    const int p0 = S == 1 ? 4 * b0 : k0, p1 = S == 1 ? 4 * b1 : k1;
-                    d[b0][k0] = ((__float_as_int(ev[0]) >= thr) & (((ysh >> p0) & 1u) != 0u)) ? unit : 0;
-                    d[b1][k1] = ((__float_as_int(ev[1]) >= thr) & (((ysh >> p1) & 1u) != 0u)) ? unit : 0;
+                    hit[b0][k0] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[0]) >= thr) & ys.m[S == 1 ? b0 : k0];
+                    hit[b1][k1] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[1]) >= thr) & ys.m[S == 1 ? b1 : k1];
                 }
-                if ((masks >> 16) | kneg) { // the edge crosses the left tile boundary (or runs left of it): row constants
-                    const uint32_t psh = (masks >> 16) >> edge_shift, nsh = kneg >> edge_shift;
+                // four straight-line variants (sign x fill / hull), one instruction per sample each
+                if (to_hull) {
+                    if (positive) {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                            for (int q = 0; q < S; ++q) add_where(hullw[b][q], hit[b][q]);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                            for (int q = 0; q < S; ++q) sub_where(hullw[b][q], hit[b][q]);
+                    }
+                } else {
+                    if (positive) {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                            for (int q = 0; q < S; ++q) add_where(winding[b][q], hit[b][q]);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                            for (int q = 0; q < S; ++q) sub_where(winding[b][q], hit[b][q]);
+                    }
+                }
+                if (kp | kn) { // the edge crosses the left tile boundary (or runs left of it): row constants
+                    const SlotMasks ps = slot_masks<S>(kp), ns = slot_masks<S>(kn);
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int q = 0; q < S; ++q) {
-                            const int p = S == 1 ? 4 * b : q;
-                            d[b][q] += (int)((psh >> p) & 1u) - (int)((nsh >> p) & 1u);
+                            if (to_hull) {
+                                add_where(hullw[b][q], ps.m[S == 1 ? b : q]);
+                                sub_where(hullw[b][q], ns.m[S == 1 ? b : q]);
+                            } else {
+                                add_where(winding[b][q], ps.m[S == 1 ? b : q]);
+                                sub_where(winding[b][q], ns.m[S == 1 ? b : q]);
+                            }
                         }
                 }
-                if (flags & kEdgeHull) {
-#pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) hullw[b][q] += d[b][q];
-                } else {
-#pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) winding[b][q] += d[b][q];
-                }
-                continue;
-            }
-            if (kind == EK_SYNTH) {
+            } else if (kind == EK_SYNTH) {
                 const uint32_t code = (flags >> 8) & 15u;
                 if (code < 4u) { // a whole-tile backdrop of the fill (0, 1) or hull (2, 3) winding
                     const int v = (code & 1u) ? -1 : 1;
@@ -845,46 +941,27 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int q = 0; q < S; ++q) {
-                            if (code < 2u)
-                                winding[b][q] += v;
-                            else
-                                hullw[b][q] += v;
+                            dw[b][q] = code < 2u ? v : 0;
+                            dh[b][q] = code < 2u ? 0 : v;
                         }
-                    continue;
-                }
-                // COVER: color_cover over the samples inside the hull (renderer.rs:340-354, 736-754): blend where winding != 0, zero the winding
-                const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
-                bool blend[ROWS][S];
-                int any_blend = 0;
-#pragma unroll
-                for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                    for (int q = 0; q < S; ++q) {
-                        const int w = winding[b][q] + bd;
-                        const bool in_hull = hullw[b][q] + hbd != 0;
-                        blend[b][q] = in_hull && (w & wmask) != 0;
-                        any_blend |= (int)blend[b][q];
-                        winding[b][q] = in_hull ? 0 : w;
-                        hullw[b][q] = 0;
-                    }
-                if (__any(any_blend)) {
-                    const float s0 = ea4.x, s1 = ea4.y, s2 = ea4.z, ca = ea4.w;
-                    const float one_minus_a = 1.0f - ca;
+                } else {
+                    // COVER: color_cover over the samples inside the hull (renderer.rs:340-354, 736-754): blend where winding != 0, zero the winding
+                    const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int q = 0; q < S; ++q) {
-                            const float n0 = s0 + col[b][q][0] * one_minus_a, n1 = s1 + col[b][q][1] * one_minus_a;
-                            const float n2 = s2 + col[b][q][2] * one_minus_a, n3 = ca + col[b][q][3] * one_minus_a;
-                            col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
-                            col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
-                            col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
-                            col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                            const int w = winding[b][q] + bd;
+                            const bool in_hull = hullw[b][q] + hbd != 0;
+                            blend[b][q] = in_hull && (w & wmask) != 0;
+                            dw[b][q] = in_hull ? -winding[b][q] : bd;
+                            dh[b][q] = -hullw[b][q];
                         }
+                    cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
+                    is_cover = true;
                 }
-                continue;
-            }
-            // ---- curve and stroke triangles: as k_raster_tile
+            } else {
+            // ---- triangles: curve and stroke triangles as k_raster_tile; cover triangles of a folded hull strip
             const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
             bool inside[ROWS][S];
             {
@@ -911,39 +988,17 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 }
             }
             if (kind == EK_COVER_TRI) { // a triangle of a hull strip drawn as the reference draws it: color_cover inside the triangle
-                bool blend[ROWS][S];
-                int any_blend = 0;
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                     for (int q = 0; q < S; ++q) {
                         blend[b][q] = inside[b][q] && (winding[b][q] & wmask) != 0;
-                        any_blend |= (int)blend[b][q];
-                        winding[b][q] = inside[b][q] ? 0 : winding[b][q];
+                        dw[b][q] = inside[b][q] ? -winding[b][q] : 0;
                     }
-                if (__any(any_blend)) {
-                    const float s0 = frag.a0[0], s1 = frag.a0[1], s2 = frag.a0[2], ca = frag.a0[3];
-                    const float one_minus_a = 1.0f - ca;
-#pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) {
-                            const float n0 = s0 + col[b][q][0] * one_minus_a, n1 = s1 + col[b][q][1] * one_minus_a;
-                            const float n2 = s2 + col[b][q][2] * one_minus_a, n3 = ca + col[b][q][3] * one_minus_a;
-                            col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
-                            col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
-                            col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
-                            col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
-                        }
-                }
-                continue;
-            }
+                cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
+                is_cover = true;
+            } else {
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
-            int dw[ROWS][S];
-#pragma unroll
-            for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                for (int q = 0; q < S; ++q) dw[b][q] = 0;
             const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
             float hx[4][S];
 #pragma unroll
@@ -1009,10 +1064,31 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         }
                 }
             }
+            } // curve / stroke triangles
+            } // triangles
+            int any_blend = 0;
 #pragma unroll
             for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                for (int q = 0; q < S; ++q) winding[b][q] += dw[b][q];
+                for (int q = 0; q < S; ++q) {
+                    winding[b][q] += dw[b][q];
+                    hullw[b][q] += dh[b][q];
+                    any_blend |= (int)blend[b][q];
+                }
+            if (is_cover && __any(any_blend)) { // color_cover: premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
+                const float one_minus_a = 1.0f - cs3;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
+                        const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
+                        col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
+                        col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
+                        col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
+                        col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                    }
+            }
         }
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
@@ -1051,7 +1127,7 @@ void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_ite
 }
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
-    (void)hipMemsetAsync(r.overflow, 0, 32, stream);                                   // overflow[4] is the pair cursor
+    (void)hipMemsetAsync(r.overflow, 0, 32 + 4 * kSubStreams, stream);                 // overflow[8 ...] are the cursors of the pair sub-streams
     if (r.n_items) {
         if (samples == 4)
             hipLaunchKernelGGL((k_bin_edges<4>), dim3(r.n_items), dim3(128), 0, stream, s, r);
