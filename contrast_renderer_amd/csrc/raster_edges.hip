@@ -244,6 +244,9 @@ CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
 CRH_D uint32_t lanes_below(unsigned long long ballot, uint32_t lane) { return (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull)); }
 // the lanes of `ballot` append one entry each
 CRH_D void stage_append(Stage& st, const RasterParams& r, uint32_t lane, unsigned long long ballot, uint32_t tile, uint32_t pos, uint32_t key) {
+#ifdef CRH_ABLATE
+    if (r.debug & 512u) return;
+#endif
     if ((ballot >> lane) & 1ull) {
         const uint32_t at = st.used + lanes_below(ballot, lane);
         st.tile[at] = tile;
@@ -371,6 +374,9 @@ struct TileTest {
 };
 // Bins up to 64 set-up triangles (lane = triangle): every lane walks the tiles of ITS OWN pixel box — a few for a curve or stroke
 // triangle; a triangle over more than kBigRect tiles is walked by the whole wavefront instead (lane = tile), one such triangle at a time.
+#ifndef CRH_BIN_WAVES
+#define CRH_BIN_WAVES 6
+#endif
 constexpr uint32_t kBigRect = 32;
 CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool drawn, const PrimCoverage& cov, uint32_t key, float s_lo, float s_hi) {
     TileTest test;
@@ -421,7 +427,7 @@ CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool d
 // lane = tile of the item's rectangle (64 per pass), uniform loop over the edges (staged in LDS): every lane accumulates the backdrops of
 // its tile and the bit mask of the edges that matter inside it, then emits its entries.
 template <int S>
-__global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAVES))) void k_bin_edges(SceneDev s, RasterParams r) {
     __shared__ uint32_t stage_tile[2][kStage], stage_pos[2][kStage], stage_key[2][kStage];
     __shared__ float4 edge_a[64], edge_b[64];
     const uint32_t item = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -432,6 +438,10 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
     if (slot0 + k.total > r.slot_capacity) return; // cannot happen: the capacity is the scan's total
     Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, blockIdx.x % kSubStreams};
     const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
+#ifdef CRH_ABLATE
+    if ((r.debug & 1024u) && wave == 0u) return;
+    if ((r.debug & 2048u) && wave == 1u) return;
+#endif
     if (wave == 0u) {
         // ---------------- triangles: 64 at a time, lane = triangle
         for (uint32_t t0 = 0; t0 < k.n_tri; t0 += 64u) {
@@ -501,6 +511,9 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
         const float W = (float)r.width, H = (float)r.height;
         const int px0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), px1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
         const int py0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), py1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
+#ifdef CRH_ABLATE
+        if (r.debug & 8192u) n_edges = 0u;
+#endif
         if (n_edges != 0u && minx <= maxx && px0 <= px1 && py0 <= py1) {
             const uint32_t tx_a = (uint32_t)px0 / kTile, tx_b = (uint32_t)px1 / kTile, ty_a = (uint32_t)py0 / kTile, ty_b = (uint32_t)py1 / kTile;
             const uint32_t nx = tx_b - tx_a + 1u, n_rect = nx * (ty_b - ty_a + 1u);
@@ -515,6 +528,9 @@ __global__ __launch_bounds__(128) void k_bin_edges(SceneDev s, RasterParams r) {
                     if (!single) stage_chunk(i0, false);
                     const uint32_t count = min(64u, n_edges - i0);
                     unsigned long long mask = 0;
+#ifdef CRH_ABLATE
+                    if (r.debug & 16384u) continue;
+#endif
                     for (uint32_t j = 0; j < count; ++j) {
                         const float4 A = edge_a[j], B = edge_b[j];
                         const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(B.w));
