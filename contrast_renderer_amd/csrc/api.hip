@@ -3,6 +3,7 @@
 // CPU fallback here and nothing under oracle/ is referenced.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -320,18 +321,23 @@ const int kSegmentFloats[5] = {2, 4, 6, 5, 10};
 // renderer.rs:29-60
 crh_status convert_options(const crh_dynamic_stroke_options& o, crh_dynamic_stroke_descriptor& out) {
     std::memset(&out, 0, sizeof(out));
+    // the Rust enums make these states unrepresentable; out-of-range values would spill into the neighbouring nibbles of `caps`
+    if (o.join > CRH_JOIN_ROUND || o.dashed > 1u) return CRH_ERR_INVALID_ARGUMENT;
     if (o.dashed) {
         if (o.pattern_len > CRH_MAX_DASH_INTERVALS) return CRH_ERR_TOO_MANY_DASH_INTERVALS;
         if (o.pattern_len == 0) return CRH_ERR_INVALID_ARGUMENT;
         out.count_dashed_join = ((o.pattern_len - 1u) << 3) | 4u | o.join;
         out.phase = o.phase;
         for (uint32_t i = 0; i < o.pattern_len; ++i) {
+            if (o.pattern[i].dash_start > CRH_CAP_BUTT || o.pattern[i].dash_end > CRH_CAP_BUTT) return CRH_ERR_INVALID_ARGUMENT;
+            if (!std::isfinite(o.pattern[i].gap_start) || !std::isfinite(o.pattern[i].gap_end)) return CRH_ERR_NON_FINITE;
             out.gap_start[i] = o.pattern[i].gap_start;
             out.gap_end[i] = o.pattern[i].gap_end;
             out.caps |= o.pattern[i].dash_start << (((i + o.pattern_len - 1u) % o.pattern_len) * 8u);
             out.caps |= o.pattern[i].dash_end << (i * 8u + 4u);
         }
     } else {
+        if (o.start > CRH_CAP_BUTT || o.end > CRH_CAP_BUTT) return CRH_ERR_INVALID_ARGUMENT;
         out.caps = o.start | (o.end << 4);
         out.count_dashed_join = o.join;
         out.phase = 0.0f;
@@ -725,7 +731,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     r->begin_marks(2);
     // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
-    if (!f->cleared) f->pairs_known = false;
+    // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
+    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled)) f->pairs_known = false;
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     for (int attempt = 0; attempt < 2; ++attempt) {
         p.tile_list = set.tile_list.as<uint32_t>();
@@ -939,8 +946,13 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
             const crh_stroke_options& o = b->stroke_options[so];
             if (o.dynamic_stroke_options_group >= n_dyn) return CRH_ERR_DYNAMIC_STROKE_OPTIONS_INDEX_OUT_OF_BOUNDS;
             if (!std::isfinite(o.width) || !std::isfinite(o.offset) || !std::isfinite(o.miter_clip) || !std::isfinite(o.angle_step)) return CRH_ERR_NON_FINITE;
+            // CurveApproximation (path.rs:153-167) is an enum; its payload sizes the vertex streams (2 x parameters per curve segment, counted
+            // in 32 bits on the device): a zero / negative angle step or a huge step count would make the counting pass wrap
+            if (o.curve_approximation > CRH_CURVE_UNIFORM_TANGENT_ANGLE || o.closed > 1u) return CRH_ERR_INVALID_ARGUMENT;
+            if (o.curve_approximation == CRH_CURVE_UNIFORM_TANGENT_ANGLE ? !(o.angle_step >= 1.0e-4f) : o.steps > (1u << 20)) return CRH_ERR_INVALID_ARGUMENT;
         }
     }
+    if ((uint64_t)b->n_segments + 2ull * b->n_paths >= 0xFFFFFFF0ull || (uint64_t)b->n_control_floats + 2ull * b->n_paths >= 0xFFFFFFF0ull) return CRH_ERR_UNSUPPORTED; // 32-bit element / pool offsets
     // ---- element stream: MOVE, segments..., END per path; pool = start point + records, -0 canonicalised (safe_float.rs:44-52)
     const uint32_t n_elems = b->n_segments + 2u * b->n_paths;
     std::vector<uint8_t> elem_type(n_elems);
@@ -994,8 +1006,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     crh_scene* sc = existing ? existing : new crh_scene;
     sc->renderer = r;
     sc->device = r->device;
-    static uint64_t next_generation = 1; // unique across scenes: a new Scene at a recycled address is not mistaken for the old one
-    sc->generation = next_generation++;
+    static std::atomic<uint64_t> next_generation{1}; // unique across scenes (and threads): a new Scene at a recycled address is not mistaken for the old one
+    sc->generation = next_generation.fetch_add(1);
     if (!sc->tess_done) {
         if (!hip_ok(hipEventCreateWithFlags(&sc->tess_done, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&sc->vertices_free, hipEventDisableTiming), "hipEventCreate") ||
@@ -1500,6 +1512,11 @@ crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
     if (!f || !out) return CRH_ERR_INVALID_ARGUMENT;
     crh_status st = settle_frame(f);
     if (st != CRH_OK) return st;
+    if (f->cleared) { // LoadOp::Clear without a pass since: the buffer still holds the previous pass' pixels, the frame is transparent
+        HIP_TRY(hipSetDevice(f->renderer->device));
+        HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)f->width * f->height * 4, f->renderer->stream));
+        HIP_TRY(hipStreamSynchronize(f->renderer->stream));
+    }
     *out = f->rgba8.p;
     return CRH_OK;
 }

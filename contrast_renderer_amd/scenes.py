@@ -360,7 +360,7 @@ def scene_mixed(n_shapes=64, size=(512, 512), seed=7):
 def default_font_path():
     """The bundled OpenSans-Regular.ttf data fixture (Apache-2.0; the reference ships the same file under examples/fonts/)."""
     import os
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fonts", "OpenSans-Regular.ttf")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "fonts", "OpenSans-Regular.ttf")
 
 
 def scene_glyphs(n_glyphs=50000, size=(2048, 2048), config_index=3, font_path=None, sizes=(12.0, 16.0, 24.0, 32.0, 48.0)):

@@ -483,11 +483,14 @@ class Scene {
   public:
     Scene(Renderer& renderer, const PathBatch& batch, Scene* existing = nullptr) : n_shapes_(batch.n_shapes()) {
         const crh_path_batch view = batch.view();
-        check(crh_scene_upload(renderer.raw(), &view, existing ? existing->release() : nullptr, &handle_));
-        check(crh_scene_tessellate(handle_));
-        const crh_status st = crh_scene_status(handle_); // surfaces the reference's panics at the call site, like the reference
-        if (st != CRH_OK) {
+        // `existing` is given up only once the upload has taken it over: a batch that fails validation leaves it with its owner
+        check(crh_scene_upload(renderer.raw(), &view, existing ? existing->raw() : nullptr, &handle_));
+        if (existing) existing->release();
+        crh_status st = crh_scene_tessellate(handle_);
+        if (st == CRH_OK) st = crh_scene_status(handle_); // surfaces the reference's panics at the call site, like the reference
+        if (st != CRH_OK) { // a constructor that throws runs no destructor: free the handle here
             crh_scene_destroy(handle_);
+            handle_ = nullptr;
             throw Error(st);
         }
     }

@@ -10,7 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "tests", "cpp", "mirror_harness.cpp")
-FONT = os.path.join(ROOT, "tests", "golden", "fonts", "OpenSans-Regular.ttf")
+FONT = os.path.join(ROOT, "contrast_renderer_amd", "data", "fonts", "OpenSans-Regular.ttf")
 
 
 def build_harness(out_dir):

@@ -8,7 +8,7 @@ import pytest
 
 from contrast_renderer_amd import text as T
 
-FONT = os.path.join(os.path.dirname(__file__), "golden", "fonts", "OpenSans-Regular.ttf")
+FONT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "contrast_renderer_amd", "data", "fonts", "OpenSans-Regular.ttf")
 
 
 @pytest.fixture(scope="module")

@@ -4,7 +4,7 @@ import subprocess
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FONT = os.path.join(ROOT, "tests", "golden", "fonts", "OpenSans-Regular.ttf")
+FONT = os.path.join(ROOT, "contrast_renderer_amd", "data", "fonts", "OpenSans-Regular.ttf")
 
 
 def test_corrupted_fonts_never_read_out_of_bounds():
