@@ -259,6 +259,15 @@ def load_library():
         "crh_frame_download": (C.c_int, [V, V]),
         "crh_frame_device_pointer": (C.c_int, [V, C.POINTER(V)]),
         "crh_composite_over": (C.c_int, [V, C.POINTER(V), C.c_uint32, C.c_uint64, V]),
+        "crh_comm_shard": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "crh_comm_slab_rows": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "crh_comm_unique_id": (C.c_int, [V]),
+        "crh_comm_create": (C.c_int, [V, C.c_uint32, C.c_uint32, V, C.POINTER(V)]),
+        "crh_comm_create_local": (C.c_int, [V, C.c_uint32, C.c_uint32, V, C.POINTER(V)]),
+        "crh_comm_destroy": (None, [V]),
+        "crh_frame_exchange": (C.c_int, [V, V, V]),
+        "crh_comm_local_exchange": (C.c_int, [V, C.POINTER(V), V]),
+        "crh_comm_last_traffic": (C.c_int, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "crh_renderer_synchronize": (C.c_int, [V]),
         "crh_renderer_stream": (V, [V]),
         "crh_renderer_enable_timing": (C.c_int, [V, C.c_int]),

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ("tessellate.hip", "raster.hip", "raster_edges.hip", "api.hip", "text.cpp", "path.cpp")  # text.cpp / path.cpp: host-only (text.rs, path.rs:639-708)
+SOURCES = ("tessellate.hip", "raster.hip", "raster_edges.hip", "api.hip", "comm.hip", "text.cpp", "path.cpp")  # text.cpp / path.cpp: host-only (text.rs, path.rs:639-708)
 HEADERS = ("ga.hpp", "fill.hpp", "stroke.hpp", "scene.hpp", "raster_params.hpp", "raster_common.hpp", "../../include/contrast_hip.h", "../../include/crh_fmath.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 OUT = os.path.join(HERE, "libcontrast_hip.so")
@@ -44,7 +44,7 @@ def build_library(force=False, verbose=False):
         if verbose and out:
             print(out.decode(), file=sys.stderr)
     if procs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-o", OUT]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-ldl", "-o", OUT]  # librccl.so is dlopen()ed by comm.hip, not linked
         subprocess.check_call(cmd)
     return OUT
 

@@ -1520,6 +1520,28 @@ crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
     *out = f->rgba8.p;
     return CRH_OK;
 }
+// ---- internal accessors for csrc/comm.hip (the multi-GPU exchange); not part of the public header
+crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device) {
+    if (!f || !f->renderer || !rgba8 || !width || !height || !device) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    const crh_status st = settle_frame_cheaply(f); // waits for the last pass into THIS frame only: the next step may already be in flight
+    if (st != CRH_OK) return st;
+    if (f->cleared) { // LoadOp::Clear without a pass since: transparent
+        HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)f->width * f->height * 4, f->renderer->aux_stream));
+        HIP_TRY(hipStreamSynchronize(f->renderer->aux_stream));
+    }
+    *rgba8 = f->rgba8.p, *width = f->width, *height = f->height, *device = f->renderer->device;
+    return CRH_OK;
+}
+crh_status crh_internal_frame_written(crh_frame* f) { // the exchange wrote the frame's pixels: it now shows an image, nothing is pending
+    if (!f) return CRH_ERR_INVALID_ARGUMENT;
+    f->cleared = false;
+    f->check_pending = false;
+    f->last_scene = nullptr;
+    return CRH_OK;
+}
+int crh_internal_renderer_device(crh_renderer* r) { return r ? r->device : -1; }
+
 crh_status crh_composite_over(crh_renderer* r, const void* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, void* dst_dev) {
     if (!r || !layers_dev || !dst_dev || n_layers == 0) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));

@@ -146,6 +146,66 @@ class Frame:
             self.handle = None
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id(lib=None):
+    """Rank 0: the 128-byte id (ncclGetUniqueId) every rank passes to Comm(...); distribute it by any means."""
+    lib = lib or _ffi.load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib.crh_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def shard_range(n_items, rank, world, lib=None):
+    """crh_comm_shard: the contiguous Shape range of a rank (host arithmetic, no GPU)."""
+    lib = lib or _ffi.load_library()
+    b, e = C.c_uint32(), C.c_uint32()
+    check(lib.crh_comm_shard(n_items, rank, world, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def slab_rows(height, rank, world, lib=None):
+    lib = lib or _ffi.load_library()
+    b, e = C.c_uint32(), C.c_uint32()
+    check(lib.crh_comm_slab_rows(height, rank, world, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+class Comm:
+    """One rank of the framebuffer exchange (include/contrast_hip.h, crh_comm_*): RCCL when `unique_id` is given, otherwise a member of an
+    in-process loopback group on one device (`rank0` = the group's founder for ranks > 0)."""
+
+    def __init__(self, renderer: Renderer, rank: int, world: int, unique_id: bytes = None, rank0: "Comm" = None):
+        self.renderer, self.lib, self.rank, self.world = renderer, renderer.lib, rank, world
+        handle = C.c_void_p()
+        if unique_id is not None:
+            ident = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+            check(self.lib.crh_comm_create(renderer.handle, rank, world, ident, C.byref(handle)))
+        else:
+            check(self.lib.crh_comm_create_local(renderer.handle, rank, world, rank0.handle if rank0 else None, C.byref(handle)))
+        self.handle = handle
+
+    def exchange(self, layer: Frame, result: Frame = None):
+        """Collective (RCCL): composites every rank's layer in rank order into rank 0's `result`."""
+        check(self.lib.crh_frame_exchange(self.handle, layer.handle, result.handle if result is not None else None))
+
+    def local_exchange(self, layers, result: Frame):
+        """Loopback group, called on rank 0's communicator: layers[k] = rank k's frame."""
+        arr = (C.c_void_p * len(layers))(*[f.handle for f in layers])
+        check(self.lib.crh_comm_local_exchange(self.handle, arr, result.handle))
+
+    def last_traffic(self):
+        sent, dense = C.c_uint64(), C.c_uint64()
+        check(self.lib.crh_comm_last_traffic(self.handle, C.byref(sent), C.byref(dense)))
+        return sent.value, dense.value
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.crh_comm_destroy(self.handle)
+            self.handle = None
+
+
 class Scene:
     """A batch of Shapes in HBM: upload + tessellate once, render many times."""
 

@@ -344,6 +344,35 @@ crh_status crh_path_list_transform(crh_path_list* list, float scale, const float
 crh_status crh_path_list_view(const crh_path_list* list, crh_path_batch* out);
 void crh_path_list_destroy(crh_path_list* list);
 
+/* ---- multi-GPU: path-index sharding + the framebuffer exchange ---------------------------------------
+ * The reference is single-GPU (no such component upstream); this group is the exchange step of SURVEY.md §8(e) behind
+ * the C ABI, so that a host in any language can shard: one process per GPU, rank g renders Shapes crh_comm_shard(n, g, world) into a
+ * private full-size layer (a crh_frame), crh_frame_exchange composites the layers in rank order — premultiplied "over", lower rank
+ * underneath — and leaves the image in rank 0's `result` frame. Only 16x16 tiles that hold something travel (occupancy bitmaps are
+ * all-gathered first); transfers are grouped ncclSend / ncclRecv of row slabs over RCCL (librccl.so is opened on first use).
+ * RGBA8 hand-off: <= 2/255 per channel against a single-GPU render of the whole scene. */
+typedef struct crh_comm crh_comm;
+#define CRH_COMM_ID_BYTES 128 /* ncclUniqueId */
+/* contiguous, order-preserving split of [0, n_items): sizes differ by at most one */
+crh_status crh_comm_shard(uint32_t n_items, uint32_t rank, uint32_t world, uint32_t* begin, uint32_t* end);
+/* the pixel rows of rank `rank`'s slab of a frame `height` pixels high (whole 16-pixel tile rows) */
+crh_status crh_comm_slab_rows(uint32_t height, uint32_t rank, uint32_t world, uint32_t* row_begin, uint32_t* row_end);
+/* rank 0 calls this and hands the 128 bytes to the other ranks by any means (ncclGetUniqueId) */
+crh_status crh_comm_unique_id(void* id128);
+/* collective over all ranks (ncclCommInitRank); the renderer names the device. CRH_ERR_UNSUPPORTED when RCCL cannot be loaded. */
+crh_status crh_comm_create(crh_renderer* renderer, uint32_t rank, uint32_t world, const void* id128, crh_comm** out);
+void crh_comm_destroy(crh_comm* comm);
+/* collective: `layer` = this rank's frame; `result` = the frame that receives the image on rank 0, NULL on every other rank.
+ * Waits for the last pass into `layer` only; runs on a stream of its own, so the renderer may already be drawing the next step. */
+crh_status crh_frame_exchange(crh_comm* comm, crh_frame* layer, crh_frame* result);
+/* bytes this rank sent in the last exchange, and what dense slabs (no empty-tile suppression) would have been */
+crh_status crh_comm_last_traffic(const crh_comm* comm, uint64_t* bytes_sent, uint64_t* bytes_dense);
+/* The same exchange without RCCL, for several communicators on ONE device driven by one thread (tests, single-GPU validation):
+ * rank 0's communicator founds the group (rank0 = NULL), ranks 1.. join it; crh_comm_local_exchange(rank 0's comm, layers[world],
+ * result) then runs every rank's part with device-to-device copies in place of the transfers. */
+crh_status crh_comm_create_local(crh_renderer* renderer, uint32_t rank, uint32_t world, crh_comm* rank0, crh_comm** out);
+crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, crh_frame* result);
+
 const char* crh_last_error(void);
 const char* crh_version(void);
 
