@@ -4,13 +4,19 @@
 One step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 crh_scene_tessellate (count / scan / emit / hull kernels) + crh_scene_render_resident (bin + tile raster kernels) of
 BASELINE.json configs[1]: 10 000 mixed integral / rational cubic paths at 4096x4096 on one MI355X.
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the paths shard by contiguous index range — every rank
-renders its own 10 000-path shard (weak scaling) into a private layer — followed by the tile-sliced RCCL exchange, the ordered
-"over" composite and the gather to rank 0.
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the Shapes shard by contiguous index range and every rank
+renders its shard into a private layer; the exchange step — occupancy bitmaps, slab all-to-all of the non-empty tiles, ordered "over"
+composite, gather to rank 0 — runs behind the C ABI (crh_frame_exchange, csrc/comm.hip) on RCCL, overlapped with the rendering of the
+next step. torch.distributed only carries the 128-byte RCCL id, the barrier and the max-over-ranks of the elapsed time.
+  --scaling weak   (default) every rank renders its own `--paths` shapes: per-GPU work fixed, value = N x paths / step time
+  --scaling strong THE scene of `--paths` shapes is split over the ranks:  total work fixed,  value = paths / step time
+  --workload s100k BASELINE configs[3]: 100 000 paths at 8192x8192 split over the ranks (strong)
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -24,46 +30,62 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 # timing mark (HIP events inside the library) -> kernel name as rocprofv3 prints it
 MARK_TO_KERNEL = {
-    "raster_tiles": "crh::k_raster_tile<1, 4, false, false>",
-    "raster_tile_fill": "crh::k_tile_walk<1, true>",
-    "raster_tile_count": "crh::k_tile_walk<1, false>",
-    "raster_prim_setup": "crh::k_prim_setup<1>",
+    "raster_tiles": "crh::k_raster_edges<1, 4, false>",
+    "raster_bin": "crh::k_bin_edges<1>",
+    "raster_scatter": "crh::k_scatter",
     "tess_emit": "crh::k_emit",
     "tess_count": "crh::k_count",
     "tess_hull": "crh::k_hull_small",
 }
 
 
-def valu_issue(mark, avg_launch_ms):
-    """Secondary roofline of the dominant kernel: VALU issue utilisation = wave-level VALU instructions (SQ_INSTS_VALU of the newest committed
-    PMC summary) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x launch time). None when the counters do not cover the kernel."""
+def kernel_source_hash():
+    """Content hash of the kernel sources: PMC summaries under profiles/ carry the hash they were measured at, and are reported only while
+    it still matches (a committed counter file silently goes stale with the next kernel change otherwise)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "contrast_renderer_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def _newest_profile(pattern):
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json")))
-    if not files or mark not in MARK_TO_KERNEL or avg_launch_ms <= 0:
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None, None
     with open(files[-1]) as f:
         doc = json.load(f)
+    if doc.get("kernel_source_hash") != kernel_source_hash():
+        return None, None  # measured on other kernels: not this run's traffic
+    return doc, os.path.basename(files[-1])
+
+
+def valu_issue(mark, avg_launch_ms):
+    """Secondary roofline of the dominant kernel: VALU issue utilisation = wave-level VALU instructions (SQ_INSTS_VALU of the committed PMC
+    summary measured on THESE kernel sources) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x launch time)."""
+    doc, source = _newest_profile("r*_sq_counters.json")
+    if not doc or mark not in MARK_TO_KERNEL or avg_launch_ms <= 0:
+        return None
     k = doc.get("per_launch", {}).get(MARK_TO_KERNEL[mark])
     if not k or "SQ_INSTS_VALU" not in k:
         return None
     simds, clock_hz = 256 * 4, 2.4e9
     return {"valu_wave_instructions": int(k["SQ_INSTS_VALU"]), "salu_wave_instructions": int(k.get("SQ_INSTS_SALU", 0)),
-            "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * avg_launch_ms * 1e-3), "source": os.path.basename(files[-1]),
+            "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * avg_launch_ms * 1e-3), "source": source,
             "note": "one wave64 VALU instruction per 4 cycles per SIMD; 256 CUs x 4 SIMDs at 2.4 GHz"}
 
 
 def measured_traffic(mark):
-    """HBM bytes per launch of the kernel behind `mark`, from the newest committed PMC summary (profiles/rNN_traffic.json, produced by
-    tools/profile.sh: separate FETCH_SIZE / WRITE_SIZE passes with the gfx950 corrections of the microarchitecture guide). The
-    counters cannot be collected from inside this process, so the committed file is the source; None when it does not cover the kernel."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files or mark not in MARK_TO_KERNEL:
+    """HBM bytes per launch of the kernel behind `mark` from the committed PMC summary (profiles/rNN_traffic.json: separate FETCH_SIZE /
+    WRITE_SIZE passes with the gfx950 corrections of the microarchitecture guide), or None when that file was measured on other sources."""
+    doc, source = _newest_profile("r*_traffic.json")
+    if not doc or mark not in MARK_TO_KERNEL:
         return None, None
-    with open(files[-1]) as f:
-        doc = json.load(f)
     k = doc.get("kernels", {}).get(MARK_TO_KERNEL[mark])
-    return (k["hbm_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
+    return (k["hbm_bytes_per_launch"], source) if k else (None, None)
 
 
 class _DeviceArray:
@@ -78,16 +100,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths", type=int, default=10000, help="paths per GPU (configs[1] = 10000)")
+    ap.add_argument("--paths", type=int, default=10000, help="shapes of the scene: per GPU (weak) or in total (strong); configs[1] = 10000")
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="nccl = RCCL over xGMI (the real thing); gloo validates the multi-rank flow "
-                    "where RCCL cannot run (e.g. two ranks on one GPU with --same-device): layers are staged through host memory")
-    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend for the barrier / id broadcast (nccl = RCCL)")
+    ap.add_argument("--exchange", default="cabi", choices=("cabi", "torch"), help="cabi: crh_frame_exchange over RCCL (the product path); torch: the "
+                    "torch.distributed statement of the same exchange (contrast_renderer_amd/distributed.py), dense slabs — validation only")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only; implies --exchange torch)")
     ap.add_argument("--check", action="store_true", help="N > 1: rank 0 also renders every shard itself and compares the composite of those layers with the gathered image")
-    ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed"),
-                    help="cubic = BASELINE configs[1] (the metric's configuration, default); glyphs = configs[2] (50 000 glyphs @ 2048^2); "
-                         "dashed = configs[4] (2 000 dashed rational-cubic strokes @ 4096^2, msaa 4). Only `cubic` is the headline line.")
+    ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed", "s100k"),
+                    help="cubic = BASELINE configs[1] (the metric's configuration); glyphs = configs[2]; dashed = configs[4]; s100k = configs[3] (100k paths @ 8192^2, split over the ranks)")
     args = ap.parse_args()
 
     import numpy as np
@@ -100,6 +123,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.same_device:
+        args.exchange = "torch"  # RCCL refuses two ranks on one device
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -112,40 +137,63 @@ def main():
 
     from contrast_renderer_amd import distributed as D
     from contrast_renderer_amd import scenes
-    from contrast_renderer_amd.renderer import Configuration, Frame, Renderer, Scene
+    from contrast_renderer_amd.renderer import Comm, Configuration, Frame, Renderer, Scene, comm_unique_id, shard_range
 
     size = (args.size, args.size)
-    if args.workload == "cubic":
-        sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
-        workload = (f"BASELINE configs[1]: {args.paths} filled closed paths x 8 cubic segments (alternating integral / rational), {size[0]}x{size[1]}, "
-                    "msaa 1, winding_counter_bits 4")
+    scaling = args.scaling
+    if args.workload == "s100k":
+        args.paths, size, scaling = 100000, (8192, 8192), "strong"
+    if args.workload in ("cubic", "s100k"):
+        label = "BASELINE configs[1]" if args.workload == "cubic" else "BASELINE configs[3]"
+        if scaling == "weak" or world == 1:
+            sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
+            shard = (0, args.paths)
+        else:  # THE scene, split by index
+            sc = scenes.scene_cubic_fill(args.paths, size, config_index=2)
+            shard = shard_range(args.paths, rank, world)
+        workload = (f"{label}: {args.paths} filled closed paths x 8 cubic segments (alternating integral / rational), {size[0]}x{size[1]}, msaa 1, "
+                    "winding_counter_bits 4")
     elif args.workload == "glyphs":
         size = (2048, 2048)
         sc = scenes.scene_glyphs(50000, size)
-        args.paths = sc["n_paths"]
+        args.paths = sc["batch"].n_shapes
+        shard = (0, args.paths) if (scaling == "weak" or world == 1) else shard_range(args.paths, rank, world)
         workload = f"BASELINE configs[2]: 50000 glyph instances ({sc['n_paths']} line/quadratic paths) via text::paths_of_text, 2048x2048, msaa 1"
     else:
         size = (4096, 4096)
         sc = scenes.scene_dashed_strokes(2000, size)
         args.paths = 2000
+        shard = (0, args.paths) if (scaling == "weak" or world == 1) else shard_range(args.paths, rank, world)
         workload = "BASELINE configs[4]: 2000 dashed rational-cubic strokes (UniformTangentAngle 0.1, miter/round joins), 4096x4096, msaa 4"
-    batch = sc["batch"]
+    batch = sc["batch"] if shard == (0, sc["batch"].n_shapes) else sc["batch"].slice_shapes(*shard)
+    transforms, colors = sc["transforms"][shard[0]:shard[1]], sc["colors"][shard[0]:shard[1]]
     renderer = Renderer(Configuration(msaa_sample_count=sc["msaa"], clip_nesting_counter_bits=4, winding_counter_bits=4), device=local_rank)
     t_up = time.perf_counter()
     scene = Scene(renderer, batch, tessellate=True)  # host -> HBM + first tessellation (sizes the output buffers): outside the timed region
     renderer.synchronize()
     upload_s = time.perf_counter() - t_up  # validation + element stream + H2D + first tessellation, once per scene
     scene.check()
-    scene.set_instances(sc["transforms"], sc["colors"])
+    scene.set_instances(transforms, colors)
     frame = Frame(renderer, *size)
     lib = renderer.lib
     import ctypes as C
 
-    # N > 1: two frames, so that the framebuffer exchange of step i (RCCL + composite + gather) runs while step i + 1 is being
-    # tessellated and rasterized into the other frame
+    # N > 1: two layers, so that the exchange of step i runs while step i + 1 is being tessellated and rasterized into the other one
     frames = [frame] + ([Frame(renderer, *size)] if world > 1 else [])
+    comm, result, exchange_note = None, None, None
     layer_views, slab = [], None
-    if world > 1:
+    if world > 1 and args.exchange == "cabi":
+        try:
+            ident = [comm_unique_id(lib) if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)  # the 128-byte RCCL id: the only payload torch.distributed carries
+            comm = Comm(renderer, rank, world, unique_id=ident[0])
+            result = Frame(renderer, *size) if rank == 0 else None
+            exchange_note = "crh_frame_exchange (C ABI): occupancy bitmaps all-gathered, non-empty tiles of row slabs all-to-all (grouped ncclSend/ncclRecv), ordered over-composite, gather to rank 0"
+        except Exception as e:  # reported, never silent: the line then says which path produced the number
+            comm = None
+            exchange_note = f"FALLBACK to torch.distributed (crh_comm_create failed: {e})"
+    if world > 1 and comm is None:
+        exchange_note = exchange_note or "torch.distributed statement of the exchange (dense slabs, validation only)"
         layer_views = [torch.as_tensor(_DeviceArray(f.device_pointer(), (size[1], size[0], 4)), device=f"cuda:{local_rank}") for f in frames]
         r0, r1 = D.slab_rows(size[1], world)[rank]
         slab = torch.empty((r1 - r0, size[0], 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
@@ -160,17 +208,20 @@ def main():
     def finish(i):
         """The exchange step of the path for step i's layer; the renderer may already be working on step i + 1."""
         f = frames[i % len(frames)]
-        f.synchronize()  # step i's raster kernel only
+        if comm is not None:
+            comm.exchange(f, result)  # waits for step i's raster kernel only, then runs on the communicator's own stream
+            return result
+        f.synchronize()
         received, _ = D.exchange_layers(layer_views[i % len(frames)], rank, world)
         if received.is_cuda:
-            torch.cuda.current_stream().synchronize()  # the RCCL transfers (not the renderer's streams: step i + 1 keeps running)
+            torch.cuda.current_stream().synchronize()
         ptrs = (C.c_void_p * world)(*[received[k].data_ptr() for k in range(world)])
         rc = lib.crh_composite_over(renderer.handle, ptrs, world, received[0].numel() // 4, C.c_void_p(slab.data_ptr()))
         assert rc == 0, rc
         return D.gather_slabs(slab, rank, world, size[1])
 
     def run(n):
-        """n steps; with N > 1 the exchange of step i overlaps the rendering of step i + 1. Returns the last gathered frame (rank 0)."""
+        """n steps; with N > 1 the exchange of step i overlaps the rendering of step i + 1. Returns the last gathered image (rank 0)."""
         out = None
         for i in range(n):
             launch(i)
@@ -179,9 +230,6 @@ def main():
         if world > 1 and n > 0:
             out = finish(n - 1)
         return out
-
-    def step():
-        return run(1)
 
     def sync():
         renderer.synchronize()
@@ -192,7 +240,7 @@ def main():
     run(args.warmup)
     sync()
     scene.check()
-    renderer.enable_timing(True)  # HIP events on the renderer's stream between kernels; drained once after the timed region
+    renderer.enable_timing(True)  # HIP events on the renderer's streams between kernels; drained once after the timed region
     sync()
     t0 = time.perf_counter()
     run(args.steps)
@@ -205,26 +253,40 @@ def main():
     kernel_times = renderer.kernel_times()
     renderer.enable_timing(False)
     scene.check()
+    # latency of ONE step, nothing overlapped (the timed loop above keeps up to three steps in flight)
+    latency = []
+    for _ in range(min(5, max(1, args.steps))):
+        sync()
+        t1 = time.perf_counter()
+        run(1)
+        renderer.synchronize()
+        latency.append(time.perf_counter() - t1)
+    latency_ms = sorted(latency)[len(latency) // 2] * 1e3
     image = frame.download()
     covered = float((image[..., 3] > 0).mean())
+    traffic_sent = comm.last_traffic() if comm is not None else None
     check = None
     if args.check and world > 1:
-        gathered = step()  # one more pass outside the timed region: the gathered frame on rank 0
+        gathered = run(1)  # one more pass outside the timed region: the gathered image on rank 0
         sync()
         if rank == 0:
+            got = gathered.download() if comm is not None else gathered.cpu().numpy()
             layers = []
             for other in range(world):  # the same shards, rendered one after the other by this rank alone
-                shard = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=other * args.paths)
-                shard_scene = Scene(renderer, shard["batch"], tessellate=True)
+                if scaling == "weak":
+                    one = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=other * args.paths)
+                    b, t, c = one["batch"], one["transforms"], one["colors"]
+                else:
+                    lo, hi = shard_range(args.paths, other, world)
+                    b, t, c = sc["batch"].slice_shapes(lo, hi), sc["transforms"][lo:hi], sc["colors"][lo:hi]
+                shard_scene = Scene(renderer, b, tessellate=True)
                 shard_frame = Frame(renderer, *size)
                 shard_frame.clear()
-                shard_scene.render(shard_frame, shard["transforms"], shard["colors"])
+                shard_scene.render(shard_frame, t, c)
                 layers.append(shard_frame.download())
             expect = D.composite_over_reference(np.stack(layers))
-            got = gathered.cpu().numpy()
             check = {"gathered_equals_ordered_composite_of_all_shards": bool(np.array_equal(got, expect)),
-                     "max_abs_difference": int(np.abs(got.astype(np.int32) - expect.astype(np.int32)).max()),
-                     "own_layer_unchanged": bool(np.array_equal(image, layers[0]))}
+                     "max_abs_difference": int(np.abs(got.astype(np.int32) - expect.astype(np.int32)).max())}
 
     # per-kernel averages
     agg = {}
@@ -237,32 +299,39 @@ def main():
     dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
-    default_workload = args.workload == "cubic" and args.paths == 10000 and args.size == 4096
+    default_workload = args.workload == "cubic" and args.paths == 10000 and args.size == 4096 and world == 1
     traffic, traffic_source = measured_traffic(dominant) if default_workload else (None, None)
 
-    total_paths = args.paths * world
-    ms_per_step = elapsed / args.steps * 1e3
+    step_s = elapsed / args.steps
+    total_paths = args.paths * world if scaling == "weak" else args.paths
+    ms_per_step = step_s * 1e3
+    # whole-step algorithmic bytes: the tessellation reads the control data and writes the emitted bytes, the raster reads the
+    # emitted bytes and writes the frame (the raster mark already carries emitted + 80 B / shape + W * H * 4); binning has none
+    step_bytes = kernels.get("tess_emit", {}).get("algorithmic_bytes", 0) + kernels.get("raster_tiles", {}).get("algorithmic_bytes", 0)
     out = {
         "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)",
-        "value": total_paths / (elapsed / args.steps),
+        "value": total_paths / step_s,
         "unit": "paths/s",
-        "mpixel_per_s": size[0] * size[1] / (elapsed / args.steps) / 1e6,
+        "mpixel_per_s": size[0] * size[1] / step_s / 1e6,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "latency_ms_per_step": latency_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": workload + "; step = tessellate (count/scan/emit/hull) + bin + tile raster, inputs resident in HBM",
-            "paths_per_gpu": args.paths,
+            "paths_per_gpu": int(batch.n_shapes),
+            "paths_total": int(total_paths),
             "segments_per_gpu": int(batch.n_segments),
-            "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} + tile-sliced RCCL all-to-all + ordered over-composite + gather (exchange of step i overlaps the rendering of step i + 1)",
+            "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} ({scaling}); {exchange_note}; the exchange of step i overlaps the rendering of step i + 1",
             "covered_fraction": covered,
         },
+        "pipelining": "ms_per_step: up to three steps in flight on three HIP streams (tessellate / bin / raster); latency_ms_per_step: one step, host synchronised before and after",
         "roofline": {
             "kernel": dominant,
             "bound": "hbm",
@@ -275,16 +344,23 @@ def main():
             "algorithmic_bytes": dk["algorithmic_bytes"],
             "valu_issue": valu_issue(dominant, dk["avg_ms"]) if default_workload else None,
             "avg_launch_ms": dk["avg_ms"],
+            "kernel_source_hash": kernel_source_hash(),
             "note": "achieved = algorithmic bytes (SURVEY.md §8(d): emitted vertex/index bytes read once + 80 B per shape + W*H*4 written once) / "
-                    "HIP-event launch time of the dominant kernel; traffic = HBM bytes per launch from rocprofv3 PMC passes (committed under "
-                    "profiles/). The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
+                    "HIP-event launch time of the dominant kernel (in the run, i.e. sharing the GPU with the other lanes of the pipeline); traffic / "
+                    "valu_issue = rocprofv3 PMC passes committed under profiles/, reported only while their kernel_source_hash equals this run's. "
+                    "The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
         },
+        "roofline_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                          "note": "all kernels of a step: control data read + emitted bytes written (tessellation), emitted bytes + 80 B / shape read and W*H*4 written (raster)"},
         "kernels": kernels,
         "check": check,
         # the boundary hands over host buffers once per scene (crh_scene_upload); never part of `value`
-        "host_inclusive": {"upload_ms": upload_s * 1e3, "paths_per_s_first_frame": args.paths / (upload_s + elapsed / args.steps),
+        "host_inclusive": {"upload_ms": upload_s * 1e3, "paths_per_s_first_frame": batch.n_shapes / (upload_s + step_s),
                            "input_bytes": int(batch.input_bytes())},
     }
+    if traffic_sent is not None:
+        out["exchange"] = {"bytes_sent_by_rank0_last_step": traffic_sent[0], "dense_slabs_would_be": traffic_sent[1]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.binding import time_tessellate
         t1 = time_tessellate(batch, 1, 1)
@@ -293,14 +369,15 @@ def main():
         cores = os.cpu_count() or 1
         tall = time_tessellate(batch, cores, max(2, repeats))
         out["cpu_baseline"] = {
-            "value": args.paths * repeats / ts,
+            "value": batch.n_shapes * repeats / ts,
             "unit": "paths/s",
             "cores": 1,
             "kind": "port",
-            "sample": f"{repeats} x full tessellation of the same {args.paths}-path scene by the C++ restatement of the reference's CPU tessellation "
+            "sample": f"{repeats} x full tessellation of the same {batch.n_shapes}-path scene by the C++ restatement of the reference's CPU tessellation "
                       f"(Shape::from_paths minus the wgpu upload; the reference itself cannot be built here), single thread as in renderer.rs:187; "
                       "tessellation only — the reference rasterizes on a GPU",
-            "all_cores": {"value": args.paths * max(2, repeats) / tall, "cores": cores},
+            "all_cores": {"value": batch.n_shapes * max(2, repeats) / tall, "cores": cores,
+                          "note": "persistent thread pool, one arena per thread, destruction outside the timed region"},
         }
     if rank == 0:
         print(json.dumps(out))

@@ -734,7 +734,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
     if (!f->cleared || (f->depth.p && r->config.depth_write_enabled)) f->pairs_known = false;
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
         p.tile_list = set.tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(set.tile_list.cap / 4);
         if (edges) {
@@ -751,10 +751,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         uint32_t ov[8];
         HIP_TRY(hipMemcpyAsync(ov, p.overflow, 32, hipMemcpyDeviceToHost, bin));
         HIP_TRY(r->sync());
-        f->pairs_known = true;
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
-        if (ov[0] == 0 && ov[5] == 0) break;
+        if (ov[0] == 0 && ov[5] == 0) {
+            f->pairs_known = true; // from now on this frame's passes run without the read-back (checked after the fact, settle_frame)
+            break;
+        }
         f->pair_capacity_bytes = grown_pair_bytes(f, ov);
         HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
         r->begin_marks(2);

@@ -209,7 +209,7 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
 // ---------------------------------------------------------------------------------------------- pair stage
 // (tile, position in the tile's list, key) triples of one wavefront, staged in LDS and written out in blocks with coalesced stores. The
 // position comes from the returning atomic on the tile's counter (addresses spread over the frame), so k_scatter needs no atomics. The
-// pair stream is cut into kSubStreams regions with a cursor each — a workgroup appends to region blockIdx % kSubStreams: ONE cursor for
+// pair stream is cut into kSubStreams regions with a cursor each — a wavefront's blocks go to the regions in turn: ONE cursor for
 // the whole frame serialises ~10^4 same-address atomics in L2 and was measured to cost more than all the binning arithmetic.
 constexpr uint32_t kStage = 512;
 constexpr uint32_t kSubStreams = 64;
@@ -218,7 +218,7 @@ struct Stage {
     uint32_t* pos;
     uint32_t* key;
     uint32_t used;
-    uint32_t sub; // the workgroup's sub-stream
+    uint32_t sub; // the sub-stream of the wavefront's next block
 };
 CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
     if (st.used == 0u) return;
@@ -240,6 +240,7 @@ CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
         }
     __builtin_amdgcn_wave_barrier();
     st.used = 0u;
+    st.sub = (st.sub + 7u) % kSubStreams; // the next block goes to another region: one huge Shape must not fill a single region
 }
 CRH_D uint32_t lanes_below(unsigned long long ballot, uint32_t lane) { return (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull)); }
 // the lanes of `ballot` append one entry each
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     const ItemSlots k = item_slots(s, it);
     const uint32_t slot0 = r.slot_begin[item];
     if (slot0 + k.total > r.slot_capacity) return; // cannot happen: the capacity is the scan's total
-    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, blockIdx.x % kSubStreams};
+    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, (2u * blockIdx.x + wave) % kSubStreams};
     const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
 #ifdef CRH_ABLATE
     if ((r.debug & 1024u) && wave == 0u) return;

@@ -11,6 +11,8 @@ import sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import kernel_source_hash  # noqa: E402  (the summaries are reported by bench.py only while this hash still matches)
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
@@ -22,6 +24,7 @@ shutil.copy(os.path.join(src, f"prof_{tag}", "stats", "r_kernel_stats.csv"), os.
 summary = json.load(open(os.path.join(src, f"prof_{tag}", "summary.json")))
 json.dump(summary, open(os.path.join(dst, f"{rnd}_bench_summary.json"), "w"), indent=1)
 traffic = {
+    "kernel_source_hash": kernel_source_hash(),
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline",
     "units": "FETCH_SIZE / WRITE_SIZE are KiB per launch; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the x2 is the gfx950 FETCH_SIZE "
              "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE calibrates 1:1 here (k_raster_tile writes exactly 4096*4096*4 B = 65536 KiB)",
@@ -40,7 +43,7 @@ for f in sorted(glob.glob(os.path.join(src, f"pmc_{tag}", "p*", "*counter_collec
         acc[(short(row["Kernel_Name"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (kernel, counter), values in acc.items():
         per_launch[kernel][counter] = sum(values) / len(values)
-json.dump({"command": "rocprofv3 --kernel-trace --pmc <set> -f csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (one pass per counter set, "
+json.dump({"kernel_source_hash": kernel_source_hash(), "command": "rocprofv3 --kernel-trace --pmc <set> -f csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline (one pass per counter set, "
                       "CRH_NO_PIPELINE unset)", "per_launch": per_launch}, open(os.path.join(dst, f"{rnd}_sq_counters.json"), "w"), indent=1)
 if len(sys.argv) > 3:
     line = [l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1]
