@@ -174,14 +174,41 @@ int oracle_render_draws(void* h, uint32_t width, uint32_t height, uint32_t msaa,
     return oracle_render_pass(h, width, height, msaa, winding_bits, clip_bits, alpha_layers, nullptr, nullptr, transforms, colors, draws, n_draws, rgba8);
 }
 
-// cpu_baseline: wall seconds of `repeats` full tessellations (restatement of the CPU part of from_paths).
+// cpu_baseline: wall seconds of `repeats` full tessellations (restatement of the CPU part of from_paths). The threads are created once,
+// before the clock starts, and take blocks of 64 Shapes from one counter over all repeats (glibc malloc serves every thread from its own
+// arena); the result scenes are destroyed after the clock stops. n_threads <= 1: the calling thread alone, like renderer.rs:187.
 double oracle_time_tessellate(const crh_path_batch* batch, int n_threads, int repeats) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < repeats; ++r) {
-        Scene* s = tessellate(batch, n_threads);
-        delete s;
+    std::vector<uint64_t> seg_off(batch->n_segments + 1, 0);
+    for (uint32_t i = 0; i < batch->n_segments; ++i) seg_off[i + 1] = seg_off[i] + SEGMENT_FLOATS[batch->segment_types[i]];
+    std::vector<Scene*> scenes((size_t)repeats);
+    for (Scene*& sc : scenes) {
+        sc = new Scene;
+        sc->shapes.resize(batch->n_shapes);
     }
-    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const uint64_t blocks_per_repeat = ((uint64_t)batch->n_shapes + 63) / 64, total_blocks = blocks_per_repeat * (uint64_t)repeats;
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    auto work = [&] {
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        for (;;) {
+            const uint64_t block = next.fetch_add(1);
+            if (block >= total_blocks) break;
+            const uint64_t r = block / blocks_per_repeat, first = (block % blocks_per_repeat) * 64;
+            build_range(batch, seg_off, *scenes[r], (uint32_t)first, (uint32_t)std::min<uint64_t>(first + 64, batch->n_shapes));
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    while (ready.load() < (int)pool.size()) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    work(); // the calling thread is one of the workers
+    for (auto& th : pool) th.join();
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (Scene* sc : scenes) delete sc;
+    return seconds;
 }
 
 // elementary functions, for the GPU bit-identity test: fn 0 atan2(a,b) 1 acos(a) 2 sin(a) 3 cos(a) 4 pow(a,b) 5 wgsl_mod(a,b)
