@@ -211,6 +211,10 @@ double oracle_time_tessellate(const crh_path_batch* batch, int n_threads, int re
     return seconds;
 }
 
+// the fragment helpers of shaders.wgsl:165-231 on their own, for the known-answer tests
+int oracle_cap(float x, float y, uint32_t cap_type) { return cap(x, y, cap_type) ? 1 : 0; }
+int oracle_stroke_dashed(const crh_dynamic_stroke_descriptor* d, float tx, float ty) { return stroke_dashed(*d, tx, ty) ? 1 : 0; }
+
 // elementary functions, for the GPU bit-identity test: fn 0 atan2(a,b) 1 acos(a) 2 sin(a) 3 cos(a) 4 pow(a,b) 5 wgsl_mod(a,b)
 void oracle_fmath_eval(int fn, const float* a, const float* b, float* out, uint64_t n) {
     for (uint64_t i = 0; i < n; ++i) {

@@ -61,6 +61,8 @@ def _load():
         lib.oracle_time_tessellate.argtypes = [C.POINTER(_ffi.PathBatchC), C.c_int, C.c_int]
         lib.oracle_fmath_eval.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]
         lib.oracle_solve.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.oracle_cap.argtypes = [C.c_float, C.c_float, C.c_uint32]
+        lib.oracle_stroke_dashed.argtypes = [C.POINTER(_ffi.DynamicStrokeDescriptorC), C.c_float, C.c_float]
         _lib = lib
     return _lib
 
@@ -197,3 +199,13 @@ def solve(degree, coefficients):
     fp = C.POINTER(C.c_float)
     n = lib.oracle_solve(degree, c.ctypes.data_as(fp), roots.ctypes.data_as(fp), C.byref(disc))
     return disc.value, roots[:3 * n].reshape(n, 3)
+
+
+def cap(x, y, cap_type):
+    """shaders.wgsl:165-189"""
+    return bool(_load().oracle_cap(x, y, cap_type))
+
+
+def stroke_dashed(descriptor, tx, ty):
+    """shaders.wgsl:205-231 on a 48-byte descriptor"""
+    return bool(_load().oracle_stroke_dashed(C.byref(descriptor), tx, ty))

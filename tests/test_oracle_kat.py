@@ -267,3 +267,77 @@ def test_canonical_scenes_are_tessellable():
     for sc in (scenes.scene_quadratic(100), scenes.scene_cubic_fill(10000), scenes.scene_dashed_strokes(300, (1024, 1024)), scenes.scene_mixed()):
         o = Oracle(sc["batch"], 4)
         assert o.status() == 0, sc["name"]
+
+
+# ---- KAT-G / H / I: fragment helpers and descriptor packing, worked out by hand from shaders.wgsl:165-231 and renderer.rs:29-60 ----------
+# (no third-party semantics involved: WGSL comparisons, `%` on positive operands and integer shifts)
+
+def test_kat_g_cap_all_seven_types():
+    """shaders.wgsl:165-189 at hand-picked texcoords; the numbers in the comments are the two sides of each comparison."""
+    from oracle.binding import cap
+    SQUARE, ROUND, OUT, IN, RIGHT, LEFT, BUTT = range(7)
+    table = [
+        (SQUARE, 0.3, 0.6, True), (SQUARE, 0.3, 0.5, False),                    # y > 0.5
+        (ROUND, 0.3, 0.39, True), (ROUND, 0.3, 0.41, False),                    # 0.09 + 0.1521 = 0.2421 < 0.25 ; 0.09 + 0.1681 = 0.2581
+        (OUT, 0.2, 0.25, True), (OUT, -0.2, 0.25, True), (OUT, 0.3, 0.25, False),   # 0.5 - 0.25 = 0.25 > |x|
+        (IN, 0.4, 0.3, True), (IN, -0.4, 0.3, True), (IN, 0.2, 0.3, False),      # y < |x|
+        (RIGHT, 0.2, 0.25, True), (RIGHT, 0.3, 0.25, False), (RIGHT, -0.4, 0.25, True),  # 0.5 - y > x (signed x)
+        (LEFT, -0.2, 0.25, True), (LEFT, -0.3, 0.25, False), (LEFT, 0.4, 0.25, True),    # y - 0.5 = -0.25 < x
+        (BUTT, 0.0, -0.01, True), (BUTT, 0.0, 0.0, False),                      # y < 0
+        (BUTT | 0x30, 0.0, -1.0, True), (SQUARE | 0x70, 0.0, 0.75, True),       # only the low nibble selects (cap_type & 15)
+        (9, 0.0, -1.0, True), (9, 0.0, 1.0, False),                             # any other value: the default arm = Butt
+    ]
+    for cap_type, x, y, expect in table:
+        assert cap(x, y, cap_type) is expect, (cap_type, x, y)
+
+
+def _descriptor(pattern, phase, join=0):
+    from contrast_renderer_amd import Cap, DashInterval, DynamicStrokeOptions, Join
+    from oracle.binding import _load
+    import ctypes as C
+    from contrast_renderer_amd import _ffi
+    o = DynamicStrokeOptions.Dashed(Join(join), [DashInterval(a, b, Cap(s), Cap(e)) for a, b, s, e in pattern], phase)
+    out = _ffi.DynamicStrokeDescriptorC()
+    rc = _load().oracle_convert_dynamic_stroke_options(C.byref(o.to_c()), C.byref(out))
+    assert rc == 0
+    return out
+
+
+def test_kat_h_descriptor_packing_for_two_three_and_four_intervals():
+    """renderer.rs:29-60: count_dashed_join = (len - 1) << 3 | 4 | join; dash_start of interval i goes to byte (i + len - 1) % len, low
+    nibble... of the PREVIOUS interval's byte; dash_end of interval i to the high nibble of byte i."""
+    BUTT, ROUND, OUT, IN, RIGHT = 6, 1, 2, 3, 4
+    d = _descriptor([(2.0, 3.0, ROUND, OUT), (5.0, 6.0, IN, RIGHT)], 0.25, join=2)
+    assert d.count_dashed_join == (1 << 3) | 4 | 2
+    assert list(d.gap_start) == [2.0, 5.0, 0.0, 0.0] and list(d.gap_end) == [3.0, 6.0, 0.0, 0.0] and d.phase == 0.25
+    # interval 0: start ROUND -> byte (0 + 1) % 2 = 1, end OUT -> byte 0 high nibble; interval 1: start IN -> byte 0, end RIGHT -> byte 1 high nibble
+    assert d.caps == (IN | (OUT << 4)) | ((ROUND | (RIGHT << 4)) << 8)
+    d = _descriptor([(1.0, 2.0, 0, 1), (3.0, 4.0, 2, 3), (5.0, 7.0, 4, 5)], 0.0, join=1)
+    assert d.count_dashed_join == (2 << 3) | 4 | 1
+    # starts: i=0 -> byte 2, i=1 -> byte 0, i=2 -> byte 1 ; ends: byte i high nibble
+    assert d.caps == (2 | (1 << 4)) | ((4 | (3 << 4)) << 8) | ((0 | (5 << 4)) << 16)
+    d = _descriptor([(1.0, 2.0, 6, 6), (3.0, 4.0, 1, 1), (5.0, 6.0, 2, 2), (7.0, 9.0, 3, 3)], 1.5)
+    assert d.count_dashed_join == (3 << 3) | 4 | 0 and list(d.gap_end) == [2.0, 4.0, 6.0, 9.0]
+    # starts: 0 -> byte 3, 1 -> byte 0, 2 -> byte 1, 3 -> byte 2
+    assert d.caps == (1 | (6 << 4)) | ((2 | (1 << 4)) << 8) | ((3 | (2 << 4)) << 16) | ((6 | (3 << 4)) << 24)
+
+
+def test_kat_i_stroke_dashed_interval_selection():
+    """shaders.wgsl:205-231 with Butt caps everywhere (cap = y < 0: never true for the positive gap distances, so a sample is filled
+    exactly when it is NOT inside a gap): pattern length = gap_end[last]; position = (y - phase) mod length; the first interval whose
+    gap_end >= position is selected (or the last one); inside its gap <=> position > gap_start."""
+    from oracle.binding import stroke_dashed
+    BUTT = 6
+    d = _descriptor([(2.0, 3.0, BUTT, BUTT), (5.0, 6.0, BUTT, BUTT)], 0.0)  # dashes [0,2] and [3,5], gaps (2,3] and (5,6], period 6
+    for y, filled in [(0.0, True), (1.99, True), (2.0, True), (2.01, False), (2.99, False), (3.0, False), (3.01, True), (4.5, True), (5.0, True),
+                      (5.5, False), (6.0 + 1.0, True), (6.0 + 2.5, False), (12.0 + 5.75, False), (-0.5, False), (-1.5, True), (-6.0 + 2.5, False)]:
+        assert stroke_dashed(d, 0.0, y) is filled, y   # negative positions wrap: -0.5 -> 5.5 (gap), -1.5 -> 4.5 (dash)
+    d = _descriptor([(2.0, 3.0, BUTT, BUTT), (5.0, 6.0, BUTT, BUTT)], 1.0)  # phase shifts the pattern by +1
+    for y, filled in [(1.0, True), (3.0, True), (3.5, False), (4.0, False), (4.01, True), (6.5, False), (6.99, False), (7.0, True), (7.5, True)]:  # position = (y - 1) mod 6: 7.0 -> 0 (a new period starts)
+        assert stroke_dashed(d, 0.0, y) is filled, y
+    # with Round caps the dash ends grow half-discs into the gap: a sample at distance 0.3 behind the dash end, on the centre line, is inside
+    ROUND = 1
+    d = _descriptor([(2.0, 3.0, ROUND, ROUND), (5.0, 6.0, ROUND, ROUND)], 0.0)
+    assert stroke_dashed(d, 0.0, 2.3) is True       # gap_start distance 0.3: 0.09 < 0.25
+    assert stroke_dashed(d, 0.0, 2.5) is False      # 0.5 from either end: 0.25 < 0.25 is false
+    assert stroke_dashed(d, 0.45, 2.3) is False     # off the centre line: 0.2025 + 0.09 = 0.2925 (start cap), 0.2025 + 0.49 (end cap)
