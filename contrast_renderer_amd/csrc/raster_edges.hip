@@ -863,21 +863,9 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             if ((r.debug & 16u) && kind == EK_SYNTH) continue;
             if ((r.debug & 32u) && kind != EK_EDGE && kind != EK_SYNTH) continue;
 #endif
-            // Every kind only produces the change of the winding counters (dw), of the hull winding (dh) and, for the covers, which samples
-            // blend; the state is updated once behind the dispatch. (Updating it inside the branches makes every iteration end with the
-            // SSA join of all state registers: a dozen register-pair copies per entry.)
-            int dw[ROWS][S], dh[ROWS][S];
-            bool blend[ROWS][S];
-#pragma unroll
-            for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                for (int q = 0; q < S; ++q) {
-                    dw[b][q] = 0;
-                    dh[b][q] = 0;
-                    blend[b][q] = false;
-                }
-            float cs0 = 0.0f, cs1 = 0.0f, cs2 = 0.0f, cs3 = 0.0f; // the premultiplied source colour of a cover
-            bool is_cover = false;
+            // Every class updates the state it owns in place, unconditionally per sample (a select with the old value where nothing
+            // changes): state that is modified under a wave-uniform inner branch, or merged behind the dispatch, costs the compiler a
+            // dozen register copies per entry at the join.
             if (kind == EK_EDGE) {
                 // w(p) += sigma * [ Y_k g(p) + A_k ],  A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k)   (see the header of this file)
                 const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z, ymin = eb4.x, ymax = eb4.y;
@@ -888,82 +876,63 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 const unsigned long long y_all = __builtin_amdgcn_ballot_w64((ymin <= sy_row) & (sy_row < ymax));
                 const uint32_t gq = (uint32_t)gq_all & 0xFFFFu, ym = (uint32_t)y_all & 0xFFFFu;
                 const uint32_t g0 = ((uint32_t)gq_all >> 16) & 1u ? 0xFFFFu : 0u, xr = (flags & 0x1000u) ? 0xFFFFu : 0u;
-                uint32_t kp = xr & gq & ~g0 & ~ym;                               // A = +1
-                uint32_t kn = (xr & ~gq & g0) | (ym & gq & (~xr | g0));          // A = -1
-                const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma = +1; otherwise every term changes sign
-                if (!positive) {
-                    const uint32_t t = kp;
-                    kp = kn, kn = t;
-                }
-                const bool to_hull = (flags & kEdgeHull) != 0u;
+                const uint32_t a_plus = xr & gq & ~g0 & ~ym;                      // A = +1
+                const uint32_t a_minus = (xr & ~gq & g0) | (ym & gq & (~xr | g0)); // A = -1
+                const int unit = (flags & kEdgeSigmaPos) ? 1 : -1;               // sigma
                 const SlotMasks ys = slot_masks<S>(ym);
                 float h[S];
 #pragma unroll
                 for (int q = 0; q < S; ++q) h[q] = fmaf(sx[q], enay, c0);
-                unsigned long long hit[ROWS][S];
+                int d[ROWS][S];
 #pragma unroll
                 for (int cmb = 0; cmb < ROWS * S; cmb += 2) {
                     const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
                     const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
                     const f32x2 ev = fma2(y, splat2(ebx), f32x2{h[k0], h[k1]});
-                    hit[b0][k0] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[0]) >= thr) & ys.m[S == 1 ? b0 : k0];
-                    hit[b1][k1] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[1]) >= thr) & ys.m[S == 1 ? b1 : k1];
+                    d[b0][k0] = ((__float_as_int(ev[0]) >= thr) & __builtin_amdgcn_inverse_ballot_w64(ys.m[S == 1 ? b0 : k0])) ? unit : 0;
+                    d[b1][k1] = ((__float_as_int(ev[1]) >= thr) & __builtin_amdgcn_inverse_ballot_w64(ys.m[S == 1 ? b1 : k1])) ? unit : 0;
                 }
-                // four straight-line variants (sign x fill / hull), one instruction per sample each
-                if (to_hull) {
-                    if (positive) {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                            for (int q = 0; q < S; ++q) add_where(hullw[b][q], hit[b][q]);
-                    } else {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                            for (int q = 0; q < S; ++q) sub_where(hullw[b][q], hit[b][q]);
-                    }
-                } else {
-                    if (positive) {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                            for (int q = 0; q < S; ++q) add_where(winding[b][q], hit[b][q]);
-                    } else {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                            for (int q = 0; q < S; ++q) sub_where(winding[b][q], hit[b][q]);
-                    }
-                }
-                if (kp | kn) { // the edge crosses the left tile boundary (or runs left of it): row constants
-                    const SlotMasks ps = slot_masks<S>(kp), ns = slot_masks<S>(kn);
+                if (a_plus | a_minus) { // the edge crosses the left tile boundary (or runs left of it): row constants (on the deltas, not on the state)
+                    const uint32_t lane_shift = S == 1 ? rq : 4u * rq; // sample (b, q) of lane (px, rq) is row bit rq + 4b (msaa 1) / 4 rq + q (msaa 4)
+                    const uint32_t psh = (unit > 0 ? a_plus : a_minus) >> lane_shift, nsh = (unit > 0 ? a_minus : a_plus) >> lane_shift;
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int q = 0; q < S; ++q) {
-                            if (to_hull) {
-                                add_where(hullw[b][q], ps.m[S == 1 ? b : q]);
-                                sub_where(hullw[b][q], ns.m[S == 1 ? b : q]);
-                            } else {
-                                add_where(winding[b][q], ps.m[S == 1 ? b : q]);
-                                sub_where(winding[b][q], ns.m[S == 1 ? b : q]);
-                            }
+                            const int p = S == 1 ? 4 * b : q;
+                            d[b][q] += (int)((psh >> p) & 1u) - (int)((nsh >> p) & 1u);
                         }
+                }
+                if (flags & kEdgeHull) {
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) hullw[b][q] += d[b][q];
+                } else {
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) winding[b][q] += d[b][q];
                 }
             } else if (kind == EK_SYNTH) {
                 const uint32_t code = (flags >> 8) & 15u;
                 if (code < 4u) { // a whole-tile backdrop of the fill (0, 1) or hull (2, 3) winding
-                    const int v = (code & 1u) ? -1 : 1;
+                    const int vw = code < 2u ? ((code & 1u) ? -1 : 1) : 0, vh = code < 2u ? 0 : ((code & 1u) ? -1 : 1);
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                         for (int q = 0; q < S; ++q) {
-                            dw[b][q] = code < 2u ? v : 0;
-                            dh[b][q] = code < 2u ? 0 : v;
+                            winding[b][q] += vw;
+                            hullw[b][q] += vh;
                         }
                 } else {
-                    // COVER: color_cover over the samples inside the hull (renderer.rs:340-354, 736-754): blend where winding != 0, zero the winding
+                    // COVER: color_cover over the samples inside the hull (renderer.rs:340-354, 736-754): blend where winding != 0, zero the
+                    // winding; premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
                     const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
+                    const float cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
+                    const float one_minus_a = 1.0f - cs3;
+                    bool blend[ROWS][S];
+                    int any_blend = 0;
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
@@ -971,11 +940,22 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                             const int w = winding[b][q] + bd;
                             const bool in_hull = hullw[b][q] + hbd != 0;
                             blend[b][q] = in_hull && (w & wmask) != 0;
-                            dw[b][q] = in_hull ? -winding[b][q] : bd;
-                            dh[b][q] = -hullw[b][q];
+                            any_blend |= (int)blend[b][q];
+                            winding[b][q] = in_hull ? 0 : w;
+                            hullw[b][q] = 0;
                         }
-                    cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
-                    is_cover = true;
+                    (void)any_blend;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) { // unconditional, in place (a select with the old value where nothing blends)
+                            const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
+                            const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
+                            col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
+                            col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
+                            col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
+                            col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                        }
                 }
             } else {
             // ---- triangles: curve and stroke triangles as k_raster_tile; cover triangles of a folded hull strip
@@ -1005,17 +985,37 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 }
             }
             if (kind == EK_COVER_TRI) { // a triangle of a hull strip drawn as the reference draws it: color_cover inside the triangle
+                const float cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
+                const float one_minus_a = 1.0f - cs3;
+                bool blend[ROWS][S];
+                int any_blend = 0;
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                     for (int q = 0; q < S; ++q) {
                         blend[b][q] = inside[b][q] && (winding[b][q] & wmask) != 0;
-                        dw[b][q] = inside[b][q] ? -winding[b][q] : 0;
+                        any_blend |= (int)blend[b][q];
+                        winding[b][q] = inside[b][q] ? 0 : winding[b][q];
                     }
-                cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
-                is_cover = true;
+                (void)any_blend;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
+                        const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
+                        col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
+                        col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
+                        col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
+                        col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                    }
             } else {
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+            int dw[ROWS][S];
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < S; ++q) dw[b][q] = 0;
             const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
             float hx[4][S];
 #pragma unroll
@@ -1081,31 +1081,12 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         }
                 }
             }
-            } // curve / stroke triangles
-            } // triangles
-            int any_blend = 0;
 #pragma unroll
             for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                for (int q = 0; q < S; ++q) {
-                    winding[b][q] += dw[b][q];
-                    hullw[b][q] += dh[b][q];
-                    any_blend |= (int)blend[b][q];
-                }
-            if (is_cover && __any(any_blend)) { // color_cover: premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
-                const float one_minus_a = 1.0f - cs3;
-#pragma unroll
-                for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                    for (int q = 0; q < S; ++q) {
-                        const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
-                        const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
-                        col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
-                        col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
-                        col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
-                        col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
-                    }
-            }
+                for (int q = 0; q < S; ++q) winding[b][q] += dw[b][q];
+            } // curve / stroke triangles
+            } // triangles
         }
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
@@ -1115,11 +1096,14 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         if (gx < r.width && gy < r.height) {
             const float inv = 1.0f / (float)S;
             uint32_t packed_px = 0;
+            float4 cq[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) cq[q] = make_float4(col[b][q][0], col[b][q][1], col[b][q][2], col[b][q][3]);
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 float sum = 0.0f;
 #pragma unroll
-                for (int q = 0; q < S; ++q) sum = sum + col[b][q][ch];
+                for (int q = 0; q < S; ++q) sum = sum + (ch == 0 ? cq[q].x : (ch == 1 ? cq[q].y : (ch == 2 ? cq[q].z : cq[q].w)));
                 float x = sum * inv;
                 x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
                 if (!(x == x)) x = 0.0f;
