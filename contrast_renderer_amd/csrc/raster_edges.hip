@@ -663,11 +663,14 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
     return k;
 }
 
+#ifndef CRH_EDGE_TILE_WAVES
+#define CRH_EDGE_TILE_WAVES 5 // measured 4: 0.321, 5: 0.322, 6: 0.331 (spills), 8: 0.421 ms on the benchmark scene
+#endif
 // One workgroup per 16x16 tile, laid out exactly as k_raster_tile (raster.hip): msaa 1 = one wavefront, four pixel rows per lane;
 // msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
 // the item being drawn and the colour; entries are walked in key order (= draw order).
 template <int S, int ROWS, bool STROKES>
-__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? 1 : CRH_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
+__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? 1 : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
@@ -852,11 +855,41 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #ifdef CRH_ABLATE
         if (r.debug & 128u) continue;
 #endif
-        for (uint32_t j = 0; j < count; ++j) {
+        // sample (b, q) of this lane inside a set-up triangle? (k_raster_tile's coverage: packed edge functions, box bits)
+        auto coverage = [&](const float4& ea4, const float4& eb4, const float4& ec4, uint32_t flags, bool (&inside)[ROWS][S]) {
+            const uint32_t bits = __float_as_uint(ea4.w);
+            const float c0 = ea4.x, c1 = ea4.y, c2 = ea4.z, bx_0 = eb4.x, bx_1 = eb4.y, bx_2 = eb4.z, nay_0 = ec4.x, nay_1 = ec4.y, nay_2 = ec4.z;
+            const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) >> row_shift : 0u;
+            const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
+            float ha[S], hb[S], hc[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                ha[q] = fmaf(sx[q], nay_0, c0);
+                hb[q] = fmaf(sx[q], nay_1, c1);
+                hc[q] = fmaf(sx[q], nay_2, c2);
+            }
+#pragma unroll
+            for (int cmb = 0; cmb < ROWS * S; cmb += 2) {
+                const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
+                const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
+                const f32x2 ea = fma2(y, splat2(bx_0), f32x2{ha[k0], ha[k1]});
+                const f32x2 eb = fma2(y, splat2(bx_1), f32x2{hb[k0], hb[k1]});
+                const f32x2 ec = fma2(y, splat2(bx_2), f32x2{hc[k0], hc[k1]});
+                inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & (1u << (4 * b0))) != 0u);
+                inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & (1u << (4 * b1))) != 0u);
+            }
+        };
+        // Two nested loops over the chunk's entries: the inner one runs over what only changes the winding counters (triangles, edges,
+        // backdrops) and stops at a cover entry, which the outer loop body handles — the ONE place where the colour registers are
+        // written. (With the colour updated inside a multi-way dispatch, every iteration ended with two dozen register copies.)
+        uint32_t j = 0;
+        while (j < count) {
+        for (; j < count; ++j) {
             const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
             const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
             const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
             const uint32_t kind = (flags >> 4) & 15u;
+            if (kind == EK_COVER_TRI || (kind == EK_SYNTH && ((flags >> 8) & 15u) >= 4u)) break; // a cover: the outer loop's business
 #ifdef CRH_ABLATE // tools/ablate_edges.sh: what does each class of entries cost?
             if ((r.debug & 256u) && lane == 0u) atomicAdd(&r.overflow[8 + (kind == EK_EDGE ? ((flags & kEdgeHull) ? 1 : 0) : (kind == EK_SYNTH ? 2 : 3))], 1u);
             if ((r.debug & 8u) && kind == EK_EDGE) continue;
@@ -914,102 +947,22 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                         for (int q = 0; q < S; ++q) winding[b][q] += d[b][q];
                 }
-            } else if (kind == EK_SYNTH) {
+            } else if (kind == EK_SYNTH) { // a whole-tile backdrop of the fill (codes 0, 1) or hull (2, 3) winding
                 const uint32_t code = (flags >> 8) & 15u;
-                if (code < 4u) { // a whole-tile backdrop of the fill (0, 1) or hull (2, 3) winding
-                    const int vw = code < 2u ? ((code & 1u) ? -1 : 1) : 0, vh = code < 2u ? 0 : ((code & 1u) ? -1 : 1);
+                const int vw = code < 2u ? ((code & 1u) ? -1 : 1) : 0, vh = code < 2u ? 0 : ((code & 1u) ? -1 : 1);
 #pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
+                for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                        for (int q = 0; q < S; ++q) {
-                            winding[b][q] += vw;
-                            hullw[b][q] += vh;
-                        }
-                } else {
-                    // COVER: color_cover over the samples inside the hull (renderer.rs:340-354, 736-754): blend where winding != 0, zero the
-                    // winding; premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
-                    const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
-                    const float cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
-                    const float one_minus_a = 1.0f - cs3;
-                    bool blend[ROWS][S];
-                    int any_blend = 0;
-#pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) {
-                            const int w = winding[b][q] + bd;
-                            const bool in_hull = hullw[b][q] + hbd != 0;
-                            blend[b][q] = in_hull && (w & wmask) != 0;
-                            any_blend |= (int)blend[b][q];
-                            winding[b][q] = in_hull ? 0 : w;
-                            hullw[b][q] = 0;
-                        }
-                    (void)any_blend;
-#pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) { // unconditional, in place (a select with the old value where nothing blends)
-                            const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
-                            const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
-                            col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
-                            col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
-                            col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
-                            col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
-                        }
-                }
+                    for (int q = 0; q < S; ++q) {
+                        winding[b][q] += vw;
+                        hullw[b][q] += vh;
+                    }
             } else {
-            // ---- triangles: curve and stroke triangles as k_raster_tile; cover triangles of a folded hull strip
+            // ---- curve and stroke triangles, as k_raster_tile
             const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
             bool inside[ROWS][S];
+            coverage(ea4, eb4, ec4, flags, inside);
             {
-                const uint32_t bits = __float_as_uint(ea4.w);
-                const float c0 = ea4.x, c1 = ea4.y, c2 = ea4.z, bx_0 = eb4.x, bx_1 = eb4.y, bx_2 = eb4.z, nay_0 = ec4.x, nay_1 = ec4.y, nay_2 = ec4.z;
-                const uint32_t lane_rows = ((bits >> px) & 1u) ? (bits >> 16) >> row_shift : 0u;
-                const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
-                float ha[S], hb[S], hc[S];
-#pragma unroll
-                for (int q = 0; q < S; ++q) {
-                    ha[q] = fmaf(sx[q], nay_0, c0);
-                    hb[q] = fmaf(sx[q], nay_1, c1);
-                    hc[q] = fmaf(sx[q], nay_2, c2);
-                }
-#pragma unroll
-                for (int cmb = 0; cmb < ROWS * S; cmb += 2) {
-                    const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
-                    const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
-                    const f32x2 ea = fma2(y, splat2(bx_0), f32x2{ha[k0], ha[k1]});
-                    const f32x2 eb = fma2(y, splat2(bx_1), f32x2{hb[k0], hb[k1]});
-                    const f32x2 ec = fma2(y, splat2(bx_2), f32x2{hc[k0], hc[k1]});
-                    inside[b0][k0] = (__float_as_int(ea[0]) >= thr0) & (__float_as_int(eb[0]) >= thr1) & (__float_as_int(ec[0]) >= thr2) & ((lane_rows & (1u << (4 * b0))) != 0u);
-                    inside[b1][k1] = (__float_as_int(ea[1]) >= thr0) & (__float_as_int(eb[1]) >= thr1) & (__float_as_int(ec[1]) >= thr2) & ((lane_rows & (1u << (4 * b1))) != 0u);
-                }
-            }
-            if (kind == EK_COVER_TRI) { // a triangle of a hull strip drawn as the reference draws it: color_cover inside the triangle
-                const float cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
-                const float one_minus_a = 1.0f - cs3;
-                bool blend[ROWS][S];
-                int any_blend = 0;
-#pragma unroll
-                for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                    for (int q = 0; q < S; ++q) {
-                        blend[b][q] = inside[b][q] && (winding[b][q] & wmask) != 0;
-                        any_blend |= (int)blend[b][q];
-                        winding[b][q] = inside[b][q] ? 0 : winding[b][q];
-                    }
-                (void)any_blend;
-#pragma unroll
-                for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                    for (int q = 0; q < S; ++q) {
-                        const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
-                        const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
-                        col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
-                        col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
-                        col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
-                        col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
-                    }
-            } else {
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
             int dw[ROWS][S];
 #pragma unroll
@@ -1087,7 +1040,64 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 for (int q = 0; q < S; ++q) winding[b][q] += dw[b][q];
             } // curve / stroke triangles
             } // triangles
+        } // run of entries that only change the winding counters
+        if (j >= count) break;
+        {
+            // ---- entry j is a cover: color_cover (renderer.rs:340-354, 736-754) — blend where the winding is not zero, zero the winding
+            //      of the covered samples; premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
+            const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
+            const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
+            const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
+            const uint32_t kind = (flags >> 4) & 15u;
+            ++j;
+#ifdef CRH_ABLATE
+            if ((r.debug & 256u) && lane == 0u) atomicAdd(&r.overflow[8 + (kind == EK_SYNTH ? 2 : 3)], 1u);
+            if ((r.debug & 16u) && kind == EK_SYNTH) continue;
+            if ((r.debug & 32u) && kind != EK_SYNTH) continue;
+#endif
+            bool blend[ROWS][S];
+            float cs0, cs1, cs2, cs3;
+            if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
+                const uint32_t code = (flags >> 8) & 15u;
+                const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
+                cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        const int w = winding[b][q] + bd;
+                        const bool in_hull = hullw[b][q] + hbd != 0;
+                        blend[b][q] = in_hull && (w & wmask) != 0;
+                        winding[b][q] = in_hull ? 0 : w;
+                        hullw[b][q] = 0;
+                    }
+            } else { // a triangle of a folded hull strip, drawn as the reference draws it
+                const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
+                bool inside[ROWS][S];
+                coverage(ea4, eb4, ec4, flags, inside);
+                cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        blend[b][q] = inside[b][q] && (winding[b][q] & wmask) != 0;
+                        winding[b][q] = inside[b][q] ? 0 : winding[b][q];
+                    }
+            }
+            const float one_minus_a = 1.0f - cs3;
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < S; ++q) { // unconditional, in place (a select with the old value where nothing blends)
+                    const float n0 = cs0 + col[b][q][0] * one_minus_a, n1 = cs1 + col[b][q][1] * one_minus_a;
+                    const float n2 = cs2 + col[b][q][2] * one_minus_a, n3 = cs3 + col[b][q][3] * one_minus_a;
+                    col[b][q][0] = blend[b][q] ? n0 : col[b][q][0];
+                    col[b][q][1] = blend[b][q] ? n1 : col[b][q][1];
+                    col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
+                    col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
+                }
         }
+        } // entries of the chunk
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
 #pragma unroll
