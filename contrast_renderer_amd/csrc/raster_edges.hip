@@ -24,6 +24,8 @@
 //   k_scatter          pair -> its slot in the tile's list (offsets from the scan of the counts).
 //   k_raster_edges<..> one wavefront per tile as in raster.hip; entries are triangles, edges and one COVER entry per (item, tile).
 // Keys are slot numbers of a 32-byte primitive heap (a triangle owns four slots = its 128-byte record); they ascend in draw order.
+#include <type_traits>
+
 #include "raster_common.hpp"
 
 namespace crh {
@@ -964,37 +966,52 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             coverage(ea4, eb4, ec4, flags, inside);
             {
             const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
-            int dw[ROWS][S];
-#pragma unroll
-            for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                for (int q = 0; q < S; ++q) dw[b][q] = 0;
             const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
-            float hx[4][S];
+            if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266), one straight-line variant per kind
+                auto curve = [&](auto kind_tag) {
+                    constexpr uint32_t K = decltype(kind_tag)::value;
+                    constexpr int NA = K == KIND_IQ ? 2 : (K == KIND_RC ? 4 : 3); // attributes the kind interpolates
+                    float hx[NA][S]; // attribute planes, tile relative: the row-independent inner fma
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float ac = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
+                    for (int t = 0; t < NA; ++t) {
+                        const float ac = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
 #pragma unroll
-                for (int q = 0; q < S; ++q) hx[t][q] = fmaf(sx[q], frag.gx[t], ac);
-            }
-            if (kind <= KIND_RC) { // the four implicit-curve tests (shaders.wgsl:236-266)
-#pragma unroll
-                for (int b = 0; b < ROWS; ++b) {
-                    bool row_touched = false;
-#pragma unroll
-                    for (int q = 0; q < S; ++q) row_touched = row_touched | inside[b][q];
-                    if (!__any(row_touched)) continue;
-#pragma unroll
-                    for (int q = 0; q < S; ++q) {
-                        const float y = sy0[q] + (float)(4 * b);
-                        const float a0 = fmaf(y, frag.gy[0], hx[0][q]), a1 = fmaf(y, frag.gy[1], hx[1][q]);
-                        const float a2 = fmaf(y, frag.gy[2], hx[2][q]), a3 = fmaf(y, frag.gy[3], hx[3][q]);
-                        const float lhs = (kind == KIND_IQ || kind == KIND_RQ) ? a0 * a0 : a0 * a0 * a0;
-                        const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? a1 * a2 * a3 : a1 * a2);
-                        dw[b][q] = (inside[b][q] && lhs - rhs <= 0.0f) ? delta : 0;
+                        for (int q = 0; q < S; ++q) hx[t][q] = fmaf(sx[q], frag.gx[t], ac);
                     }
-                }
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b) {
+                        bool row_touched = false;
+#pragma unroll
+                        for (int q = 0; q < S; ++q) row_touched = row_touched | inside[b][q];
+                        if (!__any(row_touched)) continue; // curve triangles are small: most rows of the tile are not touched
+#pragma unroll
+                        for (int q = 0; q < S; ++q) {
+                            const float y = sy0[q] + (float)(4 * b);
+                            float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                            for (int t = 0; t < NA; ++t) a[t] = fmaf(y, frag.gy[t], hx[t][q]);
+                            const float lhs = (K == KIND_IQ || K == KIND_RQ) ? a[0] * a[0] : a[0] * a[0] * a[0];
+                            const float rhs = K == KIND_IQ ? a[1] : (K == KIND_RC ? a[1] * a[2] * a[3] : a[1] * a[2]);
+                            winding[b][q] += (inside[b][q] && lhs - rhs <= 0.0f) ? delta : 0;
+                        }
+                    }
+                };
+                if (kind == KIND_IQ)
+                    curve(std::integral_constant<uint32_t, KIND_IQ>{});
+                else if (kind == KIND_IC)
+                    curve(std::integral_constant<uint32_t, KIND_IC>{});
+                else if (kind == KIND_RQ)
+                    curve(std::integral_constant<uint32_t, KIND_RQ>{});
+                else
+                    curve(std::integral_constant<uint32_t, KIND_RC>{});
             } else if (STROKES) { // KIND_LINE / KIND_JOINT: the stroke fragment stages (shaders.wgsl:268-300)
+                float hx[3][S];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float ac = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
+#pragma unroll
+                    for (int q = 0; q < S; ++q) hx[t][q] = fmaf(sx[q], frag.gx[t], ac);
+                }
                 int any_inside = 0;
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
@@ -1029,15 +1046,11 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                                     fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
                                     if (fill && dashed) fill = stroke_dashed_joint(dsc, radius, a0, a1, a2);
                                 }
-                                dw[b][q] = fill ? 1 : 0;
+                                winding[b][q] += fill ? 1 : 0;
                             }
                         }
                 }
             }
-#pragma unroll
-            for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                for (int q = 0; q < S; ++q) winding[b][q] += dw[b][q];
             } // curve / stroke triangles
             } // triangles
         } // run of entries that only change the winding counters
