@@ -350,10 +350,10 @@ __global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
 // convex_hull::andrew (convex_hull.rs:7-40) + triangle_fan_to_strip (renderer.rs:197). The candidates are sorted in SafeFloat's
 // lexicographic order (safe_float.rs:163-173; equal keys are bit-identical after -0 canonicalisation, so stability is moot), then the
 // monotone chain is walked.
-//   k_hull_small  Shapes with <= 64 candidates (the common case), 64 Shapes per workgroup. Phase 1: a wavefront sorts one Shape at a
-//                 time (lane = candidate, bitonic network on registers) into LDS. Phase 2: lane = Shape — 64 Shapes walk their
-//                 (inherently serial) monotone chains simultaneously, the stack being a byte index per entry, its two topmost points
-//                 kept in registers. A wavefront per Shape spent ~1500 VALU issues on one serial chain. Larger Shapes are queued.
+//   k_hull_small  Shapes with <= 64 candidates (the common case), kHullBatch Shapes per single-wavefront workgroup. Phase 1: the wavefront
+//                 sorts one Shape at a time (lane = candidate, bitonic network on registers) into LDS. Phase 2: a lane pair per Shape —
+//                 the Shapes walk their (inherently serial) monotone chains simultaneously, the stack being a byte index per entry, its
+//                 two topmost points kept in registers. Larger Shapes are queued.
 //   k_hull_large  Shapes with 65..2048 candidates, taken from the queue by a fixed grid: bitonic sort + chain in LDS.
 //   k_hull_huge   Shapes beyond that: the same in global memory, one workgroup per Shape.
 constexpr uint32_t kHullSmall = 64;
@@ -366,23 +366,26 @@ CRH_D float turn(float2 a, float2 b, float2 c) { return triple(vec_to_point(a.x,
 // the strip order of triangle_fan_to_strip (vertex.rs:28-35): [0, h-1, 1, h-2, ...]
 CRH_D uint32_t fan_to_strip_source(uint32_t i, uint32_t h) { return (i & 1u) == 0 ? (i >> 1) : h - 1u - (i >> 1); }
 
-constexpr uint32_t kHullBatch = 16;                 // Shapes per workgroup of k_hull_small (4 per wavefront in phase 1, one lane each in phase 2)
+// One wavefront per workgroup: next to the previous frame's raster kernel (single-wave workgroups refilling every slot the moment it
+// frees) a four-wave workgroup never found four free slots at once and waited for the raster grid to drain (0.28 ms instead of 0.03).
+constexpr uint32_t kHullWaves = 1;
+constexpr uint32_t kHullBatch = 4;                  // Shapes per workgroup of k_hull_small (phase 1: one after the other; phase 2: a lane pair each)
 constexpr uint32_t kHullRow = kHullSmall + 1;       // LDS row pitch in float2 (odd: lane-per-Shape accesses spread over the banks)
 
-__global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
+__global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
     __shared__ float2 sorted[kHullBatch][kHullRow];         // sorted candidates of the batch's Shapes
     __shared__ uint8_t stack[kHullBatch][2 * kHullSmall];   // the monotone chain as indices into `sorted`
     __shared__ uint32_t count[kHullBatch];                  // candidates per Shape; 0 = nothing to do here (empty, queued or rejected)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (!fits(s)) return;
     const uint32_t first_shape = blockIdx.x * kHullBatch;
-    // ---- phase 1: every wavefront sorts kHullBatch / 4 Shapes (lane = candidate, bitonic network on registers); the dependent
+    // ---- phase 1: every wavefront sorts kHullBatch / kHullWaves Shapes (lane = candidate, bitonic network on registers); the dependent
     // global loads (range, then candidates) of all its Shapes are issued together before the first sort
-    constexpr uint32_t kPerWave = kHullBatch / 4u;
+    constexpr uint32_t kPerWave = kHullBatch / kHullWaves;
     uint32_t n_of[kPerWave], base_of[kPerWave];
 #pragma unroll
     for (uint32_t u = 0; u < kPerWave; ++u) {
-        const uint32_t shape = first_shape + wave + 4u * u;
+        const uint32_t shape = first_shape + wave + kHullWaves * u;
         n_of[u] = 0;
         base_of[u] = 0;
         if (shape < s.n_shapes) {
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256) void k_hull_small(SceneDev s) {
     }
 #pragma unroll
     for (uint32_t u = 0; u < kPerWave; ++u) {
-        const uint32_t slot = wave + 4u * u, shape = first_shape + slot;
+        const uint32_t slot = wave + kHullWaves * u, shape = first_shape + slot;
         uint32_t n = n_of[u];
         if (shape < s.n_shapes) {
             if (n > kHullSmall) { // queue 0: up to kHullMid candidates (small LDS footprint), queue 1: up to kHullMax, queue 2: global memory
@@ -645,7 +648,7 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
         if (mark) mark(ctx, "stroke_lengths", 0);
     }
     (void)hipMemsetAsync(s.hull_large_count, 0, 16, stream);
-    hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(256), 0, stream, s);
+    hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(64 * kHullWaves), 0, stream, s);
     if (mark) mark(ctx, "tess_hull", bytes[3]);
     if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
         hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(s.n_shapes, 4096u)), dim3(64), 0, stream, s);
