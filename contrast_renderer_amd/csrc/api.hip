@@ -258,6 +258,7 @@ struct crh_frame {
     bool check_pending = false;
 };
 
+constexpr int kTessBufs = 31; // buffers a tessellation run writes (crh_scene::tess_bufs)
 struct crh_scene {
     crh_renderer* renderer; // nullptr once the renderer has been destroyed (only crh_scene_destroy is valid then)
     int device = 0;
@@ -297,6 +298,24 @@ struct crh_scene {
     hipEvent_t vertices_free = nullptr; // recorded on the raster stream after k_prim_setup (last reader of the vertex streams and hulls)
     hipEvent_t ranges_free = nullptr;   // recorded on the raster stream after the fill pass (last reader of the primitive ranges)
     bool rendered_once = false;
+    // Everything a tessellation run writes exists twice once a Scene is tessellated again (animated paths, the benchmark step): the run
+    // for frame i + 1 fills the set that frame i does NOT read, so it overlaps frame i's binning instead of waiting for it (with one set
+    // the chain tessellate -> bin of consecutive frames was serial and, not the raster kernel, set the frame rate). The members above are
+    // the current set; flip_tess_set() swaps them with this one and re-binds the pointers of `d`.
+    struct TessShadow {
+        DevBuf buf[kTessBufs];
+        hipEvent_t tess_done = nullptr, vertices_free = nullptr, ranges_free = nullptr;
+        bool allocated = false, capacity_known = false, rendered_once = false;
+        uint32_t totals_host[NCH] = {};
+        uint64_t emitted_bytes = 0;
+    } shadow;
+    bool tessellated_once = false;
+    void tess_bufs(DevBuf* (&out)[kTessBufs]) {
+        DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
+                                  &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut, &line_pair_mode,
+                                  &line_inc, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
+        for (int i = 0; i < kTessBufs; ++i) out[i] = all[i];
+    }
     // host copies for the parity taps
     std::vector<uint32_t> shape_base_host, hull_count_host;
     bool layout_valid = false;
@@ -307,6 +326,8 @@ struct crh_scene {
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
         for (DevBuf* b : all) b->release();
+        for (DevBuf& b : shadow.buf) b.release();
+        shadow.allocated = false;
         for (DevBuf& b : prim_rec) b.release();
         for (DevBuf& b : prim_proj) b.release();
         upload_t.release();
@@ -360,6 +381,68 @@ crh_status decode_status(crh_scene* scene, uint32_t word) {
     return static_cast<crh_status>(code);
 }
 
+// the pointers of sc->d into the (current) set of tessellation buffers
+void bind_tess_pointers(crh_scene* sc) {
+    SceneDev& d = sc->d;
+    d.elem_scan = sc->elem_scan.as<ElemScan>();
+    d.wg_total = sc->wg_total.as<uint32_t>();
+    d.wg_base = sc->wg_base.as<uint32_t>();
+    d.totals = sc->totals.as<uint32_t>();
+    d.shape_base = sc->shape_base.as<uint32_t>();
+    d.hull_count = sc->hull_count.as<uint32_t>();
+    d.hull_large_count = sc->hull_large.as<uint32_t>();
+    d.hull_large_list = sc->hull_large.as<uint32_t>() + 4;
+    d.status = sc->status.as<uint32_t>();
+    d.line_v = sc->line_v.as<Vertex2f1i>();
+    d.joint_v = sc->joint_v.as<Vertex3f1i>();
+    d.solid_v = sc->solid_v.as<Vertex0>();
+    d.iq_v = sc->iq_v.as<Vertex2f>();
+    d.ic_v = sc->ic_v.as<Vertex3f>();
+    d.rq_v = sc->rq_v.as<Vertex3f>();
+    d.rc_v = sc->rc_v.as<Vertex4f>();
+    d.hull_cand = sc->hull_cand.as<Vertex0>();
+    d.hull_v = sc->hull_v.as<Vertex0>();
+    d.hull_sort = sc->hull_sort.as<float2>();
+    d.hull_chain = sc->hull_chain.as<float2>();
+    d.line_i = sc->line_i.as<uint16_t>();
+    d.joint_i = sc->joint_i.as<uint16_t>();
+    d.solid_i = sc->solid_i.as<uint16_t>();
+    d.solid_flag = sc->solid_flag.as<uint8_t>();
+    d.line_pair_cut = sc->line_pair_cut.as<uint8_t>();
+    d.line_pair_mode = sc->line_pair_mode.as<uint8_t>();
+    d.line_inc = sc->line_inc.as<float>();
+}
+
+// Before a repeated tessellation run: continue on the other set of buffers (allocated like the current one the first time).
+crh_status flip_tess_set(crh_scene* sc) {
+    crh_scene::TessShadow& o = sc->shadow;
+    DevBuf* cur[kTessBufs];
+    sc->tess_bufs(cur);
+    if (!o.allocated) {
+        for (int i = 0; i < kTessBufs; ++i)
+            if (cur[i]->cap) HIP_TRY(o.buf[i].ensure(cur[i]->cap));
+        for (hipEvent_t* e : {&o.tess_done, &o.vertices_free, &o.ranges_free})
+            if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        // the same input gives the same totals: the sizes of the current set are right for this one (an overflow is caught as ever)
+        o.capacity_known = sc->capacity_known;
+        std::memcpy(o.totals_host, sc->totals_host, sizeof(o.totals_host));
+        o.emitted_bytes = sc->emitted_bytes;
+        o.rendered_once = false;
+        o.allocated = true;
+    }
+    for (int i = 0; i < kTessBufs; ++i) std::swap(*cur[i], o.buf[i]);
+    std::swap(sc->tess_done, o.tess_done);
+    std::swap(sc->vertices_free, o.vertices_free);
+    std::swap(sc->ranges_free, o.ranges_free);
+    std::swap(sc->capacity_known, o.capacity_known);
+    std::swap(sc->rendered_once, o.rendered_once);
+    std::swap(sc->emitted_bytes, o.emitted_bytes);
+    for (int c = 0; c < NCH; ++c) std::swap(sc->totals_host[c], o.totals_host[c]);
+    for (int c = 0; c < NCH; ++c) sc->d.capacity[c] = sc->capacity_known ? sc->totals_host[c] : 0u;
+    bind_tess_pointers(sc);
+    return CRH_OK;
+}
+
 crh_status ensure_outputs(crh_scene* sc) {
     const uint32_t* t = sc->totals_host;
     SceneDev& d = sc->d;
@@ -386,33 +469,21 @@ crh_status ensure_outputs(crh_scene* sc) {
         HIP_TRY(sc->hull_chain.ensure((size_t)t[CH_HULL] * 16 + 16));
     }
     for (int c = 0; c < NCH; ++c) d.capacity[c] = t[c];
-    d.line_v = sc->line_v.as<Vertex2f1i>();
-    d.joint_v = sc->joint_v.as<Vertex3f1i>();
-    d.solid_v = sc->solid_v.as<Vertex0>();
-    d.iq_v = sc->iq_v.as<Vertex2f>();
-    d.ic_v = sc->ic_v.as<Vertex3f>();
-    d.rq_v = sc->rq_v.as<Vertex3f>();
-    d.rc_v = sc->rc_v.as<Vertex4f>();
-    d.hull_cand = sc->hull_cand.as<Vertex0>();
-    d.hull_v = sc->hull_v.as<Vertex0>();
-    d.hull_sort = sc->hull_sort.as<float2>();
-    d.hull_chain = sc->hull_chain.as<float2>();
-    d.line_i = sc->line_i.as<uint16_t>();
-    d.joint_i = sc->joint_i.as<uint16_t>();
-    d.solid_i = sc->solid_i.as<uint16_t>();
-    d.solid_flag = sc->solid_flag.as<uint8_t>();
-    d.line_pair_cut = sc->line_pair_cut.as<uint8_t>();
-    d.line_pair_mode = sc->line_pair_mode.as<uint8_t>();
-    d.line_inc = sc->line_inc.as<float>();
+    bind_tess_pointers(sc);
     sc->emitted_bytes = (uint64_t)t[CH_LINE_V] * 20 + ((uint64_t)t[CH_LINE_V] + t[CH_LINE_CUT]) * 2 + (uint64_t)t[CH_JOINT] * (5 * 24 + 6 * 2) +
                         (uint64_t)t[CH_SOLID_V] * 8 + ((uint64_t)t[CH_SOLID_V] + t[CH_SOLID_END]) * 2 + (uint64_t)t[CH_IQ] * 48 + (uint64_t)t[CH_IC_V] * 20 +
                         (uint64_t)t[CH_RQ] * 60 + (uint64_t)t[CH_RC_V] * 24;
     return CRH_OK;
 }
 
-crh_status run_tessellation(crh_scene* sc) {
+crh_status run_tessellation(crh_scene* sc, bool again) {
     crh_renderer* r = sc->renderer;
     HIP_TRY(hipSetDevice(r->device));
+    if (sc->tessellated_once && !again) { // not the re-run after a capacity overflow: that one repeats on the set it overflowed
+        const crh_status st = flip_tess_set(sc);
+        if (st != CRH_OK) return st;
+    }
+    sc->tessellated_once = true;
     SceneDev& d = sc->d;
     const hipStream_t ts = r->tessellation_stream();
     // the previous frame's k_prim_setup must have consumed the vertex streams this run overwrites; its binning and raster may still run
@@ -461,7 +532,7 @@ crh_status settle_tessellation(crh_scene* sc, uint32_t* status_word) {
         HIP_TRY(r->sync());
         if (word != 0xFFFFFFFFu && (word & 0xFFu) >= 0x80u && attempt == 0) {
             sc->capacity_known = false;
-            crh_status st = run_tessellation(sc);
+            crh_status st = run_tessellation(sc, true);
             if (st != CRH_OK) return st;
             continue;
         }
@@ -1024,6 +1095,12 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
             }
     }
     sc->rendered_once = false;
+    if (sc->shadow.allocated) { // sized for the previous contents
+        if (!hip_ok(r->sync(), "sync")) return CRH_ERR_HIP;
+        for (DevBuf& buf : sc->shadow.buf) buf.release();
+        sc->shadow.allocated = false;
+    }
+    sc->tessellated_once = false;
     for (bool& used : sc->rec_used) used = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
@@ -1103,15 +1180,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.shape_dyn_begin = sc->shape_dyn_begin.as<uint32_t>();
     d.stroke_options = sc->stroke_options.as<crh_stroke_options>();
     d.descriptors = sc->descriptors.as<crh_dynamic_stroke_descriptor>();
-    d.elem_scan = sc->elem_scan.as<ElemScan>();
-    d.wg_total = sc->wg_total.as<uint32_t>();
-    d.wg_base = sc->wg_base.as<uint32_t>();
-    d.totals = sc->totals.as<uint32_t>();
-    d.shape_base = sc->shape_base.as<uint32_t>();
-    d.hull_count = sc->hull_count.as<uint32_t>();
-    d.hull_large_count = sc->hull_large.as<uint32_t>();
-    d.hull_large_list = sc->hull_large.as<uint32_t>() + 4;
-    d.status = sc->status.as<uint32_t>();
+    bind_tess_pointers(sc);
     if (!hip_ok(hipMemsetAsync(d.status, 0xFF, 4, st), "hipMemset")) {
         rc = CRH_ERR_HIP;
         goto fail;
@@ -1129,7 +1198,7 @@ fail:
 
 crh_status crh_scene_tessellate(crh_scene* sc) {
     if (!sc) return CRH_ERR_INVALID_ARGUMENT;
-    return run_tessellation(sc);
+    return run_tessellation(sc, false);
 }
 crh_status crh_scene_status(crh_scene* sc) {
     if (!sc) return CRH_ERR_INVALID_ARGUMENT;
@@ -1153,7 +1222,7 @@ void crh_scene_destroy(crh_scene* sc) {
             }
     }
     sc->release_all();
-    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free})
+    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free, sc->shadow.tess_done, sc->shadow.vertices_free, sc->shadow.ranges_free})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->rec_raster_done)
         if (e) (void)hipEventDestroy(e);
