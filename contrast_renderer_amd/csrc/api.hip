@@ -1692,6 +1692,14 @@ crh_status crh_renderer_kernel_times(crh_renderer* r, crh_kernel_time* out, uint
         ++n;
     }
     *count = n;
+    if (out && getenv("CRH_TIMELINE") && !r->marks.empty()) { // development: when every mark was reached, relative to the first one (the lanes overlap)
+        const size_t first = r->marks.size() > 120 ? r->marks.size() - 120 : 0;
+        for (size_t i = first; i < r->marks.size(); ++i) {
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, r->marks[first].event, r->marks[i].event);
+            std::fprintf(stderr, "[timeline] %9.1f us  lane %d  %s\n", ms * 1000.0f, r->marks[i].lane, r->marks[i].name.empty() ? "(begin)" : r->marks[i].name.c_str());
+        }
+    }
     if (out) { // drained
         r->marks.clear();
         r->events_used = 0;
