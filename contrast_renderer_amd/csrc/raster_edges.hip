@@ -378,9 +378,10 @@ struct TileTest {
 // Bins up to 64 set-up triangles (lane = triangle): every lane walks the tiles of ITS OWN pixel box — a few for a curve or stroke
 // triangle; a triangle over more than kBigRect tiles is walked by the whole wavefront instead (lane = tile), one such triangle at a time.
 #ifndef CRH_BIN_WAVES
-#define CRH_BIN_WAVES 6
+#define CRH_BIN_WAVES 4 // measured 4, 5, 6: the same within noise (the kernel waits for memory, not for issue slots); 4 needs no spills
 #endif
 constexpr uint32_t kBigRect = 32;
+constexpr uint32_t kRectLds = 256; // tiles of an item's rectangle whose backdrops fit the LDS table of the lane = edge path
 CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool drawn, const PrimCoverage& cov, uint32_t key, float s_lo, float s_hi) {
     TileTest test;
     test.set(cov, s_lo, s_hi);
@@ -433,6 +434,9 @@ template <int S>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAVES))) void k_bin_edges(SceneDev s, RasterParams r) {
     __shared__ uint32_t stage_tile[2][kStage], stage_pos[2][kStage], stage_key[2][kStage];
     __shared__ float4 edge_a[64], edge_b[64];
+    __shared__ int rect_bd[kRectLds], rect_hbd[kRectLds];    // lane = edge path: backdrops of the tiles of the item's rectangle ...
+    __shared__ uint32_t rect_hull_touch[kRectLds / 32u];      // ... whether a hull edge matters inside the tile ...
+    __shared__ uint32_t rect_cursor[kRectLds];                // ... and the count, then the next list position, of the edges that matter there
     const uint32_t item = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const DrawItem it = item_of(r, item);
     const float* m = r.transforms + 16u * it.instance;
@@ -478,9 +482,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
         unsigned long long faces_front = 0, faces_back = 0;
         // one chunk of (up to 64) edges -> LDS table (+ the heap records the first time)
         float minx = INFINITY, maxx = -INFINITY, miny = INFINITY, maxy = -INFINITY;
+        BinEdge kept = {}; // the lane's edge of the first chunk (most items have no other)
         auto stage_chunk = [&](uint32_t i0, bool write_records) {
             const uint32_t i = i0 + lane;
             const BinEdge e = load_edge(s, r, it, k, n_hull_chain, i, m);
+            if (write_records && i0 == 0u) kept = e;
             const uint32_t flags = (EK_EDGE << 4) | (e.tl ? kEdgeTl : 0u) | (e.sigma > 0 ? kEdgeSigmaPos : 0u) | (e.hull ? kEdgeHull : 0u);
             if (e.valid && write_records) {
                 EdgeRec er;
@@ -517,9 +523,136 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
 #ifdef CRH_ABLATE
         if (r.debug & 8192u) n_edges = 0u;
 #endif
-        if (n_edges != 0u && minx <= maxx && px0 <= px1 && py0 <= py1) {
-            const uint32_t tx_a = (uint32_t)px0 / kTile, tx_b = (uint32_t)px1 / kTile, ty_a = (uint32_t)py0 / kTile, ty_b = (uint32_t)py1 / kTile;
-            const uint32_t nx = tx_b - tx_a + 1u, n_rect = nx * (ty_b - ty_a + 1u);
+        const uint32_t tx_a = (uint32_t)max(px0, 0) / kTile, tx_b = (uint32_t)max(px1, 0) / kTile, ty_a = (uint32_t)max(py0, 0) / kTile, ty_b = (uint32_t)max(py1, 0) / kTile;
+        const uint32_t nx = tx_b - tx_a + 1u, n_rect = nx * (ty_b - ty_a + 1u);
+        const bool in_frame = n_edges != 0u && minx <= maxx && px0 <= px1 && py0 <= py1;
+        if (in_frame && n_rect <= kRectLds && (r.debug & 1u) == 0u) {
+            // ---------------- lane = EDGE (the common case: the rectangle's backdrops fit the LDS table). The transposed loop below costs
+            // edges x tiles of the rectangle; here every edge visits the tiles of its OWN box and the tile rows whose backdrop line it
+            // crosses, the backdrops being summed in LDS.
+            // Three passes: (1) every edge counts, per tile of its own box, whether it matters there (LDS counters) and adds its backdrop
+            // terms; (2) lane = tile: ONE returning atomic on the tile's global counter reserves the positions of the item's entries in the
+            // tile's list, the synthetic entries are emitted; (3) the edges walk their boxes again and take their positions from the LDS
+            // cursors. (A returning global atomic per (edge, tile) visit made the wavefront wait for a round trip to L2 per step of the walk.)
+            for (uint32_t q = lane; q < n_rect; q += 64u) rect_bd[q] = 0, rect_hbd[q] = 0, rect_cursor[q] = 0u;
+            if (lane < kRectLds / 32u) rect_hull_touch[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool one_chunk = k.n_fe + k.n_hull <= 64u;
+            auto edge_of = [&](uint32_t i) {
+                BinEdge e;
+                if (one_chunk) { // still in registers (a hull chain that is drawn as triangles drops out: i >= n_edges)
+                    e = kept;
+                    e.valid = e.valid && i < n_edges;
+                } else {
+                    e = load_edge(s, r, it, k, n_hull_chain, i, m);
+                }
+                return e;
+            };
+            // the tiles of the edge's own box (a conservative integer range; the exact test decides tile by tile), walked by all lanes together
+            auto walk = [&](const BinEdge& e, auto&& visit) {
+                uint32_t bx0 = tx_a, bx1 = tx_a, by0 = ty_a, nt = 0;
+                if (e.valid) {
+                    const int x_lo = (int)ceilf((e.lo_x - r_last) * (1.0f / (float)kTile) - 0.01f), x_hi = (int)floorf(e.hi_x * (1.0f / (float)kTile) + 0.01f);
+                    const int y_lo = (int)ceilf((e.ymin - r_last) * (1.0f / (float)kTile) - 0.01f), y_hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
+                    const int cx0 = max(x_lo, (int)tx_a), cx1 = min(x_hi, (int)tx_b), cy0 = max(y_lo, (int)ty_a), cy1 = min(y_hi, (int)ty_b);
+                    if (cx0 <= cx1 && cy0 <= cy1) bx0 = (uint32_t)cx0, bx1 = (uint32_t)cx1, by0 = (uint32_t)cy0, nt = (uint32_t)((cx1 - cx0 + 1) * (cy1 - cy0 + 1));
+                }
+                const bool up = e.nay > 0.0f; // E grows with ry (bx >= 0) and with rx iff nay > 0
+                const uint32_t longest = wave_max_u32(nt);
+                uint32_t tx = bx0, ty = by0;
+                for (uint32_t w = 0; w < longest; ++w) {
+                    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+                    const float c = e.bx * (ty0 - e.lo_y) + e.nay * (tx0 - e.lo_x);
+                    const bool gmax = accepts(fmaf(r_last, e.bx, fmaf(up ? r_last : 0.0f, e.nay, c)), e.tl), gmin = accepts(fmaf(ry_first, e.bx, fmaf(up ? 0.0f : r_last, e.nay, c)), e.tl);
+                    const bool hit = w < nt && gmax != gmin && e.ymin <= ty0 + r_last && e.ymax >= q0y && e.lo_x <= tx0 + r_last && e.hi_x >= tx0;
+                    visit(hit, tx, ty);
+                    if (++tx > bx1) tx = bx0, ++ty;
+                }
+            };
+            for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) { // ---- pass 1
+                const BinEdge e = edge_of(i0 + lane);
+                // backdrop rows: the tile rows whose line q0y lies in the edge's half-open y range; a conservative integer range first
+                uint32_t row = ty_a, rows_mine = 0;
+                if (e.valid) {
+                    const int lo = (int)ceilf((e.ymin - ry_first) * (1.0f / (float)kTile) - 0.01f), hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
+                    const int first = max(lo, (int)ty_a), last = min(hi, (int)ty_b);
+                    if (first <= last) row = (uint32_t)first, rows_mine = (uint32_t)(last - first + 1);
+                }
+                const uint32_t most_rows = wave_max_u32(rows_mine);
+                for (uint32_t rr = 0; rr < most_rows; ++rr) {
+                    const uint32_t ty = row + rr;
+                    const float ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+                    const bool crosses = rr < rows_mine && e.ymin <= q0y && q0y < e.ymax; // Y_e at the backdrop row
+                    if (!__any(crosses)) continue;
+                    int* const table = (e.hull ? rect_hbd : rect_bd) + (ty - ty_a) * nx;
+                    for (uint32_t cx = 0; cx < nx; ++cx) {
+                        const float tx0 = (float)((tx_a + cx) * kTile);
+                        const float c = e.bx * (ty0 - e.lo_y) + e.nay * (tx0 - e.lo_x);
+                        const bool gq0 = accepts(fmaf(ry_first, e.bx, fmaf(0.0f, e.nay, c)), e.tl);
+                        const int term = e.sigma * ((gq0 ? 1 : 0) - e.down); // sigma * Y(q0) * (g(q0) - down)
+                        if (crosses && term != 0) atomicAdd(&table[cx], term);
+                    }
+                }
+                walk(e, [&](bool hit, uint32_t tx, uint32_t ty) {
+                    if (hit) {
+                        const uint32_t q = (ty - ty_a) * nx + (tx - tx_a);
+                        atomicAdd(&rect_cursor[q], 1u);
+                        if (e.hull) atomicOr(&rect_hull_touch[q >> 5], 1u << (q & 31u));
+                    }
+                });
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t base = 0; base < n_rect; base += 64u) { // ---- pass 2, lane = tile (the COVER entry carries one unit of either backdrop)
+                const uint32_t q = base + lane, qy = q / nx, qx = q - qy * nx;
+                const bool active = q < n_rect;
+                const uint32_t tile = (ty_a + qy) * r.tiles_x + tx_a + qx;
+                const int bd = active ? rect_bd[q] : 0, hbd = active ? rect_hbd[q] : 0;
+                const uint32_t n_touching = active ? rect_cursor[q] : 0u;
+                const bool hull_touch = active && ((rect_hull_touch[q >> 5] >> (q & 31u)) & 1u) != 0u;
+                const uint32_t abd = (uint32_t)(bd < 0 ? -bd : bd), ahbd = (uint32_t)(hbd < 0 ? -hbd : hbd);
+                uint32_t n_cover = (active && n_hull_chain != 0u && (hbd != 0 || hull_touch)) ? 1u : 0u; // the tile is inside the hull or its boundary crosses it
+                const int cbd = bd > 0 ? 1 : (bd < 0 ? -1 : 0), chbd = hbd > 0 ? 1 : (hbd < 0 ? -1 : 0);
+                const uint32_t cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1);
+                uint32_t n_bd = n_cover ? (abd ? abd - 1u : 0u) : abd;
+                uint32_t n_hbd = n_cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
+                const uint32_t bd_key = synth_a + (bd > 0 ? 0u : 1u), hbd_key = synth_a + (hbd > 0 ? 2u : 3u);
+                uint32_t left = n_cover + n_bd + n_hbd, pos = 0;
+                if (left + n_touching) pos = atomicAdd(&r.tile_count[tile], left + n_touching);
+                if (active) rect_cursor[q] = pos + left; // where the edges' entries go
+                for (;;) {
+                    const unsigned long long ballot = __ballot(left != 0u);
+                    if (!ballot) break;
+                    uint32_t key = 0;
+                    if (left) {
+                        if (n_cover)
+                            n_cover = 0, key = cover_key;
+                        else if (n_bd)
+                            --n_bd, key = bd_key;
+                        else
+                            --n_hbd, key = hbd_key;
+                    }
+                    stage_append(st, r, lane, ballot, tile, pos, key);
+                    if (left) ++pos, --left;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) { // ---- pass 3
+                const uint32_t i = i0 + lane;
+                const BinEdge e = edge_of(i);
+                const uint32_t key = i < k.n_fe ? fe_slot0 + i : hull_slot0 + (i - k.n_fe);
+                walk(e, [&](bool hit, uint32_t tx, uint32_t ty) {
+                    const unsigned long long ballot = __ballot(hit);
+                    if (ballot) {
+                        uint32_t pos = 0;
+                        if (hit) pos = atomicAdd(&rect_cursor[(ty - ty_a) * nx + (tx - tx_a)], 1u);
+                        stage_append(st, r, lane, ballot, ty * r.tiles_x + tx, pos, key);
+                    }
+                });
+            }
+        } else if (in_frame) {
             for (uint32_t base = 0; base < n_rect; base += 64u) {
                 const uint32_t q = base + lane, qy = q / nx, qx = q - qy * nx;
                 const bool active = q < n_rect;
