@@ -801,13 +801,17 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 #ifndef CRH_EDGE_TILE_WAVES
 #define CRH_EDGE_TILE_WAVES 5 // measured 4: 0.321, 5: 0.322, 6: 0.331 (spills), 8: 0.421 ms on the benchmark scene
 #endif
+#ifndef CRH_STROKE_TILE_WAVES
+#define CRH_STROKE_TILE_WAVES 5 // dashed strokes, msaa 4 (ms): 1 (145 registers): 2.96, 4: 2.34, 5: 2.24, 6: 2.83, 8: 5.05 — the kernel waits, it does not issue
+#endif
 // One workgroup per 16x16 tile, laid out exactly as k_raster_tile (raster.hip): msaa 1 = one wavefront, four pixel rows per lane;
 // msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
 // the item being drawn and the colour; entries are walked in key order (= draw order).
 template <int S, int ROWS, bool STROKES>
-__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? 1 : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
+__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
+    __shared__ uint8_t compact_table[STROKES ? 4 / ROWS : 1][STROKES ? 256 : 4]; // (lane, slot) codes of the samples a stroke triangle has to decide
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
     const uint32_t turn = blockIdx.x >> 3;
     const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
@@ -1138,50 +1142,85 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 else
                     curve(std::integral_constant<uint32_t, KIND_RC>{});
             } else if (STROKES) { // KIND_LINE / KIND_JOINT: the stroke fragment stages (shaders.wgsl:268-300)
-                float hx[3][S];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const float ac = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
-#pragma unroll
-                    for (int q = 0; q < S; ++q) hx[t][q] = fmaf(sx[q], frag.gx[t], ac);
-                }
-                int any_inside = 0;
+                // A stroke triangle is a sliver: a few percent of the wave's 256 samples are inside it, and what is decided per sample
+                // (dash pattern walk, caps, the joint's atan2) is long and branchy. So the samples to decide — inside the triangle, stencil
+                // still zero: Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576) — are COMPACTED: their (lane, slot) codes go to
+                // an LDS table in dense order, lane d decides the d-th of them, and the verdicts return through a ballot.
+                unsigned long long cand[ROWS * S];
+                uint32_t base[ROWS * S], total = 0;
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                    for (int q = 0; q < S; ++q) any_inside |= (int)inside[b][q];
-                if (__any(any_inside)) {
+                    for (int q = 0; q < S; ++q) {
+                        cand[b * S + q] = __builtin_amdgcn_ballot_w64(inside[b][q] && (winding[b][q] & wmask) == 0);
+                        base[b * S + q] = total;
+                        total += (uint32_t)__popcll(cand[b * S + q]);
+                    }
+                if (total != 0u) {
+                    uint8_t* const table = compact_table[wave];
+                    uint32_t rank[ROWS * S];
+                    __builtin_amdgcn_wave_barrier(); // the previous entry's readers of the table are through
+#pragma unroll
+                    for (int k = 0; k < ROWS * S; ++k) {
+                        rank[k] = base[k] + __builtin_amdgcn_mbcnt_hi((uint32_t)(cand[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cand[k], 0u));
+                        if ((cand[k] >> lane) & 1ull) table[rank[k]] = (uint8_t)(lane | ((uint32_t)k << 6));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                     const crh_dynamic_stroke_descriptor dsc = load_uniform(&s.descriptors[__builtin_amdgcn_readfirstlane(__float_as_uint(ec4.w))]);
                     const uint32_t caps = dsc.caps, count_dashed_join = dsc.count_dashed_join;
                     const uint32_t flat_u = frag.flat_u;
                     const float end_y = frag.end_y;
                     const bool dashed = (count_dashed_join & 4u) != 0u;
+                    float ac[3]; // the attribute planes, tile relative
 #pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) {
-                            if (inside[b][q] && (winding[b][q] & wmask) == 0) { // Equal(0) -> IncrementWrap, both faces (renderer.rs:571-576)
-                                const float y = sy0[q] + (float)(4 * b);
-                                const float a0 = fmaf(y, frag.gy[0], hx[0][q]), a1 = fmaf(y, frag.gy[1], hx[1][q]), a2 = fmaf(y, frag.gy[2], hx[2][q]);
-                                bool fill;
-                                if (kind == KIND_LINE) {
-                                    if (dashed)
-                                        fill = stroke_dashed(dsc, a0, a1);
-                                    else if ((flat_u & 65536u) != 0u)
-                                        fill = cap_test(a0, a1 - end_y, caps >> 4);
-                                    else if (a1 < 0.0f)
-                                        fill = cap_test(a0, -a1, caps);
-                                    else
-                                        fill = true;
-                                } else {
-                                    const float radius = sqrtf(a0 * a0 + a1 * a1);
-                                    const uint32_t join = count_dashed_join & 3u;
-                                    fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
-                                    if (fill && dashed) fill = stroke_dashed_joint(dsc, radius, a0, a1, a2);
-                                }
-                                winding[b][q] += fill ? 1 : 0;
+                    for (int t = 0; t < 3; ++t) ac[t] = fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t]));
+                    for (uint32_t first = 0; first < total; first += 64u) {
+                        const uint32_t d = first + lane;
+                        const bool live = d < total;
+                        const uint32_t code = live ? table[d] : 0u;
+                        const uint32_t src = code & 63u, slot = code >> 6; // whose sample: lane (px, rq), slot (b, q)
+                        const uint32_t spx = src & 15u, srq = src >> 4;
+                        float x, y; // exactly sx[q] and sy0[q] + 4 b of that lane
+                        if (S == 1) {
+                            x = (float)spx + 0.5f;
+                            y = ((float)(first_row + srq) + 0.5f) + (float)(4u * slot);
+                        } else {
+                            const float ox = slot == 0u ? 0.375f : (slot == 1u ? 0.875f : (slot == 2u ? 0.125f : 0.625f));
+                            const float oy = slot == 0u ? 0.125f : (slot == 1u ? 0.375f : (slot == 2u ? 0.625f : 0.875f));
+                            x = (float)spx + ox;
+                            y = (float)(first_row + srq) + oy;
+                        }
+                        const float a0 = fmaf(y, frag.gy[0], fmaf(x, frag.gx[0], ac[0])), a1 = fmaf(y, frag.gy[1], fmaf(x, frag.gx[1], ac[1]));
+                        const float a2 = fmaf(y, frag.gy[2], fmaf(x, frag.gx[2], ac[2]));
+                        bool fill = false;
+                        if (live) {
+                            if (kind == KIND_LINE) {
+                                if (dashed)
+                                    fill = stroke_dashed(dsc, a0, a1);
+                                else if ((flat_u & 65536u) != 0u)
+                                    fill = cap_test(a0, a1 - end_y, caps >> 4);
+                                else if (a1 < 0.0f)
+                                    fill = cap_test(a0, -a1, caps);
+                                else
+                                    fill = true;
+                            } else {
+                                const float radius = sqrtf(a0 * a0 + a1 * a1);
+                                const uint32_t join = count_dashed_join & 3u;
+                                fill = join == 1u ? (flat_u & 65536u) != 0u : (join == 2u ? radius <= 0.5f : true);
+                                if (fill && dashed) fill = stroke_dashed_joint(dsc, radius, a0, a1, a2);
                             }
                         }
+                        const unsigned long long filled = __builtin_amdgcn_ballot_w64(fill);
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                            for (int q = 0; q < S; ++q) {
+                                const uint32_t at = rank[b * S + q] - first; // < 64 iff this pass decided the sample
+                                const bool mine = ((cand[b * S + q] >> lane) & 1ull) != 0ull && at < 64u;
+                                winding[b][q] += (mine && ((filled >> (at & 63u)) & 1ull) != 0ull) ? 1 : 0;
+                            }
+                    }
                 }
             }
             } // curve / stroke triangles

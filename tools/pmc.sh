@@ -1,12 +1,13 @@
 #!/bin/bash
 # GPU box: PMC counters for the bench (separate passes, --pmc only with kernel-trace as the guide prescribes)
+# usage: [WORKLOAD=glyphs|dashed] tools/pmc.sh <tag> <counter set> [<counter set> ...]
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 shift
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -f csv -d $out/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -f csv -d $out/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --workload ${WORKLOAD:-cubic} > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import sys, csv, collections

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: rocprofv3 evidence for the bench command (tools/profile.sh <tag>), written under gpurun_out/prof_<tag>/:
+# GPU box: rocprofv3 evidence for the bench command ([WORKLOAD=glyphs|dashed] tools/profile.sh <tag>), written under gpurun_out/prof_<tag>/:
 #   stats/   --kernel-trace --stats (per-kernel average duration; must agree with the HIP-event times bench.py prints)
 #   fetch/, write/   separate --pmc passes for FETCH_SIZE and WRITE_SIZE (they do not fit one pass), kernel trace only
 #   summary.json     per-kernel: calls, avg ns, FETCH_SIZE / WRITE_SIZE per launch (raw counter units = KiB... see below)
@@ -7,7 +7,7 @@
 tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload ${WORKLOAD:-cubic}"
 rocprofv3 --kernel-trace --stats -f csv -d $out/stats -o r -- $BENCH > $out/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $out/fetch -o r -- $BENCH > $out/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $out/write -o r -- $BENCH > $out/write.log 2>&1
