@@ -1051,6 +1051,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 const uint32_t a_plus = xr & gq & ~g0 & ~ym;                      // A = +1
                 const uint32_t a_minus = (xr & ~gq & g0) | (ym & gq & (~xr | g0)); // A = -1
                 const int unit = (flags & kEdgeSigmaPos) ? 1 : -1;               // sigma
+                if (ROWS == 1 && (ym | a_plus | a_minus) == 0u) continue;        // msaa 4: none of this wavefront's four pixel rows is in reach
                 const SlotMasks ys = slot_masks<S>(ym);
                 float h[S];
 #pragma unroll
@@ -1098,6 +1099,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     }
             } else {
             // ---- curve and stroke triangles, as k_raster_tile
+            if (ROWS == 1) { // msaa 4: this wavefront owns four of the tile's sixteen pixel rows — a sliver's box seldom reaches them all
+                const uint32_t row_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(ea4.w)) >> 16;
+                if (((row_bits >> first_row) & 15u) == 0u) continue;
+            }
             const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
             bool inside[ROWS][S];
             coverage(ea4, eb4, ec4, flags, inside);
