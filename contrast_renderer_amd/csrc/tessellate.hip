@@ -363,6 +363,9 @@ __global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
 //                 two topmost points kept in registers. Larger Shapes are queued.
 //   k_hull_large  Shapes with 65..2048 candidates, taken from the queue by a fixed grid: bitonic sort + chain in LDS.
 //   k_hull_huge   Shapes beyond that: the same in global memory, one workgroup per Shape.
+#ifndef CRH_ABLATE_HULL
+#define CRH_ABLATE_HULL 0
+#endif
 constexpr uint32_t kHullSmall = 64;
 constexpr uint32_t kHullMid = 256;
 constexpr uint32_t kHullMax = 2048; // candidates per Shape that fit the large LDS sort (16 KiB + 32 KiB chain stack)
@@ -376,8 +379,49 @@ CRH_D uint32_t fan_to_strip_source(uint32_t i, uint32_t h) { return (i & 1u) == 
 // One wavefront per workgroup: next to the previous frame's raster kernel (single-wave workgroups refilling every slot the moment it
 // frees) a four-wave workgroup never found four free slots at once and waited for the raster grid to drain (0.28 ms instead of 0.03).
 constexpr uint32_t kHullWaves = 1;
-constexpr uint32_t kHullBatch = 4;                  // Shapes per workgroup of k_hull_small (phase 1: one after the other; phase 2: a lane pair each)
+#ifndef CRH_HULL_BATCH
+#define CRH_HULL_BATCH 4
+#endif
+constexpr uint32_t kHullBatch = CRH_HULL_BATCH;                  // Shapes per workgroup of k_hull_small (phase 1: one after the other; phase 2: a lane pair each)
 constexpr uint32_t kHullRow = kHullSmall + 1;       // LDS row pitch in float2 (odd: lane-per-Shape accesses spread over the banks)
+
+// The value of lane (lane ^ J). J < 16 stays inside the 16-lane row and is a DPP operand modifier (quad permute, row rotate); only 16 and 32
+// go through ds_bpermute. (With __shfl_xor for every step of the sorting network the 50 000 glyph scene kept the LDS crossbar busier with
+// the 42 permutes per sort than the VALUs with the compares.)
+template <uint32_t J>
+CRH_D float lane_xor(float v, uint32_t lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int x = __float_as_int(v);
+    if (J == 1) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));  // quad_perm [1, 0, 3, 2]
+    if (J == 2) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));  // quad_perm [2, 3, 0, 1]
+    if (J == 8) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false)); // row_ror:8
+    if (J == 4) { // row_ror:4 brings lane - 4, row_ror:12 lane + 4 (mod 16)
+        const int down = __builtin_amdgcn_update_dpp(x, x, 0x124, 0xF, 0xF, false), up = __builtin_amdgcn_update_dpp(x, x, 0x12C, 0xF, 0xF, false);
+        return __int_as_float((lane & 4u) ? down : up);
+    }
+    return __shfl_xor(v, (int)J, 64);
+#else
+    (void)lane;
+    return v;
+#endif
+}
+// one compare-exchange step of the bitonic network on (x, y) keys in lexicographic order
+template <uint32_t J>
+CRH_D void bitonic_step(float2& p, uint32_t lane, uint32_t k) {
+    const float2 q = make_float2(lane_xor<J>(p.x, lane), lane_xor<J>(p.y, lane));
+    const bool keep_min = ((lane & J) == 0) == ((lane & k) == 0);
+    const bool q_less = q.x < p.x || (q.x == p.x && q.y < p.y);
+    p = (keep_min == q_less) ? q : p; // min keeps q when q < p, max keeps q when !(q < p); equal keys are identical
+}
+template <uint32_t K>
+CRH_D void bitonic_stage(float2& p, uint32_t lane) {
+    if (K >= 64) bitonic_step<32>(p, lane, K);
+    if (K >= 32) bitonic_step<16>(p, lane, K);
+    if (K >= 16) bitonic_step<8>(p, lane, K);
+    if (K >= 8) bitonic_step<4>(p, lane, K);
+    if (K >= 4) bitonic_step<2>(p, lane, K);
+    bitonic_step<1>(p, lane, K);
+}
 
 __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
     __shared__ float2 sorted[kHullBatch][kHullRow];         // sorted candidates of the batch's Shapes
@@ -414,23 +458,21 @@ __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
         if (shape < s.n_shapes) {
             if (n > kHullSmall) { // queue 0: up to kHullMid candidates (small LDS footprint), queue 1: up to kHullMax, queue 2: global memory
                 const uint32_t queue = n > kHullMax ? 2u : (n > kHullMid ? 1u : 0u);
+#if CRH_ABLATE_HULL != 2
                 if (lane == 0) s.hull_large_list[queue * s.n_shapes + atomicAdd(s.hull_large_count + queue, 1u)] = shape;
+#endif
                 n = 0;
             } else if (n == 0) {
                 if (lane == 0) s.hull_count[shape] = 0;
             } else {
                 float2 p = p_of[u];
                 if (n >= 3) { // fewer are returned as they are (convex_hull.rs:9-11)
-#pragma unroll
-                    for (uint32_t k = 2; k <= 64u; k <<= 1) {
-#pragma unroll
-                        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                            const float2 q = make_float2(__shfl_xor(p.x, j, 64), __shfl_xor(p.y, j, 64));
-                            const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
-                            const bool q_less = lex_less(q, p);
-                            p = (keep_min == q_less) ? q : p; // min keeps q when q < p, max keeps q when !(q < p); equal keys are identical
-                        }
-                    }
+                    bitonic_stage<2>(p, lane);
+                    bitonic_stage<4>(p, lane);
+                    bitonic_stage<8>(p, lane);
+                    bitonic_stage<16>(p, lane);
+                    bitonic_stage<32>(p, lane);
+                    bitonic_stage<64>(p, lane);
                 }
                 sorted[slot][lane] = p;
             }
@@ -440,6 +482,9 @@ __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
     __syncthreads();
     // ---- phase 2: two lanes per Shape; the lower and the upper chain of Andrew's scan are independent (the upper one starts from the last
     //      point on a stack floor of its own, convex_hull.rs:24-33), so the even lane walks the lower and the odd lane the upper chain
+#if CRH_ABLATE_HULL == 1
+    return;
+#endif
     if (wave != 0 || lane >= 2u * kHullBatch) return;
     const uint32_t slot = lane >> 1, upper = lane & 1u;
     const uint32_t n = count[slot];
