@@ -29,14 +29,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 # timing mark (HIP events inside the library) -> kernel name as rocprofv3 prints it
-MARK_TO_KERNEL = {
-    "raster_tiles": "crh::k_raster_edges<1, 4, false>",
-    "raster_bin": "crh::k_bin_edges<1>",
-    "raster_scatter": "crh::k_scatter",
-    "tess_emit": "crh::k_emit",
-    "tess_count": "crh::k_count",
-    "tess_hull": "crh::k_hull_small",
-}
+def mark_to_kernel(workload):
+    msaa4_strokes = workload == "dashed"
+    return {
+        "raster_tiles": "crh::k_raster_edges<4, 1, true>" if msaa4_strokes else "crh::k_raster_edges<1, 4, false>",
+        "raster_bin": "crh::k_bin_edges<4>" if msaa4_strokes else "crh::k_bin_edges<1>",
+        "raster_scatter": "crh::k_scatter",
+        "tess_emit": "crh::k_emit",
+        "tess_count": "crh::k_count",
+        "tess_hull": "crh::k_hull_small",
+    }
 
 
 def kernel_source_hash():
@@ -51,9 +53,10 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def _newest_profile(pattern):
+def _newest_profile(kind, workload):
+    """profiles/rNN_<kind>.json (the metric's workload) or profiles/rNN_<kind>_<workload>.json, newest round, if measured on these sources"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json" if workload in ("cubic", "s100k") else f"r[0-9][0-9]_{kind}_{workload}.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -63,13 +66,14 @@ def _newest_profile(pattern):
     return doc, os.path.basename(files[-1])
 
 
-def valu_issue(mark, avg_launch_ms):
+def valu_issue(mark, avg_launch_ms, workload):
     """Secondary roofline of the dominant kernel: VALU issue utilisation = wave-level VALU instructions (SQ_INSTS_VALU of the committed PMC
     summary measured on THESE kernel sources) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x launch time)."""
-    doc, source = _newest_profile("r*_sq_counters.json")
-    if not doc or mark not in MARK_TO_KERNEL or avg_launch_ms <= 0:
+    doc, source = _newest_profile("sq_counters", workload)
+    names = mark_to_kernel(workload)
+    if not doc or mark not in names or avg_launch_ms <= 0:
         return None
-    k = doc.get("per_launch", {}).get(MARK_TO_KERNEL[mark])
+    k = doc.get("per_launch", {}).get(names[mark])
     if not k or "SQ_INSTS_VALU" not in k:
         return None
     simds, clock_hz = 256 * 4, 2.4e9
@@ -78,14 +82,34 @@ def valu_issue(mark, avg_launch_ms):
             "note": "one wave64 VALU instruction per 4 cycles per SIMD; 256 CUs x 4 SIMDs at 2.4 GHz"}
 
 
-def measured_traffic(mark):
-    """HBM bytes per launch of the kernel behind `mark` from the committed PMC summary (profiles/rNN_traffic.json: separate FETCH_SIZE /
+def measured_traffic(mark, workload):
+    """HBM bytes per launch of the kernel behind `mark` from the committed PMC summary (profiles/rNN_traffic*.json: separate FETCH_SIZE /
     WRITE_SIZE passes with the gfx950 corrections of the microarchitecture guide), or None when that file was measured on other sources."""
-    doc, source = _newest_profile("r*_traffic.json")
-    if not doc or mark not in MARK_TO_KERNEL:
+    doc, source = _newest_profile("traffic", workload)
+    names = mark_to_kernel(workload)
+    if not doc or mark not in names:
         return None, None
-    k = doc.get("kernels", {}).get(MARK_TO_KERNEL[mark])
+    k = doc.get("kernels", {}).get(names[mark])
     return (k["hbm_bytes_per_launch"], source) if k else (None, None)
+
+
+def usable_cores():
+    """CPUs this process can actually run on: the affinity mask, capped by the cgroup's CPU quota (cpu.max / cfs_quota_us)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                quota, period = int(f.read()), int(g.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 class _DeviceArray:
@@ -255,6 +279,7 @@ def main():
     scene.check()
     # latency of ONE step, nothing overlapped (the timed loop above keeps up to three steps in flight)
     latency = []
+    renderer.enable_timing(True)
     for _ in range(min(5, max(1, args.steps))):
         sync()
         t1 = time.perf_counter()
@@ -262,6 +287,11 @@ def main():
         renderer.synchronize()
         latency.append(time.perf_counter() - t1)
     latency_ms = sorted(latency)[len(latency) // 2] * 1e3
+    alone = {}  # the kernels of those steps, each with the GPU to itself
+    for name, ms, _ in renderer.kernel_times():
+        alone.setdefault(name, []).append(ms)
+    alone = {k: sum(v) / len(v) for k, v in alone.items()}
+    renderer.enable_timing(False)
     image = frame.download()
     covered = float((image[..., 3] > 0).mean())
     traffic_sent = comm.last_traffic() if comm is not None else None
@@ -295,12 +325,15 @@ def main():
         a[0] += ms
         a[1] += 1
         a[2] = max(a[2], nbytes)
-    kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1], "algorithmic_bytes": v[2]} for k, v in agg.items()}
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1], "algorithmic_bytes": v[2], "alone_ms": alone.get(k)} for k, v in agg.items()}
+    # the dominant kernel is the one that needs the GPU longest when it has it to itself: inside the pipelined run a small kernel that shares
+    # the GPU with the raster kernel of the frame before is stretched to that kernel's length without doing more work
+    dominant = max(kernels, key=lambda k: (kernels[k]["alone_ms"] if kernels[k]["alone_ms"] is not None else kernels[k]["avg_ms"]) * kernels[k]["launches"])
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
-    default_workload = args.workload == "cubic" and args.paths == 10000 and args.size == 4096 and world == 1
-    traffic, traffic_source = measured_traffic(dominant) if default_workload else (None, None)
+    # the PMC summaries under profiles/ were measured on the default invocation of each workload
+    default_workload = world == 1 and ((args.workload == "cubic" and args.paths == 10000 and args.size == 4096) or args.workload in ("glyphs", "dashed"))
+    traffic, traffic_source = measured_traffic(dominant, args.workload) if default_workload else (None, None)
 
     step_s = elapsed / args.steps
     total_paths = args.paths * world if scaling == "weak" else args.paths
@@ -342,8 +375,9 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_source,
             "algorithmic_bytes": dk["algorithmic_bytes"],
-            "valu_issue": valu_issue(dominant, dk["avg_ms"]) if default_workload else None,
+            "valu_issue": valu_issue(dominant, dk["avg_ms"], args.workload) if default_workload else None,
             "avg_launch_ms": dk["avg_ms"],
+            "avg_launch_ms_alone": dk["alone_ms"],
             "kernel_source_hash": kernel_source_hash(),
             "note": "achieved = algorithmic bytes (SURVEY.md §8(d): emitted vertex/index bytes read once + 80 B per shape + W*H*4 written once) / "
                     "HIP-event launch time of the dominant kernel (in the run, i.e. sharing the GPU with the other lanes of the pipeline); traffic / "
@@ -366,7 +400,7 @@ def main():
         t1 = time_tessellate(batch, 1, 1)
         repeats = max(2, min(200, int(math.ceil(10.0 / max(t1, 1e-3)))))
         ts = time_tessellate(batch, 1, repeats)
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         tall = time_tessellate(batch, cores, max(2, repeats))
         out["cpu_baseline"] = {
             "value": batch.n_shapes * repeats / ts,
@@ -377,7 +411,8 @@ def main():
                       f"(Shape::from_paths minus the wgpu upload; the reference itself cannot be built here), single thread as in renderer.rs:187; "
                       "tessellation only — the reference rasterizes on a GPU",
             "all_cores": {"value": batch.n_shapes * max(2, repeats) / tall, "cores": cores,
-                          "note": "persistent thread pool, one arena per thread, destruction outside the timed region"},
+                          "note": "persistent thread pool, one malloc arena per thread, destruction outside the timed region; threads = the CPUs this process may "
+                                  "use (affinity mask and cgroup CPU quota, not the host's core count: more threads than that only time-slice)"},
         }
     if rank == 0:
         print(json.dumps(out))
