@@ -310,6 +310,21 @@ struct crh_scene {
         uint64_t emitted_bytes = 0;
     } shadow;
     bool tessellated_once = false;
+    // Which formulation draws this Scene's plain passes — boundary edges + backdrops (raster_edges.hip) or the reference's strip triangles
+    // (raster.hip) — is decided by MEASUREMENT: both give the same pixels, and which is faster depends on the content (long strips
+    // across many tiles favour the edges, tens of thousands of glyph-sized Shapes the triangles: the edge pass pays per item and per
+    // (item, tile)). Frames 0-1 after an upload run the edge pass, frames 2-3 the triangle pass; the second frame of each is timed with
+    // events around its kernels — with the tile-list capacity verified before the raster kernel runs, since a frame that overflowed
+    // draws nothing and would win every race — and the fifth frame keeps the faster one.
+    // CRH_EDGE_PASS=1 / CRH_TRIANGLE_PASS=1 pin the choice.
+    struct PassTrial {
+        hipEvent_t e[6] = {}; // around: the binning traversal (the attempt that fitted), the list fill / scatter, the raster kernel
+        bool recorded = false;
+    } pass_trial[2];
+    int pass_choice = 0;       // 0 undecided, 1 edges, 2 triangles
+    uint32_t pass_frames = 0;  // plain frames since the geometry or the frame size changed
+    uint32_t pass_width = 0, pass_height = 0;
+    float pass_ms[2] = {0.0f, 0.0f};
     void tess_bufs(DevBuf* (&out)[kTessBufs]) {
         DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                                   &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut, &line_pair_mode,
@@ -646,6 +661,51 @@ size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
     return pairs * 4;
 }
 // the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
+// the pass of this plain frame (true = edge pass) and, through `timed`, which trial (0 edges, 1 triangles) its events belong to, or -1
+bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
+    *timed = -1;
+    if (getenv("CRH_TRIANGLE_PASS")) return false;
+    if (getenv("CRH_EDGE_PASS")) return true;
+    if (sc->pass_width != f->width || sc->pass_height != f->height) { // another target: decide again
+        sc->pass_width = f->width, sc->pass_height = f->height;
+        sc->pass_choice = 0, sc->pass_frames = 0;
+        sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+    }
+    if (sc->pass_choice) return sc->pass_choice == 1;
+    const uint32_t n = sc->pass_frames++;
+    if (n < 2) { // the first frame of a pass sizes its buffers (and may run twice): the second one is timed
+        if (n == 1) *timed = 0;
+        return true;
+    }
+    if (n < 4) {
+        if (n == 3) *timed = 1;
+        return false;
+    }
+    if (sc->pass_trial[0].recorded && sc->pass_trial[1].recorded) {
+        // The host runs frames ahead of the GPU: left to a query, a pipelined caller would have submitted its whole animation on the losing
+        // pass before the verdict arrived. One wait, on the fifth frame of a Scene (the two timed frames synchronised already).
+        bool done = true;
+        for (const crh_scene::PassTrial& t : sc->pass_trial) done = done && hipEventSynchronize(t.e[5]) == hipSuccess;
+        if (done) {
+            for (int k = 0; k < 2; ++k) {
+                sc->pass_ms[k] = 0.0f;
+                for (int i = 0; i < 6; i += 2) {
+                    float ms = 0.0f;
+                    (void)hipEventElapsedTime(&ms, sc->pass_trial[k].e[i], sc->pass_trial[k].e[i + 1]);
+                    sc->pass_ms[k] += ms;
+                }
+            }
+            sc->pass_choice = sc->pass_ms[0] <= sc->pass_ms[1] ? 1 : 2;
+            if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] pass trial: edges %.3f ms, triangles %.3f ms -> %s\n", sc->pass_ms[0], sc->pass_ms[1], sc->pass_choice == 1 ? "edges" : "triangles");
+            return sc->pass_choice == 1;
+        }
+    } else { // a trial frame was skipped (could not happen in sequence): start over
+        sc->pass_frames = 0;
+        return true;
+    }
+    return false; // still waiting for the trial's events: stay on the pass of the latest frames
+}
+
 bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
     if (longest_list <= f->sort_capacity) return false;
     const uint32_t limit = 32768u / (4u * (f->renderer->config.msaa_sample_count == 4 ? 4u : 1u)); // 32 KiB of dynamic LDS per workgroup (kSortBytesMax)
@@ -791,8 +851,13 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.cull_mode = r->config.cull_mode;
     // The general pass keeps the reference's triangle strips (raster.hip): clip nesting / alpha contexts, perspective, depth, and face
     // culling (a cull decision is per strip triangle). Everything else is the edge pass (raster_edges.hip).
-    p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops) || getenv("CRH_TRIANGLE_PASS")) ? 1u : 0u;
-    const bool edges = p.general == 0u;
+    p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops)) ? 1u : 0u;
+    int timed = -1;
+    const bool edges = p.general == 0u && choose_pass(sc, f, &timed);
+    crh_scene::PassTrial* trial = (p.general == 0u && timed >= 0) ? &sc->pass_trial[timed] : nullptr;
+    if (trial)
+        for (hipEvent_t& e : trial->e)
+            if (!e) HIP_TRY(hipEventCreate(&e));
     p.slots = static_cast<uint8_t*>(sc->prim_rec[rec].p);
     p.overflow = set.overflow.as<uint32_t>();
     p.pair_cursor = set.overflow.as<uint32_t>() + 8; // 64 sub-stream cursors
@@ -803,11 +868,13 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
-    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled)) f->pairs_known = false;
+    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled) || trial) f->pairs_known = false; // (a timed frame must not be one that overflowed)
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
+    if (trial) HIP_TRY(r->sync()); // a timed frame has the GPU to itself (two frames per Scene, once)
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
         p.tile_list = set.tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(set.tile_list.cap / 4);
+        if (trial) HIP_TRY(hipEventRecord(trial->e[0], bin));
         if (edges) {
             HIP_TRY(set.pair_tile.ensure(set.tile_list.cap));
             HIP_TRY(set.pair_key.ensure(set.tile_list.cap));
@@ -818,6 +885,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
             launch_bin_edges(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         } else
         launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
+        if (trial) HIP_TRY(hipEventRecord(trial->e[1], bin));
         if (f->pairs_known) break;
         uint32_t ov[8];
         HIP_TRY(hipMemcpyAsync(ov, p.overflow, 32, hipMemcpyDeviceToHost, bin));
@@ -836,16 +904,19 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(hipEventRecord(slot.read_done, bin));
         slot.was_read = true;
     }
+    if (trial) HIP_TRY(hipEventRecord(trial->e[2], bin));
     if (edges) {
         HIP_TRY(hipEventRecord(sc->ranges_free, bin)); // k_bin_edges, the only reader of the slot ranges, is behind us
         launch_scatter(p, bin, r->mark_fn_bin(), r);
     } else {
         launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
     }
+    if (trial) HIP_TRY(hipEventRecord(trial->e[3], bin));
     HIP_TRY(hipEventRecord(set.bin_done, bin));
     // ---- raster lane
     HIP_TRY(hipStreamWaitEvent(r->stream, set.bin_done, 0));
     r->begin_marks(0);
+    if (trial) HIP_TRY(hipEventRecord(trial->e[4], r->stream));
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
@@ -855,6 +926,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
+    if (trial) {
+        HIP_TRY(hipEventRecord(trial->e[5], r->stream));
+        trial->recorded = true;
+    }
     set.used = true;
     sc->rec_used[rec] = true;
     sc->rendered_once = true;
@@ -1101,6 +1176,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         sc->shadow.allocated = false;
     }
     sc->tessellated_once = false;
+    sc->pass_choice = 0, sc->pass_frames = 0; // new geometry: measure again
+    sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
     for (bool& used : sc->rec_used) used = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
@@ -1226,6 +1303,9 @@ void crh_scene_destroy(crh_scene* sc) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->rec_raster_done)
         if (e) (void)hipEventDestroy(e);
+    for (crh_scene::PassTrial& t : sc->pass_trial)
+        for (hipEvent_t e : t.e)
+            if (e) (void)hipEventDestroy(e);
     delete sc;
 }
 crh_status crh_shape_from_paths(crh_renderer* r, const crh_path_batch* one_shape, crh_scene* existing, crh_scene** out) {
