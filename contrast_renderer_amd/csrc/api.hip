@@ -1659,6 +1659,13 @@ extern "C" crh_status crh_debug_frame_counters16(crh_frame* f, uint32_t out[16])
     HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow.p) + 32, 0, 32));
     return CRH_OK;
 }
+extern "C" crh_status crh_debug_frame_words(crh_frame* f, uint32_t out[128]) { // tools only: the whole 512-byte flag / counter block of the last set
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    HIP_TRY(f->renderer->sync());
+    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 512, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow.p) + 320, 0, 192));
+    return CRH_OK;
+}
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
     if (!f || !out) return CRH_ERR_INVALID_ARGUMENT;
     crh_status st = settle_frame(f);

@@ -427,6 +427,66 @@ CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool d
     }
 }
 
+// The same for a chunk of triangles whose common tile rectangle fits an LDS table (the usual case): the lanes walk their boxes twice — once
+// counting per tile (LDS), once emitting with positions from LDS cursors — and in between lane = tile reserves the positions with ONE
+// returning atomic per tile. (bin_triangles pays a round trip to L2 per step of the walk: 60 % of that wavefront's time.)
+CRH_D bool bin_triangles_counted(Stage& st, const RasterParams& r, uint32_t lane, bool drawn, const PrimCoverage& cov, uint32_t key, float s_lo, float s_hi,
+                                 uint32_t* cursor) {
+    const uint32_t bx0 = cov.box.x / kTile, bx1 = cov.box.y / kTile, by0 = cov.box.z / kTile, by1 = cov.box.w / kTile;
+    // the chunk's rectangle
+    uint32_t rx0 = drawn ? bx0 : 0xFFFFFFFFu, ry0 = drawn ? by0 : 0xFFFFFFFFu, rx1 = drawn ? bx1 : 0u, ry1 = drawn ? by1 : 0u;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        rx0 = min(rx0, (uint32_t)__shfl_xor((int)rx0, d, 64)), ry0 = min(ry0, (uint32_t)__shfl_xor((int)ry0, d, 64));
+        rx1 = max(rx1, (uint32_t)__shfl_xor((int)rx1, d, 64)), ry1 = max(ry1, (uint32_t)__shfl_xor((int)ry1, d, 64));
+    }
+    if (rx0 == 0xFFFFFFFFu) return true; // nothing drawn
+    const uint32_t nx = rx1 - rx0 + 1u, n_rect = nx * (ry1 - ry0 + 1u);
+    if (n_rect > kRectLds || (r.debug & 2u) != 0u) return false; // the caller takes the walk with an atomic per step (debug bit 1: always)
+    TileTest test;
+    test.set(cov, s_lo, s_hi);
+    const uint32_t bnx = bx1 - bx0 + 1u, nt = drawn ? bnx * (by1 - by0 + 1u) : 0u, longest = wave_max_u32(nt);
+    for (uint32_t q = lane; q < n_rect; q += 64u) cursor[q] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t tx = bx0, ty = by0;
+    for (uint32_t i = 0; i < longest; ++i) { // count
+        if (i < nt && test.hit(tx, ty)) atomicAdd(&cursor[(ty - ry0) * nx + (tx - rx0)], 1u);
+        if (++tx > bx1) tx = bx0, ++ty;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < n_rect; base += 64u) { // reserve
+        const uint32_t q = base + lane, qy = q / nx, qx = q - qy * nx;
+        const uint32_t n = q < n_rect ? cursor[q] : 0u;
+        if (n) cursor[q] = atomicAdd(&r.tile_count[(ry0 + qy) * r.tiles_x + rx0 + qx], n);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    tx = bx0, ty = by0;
+    for (uint32_t i = 0; i < longest; ++i) { // emit
+        const bool hit = i < nt && test.hit(tx, ty);
+        const unsigned long long ballot = __ballot(hit);
+        if (ballot) {
+            uint32_t pos = 0;
+            if (hit) pos = atomicAdd(&cursor[(ty - ry0) * nx + (tx - rx0)], 1u);
+            stage_append(st, r, lane, ballot, ty * r.tiles_x + tx, pos, key);
+        }
+        if (++tx > bx1) tx = bx0, ++ty;
+    }
+    return true;
+}
+
+#ifdef CRH_ABLATE // tools/bin_phases.py: where does a wavefront of k_bin_edges spend its time? (cycle counter deltas summed in overflow[80 ...])
+#define CRH_PHASE(k)                                                                                                   \
+    if (r.debug & 65536u) {                                                                                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+        if (lane == 0u) atomicAdd(reinterpret_cast<unsigned long long*>(r.overflow + 80) + (k) + 8u * wave, now_ - phase_t); \
+        phase_t = __builtin_amdgcn_s_memtime();                                                                        \
+    }
+#else
+#define CRH_PHASE(k)
+#endif
 // One workgroup per draw item. Wavefront 0: the stroke and curve triangles (bin_triangles). Wavefront 1: the boundary edges, transposed —
 // lane = tile of the item's rectangle (64 per pass), uniform loop over the edges (staged in LDS): every lane accumulates the backdrops of
 // its tile and the bit mask of the edges that matter inside it, then emits its entries.
@@ -437,6 +497,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     __shared__ int rect_bd[kRectLds], rect_hbd[kRectLds];    // lane = edge path: backdrops of the tiles of the item's rectangle ...
     __shared__ uint32_t rect_hull_touch[kRectLds / 32u];      // ... whether a hull edge matters inside the tile ...
     __shared__ uint32_t rect_cursor[kRectLds];                // ... and the count, then the next list position, of the edges that matter there
+    __shared__ uint32_t rect_cursor_tri[kRectLds];            // the same for the triangle wavefront (its own rectangle, per chunk of 64 triangles)
     const uint32_t item = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const DrawItem it = item_of(r, item);
     const float* m = r.transforms + 16u * it.instance;
@@ -444,6 +505,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     const uint32_t slot0 = r.slot_begin[item];
     if (slot0 + k.total > r.slot_capacity) return; // cannot happen: the capacity is the scan's total
     Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, (2u * blockIdx.x + wave) % kSubStreams};
+#ifdef CRH_ABLATE
+    unsigned long long phase_t = __builtin_amdgcn_s_memtime();
+#endif
     const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
 #ifdef CRH_ABLATE
     if ((r.debug & 1024u) && wave == 0u) return;
@@ -455,12 +519,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
             const uint32_t t = t0 + lane;
             PrimRec rec = {};
             bool drawn = false;
+            CRH_PHASE(0) // item data
             if (t < k.n_tri) {
                 const uint32_t c = t < k.cb[1] ? t : t - k.cb[1] + k.cb[2]; // the Shape's candidate numbering without the solid strips
                 drawn = setup_plain_triangle(s, r, it, k.cb, c, m, rec);
                 if (drawn) *reinterpret_cast<PrimRec*>(r.slots + (size_t)(slot0 + 4u * t) * 32u) = rec;
             }
-            bin_triangles(st, r, lane, drawn, rec.cov, slot0 + 4u * t, ry_first, r_last);
+            CRH_PHASE(1) // triangle set-up
+            if (!bin_triangles_counted(st, r, lane, drawn, rec.cov, slot0 + 4u * t, ry_first, r_last, rect_cursor_tri))
+                bin_triangles(st, r, lane, drawn, rec.cov, slot0 + 4u * t, ry_first, r_last);
+            CRH_PHASE(2) // walk
         }
     } else {
         // ---------------- boundary edges: fill chain(s) then hull chain
@@ -508,7 +576,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                 faces_back |= __ballot(e.strip_det > 0.0f);
             }
         };
+        CRH_PHASE(0) // item data, synthetic slots
         for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) stage_chunk(i0, true); // records + the box of every vertex (one chunk: the table stays)
+        CRH_PHASE(1) // edge records
         const bool hull_as_triangles = k.n_hull != 0u && ((faces_front != 0ull && faces_back != 0ull) || (r.debug & 4u) != 0u); // debug bit 2 (tests): always
         if (hull_as_triangles) { // the fill chain alone (rare: the staging is simply done again)
             n_hull_chain = 0u, n_edges = k.n_fe;
@@ -570,6 +640,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                     if (++tx > bx1) tx = bx0, ++ty;
                 }
             };
+            CRH_PHASE(2) // rectangle, LDS table cleared
             for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) { // ---- pass 1
                 const BinEdge e = edge_of(i0 + lane);
                 // backdrop rows: the tile rows whose line q0y lies in the edge's half-open y range; a conservative integer range first
@@ -604,6 +675,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            CRH_PHASE(3) // pass 1
             for (uint32_t base = 0; base < n_rect; base += 64u) { // ---- pass 2, lane = tile (the COVER entry carries one unit of either backdrop)
                 const uint32_t q = base + lane, qy = q / nx, qx = q - qy * nx;
                 const bool active = q < n_rect;
@@ -639,6 +711,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            CRH_PHASE(4) // pass 2
             for (uint32_t i0 = 0; i0 < n_edges; i0 += 64u) { // ---- pass 3
                 const uint32_t i = i0 + lane;
                 const BinEdge e = edge_of(i);
@@ -740,7 +813,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
             }
         }
     }
+    CRH_PHASE(5) // pass 3 (edges) / nothing (triangles)
     stage_flush(st, r, lane);
+    CRH_PHASE(6) // final flush
 }
 
 __global__ __launch_bounds__(256) void k_scatter(RasterParams r) {

@@ -1,0 +1,27 @@
+"""DEVELOPMENT TOOL (GPU, library built with -DCRH_ABLATE): average cycles a wavefront of k_bin_edges spends per phase."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CRH_RASTER_DEBUG"] = "65536"
+os.environ["CRH_EDGE_PASS"] = "1"
+from contrast_renderer_amd import renderer as R, scenes
+w = sys.argv[1] if len(sys.argv) > 1 else "cubic"
+sc = {"cubic": lambda: scenes.scene_cubic_fill(10000), "glyphs": lambda: scenes.scene_glyphs(50000, (2048, 2048)), "dashed": lambda: scenes.scene_dashed_strokes(2000)}[w]()
+size = {"cubic": 4096, "glyphs": 2048, "dashed": 4096}[w]
+r = R.Renderer(R.Configuration(4 if w == "dashed" else 1, 4, 4), 0)
+scene = R.Scene(r, sc["batch"]); scene.check(); scene.set_instances(sc["transforms"], sc["colors"])
+frame = R.Frame(r, size, size)
+out = (C.c_uint32 * 128)()
+for _ in range(3):
+    frame.clear(); scene.render(frame); r.synchronize()
+    r.lib.crh_debug_frame_words(frame.handle, out)
+n = scene.n_shapes
+names = [["item data", "triangle set-up", "walk", "-", "-", "-", "final flush", "-"], ["item data + synth", "edge records", "rect + clear", "pass 1", "pass 2", "pass 3", "final flush", "-"]]
+for wave in range(2):
+    tot = 0
+    for k in range(7):
+        v = out[80 + 2 * (k + 8 * wave)] | (out[81 + 2 * (k + 8 * wave)] << 32)
+        tot += v
+        print(f"wave {wave} {names[wave][k]:18s} {v / n:10.0f} ticks per item")
+    print(f"wave {wave} total {tot / n:.0f}")
