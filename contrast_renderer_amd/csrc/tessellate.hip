@@ -703,7 +703,7 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
     hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(64 * kHullWaves), 0, stream, s);
     if (mark) mark(ctx, "tess_hull", bytes[3]);
     if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
-        hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(s.n_shapes, 4096u)), dim3(64), 0, stream, s);
+        hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(s.n_shapes, 16384u)), dim3(64), 0, stream, s); // (6 KB of LDS each: the GPU holds 6 600 at once; 4096 made a wave take two Shapes one after the other)
         hipLaunchKernelGGL((k_hull_large<kHullMax, 1>), dim3(min(s.n_shapes, 1024u)), dim3(64), 0, stream, s);
         hipLaunchKernelGGL(k_hull_huge, dim3(min(s.n_shapes, 256u)), dim3(256), 0, stream, s);
         if (mark) mark(ctx, "tess_hull_large", 0);
