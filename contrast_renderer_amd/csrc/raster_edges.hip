@@ -502,20 +502,24 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     __shared__ uint32_t rect_hull_touch[kRectLds / 32u];      // ... whether a hull edge matters inside the tile ...
     __shared__ uint32_t rect_cursor[kRectLds];                // ... and the count, then the next list position, of the edges that matter there
     __shared__ uint32_t rect_cursor_tri[kRectLds];            // the same for the triangle wavefront (its own rectangle, per chunk of 64 triangles)
-    const uint32_t item = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, (2u * blockIdx.x + wave) % kSubStreams};
+    // a workgroup takes items blockIdx.x, blockIdx.x + gridDim.x, ...: the pair stage carries over from one item to the next (fewer, fuller
+    // flushes), and the two wavefronts never synchronise with each other
+    for (uint32_t item = blockIdx.x; item < r.n_items; item += gridDim.x) {
+    __builtin_amdgcn_wave_barrier(); // (the previous item's readers of the LDS tables are through)
     const DrawItem it = item_of(r, item);
     const float* m = r.transforms + 16u * it.instance;
     const ItemSlots k = item_slots(s, it);
     const uint32_t slot0 = r.slot_begin[item];
-    if (slot0 + k.total > r.slot_capacity) return; // cannot happen: the capacity is the scan's total
-    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, (2u * blockIdx.x + wave) % kSubStreams};
+    if (slot0 + k.total > r.slot_capacity) continue; // cannot happen: the capacity is the scan's total
 #ifdef CRH_ABLATE
     unsigned long long phase_t = __builtin_amdgcn_s_memtime();
 #endif
     const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
 #ifdef CRH_ABLATE
-    if ((r.debug & 1024u) && wave == 0u) return;
-    if ((r.debug & 2048u) && wave == 1u) return;
+    if ((r.debug & 1024u) && wave == 0u) continue;
+    if ((r.debug & 2048u) && wave == 1u) continue;
 #endif
     if (wave == 0u) {
         // ---------------- triangles: 64 at a time, lane = triangle
@@ -818,8 +822,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
         }
     }
     CRH_PHASE(5) // pass 3 (edges) / nothing (triangles)
+    } // items
     stage_flush(st, r, lane);
-    CRH_PHASE(6) // final flush
 }
 
 __global__ __launch_bounds__(256) void k_scatter(RasterParams r) {
@@ -1408,11 +1412,17 @@ void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_ite
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
     (void)hipMemsetAsync(r.overflow, 0, 32 + 4 * kSubStreams, stream);                 // overflow[8 ...] are the cursors of the pair sub-streams
+    // Items per workgroup. One is best while the grid is small (S10k: 0.169 ms; two: 0.189, four: 0.21 — an item is a chain of dependent
+    // memory operations, and a wavefront that takes a second item doubles it); tens of thousands of small items are bound by workgroup
+    // turnover instead (50 000 glyphs: one 0.45, two 0.31, four 0.31, eight 0.33 ms). So: about 12 000 workgroups.
+    static const uint32_t pinned = getenv("CRH_BIN_ITEMS") ? max(1, atoi(getenv("CRH_BIN_ITEMS"))) : 0u;
+    const uint32_t items_per_group = pinned ? pinned : min(8u, max(1u, (r.n_items + 12287u) / 12288u));
+    const uint32_t bin_grid = (r.n_items + items_per_group - 1u) / items_per_group;
     if (r.n_items) {
         if (samples == 4)
-            hipLaunchKernelGGL((k_bin_edges<4>), dim3(r.n_items), dim3(128), 0, stream, s, r);
+            hipLaunchKernelGGL((k_bin_edges<4>), dim3(bin_grid), dim3(128), 0, stream, s, r);
         else
-            hipLaunchKernelGGL((k_bin_edges<1>), dim3(r.n_items), dim3(128), 0, stream, s, r);
+            hipLaunchKernelGGL((k_bin_edges<1>), dim3(bin_grid), dim3(128), 0, stream, s, r);
     }
     if (after_bin) (void)hipEventRecord(after_bin, stream);
     if (mark) mark(ctx, "raster_bin", 0);
