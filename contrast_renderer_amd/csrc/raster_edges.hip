@@ -835,24 +835,6 @@ __global__ __launch_bounds__(256) void k_scatter(RasterParams r) {
 }
 
 // ---------------------------------------------------------------------------------------------- k_raster_edges
-// w += 1 / w -= 1 where the lane's bit of a 64-bit lane mask (an SGPR pair) is set: ONE VALU instruction (add / subtract with carry-in)
-CRH_D void add_where(int& w, unsigned long long mask) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(w), "=s"(carry_out) : "s"(mask));
-#else
-    (void)w, (void)mask;
-#endif
-}
-CRH_D void sub_where(int& w, unsigned long long mask) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long carry_out;
-    asm("v_subb_co_u32_e64 %0, %1, %0, 0, %2" : "+v"(w), "=s"(carry_out) : "s"(mask));
-#else
-    (void)w, (void)mask;
-#endif
-}
-
 // A 16-bit row mask -> the lane masks of the lane's sample slots. Lane (px, rq) owns row bit rq + 4b in slot b (msaa 1) or 4 rq + q in
 // slot q (msaa 4); a slot's lane mask repeats each of its four row bits over a 16-lane group. Scalar unit only: s_bitreplicate doubles
 // every bit of its 32-bit operand, a tree of 8 of them turns 16 bits into 4 x 64.
