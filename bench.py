@@ -415,7 +415,10 @@ def main():
         repeats = max(2, min(200, int(math.ceil(10.0 / max(t1, 1e-3)))))
         ts = time_tessellate(batch, 1, repeats)
         cores = usable_cores()
-        tall = time_tessellate(batch, cores, max(2, repeats))
+        # (the result scenes of all repeats stay alive until the clock stops — first-touch page faults on one address space serialise in
+        # the kernel, so a long run with gigabytes of live output measures the kernel's mm lock: 40 repeats at most)
+        repeats_all = max(2, min(repeats, 40))
+        tall = time_tessellate(batch, cores, repeats_all)
         out["cpu_baseline"] = {
             "value": batch.n_shapes * repeats / ts,
             "unit": "paths/s",
@@ -424,7 +427,7 @@ def main():
             "sample": f"{repeats} x full tessellation of the same {batch.n_shapes}-path scene by the C++ restatement of the reference's CPU tessellation "
                       f"(Shape::from_paths minus the wgpu upload; the reference itself cannot be built here), single thread as in renderer.rs:187; "
                       "tessellation only — the reference rasterizes on a GPU",
-            "all_cores": {"value": batch.n_shapes * max(2, repeats) / tall, "cores": cores,
+            "all_cores": {"value": batch.n_shapes * repeats_all / tall, "cores": cores, "repeats": repeats_all,
                           "note": "persistent thread pool, one malloc arena per thread, destruction outside the timed region; threads = the CPUs this process may "
                                   "use (affinity mask and cgroup CPU quota, not the host's core count: more threads than that only time-slice)"},
         }
