@@ -294,8 +294,21 @@ def main():
 
     # Scene set-up, before the W warm-up steps: the library draws a Scene's first frames with both raster formulations (boundary edges /
     # strip triangles: same pixels), times the second frame of each on the GPU and keeps the faster one from the fifth frame on
+    watchdog = None
+    if world > 1:  # the first exchanges of a multi-rank run: a rank that never answers must end the job with a message, not hang it
+        import threading
+
+        def _stuck():
+            sys.stderr.write(f"[bench] rank {rank}: no progress in the first exchange steps after 180 s ({exchange_note}); aborting\n")
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(180.0, _stuck)
+        watchdog.daemon = True
+        watchdog.start()
     run(6)
     sync()
+    if watchdog is not None:
+        watchdog.cancel()
     run(args.warmup)
     sync()
     scene.check()
