@@ -196,32 +196,6 @@ def main():
         workload = "BASELINE configs[4]: 2000 dashed rational-cubic strokes (UniformTangentAngle 0.1, miter/round joins), 4096x4096, msaa 4"
     batch = sc["batch"] if shard == (0, sc["batch"].n_shapes) else sc["batch"].slice_shapes(*shard)
     transforms, colors = sc["transforms"][shard[0]:shard[1]], sc["colors"][shard[0]:shard[1]]
-    # The CPU baseline (the oracle as the checker's clock, on rank 0 at N = 1 only), before the GPU part of the run
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.binding import time_tessellate
-        t1 = time_tessellate(batch, 1, 1)
-        repeats = max(2, min(200, int(math.ceil(10.0 / max(t1, 1e-3)))))
-        ts = time_tessellate(batch, 1, repeats)
-        cores = usable_cores()
-        # (the result scenes of all repeats stay alive until the clock stops — first-touch page faults on one address space serialise in
-        # the kernel, so a long run with gigabytes of live output measures the kernel's mm lock: 40 repeats at most)
-        repeats_all = max(2, min(repeats, 40))
-        time_tessellate(batch, cores, repeats_all)  # untimed: the first threaded run creates the threads' malloc arenas and faults their pages in
-        tall = min(time_tessellate(batch, cores, repeats_all) for _ in range(2))
-        cpu_baseline = {
-            "value": batch.n_shapes * repeats / ts,
-            "unit": "paths/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": f"{repeats} x full tessellation of the same {batch.n_shapes}-path scene by the C++ restatement of the reference's CPU tessellation "
-                      f"(Shape::from_paths minus the wgpu upload; the reference itself cannot be built here), single thread as in renderer.rs:187; "
-                      "tessellation only — the reference rasterizes on a GPU",
-            "all_cores": {"value": batch.n_shapes * repeats_all / tall, "cores": cores, "repeats": repeats_all,
-                          "note": "persistent thread pool, one malloc arena per thread, destruction outside the timed region, best of two runs after an "
-                                  "untimed one (a cold run is 5x slower: arena creation and first-touch page faults); threads = the CPUs this process may "
-                                  "use (affinity mask and cgroup CPU quota, not the host's core count: more threads than that only time-slice)"},
-        }
     renderer = Renderer(Configuration(msaa_sample_count=sc["msaa"], clip_nesting_counter_bits=4, winding_counter_bits=4), device=local_rank)
     t_up = time.perf_counter()
     scene = Scene(renderer, batch, tessellate=True)  # host -> HBM + first tessellation (sizes the output buffers): outside the timed region
@@ -448,6 +422,33 @@ def main():
     }
     if traffic_sent is not None:
         out["exchange"] = {"bytes_sent_by_rank0_last_step": traffic_sent[0], "dense_slabs_would_be": traffic_sent[1]}
+    # The CPU baseline (the oracle as the checker's clock, on rank 0 at N = 1 only) — after the GPU part: run before it, its sixteen busy
+    # threads left the process with a ~20 ms host stall inside the timed region in one run out of three (the GPU idle, ms_per_step doubled)
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.binding import time_tessellate
+        t1 = time_tessellate(batch, 1, 1)
+        repeats = max(2, min(200, int(math.ceil(10.0 / max(t1, 1e-3)))))
+        ts = time_tessellate(batch, 1, repeats)
+        cores = usable_cores()
+        # (the result scenes of all repeats stay alive until the clock stops — first-touch page faults on one address space serialise in
+        # the kernel, so a long run with gigabytes of live output measures the kernel's mm lock: 40 repeats at most)
+        repeats_all = max(2, min(repeats, 40))
+        time_tessellate(batch, cores, repeats_all)  # untimed: the first threaded run creates the threads' malloc arenas and faults their pages in
+        tall = min(time_tessellate(batch, cores, repeats_all) for _ in range(2))
+        cpu_baseline = {
+            "value": batch.n_shapes * repeats / ts,
+            "unit": "paths/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{repeats} x full tessellation of the same {batch.n_shapes}-path scene by the C++ restatement of the reference's CPU tessellation "
+                      f"(Shape::from_paths minus the wgpu upload; the reference itself cannot be built here), single thread as in renderer.rs:187; "
+                      "tessellation only — the reference rasterizes on a GPU",
+            "all_cores": {"value": batch.n_shapes * repeats_all / tall, "cores": cores, "repeats": repeats_all,
+                          "note": "persistent thread pool, one malloc arena per thread, destruction outside the timed region, best of two runs after an "
+                                  "untimed one (a cold run is 5x slower: arena creation and first-touch page faults); threads = the CPUs this process may "
+                                  "use (affinity mask and cgroup CPU quota, not the host's core count: more threads than that only time-slice)"},
+        }
     if cpu_baseline is not None:
         out["cpu_baseline"] = cpu_baseline
     if rank == 0:
