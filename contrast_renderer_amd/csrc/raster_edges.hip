@@ -229,6 +229,9 @@ CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
     const uint32_t region = r.pair_capacity / kSubStreams;
     uint32_t base = 0;
     if (lane == 0u) {
+#ifdef CRH_ABLATE
+        if (r.debug & 262144u) base = (st.sub * 7919u) % (region / 2u); else
+#endif
         base = atomicAdd(&r.pair_cursor[st.sub], st.used);
         if (base + st.used > region) r.overflow[5] = 1u; // this region is full: the host grows the stream and runs the pass again
     }
@@ -463,6 +466,9 @@ CRH_D bool bin_triangles_counted(Stage& st, const RasterParams& r, uint32_t lane
     for (uint32_t base = 0; base < n_rect; base += 64u) { // reserve
         const uint32_t q = base + lane, qy = q / nx, qx = q - qy * nx;
         const uint32_t n = q < n_rect ? cursor[q] : 0u;
+#ifdef CRH_ABLATE
+        if (r.debug & 131072u) { if (n) cursor[q] = q & 7u; } else
+#endif
         if (n) cursor[q] = atomicAdd(&r.tile_count[(ry0 + qy) * r.tiles_x + rx0 + qx], n);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -699,6 +705,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                 uint32_t n_hbd = n_cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
                 const uint32_t bd_key = synth_a + (bd > 0 ? 0u : 1u), hbd_key = synth_a + (hbd > 0 ? 2u : 3u);
                 uint32_t left = n_cover + n_bd + n_hbd, pos = 0;
+#ifdef CRH_ABLATE
+                if (r.debug & 131072u) pos = tile & 7u; else
+#endif
                 if (left + n_touching) pos = atomicAdd(&r.tile_count[tile], left + n_touching);
                 if (active) rect_cursor[q] = pos + left; // where the edges' entries go
                 for (;;) {
