@@ -321,9 +321,10 @@ struct crh_scene {
         hipEvent_t e[6] = {}; // around: the binning traversal (the attempt that fitted), the list fill / scatter, the raster kernel
         bool recorded = false;
     } pass_trial[2];
-    int pass_choice = 0;       // 0 undecided, 1 edges, 2 triangles
-    uint32_t pass_frames = 0;  // plain frames since the geometry or the frame size changed
-    uint32_t pass_width = 0, pass_height = 0;
+    int pass_choice = 0;       // 0 undecided, 1 edges, 2 triangles: for targets of the size class pass_class
+    uint32_t pass_frames = 0;  // plain frames of the trial under way
+    uint32_t pass_class = 0;   // size class of the target the trial / choice belongs to (log4 of its area)
+    uint8_t pass_known[16] = {}; // choices already measured, by size class: a Scene drawn into a large frame and a thumbnail in turn measures twice, not for ever
     float pass_ms[2] = {0.0f, 0.0f};
     void tess_bufs(DevBuf* (&out)[kTessBufs]) {
         DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
@@ -660,15 +661,16 @@ size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
     if (ov[5] != 0) pairs = std::max(pairs, f->pair_capacity_bytes / 4 + f->pair_capacity_bytes / 8);
     return pairs * 4;
 }
-// the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
 // the pass of this plain frame (true = edge pass) and, through `timed`, which trial (0 edges, 1 triangles) its events belong to, or -1
 bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     *timed = -1;
     if (getenv("CRH_TRIANGLE_PASS")) return false;
     if (getenv("CRH_EDGE_PASS")) return true;
-    if (sc->pass_width != f->width || sc->pass_height != f->height) { // another target: decide again
-        sc->pass_width = f->width, sc->pass_height = f->height;
-        sc->pass_choice = 0, sc->pass_frames = 0;
+    uint32_t cls = 0; // size class of the target: the faster formulation depends on how many tiles a Shape spans
+    for (uint64_t area = (uint64_t)f->width * f->height; area > 3u && cls < 15u; area >>= 2) ++cls;
+    if (cls != sc->pass_class) { // a target of another size class: its own choice, measured once
+        sc->pass_class = cls;
+        sc->pass_choice = sc->pass_known[cls], sc->pass_frames = 0;
         sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
     }
     if (sc->pass_choice) return sc->pass_choice == 1;
@@ -696,6 +698,7 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
                 }
             }
             sc->pass_choice = sc->pass_ms[0] <= sc->pass_ms[1] ? 1 : 2;
+            sc->pass_known[sc->pass_class] = (uint8_t)sc->pass_choice;
             if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] pass trial: edges %.3f ms, triangles %.3f ms -> %s\n", sc->pass_ms[0], sc->pass_ms[1], sc->pass_choice == 1 ? "edges" : "triangles");
             return sc->pass_choice == 1;
         }
@@ -706,6 +709,7 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     return false; // still waiting for the trial's events: stay on the pass of the latest frames
 }
 
+// the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
 bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
     if (longest_list <= f->sort_capacity) return false;
     const uint32_t limit = 32768u / (4u * (f->renderer->config.msaa_sample_count == 4 ? 4u : 1u)); // 32 KiB of dynamic LDS per workgroup (kSortBytesMax)
@@ -1176,7 +1180,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         sc->shadow.allocated = false;
     }
     sc->tessellated_once = false;
-    sc->pass_choice = 0, sc->pass_frames = 0; // new geometry: measure again
+    sc->pass_choice = 0, sc->pass_frames = 0, sc->pass_class = 0; // new geometry: measure again
+    std::memset(sc->pass_known, 0, sizeof(sc->pass_known));
     sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
     for (bool& used : sc->rec_used) used = false;
     sc->n_segments = b->n_segments;
