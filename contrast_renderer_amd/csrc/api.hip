@@ -666,6 +666,7 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     *timed = -1;
     if (getenv("CRH_TRIANGLE_PASS")) return false;
     if (getenv("CRH_EDGE_PASS")) return true;
+    if (sc->d.n_shapes < 256u) return true; // a handful of Shapes (the reference's one-Shape-per-call use): launch overhead either way, not worth two synchronising frames
     uint32_t cls = 0; // size class of the target: the faster formulation depends on how many tiles a Shape spans
     for (uint64_t area = (uint64_t)f->width * f->height; area > 3u && cls < 15u; area >>= 2) ++cls;
     if (cls != sc->pass_class) { // a target of another size class: its own choice, measured once
