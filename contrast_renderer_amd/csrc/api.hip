@@ -235,7 +235,7 @@ struct crh_frame {
     DevBuf item_nslots, item_slot_begin; // the edge pass: slots of the primitive heap per item
     uint32_t items_total_slots = 0;
     DevBuf item_transforms_b, item_colors_b; // second set of instance data: a re-submitted pass writes the set its predecessor did not read
-    int item_inst_cur = 0, item_inst_last = 0, item_projective_of[2] = {0, 0};
+    int item_inst_cur = 0, item_inst_last = 0, item_projective_of[2] = {0, 0}, item_tame_of[2] = {0, 0};
     PinnedUpload item_upload_t, item_upload_c;
     InstanceSlot item_slot[2];
     uint32_t n_items = 0;
@@ -289,6 +289,7 @@ struct crh_scene {
     int instances_cur = 0;
     uint64_t generation = 0;            // bumped by every upload: what a frame's cached recorded pass was built against
     bool instances_projective_of[2] = {false, false};
+    bool instances_tame_of[2] = {false, false}; // all_colors_tame of that instance buffer
     hipEvent_t rec_raster_done[kPipelineDepth] = {};
     bool rec_used[kPipelineDepth] = {};
     int next_rec = 0;
@@ -722,6 +723,15 @@ bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
 }
 
 // oracle/raster.hpp is_plain_instance, for every instance: the plain pass needs no 1/w and z/w planes
+// Colours the late start of a tile's list (k_raster_edges) may rely on: with 0 <= alpha <= 1 and bounded components, whatever stack of
+// blends precedes an opaque cover stays finite, so "source + anything x (1 - 1)" is the source — also for the colours the shortcut skipped.
+bool all_colors_tame(const float* c, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const float* v = c + 4 * i;
+        if (!(v[3] >= 0.0f && v[3] <= 1.0f) || !(std::fabs(v[0]) <= 1e30f && std::fabs(v[1]) <= 1e30f && std::fabs(v[2]) <= 1e30f)) return false;
+    }
+    return true;
+}
 bool all_instances_plain(const float* t, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         const float* m = t + 16 * i;
@@ -833,7 +843,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         const size_t prim_capacity = (size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_SOLID_V] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u + t[CH_HULL] + 64;
         // the edge pass: four slots per stroke / curve triangle, one per polygon vertex and hull vertex, the per-Shape cover slots
         const size_t slot_capacity = 4u * ((size_t)t[CH_LINE_V] + 3u * (size_t)t[CH_JOINT] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u) + t[CH_SOLID_V] + 4u * (size_t)t[CH_HULL] +
-                                     24u * (size_t)sc->d.n_shapes + 64; // item_slots(): the hull region is sized for cover triangles (hull vertices <= candidates)
+                                     40u * (size_t)sc->d.n_shapes + 64; // item_slots(): the hull region is sized for cover triangles (hull vertices <= candidates)
         if (prim_capacity >= 0xFFFFFFF0u || slot_capacity >= 0xFFFFFFF0u) return CRH_ERR_UNSUPPORTED; // 0xFFFFFFFF pads the tile sort
         HIP_TRY(sc->prim_rec[rec].ensure(std::max(prim_capacity * 128, slot_capacity * 32)));
         p.prim_capacity = (uint32_t)prim_capacity;
@@ -845,6 +855,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     InstanceSlot& slot = recorded ? f->item_slot[item_inst] : sc->slot[inst];
     if (slot.was_written) HIP_TRY(hipStreamWaitEvent(bin, slot.ready, 0)); // the copy of this set on the upload stream
     const bool projective = recorded ? f->item_projective_of[item_inst] != 0 : sc->instances_projective_of[inst];
+    const bool tame_colors = recorded ? f->item_tame_of[item_inst] != 0 : sc->instances_tame_of[inst];
     p.prim_proj = nullptr;
     if (projective) {
         HIP_TRY(sc->prim_proj[rec].ensure((size_t)p.prim_capacity * 32));
@@ -869,6 +880,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
+    p.occlude = tame_colors ? 1u : 0u;
     r->begin_marks(2);
     // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
@@ -1534,6 +1546,7 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
     }
     sc->instances_cur = next;
     sc->instances_projective_of[next] = !all_instances_plain(transforms, sc->d.n_shapes);
+    sc->instances_tame_of[next] = all_colors_tame(colors, sc->d.n_shapes);
     sc->instances_projective = sc->instances_projective_of[next];
     sc->instances_set = true;
     return CRH_OK;
@@ -1609,6 +1622,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
         slot.was_written = true;
         f->item_inst_cur = next;
         f->item_projective_of[next] = all_instances_plain(transforms, n_instances) ? 0 : 1;
+        f->item_tame_of[next] = all_colors_tame(colors, n_instances) ? 1 : 0;
         return render_impl(sc, f);
     }
     if (f->check_pending) { // the frame's recorded pass (its remedy for an overflowed tile list) is about to be replaced
@@ -1630,6 +1644,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     f->items_generation = sc->generation;
     f->items_ranges_valid = false; // computed by render_impl together with the primitive total
     f->item_projective_of[0] = all_instances_plain(transforms, n_instances) ? 0 : 1;
+    f->item_tame_of[0] = all_colors_tame(colors, n_instances) ? 1 : 0;
     f->pairs_known = false; // a different pass: re-learn the tile list size
     return render_impl(sc, f);
 }

@@ -33,6 +33,13 @@ namespace crh {
 void launch_scan_tiles(const RasterParams& r, hipStream_t stream); // raster.hip: exclusive scan of tile_count -> tile_offset, pair total, longest list
 
 constexpr uint32_t EK_EDGE = 0, EK_SYNTH = 7, EK_COVER_TRI = 8; // kinds 1..6 = KIND_IQ .. KIND_JOINT as in raster_common.hpp (flags bits 4-7)
+// Two refinements of a COVER entry's code, decided by the bin kernel per (item, tile):
+//   + kCoverHull    the whole tile lies inside the item's hull (no hull edge matters there, hull backdrop non-zero): the cover resets the
+//                   winding of EVERY sample of the tile;
+//   + kCoverOpaque  also: the item is opaque and the whole tile lies inside its fill (no fill edge matters, backdrop winding non-zero under
+//                   the winding rule): unless a sample inherits a winding that cancels the backdrop, the cover REPLACES the tile.
+// k_raster_edges uses them to start a tile's list late (see there): painter's-order occlusion, verified per tile, exact.
+constexpr uint32_t kCoverHull = 9u, kCoverOpaque = 18u;
 constexpr uint32_t kEdgeTl = 1u, kEdgeSigmaPos = 2u, kEdgeHull = 4u;
 // Synthetic slots of an item (flags bits 8-11 = code): 0 BD+1, 1 BD-1 (fill winding of the whole tile), 2 HBD+1, 3 HBD-1 (hull winding of the
 // whole tile); 4 + (bd + 1) + 3 * (hbd + 1): COVER with one unit of both backdrops folded in (bd, hbd in -1..1).
@@ -45,8 +52,9 @@ struct EdgeRec {
     float lo_x, lo_y, hi_x, hi_y, bx, nay;
 };
 struct SynthRec {
-    uint32_t flags, pad0;
-    float r, g, b, a, pad1, pad2;
+    uint32_t flags, first_slot; // first_slot: the item's first slot (its triangles and fill edges lie in [first_slot, synth_a))
+    float r, g, b, a;
+    uint32_t synth_a, pad;      // the item's first backdrop slot
 };
 static_assert(sizeof(EdgeRec) == 32 && sizeof(SynthRec) == 32, "slots");
 
@@ -68,7 +76,7 @@ CRH_D ItemSlots item_slots(const SceneDev& s, const DrawItem& it) {
     k.synth_a = k.fe0 + ((k.n_fe + 3u) & ~3u);
     k.hull0 = k.synth_a + 4u;
     k.synth_b = k.hull0 + (k.n_hull ? 4u * (k.n_hull - 2u) : 0u);
-    k.total = k.synth_b + 12u;
+    k.total = k.synth_b + 28u; // 9 COVER codes, the same 9 as "the whole tile inside the hull" (kCoverHull) and as "opaque over the whole tile" (kCoverOpaque)
     return k;
 }
 __global__ __launch_bounds__(256) void k_item_nslots(SceneDev s, RasterParams r, uint32_t n_items, uint32_t* out) {
@@ -547,13 +555,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     } else {
         // ---------------- boundary edges: fill chain(s) then hull chain
         const uint32_t fe_slot0 = slot0 + k.fe0, synth_a = slot0 + k.synth_a, hull_slot0 = slot0 + k.hull0, synth_b = slot0 + k.synth_b;
-        if (lane < 13u) { // the item's synthetic slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
+        const float* item_color = r.colors + 4u * it.instance;
+        const bool opaque_item = item_color[3] == 1.0f && is_finite(item_color[0]) && is_finite(item_color[1]) && is_finite(item_color[2]) &&
+                                 r.occlude != 0u && (r.debug & 32768u) == 0u; // debug bit 15 (tests, A/B runs): no tile is ever treated as replaced
+        if (lane < 13u + kCoverOpaque) { // 4 backdrop + 27 COVER slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
             SynthRec sr = {};
             sr.flags = (EK_SYNTH << 4) | (lane << 8);
-            if (lane >= 4u) {
-                const float* color = r.colors + 4u * it.instance;
-                sr.r = color[0] * color[3], sr.g = color[1] * color[3], sr.b = color[2] * color[3], sr.a = color[3];
-            }
+            sr.first_slot = slot0, sr.synth_a = synth_a;
+            if (lane >= 4u) sr.r = item_color[0] * item_color[3], sr.g = item_color[1] * item_color[3], sr.b = item_color[2] * item_color[3], sr.a = item_color[3];
             *reinterpret_cast<SynthRec*>(r.slots + (size_t)(lane < 4u ? synth_a + lane : synth_b + lane - 4u) * 32u) = sr;
         }
         // Do all triangles of the hull strip face the same way? Then the cover — the UNION of those triangles (renderer.rs:340-354) — is
@@ -700,7 +709,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                 const uint32_t abd = (uint32_t)(bd < 0 ? -bd : bd), ahbd = (uint32_t)(hbd < 0 ? -hbd : hbd);
                 uint32_t n_cover = (active && n_hull_chain != 0u && (hbd != 0 || hull_touch)) ? 1u : 0u; // the tile is inside the hull or its boundary crosses it
                 const int cbd = bd > 0 ? 1 : (bd < 0 ? -1 : 0), chbd = hbd > 0 ? 1 : (hbd < 0 ? -1 : 0);
-                const uint32_t cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1);
+                const bool hull_over_tile = n_cover != 0u && hbd != 0 && !hull_touch;
+                const bool replaces_tile = hull_over_tile && opaque_item && n_touching == 0u && (bd & (int)r.winding_mask) != 0;
+                const uint32_t cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1) + (replaces_tile ? kCoverOpaque : (hull_over_tile ? kCoverHull : 0u));
                 uint32_t n_bd = n_cover ? (abd ? abd - 1u : 0u) : abd;
                 uint32_t n_hbd = n_cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
                 const uint32_t bd_key = synth_a + (bd > 0 ? 0u : 1u), hbd_key = synth_a + (hbd > 0 ? 2u : 3u);
@@ -785,7 +796,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                     if (last_chunk && active) {
                         n_cover = (n_hull_chain != 0u && (hbd != 0 || hull_touch)) ? 1u : 0u; // the tile is inside the hull or its boundary crosses it
                         const int cbd = bd > 0 ? 1 : (bd < 0 ? -1 : 0), chbd = hbd > 0 ? 1 : (hbd < 0 ? -1 : 0);
-                        cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1);
+                        cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1) + ((n_cover != 0u && hbd != 0 && !hull_touch) ? kCoverHull : 0u);
                         n_bd = n_cover ? (abd ? abd - 1u : 0u) : abd; // the COVER entry carries one unit of either backdrop
                         n_hbd = n_cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
                     }
@@ -1031,6 +1042,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         const uint32_t count = min(64u, n - q0);
         // ---- entry setup, vectorised across the chunk: lane j prepares entry j
         float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0;
+        bool hull_over_tile = false, replaces_tile = false; // this lane's entry is a cover that resets every sample / an opaque cover over the whole tile
+        uint32_t item_first = 0, item_synth_a = 0;
         if (lane < count) {
             const uint8_t* slot = slots + (size_t)my_key * 32u;
             const uint32_t flags = *reinterpret_cast<const uint32_t*>(slot);
@@ -1045,6 +1058,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
                 e0 = make_float4(sr.r, sr.g, sr.b, sr.a);
                 e1.w = __uint_as_float(flags);
+                const uint32_t code_all = (flags >> 8) & 31u;
+                hull_over_tile = code_all >= 4u + kCoverHull;
+                replaces_tile = code_all >= 4u + kCoverOpaque;
+                item_first = sr.first_slot, item_synth_a = sr.synth_a;
             } else {
                 const PrimCoverage mine = *reinterpret_cast<const PrimCoverage*>(slot);
                 const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
@@ -1095,14 +1112,37 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         // Two nested loops over the chunk's entries: the inner one runs over what only changes the winding counters (triangles, edges,
         // backdrops) and stops at a cover entry, which the outer loop body handles — the ONE place where the colour registers are
         // written. (With the colour updated inside a multi-way dispatch, every iteration ended with two dozen register copies.)
-        uint32_t j = 0;
+        // Occlusion. If the list holds an opaque cover over the whole tile (X, the last one; none of its item's triangles in the tile), what was
+        // drawn before X only matters through the winding a sample may still carry when X tests it (an item whose hull boundary crosses the
+        // tile can leave one just outside its hull). The winding is zero everywhere behind a cover that resets the whole tile (R, the last one
+        // before X): the list is started behind R with cleared counters — exact for the winding; the colours it misses are all overwritten by
+        // X unless some sample fails X's stencil test, and then (verify_at) the tile is done again from the top.
+        uint32_t j = 0, verify_at = 0xFFFFFFFFu;
+        if (n <= 64u && !r.load_existing) { // (the whole list is in this chunk, and the tile starts from a known colour)
+            unsigned long long candidates = __builtin_amdgcn_ballot_w64(replaces_tile);
+            const unsigned long long resets = __builtin_amdgcn_ballot_w64(hull_over_tile);
+            while (candidates) {
+                const uint32_t at = 63u - (uint32_t)__builtin_clzll(candidates);
+                const uint32_t first_slot = __builtin_amdgcn_readlane(item_first, at), synth_a = __builtin_amdgcn_readlane(item_synth_a, at);
+                // the bin kernel vouched for the item's edges; its triangles are binned by another wavefront: one of them in this tile has a key
+                // in [first_slot, synth_a), and keys ascend
+                const uint32_t below = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(lane < count && my_key < synth_a));
+                if (below == 0u || __builtin_amdgcn_readlane(my_key, below - 1u) < first_slot) {
+                    const unsigned long long before = resets & ((1ull << at) - 1ull);
+                    j = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u; // behind the last whole-tile reset before X
+                    verify_at = j ? at : 0xFFFFFFFFu;
+                    break;
+                }
+                candidates &= ~(1ull << at);
+            }
+        }
         while (j < count) {
         for (; j < count; ++j) {
             const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
             const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
             const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
             const uint32_t kind = (flags >> 4) & 15u;
-            if (kind == EK_COVER_TRI || (kind == EK_SYNTH && ((flags >> 8) & 15u) >= 4u)) break; // a cover: the outer loop's business
+            if (kind == EK_COVER_TRI || (kind == EK_SYNTH && ((flags >> 8) & 31u) >= 4u)) break; // a cover: the outer loop's business
 #ifdef CRH_ABLATE // tools/ablate_edges.sh: what does each class of entries cost?
             if ((r.debug & 256u) && lane == 0u) atomicAdd(&r.overflow[8 + (kind == EK_EDGE ? ((flags & kEdgeHull) ? 1 : 0) : (kind == EK_SYNTH ? 2 : 3))], 1u);
             if ((r.debug & 8u) && kind == EK_EDGE) continue;
@@ -1162,7 +1202,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         for (int q = 0; q < S; ++q) winding[b][q] += d[b][q];
                 }
             } else if (kind == EK_SYNTH) { // a whole-tile backdrop of the fill (codes 0, 1) or hull (2, 3) winding
-                const uint32_t code = (flags >> 8) & 15u;
+                const uint32_t code = (flags >> 8) & 31u;
                 const int vw = code < 2u ? ((code & 1u) ? -1 : 1) : 0, vh = code < 2u ? 0 : ((code & 1u) ? -1 : 1);
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
@@ -1322,7 +1362,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             bool blend[ROWS][S];
             float cs0, cs1, cs2, cs3;
             if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
-                const uint32_t code = (flags >> 8) & 15u;
+                const uint32_t code = 4u + (((flags >> 8) & 31u) - 4u) % 9u;
                 const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
                 cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
 #pragma unroll
@@ -1335,6 +1375,25 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         winding[b][q] = in_hull ? 0 : w;
                         hullw[b][q] = 0;
                     }
+                if (j - 1u == verify_at) { // X of the late start: does it overwrite every sample? (it does unless a sample inherited a winding)
+                    bool every = true;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int q = 0; q < S; ++q) every = every && blend[b][q];
+                    verify_at = 0xFFFFFFFFu;
+                    if (__builtin_amdgcn_ballot_w64(every) != ~0ull) { // no: the colours behind it matter — the whole list, from cleared state
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                            for (int q = 0; q < S; ++q) {
+                                winding[b][q] = 0, hullw[b][q] = 0;
+                                col[b][q][0] = col[b][q][1] = col[b][q][2] = col[b][q][3] = 0.0f;
+                            }
+                        j = 0;
+                        continue;
+                    }
+                }
             } else { // a triangle of a folded hull strip, drawn as the reference draws it
                 const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
                 bool inside[ROWS][S];

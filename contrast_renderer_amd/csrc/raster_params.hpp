@@ -46,6 +46,7 @@ struct RasterParams {
     uint32_t depth_write;             // Configuration::depth_write_enabled
     uint32_t cull_mode;               // crh_cull of the colour cover
     uint32_t debug;                   // CRH_RASTER_DEBUG (tools only)
+    uint32_t occlude;                 // every colour of the pass has 0 <= alpha <= 1 and |rgb| <= 1e30: a tile's list may be started late (k_raster_edges)
     // ---- the edge pass (raster_edges.hip): the plain Stencil + Color pass binned in ONE traversal
     uint8_t* slots;                   // [slot_capacity][32 B] primitive heap: set-up triangles (4 slots), boundary edges and per-item cover slots (1 slot)
     uint32_t slot_capacity;
