@@ -957,6 +957,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     if (n > r.sort_capacity && n <= kLdsSortMax) n = 0; // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
 #ifdef CRH_ABLATE
     if (r.debug & 64u) n = 0;
+    if ((r.debug & 524288u) && n > 64u) n = 0;   // only the lists that fit one chunk
+    if ((r.debug & 1048576u) && n <= 64u) n = 0; // only the longer ones
 #endif
     uint32_t my_key = 0xFFFFFFFFu;
     const bool sorted_in_place = n > kLdsSortMax;
