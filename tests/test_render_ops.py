@@ -149,3 +149,39 @@ def test_recorded_pass_errors_match_the_reference(oracle_lib):
     assert e.value.status == _ffi.ERR_TOO_MANY_NESTED_OPACITY_GROUPS
     with pytest.raises(ContrastError):
         scene.render_draws(frame, t, c, [(9, 0, Op.Stencil, 0, 0)])  # no such Shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+@pytest.mark.parametrize("pin", ["CRH_EDGE_PASS", "CRH_TRIANGLE_PASS"])
+def test_an_opaque_cover_that_does_not_overwrite_its_tiles(msaa, pin, oracle_lib, monkeypatch):
+    """The raster kernel's late start of a tile's list must notice when the opaque cover it relies on does not paint every sample: a
+    counter-clockwise rectangle is stencilled (winding -1) between an opaque background and an opaque foreground; inside it the
+    foreground's +1 sums to zero, the stencil test fails, and the BACKGROUND stays visible (renderer.rs:340-354, 577-582) — in tiles that
+    lie wholly inside all three shapes the kernel starts behind the background's cover, finds the foreground not overwriting, and does
+    the tile again from the top. Also with a translucent background (the colour under the hole then needs the whole history)."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    monkeypatch.setenv(pin, "1")
+    hole = Path.from_rect((0.1, -0.05), (0.45, 0.4))
+    hole.reverse()
+    shapes = [rect(0.0, 0.0, 0.95, 0.95), rect(0.05, 0.0, 0.9, 0.85), ([], [hole]), rect(0.0, 0.0, 0.8, 0.8)]
+    batch = batch_from_shapes(shapes)
+    t = np.tile(IDENTITY, (4, 1))
+    draws = [(0, 0, Op.Stencil, 0, 0), (0, 0, Op.Color, 0, 0), (1, 1, Op.Stencil, 0, 0), (1, 1, Op.Color, 0, 0),
+             (2, 2, Op.Stencil, 0, 0),                                       # no Color: the winding stays in the stencil
+             (3, 3, Op.Stencil, 0, 0), (3, 3, Op.Color, 0, 0)]
+    for background_alpha in (1.0, 0.5):
+        c = np.array([[0.2, 0.3, 0.9, 1.0], [0.1, 0.8, 0.3, background_alpha], [0, 0, 0, 1], [0.9, 0.2, 0.1, 1.0]], dtype=np.float32)
+        r = R.Renderer(R.Configuration(msaa_sample_count=msaa, clip_nesting_counter_bits=4, winding_counter_bits=4, alpha_layer_count=2), device=0)
+        scene = R.Scene(r, batch)
+        assert scene.status() == 0
+        frame = R.Frame(r, 256, 256)
+        frame.clear()
+        scene.render_draws(frame, t, c, draws)
+        image = frame.download()
+        expect = oracle_image(batch, t, c, draws, size=256, msaa=msaa)
+        assert np.array_equal(image, expect), f"{(image != expect).any(axis=2).sum()} pixels differ"
+        inside_hole, outside = image[128 + 6, 128 + 13], image[128 + 90, 128]  # (y down) a pixel inside the hole, one below it inside the foreground
+        assert tuple(outside[:3]) == (230, 51, 26) and tuple(inside_hole[:3]) != (230, 51, 26)  # the hole shows what lies under the foreground
