@@ -258,7 +258,7 @@ struct crh_frame {
     bool check_pending = false;
 };
 
-constexpr int kTessBufs = 31; // buffers a tessellation run writes (crh_scene::tess_bufs)
+constexpr int kTessBufs = 32; // buffers a tessellation run writes (crh_scene::tess_bufs)
 struct crh_scene {
     crh_renderer* renderer; // nullptr once the renderer has been destroyed (only crh_scene_destroy is valid then)
     int device = 0;
@@ -272,7 +272,7 @@ struct crh_scene {
     // inputs
     DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
     // scan state
-    DevBuf elem_scan, wg_total, wg_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status;
+    DevBuf elem_scan, wg_total, wg_base, group_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status;
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
@@ -328,7 +328,7 @@ struct crh_scene {
     uint8_t pass_known[16] = {}; // choices already measured, by size class: a Scene drawn into a large frame and a thumbnail in turn measures twice, not for ever
     float pass_ms[2] = {0.0f, 0.0f};
     void tess_bufs(DevBuf* (&out)[kTessBufs]) {
-        DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
+        DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                                   &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut, &line_pair_mode,
                                   &line_inc, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
         for (int i = 0; i < kTessBufs; ++i) out[i] = all[i];
@@ -339,7 +339,7 @@ struct crh_scene {
 
     void release_all() {
         DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
-                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
+                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
         for (DevBuf* b : all) b->release();
@@ -404,6 +404,7 @@ void bind_tess_pointers(crh_scene* sc) {
     d.elem_scan = sc->elem_scan.as<ElemScan>();
     d.wg_total = sc->wg_total.as<uint32_t>();
     d.wg_base = sc->wg_base.as<uint32_t>();
+    d.group_base = sc->group_base.as<uint32_t>();
     d.totals = sc->totals.as<uint32_t>();
     d.shape_base = sc->shape_base.as<uint32_t>();
     d.hull_count = sc->hull_count.as<uint32_t>();
@@ -1252,7 +1253,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     }
 #undef UP
     if (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
-        !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") ||
+        !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->group_base.ensure(((size_t)d.n_wg / 64 + 2) * NCH * 4), "hipMalloc") ||
         !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
         !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((3 * (size_t)b->n_shapes + 4) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||

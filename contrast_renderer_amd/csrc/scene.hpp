@@ -80,7 +80,8 @@ struct SceneDev {
     // ---- scan state ----
     ElemScan* elem_scan;   // [n_elems]
     uint32_t* wg_total;    // [n_wg][NCH]
-    uint32_t* wg_base;     // [n_wg][NCH]
+    uint32_t* wg_base;     // [n_wg][NCH]: exclusive prefix of the row inside its group of 64 rows (k_scan_rows)
+    uint32_t* group_base;  // [n_wg / 64 + 2][NCH]: exclusive prefix of the group (k_scan_groups); its first NCH words double as the group totals before that
     uint32_t* totals;      // [NCH]
     uint32_t* shape_base;  // [n_shapes + 1][NCH] global exclusive prefix at each shape's first element
     // ---- outputs ----
@@ -112,6 +113,9 @@ struct SceneDev {
 __device__ __forceinline__ void raise_error(const SceneDev& s, uint32_t path, uint32_t code) { atomicMin(s.status, (path << 8) | code); }
 
 // global exclusive prefix of channel ch at element e
-__device__ __forceinline__ uint32_t gscan(const SceneDev& s, uint32_t e, int ch) { return s.wg_base[(e >> kTessBlockShift) * NCH + ch] + s.elem_scan[e].v[ch]; }
+__device__ __forceinline__ uint32_t gscan(const SceneDev& s, uint32_t e, int ch) {
+    const uint32_t row = e >> kTessBlockShift;
+    return s.group_base[(row >> 6) * NCH + ch] + s.wg_base[row * NCH + ch] + s.elem_scan[e].v[ch];
+}
 
 } // namespace crh

@@ -181,61 +181,51 @@ __global__ __launch_bounds__(kTessBlock) void k_count(SceneDev s) {
 }
 
 // ------------------------------------------------------------------------------------------------ k_scan
-constexpr uint32_t kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void k_scan(SceneDev s) {
-    // One block; lane = workgroup row, kScanThreads consecutive rows per pass (neighbouring lanes read neighbouring rows), all ten channels
-    // scanned together: a wave scan per channel, then (wave, channel) threads turn the wave totals in LDS into per-wave offsets. A pass
-    // waits for its rows to arrive from memory, so the passes are few and the next pass's rows are requested before this one's are summed.
-    // (256 threads with a contiguous chunk of rows each, summed serially and read twice, took 74 us on the 50 000 glyph scene — 5300 rows.)
-    constexpr uint32_t kWaves = kScanThreads / 64u;
-    __shared__ uint32_t wave_total[kWaves][NCH], wave_before[kWaves][NCH], pass_total[NCH];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t total[NCH]; // of the rows before this pass
+// The scan over the workgroups' totals (rows) in two small launches of SINGLE-WAVE workgroups: k_scan_rows — a wavefront per group of 64
+// rows: exclusive prefix inside the group (all ten channels, wave shuffles), group totals; k_scan_groups — one wavefront: exclusive prefix of
+// the groups, scene totals, sentinel rows. gscan() adds group_base + wg_base + elem_scan. (One 1024-thread workgroup did it in one launch — 45 us
+// for the 5300 rows of the 50 000 glyph scene — but sixteen wavefronts need sixteen free slots on ONE compute unit, and next to the raster kernel of
+// the frame before they waited for its whole grid to drain: 1.3 ms in the run on the 100 000 path scene.)
+__global__ __launch_bounds__(64) void k_scan_rows(SceneDev s) {
+    const uint32_t lane = threadIdx.x, w = blockIdx.x * 64u + lane;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) total[c] = 0;
-    uint32_t next[NCH];
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t mine = w < s.n_wg ? s.wg_total[w * NCH + c] : 0u;
+        uint32_t v = mine;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) next[c] = threadIdx.x < s.n_wg ? s.wg_total[threadIdx.x * NCH + c] : 0u;
-    for (uint32_t first = 0; first < s.n_wg; first += kScanThreads) {
-        const uint32_t w = first + threadIdx.x, w_next = w + kScanThreads;
-        uint32_t mine[NCH], incl[NCH];
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += up;
+        }
+        if (w < s.n_wg) s.wg_base[w * NCH + c] = v - mine;
+        if (lane == 63) s.group_base[blockIdx.x * NCH + c] = v; // the group's total: k_scan_groups turns it into the group's base
+    }
+}
+__global__ __launch_bounds__(64) void k_scan_groups(SceneDev s) {
+    const uint32_t lane = threadIdx.x, n_groups = (s.n_wg + 63u) / 64u;
+    uint32_t running[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) mine[c] = next[c];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) next[c] = w_next < s.n_wg ? s.wg_total[w_next * NCH + c] : 0u;
+    for (int c = 0; c < NCH; ++c) running[c] = 0;
+    for (uint32_t first = 0; first < n_groups; first += 64u) {
+        const uint32_t g = first + lane;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            uint32_t v = mine[c];
+            const uint32_t mine = g < n_groups ? s.group_base[g * NCH + c] : 0u;
+            uint32_t v = mine;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t up = __shfl_up(v, d, 64);
                 if (lane >= (uint32_t)d) v += up;
             }
-            incl[c] = v;
-            if (lane == 63) wave_total[wave][c] = v;
+            if (g < n_groups) s.group_base[g * NCH + c] = running[c] + v - mine;
+            running[c] += (uint32_t)__shfl((int)v, 63, 64);
         }
-        __syncthreads();
-        if (threadIdx.x < kWaves * NCH) { // thread (k, c): the rows of the waves before wave k; thread (kWaves - 1, c) also the pass total
-            const uint32_t k = threadIdx.x / NCH, c = threadIdx.x - k * NCH;
-            uint32_t before = 0;
-            for (uint32_t j = 0; j < k; ++j) before += wave_total[j][c];
-            wave_before[k][c] = before;
-            if (k == kWaves - 1u) pass_total[c] = before + wave_total[k][c];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (w < s.n_wg) s.wg_base[w * NCH + c] = total[c] + wave_before[wave][c] + incl[c] - mine[c];
-            total[c] += pass_total[c];
-        }
-        // (the next pass writes wave_total only after every thread has passed the second barrier, and wave_before / pass_total only after
-        // its own first barrier, which the readers above reach first)
     }
-    if (threadIdx.x < NCH) {
-        const uint32_t c = threadIdx.x;
+    if (lane < NCH) {
+        const uint32_t c = lane;
         uint32_t t = 0;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) t = c == (uint32_t)k ? total[k] : t;
+        for (int k = 0; k < NCH; ++k) t = c == (uint32_t)k ? running[k] : t;
         s.totals[c] = t;
         // the sentinel row, and the rows of trailing empty Shapes (they have no element to publish them)
         for (uint32_t shape = s.n_shapes;; --shape) {
@@ -688,7 +678,8 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*
     }
     hipLaunchKernelGGL(k_count, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
     if (mark) mark(ctx, "tess_count", bytes[0]);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(kScanThreads), 0, stream, s);
+    hipLaunchKernelGGL(k_scan_rows, dim3((s.n_wg + 63u) / 64u), dim3(64), 0, stream, s);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(64), 0, stream, s);
     if (mark) mark(ctx, "tess_scan", bytes[1]);
 }
 void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes) {
