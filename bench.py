@@ -124,6 +124,137 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
+def run_loopback(args, size, scaling, np):
+    """ONE GPU plays all N ranks: shard k of the scene -> its own Scene and full-size layer, the N layers -> crh_comm_local_exchange.
+    A step = tessellate + render of every shard + the exchange; what a rank of an N-GPU node does per step is 1/N of the former and its
+    part of the latter, so the line also reports the exchange alone: GPU time per phase (HIP events on each rank's stream), bytes each
+    rank puts on the wire against dense slabs, and the transfer time those bytes cost at one xGMI link per peer."""
+    from contrast_renderer_amd import scenes
+    from contrast_renderer_amd.renderer import FORMAT_RGBA8, FORMAT_RGBA16F, Comm, Configuration, Frame, Renderer, Scene, shard_range
+    n = args.loopback
+    fmt = FORMAT_RGBA16F if args.layers == "rgba16f" else FORMAT_RGBA8
+    renderer = Renderer(Configuration(msaa_sample_count=1, clip_nesting_counter_bits=4, winding_counter_bits=4), device=0)
+    shards = []
+    if scaling == "strong":
+        sc = scenes.scene_cubic_fill(args.paths, size, config_index=2)
+        for k in range(n):
+            lo, hi = shard_range(args.paths, k, n)
+            shards.append((sc["batch"].slice_shapes(lo, hi), sc["transforms"][lo:hi], sc["colors"][lo:hi]))
+    else:
+        for k in range(n):
+            one = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=k * args.paths)
+            shards.append((one["batch"], one["transforms"], one["colors"]))
+    scene_objs, layers = [], []
+    for batch, t, c in shards:
+        scene = Scene(renderer, batch, tessellate=True)
+        scene.check()
+        scene.set_instances(t, c)
+        scene_objs.append(scene)
+        layers.append(Frame(renderer, *size, fmt))
+    comms = [Comm(renderer, 0, n)]
+    comms += [Comm(renderer, k, n, rank0=comms[0]) for k in range(1, n)]
+    result = Frame(renderer, *size)
+
+    def draw():
+        for scene, layer in zip(scene_objs, layers):
+            scene.tessellate()
+            layer.clear()
+            scene.render(layer)
+
+    def step():
+        draw()
+        comms[0].local_exchange(layers, result)
+
+    for _ in range(6 + args.warmup):  # (the library's pass trial, as in the default run)
+        step()
+    renderer.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    renderer.synchronize()
+    for c in comms:
+        c.last_timing()  # waits for the communicator's stream: the tail of the last exchange is inside the clock
+    elapsed = time.perf_counter() - t0
+    # the exchange alone: layers final, nothing else on the GPU
+    wall, phases = [], []
+    for _ in range(5):
+        renderer.synchronize()
+        t1 = time.perf_counter()
+        comms[0].local_exchange(layers, result)
+        per_rank = [c.last_timing() for c in comms]
+        wall.append(time.perf_counter() - t1)
+        phases.append(per_rank)
+    last = phases[-1]
+    phase_ms = {name: {"max_over_ranks": max(p[name] for p in last), "sum_over_ranks": sum(p[name] for p in last)} for name in Comm.PHASES}
+    # the drawing alone (all N shards, no exchange)
+    renderer.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        draw()
+    renderer.synchronize()
+    draw_s = (time.perf_counter() - t2) / max(1, args.steps)
+    traffic = [c.last_traffic() for c in comms]
+    peers = [c.last_peer_bytes() for c in comms]
+    link_gbs = 153.0  # one xGMI link between every pair of GPUs of the node, per direction (MI355X_MICROARCH.md)
+    tile_bytes = 2048 if fmt == FORMAT_RGBA16F else 1024
+    n_tiles = ((size[0] + 15) // 16) * ((size[1] + 15) // 16)
+    gather_bytes = [t[0] - sum(p) for t, p in zip(traffic, peers)]  # what a rank sends to rank 0 in the gather
+    total_paths = args.paths if scaling == "strong" else args.paths * n
+    step_s = elapsed / max(1, args.steps)
+    image = result.download()
+    out = {
+        "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)",
+        "value": total_paths / step_s,
+        "unit": "paths/s",
+        "mpixel_per_s": size[0] * size[1] / step_s / 1e6,
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3,
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"LOOPBACK x{n} on ONE GPU — {'BASELINE configs[3]' if args.workload == 's100k' else 'BASELINE configs[1]'}: {total_paths} filled closed cubic paths, "
+                         f"{size[0]}x{size[1]}, msaa 1; the {n} contiguous shards ({scaling}) are rendered one after the other into {n} {args.layers} layers, then "
+                         "crh_comm_local_exchange (occupancy bitmaps, sparse slab all-to-all, ordered over-composite, gather: csrc/comm.hip with D2D copies in place of RCCL)"),
+            "paths_total": int(total_paths),
+            "parallelism": f"one GPU plays {n} ranks; `value` = {total_paths} paths / (all {n} shards drawn + one exchange) — NOT an {n}-GPU number",
+            "covered_fraction": float((image[..., 3] > 0).mean()),
+        },
+        "loopback": {
+            "ranks": n,
+            "draw_all_shards_ms": draw_s * 1e3,
+            "draw_per_rank_ms": draw_s * 1e3 / n,
+            "exchange_wall_ms": {"median": sorted(wall)[len(wall) // 2] * 1e3, "min": min(wall) * 1e3,
+                                 "note": f"host clock around crh_comm_local_exchange + its completion, all {n} ranks' kernels and copies on one GPU"},
+            "exchange_phase_ms": phase_ms,
+            "bytes_sent_per_rank": [t[0] for t in traffic],
+            "bytes_dense_per_rank": [t[1] for t in traffic],
+            "sent_over_dense": sum(t[0] for t in traffic) / max(1, sum(t[1] for t in traffic)),
+            "tile_bytes": tile_bytes,
+            "n_tiles": n_tiles,
+            "xgmi_estimate": {
+                "link_GBps": link_gbs,
+                "alltoall_ms": max(max(p) for p in peers) / (link_gbs * 1e9) * 1e3,
+                "gather_ms": max(gather_bytes) / (link_gbs * 1e9) * 1e3,
+                "note": "largest single rank->peer transfer of the all-to-all / rank->0 transfer of the gather at one link's bandwidth: every pair of GPUs "
+                        "has its own link, all transfers of a phase run at once — an estimate from measured bytes, NOT a measurement (no multi-GPU box here)",
+            },
+            "per_rank_estimate_ms": {
+                "draw": draw_s * 1e3 / n,
+                "exchange_gpu_phases_max": sum(v["max_over_ranks"] for v in phase_ms.values()),
+                "note": f"what ONE rank of an {n}-GPU node spends per step: 1/{n} of the drawing + its own exchange phases (kernels measured here; transfers per xgmi_estimate); "
+                        "the exchange of step i overlaps the drawing of step i + 1 (bench.py --gpus N)",
+            },
+        },
+        "roofline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +269,10 @@ def main():
                     "torch.distributed statement of the same exchange (contrast_renderer_amd/distributed.py), dense slabs — validation only")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only; implies --exchange torch)")
     ap.add_argument("--check", action="store_true", help="N > 1: rank 0 also renders every shard itself and compares the composite of those layers with the gathered image")
+    ap.add_argument("--loopback", type=int, default=0, help="N > 1 (with --gpus 1): ONE GPU plays all N ranks of the sharded path — the N shards are rendered one after "
+                    "the other into N layers and exchanged through crh_comm_local_exchange (csrc/comm.hip with device-to-device copies in place of RCCL): "
+                    "the whole of BASELINE configs[3] on one box, with the exchange's per-phase GPU time and bytes on the wire")
+    ap.add_argument("--layers", default="rgba8", choices=("rgba8", "rgba16f"), help="--loopback: storage format of the per-rank layers")
     ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed", "s100k"),
                     help="cubic = BASELINE configs[1] (the metric's configuration); glyphs = configs[2]; dashed = configs[4]; s100k = configs[3] (100k paths @ 8192^2, split over the ranks)")
     args = ap.parse_args()
@@ -172,6 +307,10 @@ def main():
     scaling = args.scaling
     if args.workload == "s100k":
         args.paths, size, scaling = 100000, (8192, 8192), "strong"
+    if args.loopback > 1:
+        if world != 1 or args.workload not in ("cubic", "s100k"):
+            raise SystemExit("--loopback N runs in one process on one GPU (--gpus 1), workloads cubic / s100k")
+        return run_loopback(args, size, scaling, np)
     if args.workload in ("cubic", "s100k"):
         label = "BASELINE configs[1]" if args.workload == "cubic" else "BASELINE configs[3]"
         if scaling == "weak" or world == 1:

@@ -246,6 +246,8 @@ def load_library():
         "crh_scene_traffic": (C.c_int, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "crh_scene_set_dynamic_stroke_options": (C.c_int, [V, C.c_uint32, C.c_uint32, C.POINTER(DynamicStrokeOptionsC)]),
         "crh_frame_create": (C.c_int, [V, C.c_uint32, C.c_uint32, C.POINTER(V)]),
+        "crh_frame_create_format": (C.c_int, [V, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(V)]),
+        "crh_frame_format": (C.c_int, [V, C.POINTER(C.c_uint32)]),
         "crh_frame_destroy": (None, [V]),
         "crh_frame_clear": (C.c_int, [V]),
         "crh_frame_synchronize": (C.c_int, [V]),
@@ -257,6 +259,7 @@ def load_library():
         "crh_scene_render_resident": (C.c_int, [V, V]),
         "crh_scene_render_draws": (C.c_int, [V, V, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(DrawC), C.c_uint32]),
         "crh_frame_download": (C.c_int, [V, V]),
+        "crh_frame_download_f16": (C.c_int, [V, V]),
         "crh_frame_device_pointer": (C.c_int, [V, C.POINTER(V)]),
         "crh_composite_over": (C.c_int, [V, C.POINTER(V), C.c_uint32, C.c_uint64, V]),
         "crh_comm_shard": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -268,6 +271,8 @@ def load_library():
         "crh_frame_exchange": (C.c_int, [V, V, V]),
         "crh_comm_local_exchange": (C.c_int, [V, C.POINTER(V), V]),
         "crh_comm_last_traffic": (C.c_int, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "crh_comm_last_timing": (C.c_int, [V, C.POINTER(C.c_float)]),
+        "crh_comm_last_peer_bytes": (C.c_int, [V, C.POINTER(C.c_uint64)]),
         "crh_renderer_synchronize": (C.c_int, [V]),
         "crh_renderer_stream": (V, [V]),
         "crh_renderer_enable_timing": (C.c_int, [V, C.c_int]),

@@ -220,7 +220,15 @@ struct crh_frame {
     crh_renderer* renderer; // nullptr once the renderer has been destroyed (only crh_frame_destroy is valid then)
     int device = 0;
     uint32_t width, height, tiles_x, tiles_y, n_tiles;
+    uint32_t format = CRH_FORMAT_RGBA8; // CRH_FORMAT_RGBA16F: a layer of the multi-GPU exchange kept at half precision (8 bytes per pixel)
+    size_t pixel_bytes() const { return format == CRH_FORMAT_RGBA16F ? 8u : 4u; }
+    size_t image_bytes() const { return (size_t)width * height * pixel_bytes(); }
     DevBuf rgba8;
+    // The exchange (csrc/comm.hip) reads a layer and writes the result frame on a stream of its own and does not wait for either on the
+    // host: ext_read = its last read of this frame's pixels, ext_write = its last write. Whatever touches the pixels next is ordered
+    // behind them on its stream (order_after_external).
+    hipEvent_t ext_read = nullptr, ext_write = nullptr;
+    bool ext_read_set = false, ext_write_set = false;
     // Two sets of binning buffers, used alternately: frame N + 1 is binned while frame N's raster kernel still reads the other set.
     struct BinSet {
         DevBuf tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
@@ -755,6 +763,13 @@ uint32_t depth_pass_mask(uint32_t compare) { // bit 0: fragment < stored passes,
 
 crh_status settle_frame(crh_frame* f);
 crh_status settle_frame_cheaply(crh_frame* f);
+// whatever touches the frame's pixels on `stream` next runs behind the exchange's last read and write of them (csrc/comm.hip)
+hipError_t order_after_external(crh_frame* f, hipStream_t stream) {
+    hipError_t e = hipSuccess;
+    if (f->ext_read_set) e = hipStreamWaitEvent(stream, f->ext_read, 0);
+    if (e == hipSuccess && f->ext_write_set) e = hipStreamWaitEvent(stream, f->ext_write, 0);
+    return e;
+}
 // The check whether a frame's optimistic tile-list capacity sufficed is deferred to the next call that synchronises; its remedy renders
 // the frame again FROM THE SCENE, so the scene must still hold what the frame shows: everything that changes a scene (new geometry,
 // instance data, stroke descriptors, destruction) first settles the frames that were rendered from it.
@@ -880,6 +895,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.pair_cursor = set.overflow.as<uint32_t>() + 8; // 64 sub-stream cursors
     p.sort_capacity = f->sort_capacity;
     p.rgba8 = f->rgba8.as<uint8_t>();
+    p.format = f->format;
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
     p.occlude = tame_colors ? 1u : 0u;
     r->begin_marks(2);
@@ -933,11 +949,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     HIP_TRY(hipEventRecord(set.bin_done, bin));
     // ---- raster lane
     HIP_TRY(hipStreamWaitEvent(r->stream, set.bin_done, 0));
+    HIP_TRY(order_after_external(f, r->stream));
     r->begin_marks(0);
     if (trial) HIP_TRY(hipEventRecord(trial->e[4], r->stream));
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
-    const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->width * f->height * 4;
+    const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->image_bytes();
     if (edges)
         launch_raster_edges(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     else
@@ -1415,19 +1432,27 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* sc, uint32_t shape, u
     return CRH_OK;
 }
 
-crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, crh_frame** out) {
+crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, crh_frame** out) { return crh_frame_create_format(r, width, height, CRH_FORMAT_RGBA8, out); }
+crh_status crh_frame_format(const crh_frame* f, uint32_t* format) {
+    if (!f || !format) return CRH_ERR_INVALID_ARGUMENT;
+    *format = f->format;
+    return CRH_OK;
+}
+crh_status crh_frame_create_format(crh_renderer* r, uint32_t width, uint32_t height, uint32_t format, crh_frame** out) {
     // pixel boxes are 16-bit (0xFFFF = nothing to draw), so a frame is at most 65 535 pixels wide and high
-    if (!r || !out || width == 0 || height == 0 || width > 65535u || height > 65535u) return CRH_ERR_INVALID_ARGUMENT;
+    if (!r || !out || width == 0 || height == 0 || width > 65535u || height > 65535u || format > CRH_FORMAT_RGBA16F) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     crh_frame* f = new crh_frame;
     f->renderer = r;
+    f->format = format;
     f->device = r->device;
     f->width = width;
     f->height = height;
     f->tiles_x = (width + 15) / 16;
     f->tiles_y = (height + 15) / 16;
     f->n_tiles = f->tiles_x * f->tiles_y;
-    bool ok = hip_ok(f->rgba8.ensure((size_t)width * height * 4), "hipMalloc frame");
+    bool ok = hip_ok(f->rgba8.ensure(f->image_bytes()), "hipMalloc frame") && hip_ok(hipEventCreateWithFlags(&f->ext_read, hipEventDisableTiming), "hipEventCreate") &&
+              hip_ok(hipEventCreateWithFlags(&f->ext_write, hipEventDisableTiming), "hipEventCreate");
     for (crh_frame::BinSet& set : f->sets)
         ok = ok && hip_ok(set.tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") && hip_ok(set.tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") &&
              hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") && hip_ok(set.overflow.ensure(512), "hipMalloc") &&
@@ -1437,7 +1462,7 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
         crh_frame_destroy(f);
         return CRH_ERR_HIP;
     }
-    HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)width * height * 4, r->stream));
+    HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, f->image_bytes(), r->stream));
     if (r->config.depth_compare != CRH_COMPARE_ALWAYS || r->config.depth_write_enabled) { // the depth attachment, cleared to 1.0 (main.rs:223-226)
         const size_t n = (size_t)width * height * r->config.msaa_sample_count;
         HIP_TRY(f->depth.ensure(n * 4));
@@ -1452,6 +1477,8 @@ crh_status crh_frame_create(crh_renderer* r, uint32_t width, uint32_t height, cr
 void crh_frame_destroy(crh_frame* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
+    if (f->ext_read_set) (void)hipEventSynchronize(f->ext_read);
+    if (f->ext_write_set) (void)hipEventSynchronize(f->ext_write);
     if (f->renderer) {
         (void)f->renderer->sync();
         for (size_t i = 0; i < f->renderer->frames.size(); ++i)
@@ -1471,6 +1498,14 @@ void crh_frame_destroy(crh_frame* f) {
         for (DevBuf* b : bins) b->release();
         if (set.bin_done) (void)hipEventDestroy(set.bin_done);
         if (set.raster_done) (void)hipEventDestroy(set.raster_done);
+    }
+    if (f->ext_read) { // an exchange may still be reading or writing the pixels on its own stream
+        if (f->ext_read_set) (void)hipEventSynchronize(f->ext_read);
+        (void)hipEventDestroy(f->ext_read);
+    }
+    if (f->ext_write) {
+        if (f->ext_write_set) (void)hipEventSynchronize(f->ext_write);
+        (void)hipEventDestroy(f->ext_write);
     }
     delete f;
 }
@@ -1596,7 +1631,10 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
     }
     if (items.empty()) { // an empty pass still resolves a cleared frame
         f->n_items = 0;
-        if (f->cleared) HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)f->width * f->height * 4, r->stream));
+        if (f->cleared) {
+            HIP_TRY(order_after_external(f, r->stream));
+            HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, f->image_bytes(), r->stream));
+        }
         f->cleared = false;
         return CRH_OK;
     }
@@ -1654,20 +1692,25 @@ crh_status crh_scene_render(crh_scene* sc, crh_frame* f, const float* transforms
     if (st != CRH_OK) return st;
     return crh_scene_render_resident(sc, f);
 }
-crh_status crh_frame_download(crh_frame* f, void* rgba8) {
-    if (!f || !rgba8) return CRH_ERR_INVALID_ARGUMENT;
+namespace {
+crh_status download_pixels(crh_frame* f, void* out, uint32_t format) {
+    if (!f || !out || f->format != format) return CRH_ERR_INVALID_ARGUMENT;
     crh_renderer* r = f->renderer;
     HIP_TRY(hipSetDevice(r->device));
     crh_status st = settle_frame(f);
     if (st != CRH_OK) return st;
     if (f->cleared) { // LoadOp::Clear without a pass since: transparent
-        memset(rgba8, 0, (size_t)f->width * f->height * 4);
+        memset(out, 0, f->image_bytes());
         return CRH_OK;
     }
-    HIP_TRY(hipMemcpyAsync(rgba8, f->rgba8.p, (size_t)f->width * f->height * 4, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(order_after_external(f, r->stream));
+    HIP_TRY(hipMemcpyAsync(out, f->rgba8.p, f->image_bytes(), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
     return CRH_OK;
 }
+} // namespace
+crh_status crh_frame_download(crh_frame* f, void* rgba8) { return download_pixels(f, rgba8, CRH_FORMAT_RGBA8); }
+crh_status crh_frame_download_f16(crh_frame* f, void* rgba16f) { return download_pixels(f, rgba16f, CRH_FORMAT_RGBA16F); }
 extern "C" crh_status crh_debug_frame_counters(crh_frame* f, uint32_t out[8]) { // tools only (not in the public header)
     HIP_TRY(hipSetDevice(f->renderer->device));
     HIP_TRY(f->renderer->sync());
@@ -1692,32 +1735,46 @@ crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
     if (!f || !out) return CRH_ERR_INVALID_ARGUMENT;
     crh_status st = settle_frame(f);
     if (st != CRH_OK) return st;
-    if (f->cleared) { // LoadOp::Clear without a pass since: the buffer still holds the previous pass' pixels, the frame is transparent
-        HIP_TRY(hipSetDevice(f->renderer->device));
-        HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)f->width * f->height * 4, f->renderer->stream));
-        HIP_TRY(hipStreamSynchronize(f->renderer->stream));
-    }
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    HIP_TRY(order_after_external(f, f->renderer->stream));
+    if (f->cleared) // LoadOp::Clear without a pass since: the buffer still holds the previous pass' pixels, the frame is transparent
+        HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, f->image_bytes(), f->renderer->stream));
+    HIP_TRY(hipStreamSynchronize(f->renderer->stream));
     *out = f->rgba8.p;
     return CRH_OK;
 }
 // ---- internal accessors for csrc/comm.hip (the multi-GPU exchange); not part of the public header
+crh_status crh_internal_frame_geometry(crh_frame* f, uint32_t* width, uint32_t* height, uint32_t* format, int* device) { // no waiting, cannot fail for a live frame
+    if (!f || !f->renderer || !width || !height || !format || !device) return CRH_ERR_INVALID_ARGUMENT;
+    *width = f->width, *height = f->height, *format = f->format, *device = f->renderer->device;
+    return CRH_OK;
+}
 crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device) {
     if (!f || !f->renderer || !rgba8 || !width || !height || !device) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(f->renderer->device));
     const crh_status st = settle_frame_cheaply(f); // waits for the last pass into THIS frame only: the next step may already be in flight
     if (st != CRH_OK) return st;
     if (f->cleared) { // LoadOp::Clear without a pass since: transparent
-        HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, (size_t)f->width * f->height * 4, f->renderer->aux_stream));
+        HIP_TRY(order_after_external(f, f->renderer->aux_stream));
+        HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, f->image_bytes(), f->renderer->aux_stream));
         HIP_TRY(hipStreamSynchronize(f->renderer->aux_stream));
     }
     *rgba8 = f->rgba8.p, *width = f->width, *height = f->height, *device = f->renderer->device;
     return CRH_OK;
 }
-crh_status crh_internal_frame_written(crh_frame* f) { // the exchange wrote the frame's pixels: it now shows an image, nothing is pending
+// The exchange read (written = 0) or wrote (written = 1) the frame's pixels with work enqueued on `stream`: recorded as an event, so that
+// the exchange need not wait on the host and the frame's next pass / download is ordered behind it.
+crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written) {
     if (!f) return CRH_ERR_INVALID_ARGUMENT;
-    f->cleared = false;
-    f->check_pending = false;
-    f->last_scene = nullptr;
+    HIP_TRY(hipEventRecord(written ? f->ext_write : f->ext_read, static_cast<hipStream_t>(stream)));
+    if (written) {
+        f->ext_write_set = true;
+        f->cleared = false; // it now shows an image, nothing of its own is pending
+        f->check_pending = false;
+        f->last_scene = nullptr;
+    } else {
+        f->ext_read_set = true;
+    }
     return CRH_OK;
 }
 int crh_internal_renderer_device(crh_renderer* r) { return r ? r->device : -1; }

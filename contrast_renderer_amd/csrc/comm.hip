@@ -1,25 +1,31 @@
 // csrc/comm.hip — the exchange step of the path-sharded renderer behind the C ABI (the reference has no multi-GPU
 // code, component 18 of SURVEY.md §2 is absent upstream).
 //
-// One process per GPU. Rank g renders the contiguous Shape range crh_comm_shard() gives it into a private full-size premultiplied RGBA8
-// layer; this file turns the `world` layers into one image on rank 0:
-//   1. occupancy   a bitmap of the layer's 16x16 tiles that hold anything, and the non-empty tiles packed in tile order (1 KiB each);
-//   2. all-gather  of the bitmaps (n_tiles / 8 bytes per rank) — afterwards every rank can compute every transfer size on the host;
+// One process per GPU. Rank g renders the contiguous Shape range crh_comm_shard() gives it into a private full-size premultiplied
+// layer (RGBA8, or RGBA16F: CRH_FORMAT_RGBA16F frames); this file turns the `world` layers into one RGBA8 image on rank 0:
+//   1. occupancy   a bitmap of the layer's 16x16 tiles that hold anything, and the non-empty tiles packed in tile order (1 or 2 KiB each);
+//   2. all-gather  of [4 header words | bitmap] (n_tiles / 8 bytes per rank) — afterwards every rank can compute every transfer size on
+//                  the host, and knows whether every rank's layer was readable (header: magic, width, height | format << 24, status);
 //   3. all-to-all  the frame is cut into `world` slabs of tile rows; rank r receives the non-empty tiles of slab r of every layer: one
 //                  grouped ncclSend / ncclRecv per peer, so a GPU drives all its xGMI links at once with 1/world of what it drew (xGMI is
 //                  point to point: a ring reduction would be per-link bound and world - 1 steps deep, and "over" does not commute);
 //   4. composite   rank r blends its slab in rank order — dst = src + dst * (1 - src.a), lower rank underneath — reading only the tiles
-//                  that exist, and packs the non-empty result tiles;
+//                  that exist, quantises ONCE to RGBA8 and packs the non-empty result tiles;
 //   5. gather      those go to rank 0 (again only non-empty tiles), which unpacks them into the result frame.
 // Empty tiles never travel: for the benchmark scene a rank's layer of 1/8 of the Shapes is mostly empty.
-// Transports: RCCL (librccl.so is opened on first use, so single-GPU users need no RCCL) and an in-process loopback over several
-// communicators of ONE device (crh_comm_create_local / crh_comm_local_exchange), which runs the same kernels and host logic and is what
-// the single-GPU tests drive.
+// Host synchronisation: ONE wait per exchange, for the gathered bitmaps in pinned memory (the transfer sizes ncclSend / ncclRecv take are
+// host arguments). Reads of the layer and writes of the result frame are handed to the frames as events (crh_internal_frame_touched), so
+// the call returns with the tail of the exchange still in flight on the communicator's stream.
+// Transports: RCCL (the librccl the process has already mapped, else librccl.so; resolved on first use, so single-GPU users need no
+// RCCL) and an in-process loopback over several communicators of ONE device (crh_comm_create_local / crh_comm_local_exchange), which
+// runs the same kernels and host logic with device-to-device copies and is what the single-GPU tests and bench.py --loopback drive.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <link.h>
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,8 +35,9 @@ namespace crh {
 void set_last_error(const std::string& text);
 }
 // internal accessors of api.hip (not part of the public header)
+extern "C" crh_status crh_internal_frame_geometry(crh_frame* f, uint32_t* width, uint32_t* height, uint32_t* format, int* device);
 extern "C" crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device);
-extern "C" crh_status crh_internal_frame_written(crh_frame* f);
+extern "C" crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written);
 extern "C" int crh_internal_renderer_device(crh_renderer* r);
 
 namespace {
@@ -38,6 +45,7 @@ using crh::set_last_error;
 
 struct Rccl { // the entry points used, resolved with dlsym
     void* lib = nullptr;
+    std::string path;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -48,14 +56,30 @@ struct Rccl { // the entry points used, resolved with dlsym
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
+// A process that imported torch has torch's bundled librccl mapped already; a second copy opened by bare name would be a second RCCL
+// runtime in one process (two sets of proxy threads and IPC state). So: the path of a librccl that is already mapped, if there is one.
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+    if (info->dlpi_name && std::strstr(info->dlpi_name, "librccl.so")) {
+        *static_cast<std::string*>(out) = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
 Rccl* rccl() {
     static Rccl api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::string loaded;
+        dl_iterate_phdr(find_loaded_rccl, &loaded);
+        std::vector<std::string> names;
+        if (!loaded.empty()) names.push_back(loaded);
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) names.push_back(name);
+        for (const std::string& name : names) {
+            api.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) {
+                api.path = name;
+                break;
+            }
         }
         if (api.lib) {
 #define CRH_SYM(field, symbol) api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, symbol))
@@ -74,7 +98,7 @@ Rccl* rccl() {
                 api.lib = nullptr;
             }
         }
-    }
+    });
     return api.lib ? &api : nullptr;
 }
 
@@ -87,13 +111,15 @@ bool hip_ok(hipError_t e, const char* what) {
     do {                                               \
         if (!hip_ok((expr), #expr)) return CRH_ERR_HIP; \
     } while (0)
-#define NCCL_TRY(expr)                                                                                                        \
-    do {                                                                                                                      \
-        const ncclResult_t rc_ = (expr);                                                                                      \
-        if (rc_ != ncclSuccess) {                                                                                             \
-            set_last_error(std::string(#expr) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(rc_) : "RCCL error")); \
-            return CRH_ERR_HIP;                                                                                               \
-        }                                                                                                                     \
+bool nccl_ok(ncclResult_t rc, const char* what) {
+    if (rc == ncclSuccess) return true;
+    Rccl* api = rccl();
+    set_last_error(std::string(what) + ": " + ((api && api->GetErrorString) ? api->GetErrorString(rc) : "RCCL error"));
+    return false;
+}
+#define NCCL_TRY(expr)                                    \
+    do {                                                  \
+        if (!nccl_ok((expr), #expr)) return CRH_ERR_HIP;  \
     } while (0)
 
 struct Buf {
@@ -117,22 +143,66 @@ struct Buf {
         return static_cast<T*>(p);
     }
 };
+struct PinnedBuf { // host memory the device copies into / out of without staging
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr, cap = 0;
+        const size_t want = bytes < 256 ? 256 : bytes;
+        const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr, cap = 0;
+    }
+    template <typename T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
 
 constexpr uint32_t kTilePixels = 256; // 16 x 16
-constexpr size_t kTileBytes = 1024;
+constexpr size_t kResultTileBytes = 1024; // a composited (RGBA8) tile
+constexpr uint32_t kHeaderWords = 4;  // in front of every rank's bitmap: magic, width, height | format << 24, status of the rank's layer
+constexpr uint32_t kMagic = 0x43524831u; // "CRH1"
 
 // ---------------------------------------------------------------------------------------------- kernels
+// A layer's pixel: P = uint32_t (RGBA8 unorm) or uint2 (four binary16).
+__device__ __forceinline__ bool pixel_nonzero(uint32_t v) { return v != 0u; }
+__device__ __forceinline__ bool pixel_nonzero(uint2 v) { return ((v.x | v.y) & 0x7FFF7FFFu) != 0u; } // (-0.0 is empty too)
+__device__ __forceinline__ void pixel_rgba(uint32_t p, float out[4]) {
+    out[0] = (float)(p & 255u) * (1.0f / 255.0f), out[1] = (float)((p >> 8) & 255u) * (1.0f / 255.0f);
+    out[2] = (float)((p >> 16) & 255u) * (1.0f / 255.0f), out[3] = (float)(p >> 24) * (1.0f / 255.0f);
+}
+__device__ __forceinline__ void pixel_rgba(uint2 p, float out[4]) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 a = __builtin_bit_cast(h2, p.x), b = __builtin_bit_cast(h2, p.y);
+    out[0] = (float)a[0], out[1] = (float)a[1], out[2] = (float)b[0], out[3] = (float)b[1];
+}
+template <typename P>
+__device__ __forceinline__ P pixel_zero();
+template <>
+__device__ __forceinline__ uint32_t pixel_zero<uint32_t>() { return 0u; }
+template <>
+__device__ __forceinline__ uint2 pixel_zero<uint2>() { return make_uint2(0u, 0u); }
+
 // bit t of `bitmap` <=> tile t of the layer holds a non-zero pixel (one workgroup per tile, one pixel per lane)
-__global__ __launch_bounds__(256) void k_tile_occupancy(const uint32_t* rgba8, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t* bitmap) {
+template <typename P>
+__global__ __launch_bounds__(256) void k_tile_occupancy(const P* pixels, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t* bitmap) {
     const uint32_t tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
     const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
-    const uint32_t v = (x < width && y < height) ? rgba8[(size_t)y * width + x] : 0u;
-    if (__syncthreads_or(v != 0u) && threadIdx.x == 0) atomicOr(&bitmap[tile >> 5], 1u << (tile & 31u));
+    const bool any = (x < width && y < height) ? pixel_nonzero(pixels[(size_t)y * width + x]) : false;
+    if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(&bitmap[tile >> 5], 1u << (tile & 31u));
 }
-// prefix[w] = number of set bits in words [0, w) of one bitmap; one workgroup per bitmap (blockIdx.x), prefix has n_words + 1 entries
-__global__ __launch_bounds__(1024) void k_bit_prefix(const uint32_t* bitmaps, uint32_t n_words, uint32_t* prefixes) {
+// prefix[w] = number of set bits in words [0, w) of one bitmap; one workgroup per bitmap (blockIdx.x): bitmap k starts at word
+// k * bitmap_stride of `bitmaps`, its prefix (n_words + 1 entries) at k * (n_words + 1) of `prefixes`
+__global__ __launch_bounds__(1024) void k_bit_prefix(const uint32_t* bitmaps, uint32_t bitmap_stride, uint32_t n_words, uint32_t* prefixes) {
     __shared__ uint32_t partial[1024];
-    const uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * n_words;
+    const uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * bitmap_stride;
     uint32_t* prefix = prefixes + (size_t)blockIdx.x * (n_words + 1u);
     const uint32_t per = (n_words + 1023u) / 1024u, begin = threadIdx.x * per, end = min(n_words, begin + per);
     uint32_t sum = 0;
@@ -157,38 +227,38 @@ __device__ __forceinline__ uint32_t tile_rank(const uint32_t* bitmap, const uint
     return prefix[tile >> 5] + (uint32_t)__popc(bitmap[tile >> 5] & ((1u << (tile & 31u)) - 1u));
 }
 // the non-empty tiles of the layer, packed in tile order: 256 pixels (row-major inside the tile) per tile
-__global__ __launch_bounds__(256) void k_pack_tiles(const uint32_t* rgba8, uint32_t width, uint32_t height, uint32_t tiles_x, const uint32_t* bitmap,
-                                                    const uint32_t* prefix, uint32_t* pack) {
+template <typename P>
+__global__ __launch_bounds__(256) void k_pack_tiles(const P* pixels, uint32_t width, uint32_t height, uint32_t tiles_x, const uint32_t* bitmap, const uint32_t* prefix, P* pack) {
     const uint32_t tile = blockIdx.x;
     if (!tile_bit(bitmap, tile)) return;
     const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
     const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
-    pack[(size_t)tile_rank(bitmap, prefix, tile) * kTilePixels + threadIdx.x] = (x < width && y < height) ? rgba8[(size_t)y * width + x] : 0u;
+    pack[(size_t)tile_rank(bitmap, prefix, tile) * kTilePixels + threadIdx.x] = (x < width && y < height) ? pixels[(size_t)y * width + x] : pixel_zero<P>();
 }
 // Rank r's slab = tiles [slab_begin, slab_end): ordered premultiplied "over" of the `world` layers (layer k = recv[k], the non-empty tiles
-// of this slab of rank k's layer in tile order), written as the non-empty tiles of the result in tile order. f32 accumulation, one
+// of this slab of rank k's layer in tile order), written as the non-empty RGBA8 tiles of the result in tile order. f32 accumulation, one
 // RGBA8 quantisation — the arithmetic of k_composite (raster.hip); a tile a layer does not have is a transparent layer (exact).
 struct CompositeJob {
-    const uint32_t* bitmaps;  // [world][n_words]
+    const uint32_t* bitmaps;  // [world] bitmaps, `bitmap_stride` words apart
     const uint32_t* prefixes; // [world][n_words + 1]
-    const uint32_t* const* recv; // [world]
+    const void* const* recv;  // [world]
     const uint32_t* or_bitmap;
     const uint32_t* or_prefix;
-    uint32_t world, n_words, slab_begin, slab_end;
+    uint32_t world, n_words, bitmap_stride, slab_begin, slab_end;
     uint32_t* out; // packed result tiles of the slab
 };
+template <typename P>
 __global__ __launch_bounds__(256) void k_composite_tiles(CompositeJob j) {
     const uint32_t tile = j.slab_begin + blockIdx.x;
     if (!tile_bit(j.or_bitmap, tile)) return;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (uint32_t k = 0; k < j.world; ++k) {
-        const uint32_t* bitmap = j.bitmaps + (size_t)k * j.n_words;
+        const uint32_t* bitmap = j.bitmaps + (size_t)k * j.bitmap_stride;
         if (!tile_bit(bitmap, tile)) continue;
         const uint32_t* prefix = j.prefixes + (size_t)k * (j.n_words + 1u);
         const uint32_t slot = tile_rank(bitmap, prefix, tile) - tile_rank(bitmap, prefix, j.slab_begin);
-        const uint32_t p = j.recv[k][(size_t)slot * kTilePixels + threadIdx.x];
-        const float sr[4] = {(float)(p & 255u) * (1.0f / 255.0f), (float)((p >> 8) & 255u) * (1.0f / 255.0f), (float)((p >> 16) & 255u) * (1.0f / 255.0f),
-                             (float)(p >> 24) * (1.0f / 255.0f)};
+        float sr[4];
+        pixel_rgba(static_cast<const P*>(j.recv[k])[(size_t)slot * kTilePixels + threadIdx.x], sr);
         const float keep = 1.0f - sr[3];
         for (int c = 0; c < 4; ++c) acc[c] = sr[c] + acc[c] * keep;
     }
@@ -200,11 +270,11 @@ __global__ __launch_bounds__(256) void k_composite_tiles(CompositeJob j) {
     const uint32_t slot = tile_rank(j.or_bitmap, j.or_prefix, tile) - tile_rank(j.or_bitmap, j.or_prefix, j.slab_begin);
     j.out[(size_t)slot * kTilePixels + threadIdx.x] = packed;
 }
-__global__ __launch_bounds__(256) void k_or_bitmaps(const uint32_t* bitmaps, uint32_t world, uint32_t n_words, uint32_t* out) {
+__global__ __launch_bounds__(256) void k_or_bitmaps(const uint32_t* bitmaps, uint32_t bitmap_stride, uint32_t world, uint32_t n_words, uint32_t* out) {
     const uint32_t w = blockIdx.x * 256u + threadIdx.x;
     if (w >= n_words) return;
     uint32_t v = 0;
-    for (uint32_t k = 0; k < world; ++k) v |= bitmaps[(size_t)k * n_words + w];
+    for (uint32_t k = 0; k < world; ++k) v |= bitmaps[(size_t)k * bitmap_stride + w];
     out[w] = v;
 }
 // rank 0: the gathered tiles -> the result frame (tiles nobody drew are cleared)
@@ -224,16 +294,28 @@ struct crh_comm {
     ncclComm_t nccl = nullptr; // RCCL transport
     std::vector<crh_comm*>* local_group = nullptr; // loopback transport: the communicators of the group, by rank (owned by rank 0's)
     hipStream_t stream = nullptr;
-    // geometry of the last exchange
-    uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0, n_tiles = 0, n_words = 0;
-    Buf bitmap, prefix, pack;        // this rank's layer
-    Buf bitmaps_all, prefixes_all;   // every rank's bitmap (all-gather) and their prefix sums
+    // geometry of the last exchange, and the geometry all ranks were found to agree on (checked once per change, with one extra wait)
+    uint32_t width = 0, height = 0, format = 0, tiles_x = 0, tiles_y = 0, n_tiles = 0, n_words = 0;
+    uint32_t agreed_width = 0, agreed_height = 0, agreed_format = 0;
+    bool agreed = false;
+    size_t tile_bytes() const { return format == CRH_FORMAT_RGBA16F ? 2048u : 1024u; }
+    uint32_t stride() const { return kHeaderWords + n_words; } // words per rank in bitmaps_all
+    Buf bitmap, prefix, pack;        // this rank's layer: [header | bitmap], prefix sums of the bitmap, the packed non-empty tiles
+    Buf bitmaps_all, prefixes_all;   // every rank's [header | bitmap] (all-gather) and the prefix sums of the bitmaps
     Buf or_bitmap, or_prefix;        // union: the tiles of the composited image
     Buf recv, recv_table;            // received slab tiles, [world] pointers into `recv`
     Buf slab_out, gathered;          // this rank's composited slab (packed); rank 0: all slabs (packed, tile order)
-    std::vector<uint32_t> host_bitmaps; // [world][n_words]
-    // statistics of the last exchange (crh_comm_last_traffic)
+    PinnedBuf host_all, host_table, host_header;  // bitmaps_all on the host; the pointer table on its way to recv_table; this rank's header on its way to `bitmap`
+    std::vector<uint32_t> or_bits;   // union of the bitmaps (host)
+    hipEvent_t bitmaps_on_host = nullptr; // THE host wait of an exchange
+    hipEvent_t phase[CRH_COMM_PHASES + 1] = {}; // timing marks around the phases of the last exchange
+    hipEvent_t packed = nullptr, composited = nullptr; // loopback: what the other communicators' streams wait for
+    bool timed = false;
+    // statistics of the last exchange (crh_comm_last_traffic / _peer_bytes)
     uint64_t bytes_sent = 0, bytes_dense = 0;
+    std::vector<uint64_t> peer_bytes;
+    const uint32_t* host_bitmap(uint32_t k) const { return host_all.as<uint32_t>() + (size_t)k * stride() + kHeaderWords; }
+    const uint32_t* host_header_of(uint32_t k) const { return host_all.as<uint32_t>() + (size_t)k * stride(); }
 };
 
 namespace {
@@ -256,122 +338,174 @@ uint32_t host_rank(const uint32_t* bitmap, uint32_t tile) { // set bits below `t
 }
 uint32_t host_count(const uint32_t* bitmap, uint32_t begin, uint32_t end) { return host_rank(bitmap, end) - host_rank(bitmap, begin); }
 
-// phase 1: occupancy bitmap, its prefix sums and the packed tiles of this rank's layer (all on the communicator's stream)
-crh_status phase_pack(crh_comm* c, crh_frame* layer) {
-    void* pixels = nullptr;
-    uint32_t w = 0, h = 0;
-    int device = 0;
-    crh_status st = crh_internal_frame_info(layer, &pixels, &w, &h, &device); // settles the frame: its pixels are final and visible
-    if (st != CRH_OK) return st;
-    if (device != c->device) return CRH_ERR_INVALID_ARGUMENT;
-    HIP_TRY(hipSetDevice(c->device));
-    c->width = w, c->height = h;
+void set_geometry(crh_comm* c, uint32_t w, uint32_t h, uint32_t format) {
+    c->width = w, c->height = h, c->format = format;
     c->tiles_x = (w + 15u) / 16u, c->tiles_y = (h + 15u) / 16u, c->n_tiles = c->tiles_x * c->tiles_y;
     c->n_words = (c->n_tiles + 31u) / 32u;
-    HIP_TRY(c->bitmap.ensure((size_t)c->n_words * 4));
+}
+crh_status ensure_buffers(crh_comm* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->bitmap.ensure((size_t)c->stride() * 4));
     HIP_TRY(c->prefix.ensure((size_t)(c->n_words + 1) * 4));
-    HIP_TRY(c->pack.ensure((size_t)c->n_tiles * kTileBytes));
-    HIP_TRY(c->bitmaps_all.ensure((size_t)c->world * c->n_words * 4));
+    HIP_TRY(c->pack.ensure((size_t)c->n_tiles * c->tile_bytes()));
+    HIP_TRY(c->bitmaps_all.ensure((size_t)c->world * c->stride() * 4));
     HIP_TRY(c->prefixes_all.ensure((size_t)c->world * (c->n_words + 1) * 4));
     HIP_TRY(c->or_bitmap.ensure((size_t)c->n_words * 4));
     HIP_TRY(c->or_prefix.ensure((size_t)(c->n_words + 1) * 4));
-    HIP_TRY(hipMemsetAsync(c->bitmap.p, 0, (size_t)c->n_words * 4, c->stream));
-    hipLaunchKernelGGL(k_tile_occupancy, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, c->bitmap.as<uint32_t>());
-    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, c->bitmap.as<uint32_t>(), c->n_words, c->prefix.as<uint32_t>());
-    hipLaunchKernelGGL(k_pack_tiles, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, c->bitmap.as<uint32_t>(),
-                       c->prefix.as<uint32_t>(), c->pack.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(c->host_all.ensure((size_t)c->world * c->stride() * 4));
+    HIP_TRY(c->host_table.ensure(sizeof(void*) * c->world));
+    HIP_TRY(c->host_header.ensure(kHeaderWords * 4));
+    HIP_TRY(c->recv_table.ensure(sizeof(void*) * c->world));
     return CRH_OK;
 }
-// phase 2 (after the bitmaps of all ranks are in bitmaps_all): prefix sums, union, host copy of the bitmaps, receive buffers
+void mark(crh_comm* c, int k) { (void)hipEventRecord(c->phase[k], c->stream); }
+
+// phase 1: [header | occupancy bitmap], its prefix sums and the packed tiles of this rank's layer (all on the communicator's stream).
+// A layer that cannot be read (its pass failed) leaves an empty bitmap and its status in the header: the rank still takes part in the
+// collectives, and every rank learns of it from the gathered headers.
+crh_status phase_pack(crh_comm* c, crh_frame* layer) {
+    uint32_t w = 0, h = 0, format = 0;
+    int device = 0;
+    crh_status st = crh_internal_frame_geometry(layer, &w, &h, &format, &device);
+    if (st != CRH_OK) return st;
+    if (device != c->device) return CRH_ERR_INVALID_ARGUMENT;
+    set_geometry(c, w, h, format);
+    if ((st = ensure_buffers(c)) != CRH_OK) return st;
+    void* pixels = nullptr;
+    const crh_status layer_status = crh_internal_frame_info(layer, &pixels, &w, &h, &device); // settles the frame: its pixels are final and visible
+    HIP_TRY(hipSetDevice(c->device));
+    mark(c, 0);
+    uint32_t* header = c->host_header.as<uint32_t>(); // (the previous exchange's copy of it was waited for with its bitmaps)
+    header[0] = kMagic, header[1] = w, header[2] = h | (format << 24), header[3] = (uint32_t)layer_status;
+    HIP_TRY(hipMemcpyAsync(c->bitmap.p, header, kHeaderWords * 4, hipMemcpyHostToDevice, c->stream));
+    uint32_t* bitmap = c->bitmap.as<uint32_t>() + kHeaderWords;
+    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)c->n_words * 4, c->stream));
+    if (layer_status == CRH_OK) {
+        if (format == CRH_FORMAT_RGBA16F)
+            hipLaunchKernelGGL(k_tile_occupancy<uint2>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, bitmap);
+        else
+            hipLaunchKernelGGL(k_tile_occupancy<uint32_t>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, bitmap);
+    }
+    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, bitmap, c->n_words, c->n_words, c->prefix.as<uint32_t>());
+    if (layer_status == CRH_OK) {
+        if (format == CRH_FORMAT_RGBA16F)
+            hipLaunchKernelGGL(k_pack_tiles<uint2>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, bitmap, c->prefix.as<uint32_t>(),
+                               c->pack.as<uint2>());
+        else
+            hipLaunchKernelGGL(k_pack_tiles<uint32_t>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, bitmap,
+                               c->prefix.as<uint32_t>(), c->pack.as<uint32_t>());
+        st = crh_internal_frame_touched(layer, c->stream, 0); // the layer's next pass is ordered behind the packing
+        if (st != CRH_OK) return st;
+    }
+    HIP_TRY(hipGetLastError());
+    mark(c, 1);
+    return CRH_OK;
+}
+// phase 2 (the [header | bitmap] records of all ranks are in bitmaps_all, or on their way there on the stream): copy to the host, prefix
+// sums and union on the device meanwhile, then THE host wait; the gathered headers decide whether the exchange goes ahead.
 crh_status phase_plan(crh_comm* c) {
-    hipLaunchKernelGGL(k_bit_prefix, dim3(c->world), dim3(1024), 0, c->stream, c->bitmaps_all.as<uint32_t>(), c->n_words, c->prefixes_all.as<uint32_t>());
-    hipLaunchKernelGGL(k_or_bitmaps, dim3((c->n_words + 255u) / 256u), dim3(256), 0, c->stream, c->bitmaps_all.as<uint32_t>(), c->world, c->n_words, c->or_bitmap.as<uint32_t>());
-    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, c->or_bitmap.as<uint32_t>(), c->n_words, c->or_prefix.as<uint32_t>());
-    c->host_bitmaps.resize((size_t)c->world * c->n_words);
-    HIP_TRY(hipMemcpyAsync(c->host_bitmaps.data(), c->bitmaps_all.p, c->host_bitmaps.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream)); // the one host synchronisation of the exchange: every transfer size follows from the bitmaps
+    HIP_TRY(hipMemcpyAsync(c->host_all.p, c->bitmaps_all.p, (size_t)c->world * c->stride() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->bitmaps_on_host, c->stream));
+    const uint32_t* first = c->bitmaps_all.as<uint32_t>() + kHeaderWords;
+    hipLaunchKernelGGL(k_bit_prefix, dim3(c->world), dim3(1024), 0, c->stream, first, c->stride(), c->n_words, c->prefixes_all.as<uint32_t>());
+    hipLaunchKernelGGL(k_or_bitmaps, dim3((c->n_words + 255u) / 256u), dim3(256), 0, c->stream, first, c->stride(), c->world, c->n_words, c->or_bitmap.as<uint32_t>());
+    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, c->or_bitmap.as<uint32_t>(), c->n_words, c->n_words, c->or_prefix.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(c->bitmaps_on_host)); // every transfer size follows from the bitmaps
+    crh_status peer = CRH_OK;
+    for (uint32_t k = 0; k < c->world; ++k) {
+        const uint32_t* hd = c->host_header_of(k);
+        if (hd[0] != kMagic || hd[1] != c->width || hd[2] != (c->height | (c->format << 24))) {
+            set_last_error("crh_frame_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
+            return CRH_ERR_INVALID_ARGUMENT; // (every rank sees the same headers and returns here together)
+        }
+        if (hd[3] != CRH_OK && peer == CRH_OK) {
+            peer = (crh_status)hd[3];
+            if (k != c->rank) set_last_error("crh_frame_exchange: the layer of rank " + std::to_string(k) + " could not be read (status " + std::to_string(hd[3]) + ")");
+        }
+    }
+    if (peer != CRH_OK) return peer;
+    c->or_bits.assign(c->n_words, 0u);
+    for (uint32_t k = 0; k < c->world; ++k) {
+        const uint32_t* b = c->host_bitmap(k);
+        for (uint32_t w = 0; w < c->n_words; ++w) c->or_bits[w] |= b[w];
+    }
     uint32_t s0, s1;
     slab_tiles(c, c->rank, &s0, &s1);
     size_t total = 0;
-    std::vector<const uint32_t*> table(c->world);
     std::vector<size_t> offset(c->world);
     for (uint32_t k = 0; k < c->world; ++k) {
         offset[k] = total;
-        total += (size_t)host_count(&c->host_bitmaps[(size_t)k * c->n_words], s0, s1) * kTileBytes;
+        total += (size_t)host_count(c->host_bitmap(k), s0, s1) * c->tile_bytes();
     }
-    HIP_TRY(c->recv.ensure(total + kTileBytes));
-    HIP_TRY(c->recv_table.ensure(sizeof(void*) * c->world));
-    for (uint32_t k = 0; k < c->world; ++k) table[k] = reinterpret_cast<const uint32_t*>(static_cast<uint8_t*>(c->recv.p) + offset[k]);
-    HIP_TRY(hipMemcpyAsync(c->recv_table.p, table.data(), sizeof(void*) * c->world, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream)); // `table` goes out of scope
+    HIP_TRY(c->recv.ensure(total + c->tile_bytes()));
+    const void** table = c->host_table.as<const void*>(); // pinned: the copy below needs no wait (the previous exchange's use of it is behind the wait above)
+    for (uint32_t k = 0; k < c->world; ++k) table[k] = static_cast<uint8_t*>(c->recv.p) + offset[k];
+    HIP_TRY(hipMemcpyAsync(c->recv_table.p, table, sizeof(void*) * c->world, hipMemcpyHostToDevice, c->stream));
+    mark(c, 2);
     return CRH_OK;
 }
 // where rank k's tiles of slab r start inside rank k's pack buffer / how many bytes they are
 void segment(const crh_comm* c, uint32_t k, uint32_t r, size_t* offset, size_t* bytes) {
     uint32_t s0, s1;
     slab_tiles(c, r, &s0, &s1);
-    const uint32_t* bitmap = &c->host_bitmaps[(size_t)k * c->n_words];
-    *offset = (size_t)host_rank(bitmap, s0) * kTileBytes;
-    *bytes = (size_t)host_count(bitmap, s0, s1) * kTileBytes;
+    const uint32_t* bitmap = c->host_bitmap(k);
+    *offset = (size_t)host_rank(bitmap, s0) * c->tile_bytes();
+    *bytes = (size_t)host_count(bitmap, s0, s1) * c->tile_bytes();
 }
-uint8_t* recv_slot(const crh_comm* c, uint32_t k) { // where layer k's tiles of my slab are received
-    size_t offset = 0;
-    uint32_t s0, s1;
-    slab_tiles(c, c->rank, &s0, &s1);
-    for (uint32_t q = 0; q < k; ++q) offset += (size_t)host_count(&c->host_bitmaps[(size_t)q * c->n_words], s0, s1) * kTileBytes;
-    return static_cast<uint8_t*>(c->recv.p) + offset;
-}
+uint8_t* recv_slot(const crh_comm* c, uint32_t k) { return static_cast<uint8_t*>(const_cast<void*>(c->host_table.as<const void*>()[k])); } // where layer k's tiles of my slab are received
 // phase 4: composite my slab (after the slab tiles of every layer are in `recv`)
 crh_status phase_composite(crh_comm* c) {
     uint32_t s0, s1;
     slab_tiles(c, c->rank, &s0, &s1);
-    std::vector<uint32_t> or_bits(c->n_words, 0u);
-    for (uint32_t k = 0; k < c->world; ++k)
-        for (uint32_t w = 0; w < c->n_words; ++w) or_bits[w] |= c->host_bitmaps[(size_t)k * c->n_words + w];
-    const size_t out_tiles = host_count(or_bits.data(), s0, s1);
-    HIP_TRY(c->slab_out.ensure(out_tiles * kTileBytes + kTileBytes));
+    const size_t out_tiles = host_count(c->or_bits.data(), s0, s1);
+    HIP_TRY(c->slab_out.ensure(out_tiles * kResultTileBytes + kResultTileBytes));
     if (s1 > s0) {
         CompositeJob j;
-        j.bitmaps = c->bitmaps_all.as<uint32_t>(), j.prefixes = c->prefixes_all.as<uint32_t>();
-        j.recv = static_cast<const uint32_t* const*>(c->recv_table.p);
+        j.bitmaps = c->bitmaps_all.as<uint32_t>() + kHeaderWords, j.prefixes = c->prefixes_all.as<uint32_t>();
+        j.recv = static_cast<const void* const*>(c->recv_table.p);
         j.or_bitmap = c->or_bitmap.as<uint32_t>(), j.or_prefix = c->or_prefix.as<uint32_t>();
-        j.world = c->world, j.n_words = c->n_words, j.slab_begin = s0, j.slab_end = s1;
+        j.world = c->world, j.n_words = c->n_words, j.bitmap_stride = c->stride(), j.slab_begin = s0, j.slab_end = s1;
         j.out = c->slab_out.as<uint32_t>();
-        hipLaunchKernelGGL(k_composite_tiles, dim3(s1 - s0), dim3(256), 0, c->stream, j);
+        if (c->format == CRH_FORMAT_RGBA16F)
+            hipLaunchKernelGGL(k_composite_tiles<uint2>, dim3(s1 - s0), dim3(256), 0, c->stream, j);
+        else
+            hipLaunchKernelGGL(k_composite_tiles<uint32_t>, dim3(s1 - s0), dim3(256), 0, c->stream, j);
     }
     HIP_TRY(hipGetLastError());
+    mark(c, 4);
     return CRH_OK;
 }
-// phase 6 (rank 0, after every slab's tiles are in `gathered`): unpack into the result frame
+// phase 6 (rank 0, after every slab's tiles are in `gathered`): unpack into the result frame; no host wait — the frame is told
 crh_status phase_unpack(crh_comm* c, crh_frame* result) {
-    void* pixels = nullptr;
-    uint32_t w = 0, h = 0;
+    uint32_t w = 0, h = 0, format = 0;
     int device = 0;
-    crh_status st = crh_internal_frame_info(result, &pixels, &w, &h, &device);
+    crh_status st = crh_internal_frame_geometry(result, &w, &h, &format, &device);
     if (st != CRH_OK) return st;
-    if (w != c->width || h != c->height || device != c->device) return CRH_ERR_INVALID_ARGUMENT;
+    if (w != c->width || h != c->height || device != c->device || format != CRH_FORMAT_RGBA8) return CRH_ERR_INVALID_ARGUMENT;
+    void* pixels = nullptr;
+    if ((st = crh_internal_frame_info(result, &pixels, &w, &h, &device)) != CRH_OK) return st; // what the frame showed so far is settled (and discarded)
+    HIP_TRY(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_unpack_tiles, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<uint32_t*>(pixels), w, h, c->tiles_x, c->or_bitmap.as<uint32_t>(),
                        c->or_prefix.as<uint32_t>(), c->gathered.as<uint32_t>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return crh_internal_frame_written(result);
+    mark(c, 6);
+    return crh_internal_frame_touched(result, c->stream, 1);
 }
 void account(crh_comm* c) { // what this rank put on the wire vs. what dense slabs would have cost
     c->bytes_sent = 0;
+    c->peer_bytes.assign(c->world, 0);
     for (uint32_t p = 0; p < c->world; ++p) {
         if (p == c->rank) continue;
         size_t off, bytes;
         segment(c, c->rank, p, &off, &bytes);
+        c->peer_bytes[p] = bytes;
         c->bytes_sent += bytes;
     }
     uint32_t s0, s1;
     slab_tiles(c, c->rank, &s0, &s1);
-    std::vector<uint32_t> or_bits(c->n_words, 0u);
-    for (uint32_t k = 0; k < c->world; ++k)
-        for (uint32_t w = 0; w < c->n_words; ++w) or_bits[w] |= c->host_bitmaps[(size_t)k * c->n_words + w];
-    if (c->rank != 0) c->bytes_sent += (size_t)host_count(or_bits.data(), s0, s1) * kTileBytes;
-    c->bytes_dense = (uint64_t)(c->n_tiles - (s1 - s0)) * kTileBytes + (c->rank != 0 ? (uint64_t)(s1 - s0) * kTileBytes : 0ull);
+    if (c->rank != 0) c->bytes_sent += (size_t)host_count(c->or_bits.data(), s0, s1) * kResultTileBytes;
+    c->bytes_dense = (uint64_t)(c->n_tiles - (s1 - s0)) * c->tile_bytes() + (c->rank != 0 ? (uint64_t)(s1 - s0) * kResultTileBytes : 0ull);
 }
 crh_status create_common(crh_renderer* r, uint32_t rank, uint32_t world, crh_comm** out) {
     if (!r || !out || world == 0 || rank >= world) return CRH_ERR_INVALID_ARGUMENT;
@@ -379,8 +513,13 @@ crh_status create_common(crh_renderer* r, uint32_t rank, uint32_t world, crh_com
     c->renderer = r;
     c->device = crh_internal_renderer_device(r);
     c->rank = rank, c->world = world;
-    if (!hip_ok(hipSetDevice(c->device), "hipSetDevice") || !hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) {
-        delete c;
+    bool ok = hip_ok(hipSetDevice(c->device), "hipSetDevice") && hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate") &&
+              hip_ok(hipEventCreateWithFlags(&c->bitmaps_on_host, hipEventDisableTiming), "hipEventCreate") &&
+              hip_ok(hipEventCreateWithFlags(&c->packed, hipEventDisableTiming), "hipEventCreate") &&
+              hip_ok(hipEventCreateWithFlags(&c->composited, hipEventDisableTiming), "hipEventCreate");
+    for (hipEvent_t& e : c->phase) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
+    if (!ok) {
+        crh_comm_destroy(c);
         return CRH_ERR_HIP;
     }
     *out = c;
@@ -428,17 +567,16 @@ crh_status crh_comm_create(crh_renderer* r, uint32_t rank, uint32_t world, const
     if (st != CRH_OK) return st;
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
-    const ncclResult_t rc = api->CommInitRank(&c->nccl, (int)world, id, (int)rank);
-    if (rc != ncclSuccess) {
-        set_last_error(std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(rc) : "RCCL error"));
-        (void)hipStreamDestroy(c->stream);
-        delete c;
+    if (!nccl_ok(api->CommInitRank(&c->nccl, (int)world, id, (int)rank), "ncclCommInitRank")) {
+        c->nccl = nullptr;
+        crh_comm_destroy(c);
         return CRH_ERR_HIP;
     }
     *out = c;
     return CRH_OK;
 }
 crh_status crh_comm_create_local(crh_renderer* r, uint32_t rank, uint32_t world, crh_comm* rank0, crh_comm** out) {
+    if (world == 0 || rank >= world) return CRH_ERR_INVALID_ARGUMENT;
     if ((rank == 0) != (rank0 == nullptr)) return CRH_ERR_INVALID_ARGUMENT; // rank 0 founds the group, the others join it
     if (rank0 && (!rank0->local_group || rank0->world != world || (*rank0->local_group)[rank] != nullptr)) return CRH_ERR_INVALID_ARGUMENT;
     crh_comm* c = nullptr;
@@ -452,7 +590,7 @@ crh_status crh_comm_create_local(crh_renderer* r, uint32_t rank, uint32_t world,
 void crh_comm_destroy(crh_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && rccl()) (void)rccl()->CommDestroy(c->nccl);
     if (c->local_group) {
         (*c->local_group)[c->rank] = nullptr;
@@ -461,7 +599,12 @@ void crh_comm_destroy(crh_comm* c) {
         if (empty) delete c->local_group;
     }
     for (Buf* b : {&c->bitmap, &c->prefix, &c->pack, &c->bitmaps_all, &c->prefixes_all, &c->or_bitmap, &c->or_prefix, &c->recv, &c->recv_table, &c->slab_out, &c->gathered}) b->release();
-    (void)hipStreamDestroy(c->stream);
+    for (PinnedBuf* b : {&c->host_all, &c->host_table, &c->host_header}) b->release();
+    for (hipEvent_t e : {c->bitmaps_on_host, c->packed, c->composited})
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->phase)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 crh_status crh_comm_last_traffic(const crh_comm* c, uint64_t* bytes_sent, uint64_t* bytes_dense) {
@@ -470,56 +613,92 @@ crh_status crh_comm_last_traffic(const crh_comm* c, uint64_t* bytes_sent, uint64
     if (bytes_dense) *bytes_dense = c->bytes_dense;
     return CRH_OK;
 }
+crh_status crh_comm_last_peer_bytes(const crh_comm* c, uint64_t* per_peer) {
+    if (!c || !per_peer) return CRH_ERR_INVALID_ARGUMENT;
+    for (uint32_t p = 0; p < c->world; ++p) per_peer[p] = p < c->peer_bytes.size() ? c->peer_bytes[p] : 0;
+    return CRH_OK;
+}
+crh_status crh_comm_last_timing(crh_comm* c, float ms[CRH_COMM_PHASES]) {
+    if (!c || !ms) return CRH_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < CRH_COMM_PHASES; ++k) ms[k] = 0.0f;
+    if (!c->timed) return CRH_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int last = c->rank == 0 ? CRH_COMM_PHASES : CRH_COMM_PHASES - 1; // only rank 0 unpacks
+    for (int k = 0; k < last; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], c->phase[k], c->phase[k + 1]));
+    return CRH_OK;
+}
 
 // The collective: every rank calls it with its layer; rank 0 also passes the frame that receives the image (the others pass NULL).
 crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) {
     if (!c || !layer || !c->nccl || (c->rank == 0) != (result != nullptr)) return CRH_ERR_INVALID_ARGUMENT;
     Rccl* api = rccl();
+    c->timed = false;
     crh_status st = phase_pack(c, layer);
-    if (st != CRH_OK) return st;
-    NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, (size_t)c->n_words * 4, ncclUint8, c->nccl, c->stream));
-    if ((st = phase_plan(c)) != CRH_OK) return st;
-    // all-to-all of the slab tiles: one group, so that all links are driven at once
-    NCCL_TRY(api->GroupStart());
-    for (uint32_t p = 0; p < c->world; ++p) {
+    if (st != CRH_OK) return st; // (only argument errors end here: a layer that cannot be read still takes part)
+    // Sizes of the collectives follow from the frame geometry, which therefore has to be the same on every rank BEFORE a count is derived
+    // from it: when it changes (the first exchange, a resized target) the headers alone are gathered and compared first, with one more wait.
+    if (!c->agreed || c->agreed_width != c->width || c->agreed_height != c->height || c->agreed_format != c->format) {
+        NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, kHeaderWords * 4, ncclUint8, c->nccl, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->host_all.p, c->bitmaps_all.p, (size_t)c->world * kHeaderWords * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->bitmaps_on_host, c->stream));
+        HIP_TRY(hipEventSynchronize(c->bitmaps_on_host));
+        for (uint32_t k = 0; k < c->world; ++k) {
+            const uint32_t* hd = c->host_all.as<uint32_t>() + (size_t)k * kHeaderWords;
+            if (hd[0] != kMagic || hd[1] != c->width || hd[2] != (c->height | (c->format << 24))) {
+                set_last_error("crh_frame_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
+                return CRH_ERR_INVALID_ARGUMENT; // on every rank
+            }
+        }
+        c->agreed = true, c->agreed_width = c->width, c->agreed_height = c->height, c->agreed_format = c->format;
+    }
+    NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, (size_t)c->stride() * 4, ncclUint8, c->nccl, c->stream));
+    if ((st = phase_plan(c)) != CRH_OK) return st; // (a peer's failure is seen by all ranks here: they return together, nothing is in flight)
+    // all-to-all of the slab tiles: one group, so that all links are driven at once. An error inside the group still closes it.
+    bool ok = nccl_ok(api->GroupStart(), "ncclGroupStart");
+    if (!ok) return CRH_ERR_HIP;
+    for (uint32_t p = 0; p < c->world && ok; ++p) {
         size_t off, bytes;
         segment(c, c->rank, p, &off, &bytes); // my tiles of slab p
         if (p == c->rank) {
-            if (bytes) HIP_TRY(hipMemcpyAsync(recv_slot(c, c->rank), static_cast<uint8_t*>(c->pack.p) + off, bytes, hipMemcpyDeviceToDevice, c->stream));
+            if (bytes) ok = hip_ok(hipMemcpyAsync(recv_slot(c, c->rank), static_cast<uint8_t*>(c->pack.p) + off, bytes, hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
             continue;
         }
-        if (bytes) NCCL_TRY(api->Send(static_cast<uint8_t*>(c->pack.p) + off, bytes, ncclUint8, (int)p, c->nccl, c->stream));
+        if (bytes) ok = nccl_ok(api->Send(static_cast<uint8_t*>(c->pack.p) + off, bytes, ncclUint8, (int)p, c->nccl, c->stream), "ncclSend");
         segment(c, p, c->rank, &off, &bytes); // rank p's tiles of my slab
-        if (bytes) NCCL_TRY(api->Recv(recv_slot(c, p), bytes, ncclUint8, (int)p, c->nccl, c->stream));
+        if (bytes && ok) ok = nccl_ok(api->Recv(recv_slot(c, p), bytes, ncclUint8, (int)p, c->nccl, c->stream), "ncclRecv");
     }
-    NCCL_TRY(api->GroupEnd());
+    ok = nccl_ok(api->GroupEnd(), "ncclGroupEnd") && ok;
+    if (!ok) return CRH_ERR_HIP;
+    mark(c, 3);
     if ((st = phase_composite(c)) != CRH_OK) return st;
     // gather of the composited slabs' non-empty tiles on rank 0 (tile order = slab order)
-    std::vector<uint32_t> or_bits(c->n_words, 0u);
-    for (uint32_t k = 0; k < c->world; ++k)
-        for (uint32_t w = 0; w < c->n_words; ++w) or_bits[w] |= c->host_bitmaps[(size_t)k * c->n_words + w];
-    if (c->rank == 0) HIP_TRY(c->gathered.ensure((size_t)host_rank(or_bits.data(), c->n_tiles) * kTileBytes + kTileBytes));
-    NCCL_TRY(api->GroupStart());
-    for (uint32_t p = 0; p < c->world; ++p) {
+    if (c->rank == 0) HIP_TRY(c->gathered.ensure((size_t)host_rank(c->or_bits.data(), c->n_tiles) * kResultTileBytes + kResultTileBytes));
+    ok = nccl_ok(api->GroupStart(), "ncclGroupStart");
+    if (!ok) return CRH_ERR_HIP;
+    for (uint32_t p = 0; p < c->world && ok; ++p) {
         uint32_t s0, s1;
         slab_tiles(c, p, &s0, &s1);
-        const size_t off = (size_t)host_rank(or_bits.data(), s0) * kTileBytes, bytes = (size_t)host_count(or_bits.data(), s0, s1) * kTileBytes;
+        const size_t off = (size_t)host_rank(c->or_bits.data(), s0) * kResultTileBytes, bytes = (size_t)host_count(c->or_bits.data(), s0, s1) * kResultTileBytes;
         if (!bytes) continue;
         if (c->rank == 0 && p == 0)
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(c->gathered.p) + off, c->slab_out.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+            ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(c->gathered.p) + off, c->slab_out.p, bytes, hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
         else if (c->rank == 0)
-            NCCL_TRY(api->Recv(static_cast<uint8_t*>(c->gathered.p) + off, bytes, ncclUint8, (int)p, c->nccl, c->stream));
+            ok = nccl_ok(api->Recv(static_cast<uint8_t*>(c->gathered.p) + off, bytes, ncclUint8, (int)p, c->nccl, c->stream), "ncclRecv");
         else if (p == c->rank)
-            NCCL_TRY(api->Send(c->slab_out.p, bytes, ncclUint8, 0, c->nccl, c->stream));
+            ok = nccl_ok(api->Send(c->slab_out.p, bytes, ncclUint8, 0, c->nccl, c->stream), "ncclSend");
     }
-    NCCL_TRY(api->GroupEnd());
+    ok = nccl_ok(api->GroupEnd(), "ncclGroupEnd") && ok;
+    if (!ok) return CRH_ERR_HIP;
+    mark(c, 5);
     account(c);
+    c->timed = true;
     if (c->rank == 0) return phase_unpack(c, result);
-    HIP_TRY(hipStreamSynchronize(c->stream)); // the layer and the buffers may be reused
-    return CRH_OK;
+    return CRH_OK; // no wait: the layer's next pass is ordered behind its packing, the buffers' next use is on this stream
 }
 
-// The same exchange over a loopback group (all communicators on one device, one thread): layers[k] = rank k's layer.
+// The same exchange over a loopback group (all communicators on one device, one thread): layers[k] = rank k's layer. Streams wait for
+// each other through events where a rank reads what another one produced.
 crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, crh_frame* result) {
     if (!rank0 || !rank0->local_group || rank0->rank != 0 || !layers || !result) return CRH_ERR_INVALID_ARGUMENT;
     std::vector<crh_comm*>& g = *rank0->local_group;
@@ -527,37 +706,54 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
     for (uint32_t k = 0; k < world; ++k)
         if (!g[k] || !layers[k]) return CRH_ERR_INVALID_ARGUMENT;
     crh_status st;
-    for (uint32_t k = 0; k < world; ++k)
+    for (uint32_t k = 0; k < world; ++k) {
+        g[k]->timed = false;
         if ((st = phase_pack(g[k], layers[k])) != CRH_OK) return st;
-    for (uint32_t k = 0; k < world; ++k) HIP_TRY(hipStreamSynchronize(g[k]->stream));
+        HIP_TRY(hipEventRecord(g[k]->packed, g[k]->stream));
+    }
     for (uint32_t k = 0; k < world; ++k) { // "all-gather"
-        if (g[k]->n_tiles != g[0]->n_tiles || g[k]->width != g[0]->width) return CRH_ERR_INVALID_ARGUMENT;
-        for (uint32_t q = 0; q < world; ++q)
-            HIP_TRY(hipMemcpyAsync(g[k]->bitmaps_all.as<uint32_t>() + (size_t)q * g[k]->n_words, g[q]->bitmap.p, (size_t)g[k]->n_words * 4, hipMemcpyDeviceToDevice, g[k]->stream));
+        if (g[k]->n_tiles != g[0]->n_tiles || g[k]->width != g[0]->width || g[k]->height != g[0]->height || g[k]->format != g[0]->format) {
+            set_last_error("crh_comm_local_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
+            return CRH_ERR_INVALID_ARGUMENT;
+        }
+        for (uint32_t q = 0; q < world; ++q) {
+            if (q != k) HIP_TRY(hipStreamWaitEvent(g[k]->stream, g[q]->packed, 0));
+            HIP_TRY(hipMemcpyAsync(g[k]->bitmaps_all.as<uint32_t>() + (size_t)q * g[k]->stride(), g[q]->bitmap.p, (size_t)g[k]->stride() * 4, hipMemcpyDeviceToDevice, g[k]->stream));
+        }
     }
     for (uint32_t k = 0; k < world; ++k)
         if ((st = phase_plan(g[k])) != CRH_OK) return st;
-    for (uint32_t k = 0; k < world; ++k) // "all-to-all": rank k pulls its slab's tiles out of every rank's pack buffer
+    for (uint32_t k = 0; k < world; ++k) { // "all-to-all": rank k pulls its slab's tiles out of every rank's pack buffer (packed long ago: the plan waited)
         for (uint32_t q = 0; q < world; ++q) {
             size_t off, bytes;
             segment(g[k], q, k, &off, &bytes);
             if (bytes) HIP_TRY(hipMemcpyAsync(recv_slot(g[k], q), static_cast<uint8_t*>(g[q]->pack.p) + off, bytes, hipMemcpyDeviceToDevice, g[k]->stream));
         }
-    for (uint32_t k = 0; k < world; ++k)
+        mark(g[k], 3);
+    }
+    for (uint32_t k = 0; k < world; ++k) {
         if ((st = phase_composite(g[k])) != CRH_OK) return st;
-    for (uint32_t k = 0; k < world; ++k) HIP_TRY(hipStreamSynchronize(g[k]->stream));
+        HIP_TRY(hipEventRecord(g[k]->composited, g[k]->stream));
+    }
     crh_comm* c = g[0];
-    std::vector<uint32_t> or_bits(c->n_words, 0u);
-    for (uint32_t k = 0; k < world; ++k)
-        for (uint32_t w = 0; w < c->n_words; ++w) or_bits[w] |= c->host_bitmaps[(size_t)k * c->n_words + w];
-    HIP_TRY(c->gathered.ensure((size_t)host_rank(or_bits.data(), c->n_tiles) * kTileBytes + kTileBytes));
+    HIP_TRY(c->gathered.ensure((size_t)host_rank(c->or_bits.data(), c->n_tiles) * kResultTileBytes + kResultTileBytes));
     for (uint32_t p = 0; p < world; ++p) { // "gather"
         uint32_t s0, s1;
         slab_tiles(c, p, &s0, &s1);
-        const size_t off = (size_t)host_rank(or_bits.data(), s0) * kTileBytes, bytes = (size_t)host_count(or_bits.data(), s0, s1) * kTileBytes;
+        const size_t off = (size_t)host_rank(c->or_bits.data(), s0) * kResultTileBytes, bytes = (size_t)host_count(c->or_bits.data(), s0, s1) * kResultTileBytes;
+        if (p != 0) HIP_TRY(hipStreamWaitEvent(c->stream, g[p]->composited, 0));
         if (bytes) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(c->gathered.p) + off, g[p]->slab_out.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
-    for (uint32_t k = 0; k < world; ++k) account(g[k]);
+    for (uint32_t k = 0; k < world; ++k) {
+        mark(g[k], 5);
+        account(g[k]);
+        g[k]->timed = true;
+    }
+    // the other ranks' pack buffers are read by rank k's stream: the next exchange's packing on rank q must come behind those reads
+    for (uint32_t k = 0; k < world; ++k) HIP_TRY(hipEventRecord(g[k]->composited, g[k]->stream));
+    for (uint32_t q = 0; q < world; ++q)
+        for (uint32_t k = 0; k < world; ++k)
+            if (k != q) HIP_TRY(hipStreamWaitEvent(g[q]->stream, g[k]->composited, 0));
     return phase_unpack(c, result);
 }
 }

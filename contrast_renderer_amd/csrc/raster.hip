@@ -616,14 +616,9 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         for (int b = 0; b < ROWS; ++b) {
             const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
             if (gx < r.width && gy < r.height) {
-                const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[(size_t)gy * r.width + gx];
+                const float4 d = load_pixel(r, gx, gy);
 #pragma unroll
-                for (int k = 0; k < S; ++k) {
-                    col[b][k][0] = (float)d.x * (1.0f / 255.0f);
-                    col[b][k][1] = (float)d.y * (1.0f / 255.0f);
-                    col[b][k][2] = (float)d.z * (1.0f / 255.0f);
-                    col[b][k][3] = (float)d.w * (1.0f / 255.0f);
-                }
+                for (int k = 0; k < S; ++k) col[b][k][0] = d.x, col[b][k][1] = d.y, col[b][k][2] = d.z, col[b][k][3] = d.w;
             }
         }
     }
@@ -1013,18 +1008,15 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
         if (gx < r.width && gy < r.height) {
             const float inv = 1.0f / (float)S;
-            uint32_t packed_px = 0;
+            float avg[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 float sum = 0.0f;
 #pragma unroll
                 for (int k = 0; k < S; ++k) sum = sum + col[b][k][ch];
-                float x = sum * inv;
-                x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-                if (!(x == x)) x = 0.0f;
-                packed_px |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+                avg[ch] = sum * inv;
             }
-            reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed_px;
+            store_pixel(r, gx, gy, avg[0], avg[1], avg[2], avg[3]);
         }
     }
 }

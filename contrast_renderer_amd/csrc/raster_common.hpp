@@ -29,6 +29,40 @@ CRH_D float2 to_framebuffer(const float* m, float w, float h, float x, float y) 
     return make_float2((cx * 0.5f + 0.5f) * w, (0.5f - cy * 0.5f) * h);
 }
 
+// The target's pixel (gx, gy): the resolved premultiplied colour, clamped to [0, 1] (NaN -> 0) and stored as RGBA8 unorm or — the layers
+// of the multi-GPU exchange — as four binary16 values (round to nearest even; the clamp is the same, so a 16F layer holds what the RGBA8
+// target would have quantised).
+CRH_D void store_pixel(const RasterParams& r, uint32_t gx, uint32_t gy, float c0, float c1, float c2, float c3) {
+    float v[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        float x = v[ch];
+        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        if (!(x == x)) x = 0.0f;
+        v[ch] = x;
+    }
+    const size_t at = (size_t)gy * r.width + gx;
+    if (r.format == CRH_FORMAT_RGBA16F) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        reinterpret_cast<h4*>(r.rgba8)[at] = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else {
+        uint32_t packed_px = 0;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) packed_px |= (uint32_t)(int)(v[ch] * 255.0f + 0.5f) << (8 * ch);
+        reinterpret_cast<uint32_t*>(r.rgba8)[at] = packed_px;
+    }
+}
+CRH_D float4 load_pixel(const RasterParams& r, uint32_t gx, uint32_t gy) {
+    const size_t at = (size_t)gy * r.width + gx;
+    if (r.format == CRH_FORMAT_RGBA16F) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 d = reinterpret_cast<const h4*>(r.rgba8)[at];
+        return make_float4((float)d[0], (float)d[1], (float)d[2], (float)d[3]);
+    }
+    const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[at];
+    return make_float4((float)d.x * (1.0f / 255.0f), (float)d.y * (1.0f / 255.0f), (float)d.z * (1.0f / 255.0f), (float)d.w * (1.0f / 255.0f));
+}
+
 enum : uint32_t { KIND_SOLID = 0, KIND_IQ = 1, KIND_IC = 2, KIND_RQ = 3, KIND_RC = 4, KIND_LINE = 5, KIND_JOINT = 6, KIND_COVER = 7 };
 
 // One set-up triangle, tile independent: two 64-byte halves, each fetched with one scalar load.

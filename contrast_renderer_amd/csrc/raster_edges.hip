@@ -940,14 +940,9 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         for (int b = 0; b < ROWS; ++b) {
             const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
             if (gx < r.width && gy < r.height) {
-                const uchar4 d = reinterpret_cast<const uchar4*>(r.rgba8)[(size_t)gy * r.width + gx];
+                const float4 d = load_pixel(r, gx, gy);
 #pragma unroll
-                for (int q = 0; q < S; ++q) {
-                    col[b][q][0] = (float)d.x * (1.0f / 255.0f);
-                    col[b][q][1] = (float)d.y * (1.0f / 255.0f);
-                    col[b][q][2] = (float)d.z * (1.0f / 255.0f);
-                    col[b][q][3] = (float)d.w * (1.0f / 255.0f);
-                }
+                for (int q = 0; q < S; ++q) col[b][q][0] = d.x, col[b][q][1] = d.y, col[b][q][2] = d.z, col[b][q][3] = d.w;
             }
         }
     }
@@ -1430,21 +1425,15 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
         if (gx < r.width && gy < r.height) {
             const float inv = 1.0f / (float)S;
-            uint32_t packed_px = 0;
-            float4 cq[S];
-#pragma unroll
-            for (int q = 0; q < S; ++q) cq[q] = make_float4(col[b][q][0], col[b][q][1], col[b][q][2], col[b][q][3]);
+            float avg[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 float sum = 0.0f;
 #pragma unroll
-                for (int q = 0; q < S; ++q) sum = sum + (ch == 0 ? cq[q].x : (ch == 1 ? cq[q].y : (ch == 2 ? cq[q].z : cq[q].w)));
-                float x = sum * inv;
-                x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-                if (!(x == x)) x = 0.0f;
-                packed_px |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+                for (int q = 0; q < S; ++q) sum = sum + col[b][q][ch];
+                avg[ch] = sum * inv;
             }
-            reinterpret_cast<uint32_t*>(r.rgba8)[(size_t)gy * r.width + gx] = packed_px;
+            store_pixel(r, gx, gy, avg[0], avg[1], avg[2], avg[3]);
         }
     }
 }

@@ -37,7 +37,8 @@ struct RasterParams {
     uint32_t* scan_scratch;           // block sums of the scans
     PrimRec* prim_rec;                // [prim capacity] 128-byte set-up triangles
     uint32_t prim_capacity;
-    uint8_t* rgba8;                   // [height][width][4]
+    uint8_t* rgba8;                   // [height][width][4] unorm8, or [height][width][4] binary16 when format == CRH_FORMAT_RGBA16F
+    uint32_t format;                  // CRH_FORMAT_* of the target
     // ---- the general pass (perspective instances, depth test): selects the OPS variant of the raster kernel
     uint32_t general;                 // 1: some instance is not plain (clip.w != 1 or clip.z not a constant in [0, 1]) or depth is tested / written
     PrimProj* prim_proj;              // [prim capacity] 1/w and z/w planes of the primitives of projective instances, or nullptr

@@ -93,10 +93,11 @@ def gather_slabs(slab, rank: int, world: int, height: int, group=None):
 
 def composite_over_reference(layers: np.ndarray) -> np.ndarray:
     """numpy statement of the ordered "over" (dst = src + dst * (1 - src.a), layer 0 at the bottom) with the same f32 operation
-    order and RGBA8 rounding as k_composite — used by the gloo tests, where no GPU exists. Not a product path."""
+    order and RGBA8 rounding as k_composite / k_composite_tiles — used by the gloo tests, where no GPU exists, and as the checker of the
+    C-ABI exchange. uint8 layers are RGBA8 unorm, float16 layers RGBA16F (CRH_FORMAT_RGBA16F). Not a product path."""
     acc = np.zeros(layers.shape[1:], dtype=np.float32)
     for layer in layers:
-        src = layer.astype(np.float32) * np.float32(1.0 / 255.0)
+        src = layer.astype(np.float32) * np.float32(1.0 / 255.0) if layer.dtype == np.uint8 else layer.astype(np.float32)
         k = (np.float32(1.0) - src[..., 3:4]).astype(np.float32)
         acc = (src + acc * k).astype(np.float32)
     acc = np.clip(acc, 0.0, 1.0)

@@ -97,15 +97,18 @@ class Renderer:
             self.handle = None
 
 
-class Frame:
-    """The colour attachment (RGBA8, premultiplied) and per-sample winding state of one render pass."""
+FORMAT_RGBA8, FORMAT_RGBA16F = 0, 1
 
-    def __init__(self, renderer: Renderer, width: int, height: int):
+
+class Frame:
+    """The colour attachment (premultiplied; RGBA8, or RGBA16F for the layers of the multi-GPU exchange) and per-sample winding state of one render pass."""
+
+    def __init__(self, renderer: Renderer, width: int, height: int, format: int = FORMAT_RGBA8):
         self.renderer = renderer
         self.lib = renderer.lib
-        self.width, self.height = width, height
+        self.width, self.height, self.format = width, height, format
         handle = C.c_void_p()
-        check(self.lib.crh_frame_create(renderer.handle, width, height, C.byref(handle)))
+        check(self.lib.crh_frame_create_format(renderer.handle, width, height, format, C.byref(handle)))
         self.handle = handle
 
     def clear(self):
@@ -131,6 +134,11 @@ class Frame:
         return out
 
     def download(self):
+        """-> [height, width, 4] uint8 (an RGBA8 frame) or float16 (an RGBA16F frame)."""
+        if self.format == FORMAT_RGBA16F:
+            out = np.zeros((self.height, self.width, 4), dtype=np.float16)
+            check(self.lib.crh_frame_download_f16(self.handle, out.ctypes.data))
+            return out
         out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
         check(self.lib.crh_frame_download(self.handle, out.ctypes.data))
         return out
@@ -199,6 +207,20 @@ class Comm:
         sent, dense = C.c_uint64(), C.c_uint64()
         check(self.lib.crh_comm_last_traffic(self.handle, C.byref(sent), C.byref(dense)))
         return sent.value, dense.value
+
+    PHASES = ("pack", "allgather_plan", "alltoall", "composite", "gather", "unpack")
+
+    def last_timing(self):
+        """GPU milliseconds of the phases of this rank's last exchange (waits for it): dict by phase name."""
+        ms = (C.c_float * len(self.PHASES))()
+        check(self.lib.crh_comm_last_timing(self.handle, ms))
+        return dict(zip(self.PHASES, [float(v) for v in ms]))
+
+    def last_peer_bytes(self):
+        """Bytes this rank sent to every peer in the all-to-all of the last exchange."""
+        out = (C.c_uint64 * self.world)()
+        check(self.lib.crh_comm_last_peer_bytes(self.handle, out))
+        return [int(v) for v in out]
 
     def __del__(self):
         if getattr(self, "handle", None):

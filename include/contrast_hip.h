@@ -209,6 +209,12 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* scene, uint32_t shape
 
 /* The colour target (RGBA8 unorm, premultiplied) plus the per-sample winding ("stencil") state. */
 crh_status crh_frame_create(crh_renderer* renderer, uint32_t width, uint32_t height, crh_frame** out);
+/* The same with the storage format of the resolved image named. CRH_FORMAT_RGBA8 is the reference's target (main.rs:205-215 renders to
+ * the surface format, 8 bits per channel). CRH_FORMAT_RGBA16F keeps four binary16 values per pixel — the per-rank LAYERS of the multi-GPU
+ * exchange (layers exchanged as RGBA16F keep the composite within 1/255 of a single-GPU render, RGBA8 layers within 2/255). */
+enum { CRH_FORMAT_RGBA8 = 0, CRH_FORMAT_RGBA16F = 1 };
+crh_status crh_frame_create_format(crh_renderer* renderer, uint32_t width, uint32_t height, uint32_t format, crh_frame** out);
+crh_status crh_frame_format(const crh_frame* frame, uint32_t* format);
 void crh_frame_destroy(crh_frame* frame);
 /* LoadOp::Clear(TRANSPARENT) + depth clear 1.0 + stencil clear 0 (examples/showcase/main.rs:217-230) */
 crh_status crh_frame_clear(crh_frame* frame);
@@ -252,6 +258,8 @@ crh_status crh_scene_render_draws(crh_scene* scene, crh_frame* frame, const floa
 
 /* MSAA resolve (box average, examples/showcase/main.rs:215) + copy to host, `rgba8` = width*height*4 bytes, row 0 = top. */
 crh_status crh_frame_download(crh_frame* frame, void* rgba8);
+/* The same for a CRH_FORMAT_RGBA16F frame: width*height*8 bytes (four IEEE binary16 per pixel). Each entry point refuses the other format. */
+crh_status crh_frame_download_f16(crh_frame* frame, void* rgba16f);
 /* Device pointer of the resolved RGBA8 image (for the RCCL tile exchange); valid until the frame is destroyed. */
 crh_status crh_frame_device_pointer(crh_frame* frame, void** rgba8_dev);
 /* Ordered premultiplied "over" of n_layers RGBA8 images that live in HBM: dst = layers[0] under layers[1] ....
@@ -349,8 +357,11 @@ void crh_path_list_destroy(crh_path_list* list);
  * the C ABI, so that a host in any language can shard: one process per GPU, rank g renders Shapes crh_comm_shard(n, g, world) into a
  * private full-size layer (a crh_frame), crh_frame_exchange composites the layers in rank order — premultiplied "over", lower rank
  * underneath — and leaves the image in rank 0's `result` frame. Only 16x16 tiles that hold something travel (occupancy bitmaps are
- * all-gathered first); transfers are grouped ncclSend / ncclRecv of row slabs over RCCL (librccl.so is opened on first use).
- * RGBA8 hand-off: <= 2/255 per channel against a single-GPU render of the whole scene. */
+ * all-gathered first); transfers are grouped ncclSend / ncclRecv of row slabs over RCCL (the librccl the process has already mapped —
+ * e.g. the one bundled with torch — or librccl.so, opened on first use).
+ * Layers may be RGBA8 frames (<= 2/255 per channel against a single-GPU render of the whole scene) or CRH_FORMAT_RGBA16F frames
+ * (<= 1/255: one RGBA8 quantisation, in the composite); all ranks use the same format, the result frame is RGBA8.
+ * A rank whose layer cannot be read (a failed pass) still takes part in the collective and every rank returns an error together. */
 typedef struct crh_comm crh_comm;
 #define CRH_COMM_ID_BYTES 128 /* ncclUniqueId */
 /* contiguous, order-preserving split of [0, n_items): sizes differ by at most one */
@@ -367,6 +378,13 @@ void crh_comm_destroy(crh_comm* comm);
 crh_status crh_frame_exchange(crh_comm* comm, crh_frame* layer, crh_frame* result);
 /* bytes this rank sent in the last exchange, and what dense slabs (no empty-tile suppression) would have been */
 crh_status crh_comm_last_traffic(const crh_comm* comm, uint64_t* bytes_sent, uint64_t* bytes_dense);
+/* GPU time of the phases of this rank's last exchange, in milliseconds (HIP events on the communicator's stream; waits for the exchange):
+ * [0] occupancy bitmap + packing of the non-empty tiles, [1] all-gather of the bitmaps + their prefix sums, [2] all-to-all of the slab
+ * tiles, [3] ordered composite of the slab, [4] gather of the composited tiles on rank 0, [5] unpacking into the result frame (rank 0). */
+#define CRH_COMM_PHASES 6
+crh_status crh_comm_last_timing(crh_comm* comm, float ms[CRH_COMM_PHASES]);
+/* bytes this rank sent to every peer in the all-to-all of the last exchange: per_peer[world] (its own entry is 0) */
+crh_status crh_comm_last_peer_bytes(const crh_comm* comm, uint64_t* per_peer);
 /* The same exchange without RCCL, for several communicators on ONE device driven by one thread (tests, single-GPU validation):
  * rank 0's communicator founds the group (rank0 = NULL), ranks 1.. join it; crh_comm_local_exchange(rank 0's comm, layers[world],
  * result) then runs every rank's part with device-to-device copies in place of the transfers. */

@@ -2,8 +2,10 @@
 
 CPU: the sharding arithmetic the C ABI exports equals contrast_renderer_amd/distributed.py (which the gloo tests drive end to end).
 GPU (one device): an in-process loopback group of 2 / 3 / 5 communicators runs the whole exchange — occupancy bitmaps, packed non-empty
-tiles, slab all-to-all, ordered composite, gather, unpack — with device-to-device copies in place of the RCCL transfers, and an RCCL
-communicator of world size 1 runs the real ncclAllGather / grouped send-recv code path against itself."""
+tiles, slab all-to-all, ordered composite, gather, unpack — with device-to-device copies in place of the RCCL transfers (RGBA8 and
+RGBA16F layers; BASELINE configs[3] whole: eight shards of the 100 000-path scene at 8192x8192), and an RCCL communicator of world
+size 1 runs ncclCommInitRank / ncclAllGather for real (its only peer is itself, so no ncclSend / ncclRecv is issued: the first real
+point-to-point transfer of this code happens on a multi-GPU node)."""
 import numpy as np
 import pytest
 
@@ -73,7 +75,8 @@ def test_loopback_exchange_equals_the_ordered_composite_of_the_layers(world, siz
 
 @pytest.mark.gpu
 def test_rccl_exchange_with_itself(oracle_lib):
-    """World size 1 over RCCL: ncclCommInitRank, ncclAllGather and the grouped transfers of crh_frame_exchange run for real."""
+    """World size 1 over RCCL: ncclCommInitRank, ncclAllGather and an (empty) ncclGroupStart / End pair run for real; the slab "transfer"
+    to itself is a device-to-device copy, so ncclSend / ncclRecv are NOT reached here (they need a peer: a multi-GPU node)."""
     import torch
     assert torch.cuda.is_available()
     from contrast_renderer_amd import renderer as R
@@ -86,3 +89,124 @@ def test_rccl_exchange_with_itself(oracle_lib):
     # and again into the same frames while the renderer already draws the next step into the layer's sibling
     comm.exchange(layers[0], result)
     assert np.array_equal(result.download(), layers[0].download())
+
+
+@pytest.mark.gpu
+def test_exchange_refuses_layers_of_different_sizes_and_formats(oracle_lib):
+    """Every rank's layer has the same size and format (the collectives' counts follow from them): checked before anything is sent."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    r = R.Renderer(R.Configuration(1, 4, 4), device=0)
+    comms = [R.Comm(r, 0, 2)]
+    comms.append(R.Comm(r, 1, 2, rank0=comms[0]))
+    result = R.Frame(r, 64, 64)
+    for other in (R.Frame(r, 64, 48), R.Frame(r, 64, 64, R.FORMAT_RGBA16F)):
+        with pytest.raises(R.ContrastError) as e:
+            comms[0].local_exchange([R.Frame(r, 64, 64), other], result)
+        assert e.value.status == 10  # CRH_ERR_INVALID_ARGUMENT
+    with pytest.raises(R.ContrastError):  # the result frame is RGBA8 (the composite quantises once)
+        comms[0].local_exchange([R.Frame(r, 64, 64), R.Frame(r, 64, 64)], R.Frame(r, 64, 64, R.FORMAT_RGBA16F))
+    with pytest.raises(R.ContrastError):  # rank out of range
+        R.Comm(r, 2, 2, rank0=comms[0])
+    comms[0].local_exchange([R.Frame(r, 64, 64), R.Frame(r, 64, 64)], result)  # two cleared layers: a transparent image
+    assert not result.download().any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,size,msaa", [(4, (320, 256), 1), (3, (200, 136), 4)])
+def test_rgba16f_layers_keep_the_exchange_within_one_255th(world, size, msaa, oracle_lib):
+    """layers exchanged as RGBA16F -> the composite is within 1/255 of the single-GPU render of the whole scene (RGBA8
+    layers: 2/255). The layer itself is the resolved colour rounded to binary16: within half a unit of the RGBA8 layer everywhere."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from contrast_renderer_amd import scenes
+    from oracle.binding import Oracle
+    sc = scenes.scene_mixed(60, size, seed=21 + world)
+    r = R.Renderer(R.Configuration(msaa, 4, 4), device=0)
+    layers16, layers8, keep = [], [], []
+    for rank in range(world):
+        b, e = D.shard_range(sc["batch"].n_shapes, rank, world)
+        scene = R.Scene(r, sc["batch"].slice_shapes(b, e))
+        keep.append(scene)
+        for fmt, out in ((R.FORMAT_RGBA16F, layers16), (R.FORMAT_RGBA8, layers8)):
+            frame = R.Frame(r, *size, fmt)
+            frame.clear()
+            scene.render(frame, sc["transforms"][b:e], sc["colors"][b:e])
+            out.append(frame)
+    comms = [R.Comm(r, 0, world)]
+    comms += [R.Comm(r, k, world, rank0=comms[0]) for k in range(1, world)]
+    result = R.Frame(r, *size)
+    comms[0].local_exchange(layers16, result)
+    image = result.download()
+    halves = np.stack([f.download() for f in layers16])
+    assert halves.dtype == np.float16
+    assert np.array_equal(image, D.composite_over_reference(halves))  # bit for bit: sparse tiles, f32 accumulation, one quantisation
+    bytes8 = np.stack([f.download() for f in layers8])
+    assert np.abs(halves.astype(np.float64) * 255.0 - bytes8).max() <= 0.5 + 255.0 * 2.0 ** -11  # the same colours, rounded to binary16 instead of to 1/255
+    whole = Oracle(sc["batch"]).render(size[0], size[1], msaa, 4, sc["transforms"], sc["colors"])
+    assert np.abs(image.astype(int) - whole.astype(int)).max() <= 1
+    # a 16F layer drawn over its own content (LoadOp::Load) reads the halves back
+    layers16[0].clear()
+    keep[0].render(layers16[0])
+    again = layers16[0].download()
+    assert np.array_equal(again, halves[0])
+    # 2 KiB tiles travel instead of 1 KiB ones
+    sent16 = comms[1].last_traffic()[0]
+    comms[0].local_exchange(layers8, result)
+    assert comms[1].last_traffic()[0] < sent16
+    timing = comms[0].last_timing()
+    assert set(timing) == set(R.Comm.PHASES) and all(v >= 0.0 for v in timing.values()) and timing["pack"] > 0.0
+
+
+@pytest.mark.gpu
+def test_config4_whole_scene_eight_shards_through_the_exchange(oracle_lib):
+    """BASELINE.json configs[3] as a whole on one GPU: the 100 000-path scene at 8192x8192 split into the eight contiguous shards the
+    eight ranks would draw, each rendered into its own full-size layer, the eight layers through crh_comm_local_exchange (the C-ABI
+    exchange: occupancy bitmaps, sparse slab all-to-all, ordered composite, gather) — against (a) the ordered composite of the eight
+    layers computed on the host, bit for bit, and (b) the oracle's single render of all 100 000 paths, within the 2/255 the RGBA8
+    hand-off between ranks costs."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from contrast_renderer_amd import scenes
+    from oracle.binding import Oracle
+    world, size, n = 8, (8192, 8192), 100000
+    sc = scenes.scene_cubic_fill(n, size, config_index=2)
+    r = R.Renderer(R.Configuration(1, 4, 4), device=0)
+    layers = []
+    for rank in range(world):
+        b, e = R.shard_range(n, rank, world)
+        assert e - b == 12500
+        scene = R.Scene(r, sc["batch"].slice_shapes(b, e))
+        assert scene.status() == 0
+        frame = R.Frame(r, *size)
+        frame.clear()
+        scene.render(frame, sc["transforms"][b:e], sc["colors"][b:e])
+        frame.synchronize()
+        layers.append(frame)
+        del scene
+    comms = [R.Comm(r, 0, world)]
+    comms += [R.Comm(r, k, world, rank0=comms[0]) for k in range(1, world)]
+    result = R.Frame(r, *size)
+    comms[0].local_exchange(layers, result)
+    image = result.download()
+    sent, dense = zip(*[c.last_traffic() for c in comms])
+    assert all(s < d for s, d in zip(sent, dense))  # a shard of 1/8 of the paths leaves empty tiles, and they do not travel
+    # (a) the ordered composite of the eight layers, in row bands (eight full layers as f32 would be 8.6 GB)
+    band = 1024
+    host_layers = [f.download() for f in layers]
+    for y in range(0, size[1], band):
+        expect = D.composite_over_reference(np.stack([layer[y:y + band] for layer in host_layers]))
+        assert np.array_equal(image[y:y + band], expect), f"rows {y}..{y + band}: the exchange differs from the ordered composite of the layers"
+    del host_layers
+    # (b) the oracle's render of the whole scene
+    oracle = Oracle(sc["batch"], 16)
+    assert oracle.status() == 0
+    whole = oracle.render(size[0], size[1], 1, 4, sc["transforms"], sc["colors"])
+    worst = 0
+    for y in range(0, size[1], band):
+        worst = max(worst, int(np.abs(image[y:y + band].astype(np.int16) - whole[y:y + band].astype(np.int16)).max()))
+    assert worst <= 2, worst
+    assert (image[..., 3] > 0).mean() > 0.5
