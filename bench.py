@@ -185,6 +185,7 @@ def run_loopback(args, size, scaling, np):
         wall.append(time.perf_counter() - t1)
         phases.append(per_rank)
     last = phases[-1]
+    serial = os.environ.get("CRH_LOOPBACK_SERIAL") is not None
     phase_ms = {name: {"max_over_ranks": max(p[name] for p in last), "sum_over_ranks": sum(p[name] for p in last)} for name in Comm.PHASES}
     # the drawing alone (all N shards, no exchange)
     renderer.synchronize()
@@ -231,6 +232,8 @@ def run_loopback(args, size, scaling, np):
             "exchange_wall_ms": {"median": sorted(wall)[len(wall) // 2] * 1e3, "min": min(wall) * 1e3,
                                  "note": f"host clock around crh_comm_local_exchange + its completion, all {n} ranks' kernels and copies on one GPU"},
             "exchange_phase_ms": phase_ms,
+            "exchange_phase_mode": ("CRH_LOOPBACK_SERIAL=1: every rank's part of a phase ran with the GPU to itself — max_over_ranks is what ONE rank's kernels and copies cost on a GPU of its own"
+                                    if serial else f"all {n} ranks' kernels and copies share the one GPU: the per-rank times are stretched by the other ranks' work"),
             "bytes_sent_per_rank": [t[0] for t in traffic],
             "bytes_dense_per_rank": [t[1] for t in traffic],
             "sent_over_dense": sum(t[0] for t in traffic) / max(1, sum(t[1] for t in traffic)),

