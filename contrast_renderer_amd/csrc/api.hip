@@ -233,6 +233,7 @@ struct crh_frame {
     struct BinSet {
         DevBuf tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
         DevBuf pair_tile, pair_pos, pair_key;       // the edge pass: (tile, key) pairs as the binning waves produced them (same capacity as tile_list)
+        DevBuf bin_queue;                           // the edge pass: items handed from k_bin_flat to k_bin_edges
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
         hipEvent_t raster_done = nullptr; // recorded on the raster stream after the raster kernel that read this set
         bool used = false;
@@ -264,6 +265,10 @@ struct crh_frame {
     // last render, for the transparent re-run after a bin-capacity overflow
     crh_scene* last_scene = nullptr;
     bool check_pending = false;
+    // The edge pass met a boundary edge with a non-finite endpoint on this frame (finite vertices times a finite matrix can overflow): an
+    // unclosed chain has no backdrops, so passes of that Scene into this frame are drawn by the triangle pass, which skips exactly the
+    // strip triangles with a non-finite determinant — as the reference's rasterizer does.
+    crh_scene* triangle_pass_for = nullptr;
 };
 
 constexpr int kTessBufs = 32; // buffers a tessellation run writes (crh_scene::tess_bufs)
@@ -674,6 +679,7 @@ size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
 // the pass of this plain frame (true = edge pass) and, through `timed`, which trial (0 edges, 1 triangles) its events belong to, or -1
 bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     *timed = -1;
+    if (f->triangle_pass_for == sc) return false;
     if (getenv("CRH_TRIANGLE_PASS")) return false;
     if (getenv("CRH_EDGE_PASS")) return true;
     if (sc->d.n_shapes < 256u) return true; // a handful of Shapes (the reference's one-Shape-per-call use): launch overhead either way, not worth two synchronising frames
@@ -916,6 +922,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
             p.pair_pos = set.pair_pos.as<uint32_t>();
             p.pair_tile = set.pair_tile.as<uint32_t>();
             p.pair_key = set.pair_key.as<uint32_t>();
+            HIP_TRY(set.bin_queue.ensure((size_t)p.n_items * 4 + 4));
+            p.bin_queue = set.bin_queue.as<uint32_t>();
             launch_bin_edges(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         } else
         launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
@@ -926,9 +934,17 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(r->sync());
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
+        if (edges && ov[7] != 0) { // an unclosed boundary chain: this pass and the following ones of this Scene into this frame as strip triangles
+            f->triangle_pass_for = sc;
+            return render_impl(sc, f, again);
+        }
         if (ov[0] == 0 && ov[5] == 0) {
             f->pairs_known = true; // from now on this frame's passes run without the read-back (checked after the fact, settle_frame)
             break;
+        }
+        if (attempt == 5) { // (six doublings of the pair stream were not enough: not a capacity problem)
+            g_error = "the tile lists of this pass do not fit after six attempts";
+            return CRH_ERR_UNSUPPORTED;
         }
         f->pair_capacity_bytes = grown_pair_bytes(f, ov);
         HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
@@ -991,8 +1007,10 @@ crh_status settle_frame(crh_frame* f) {
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
-    if (ov[0] != 0 || ov[5] != 0 || sort_overflow) {
-        f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
+    const bool unclosed = ov[7] != 0 && f->last_scene && f->triangle_pass_for != f->last_scene; // (the edge pass drew it: see crh_frame::triangle_pass_for)
+    if (unclosed) f->triangle_pass_for = f->last_scene;
+    if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed) {
+        if (ov[0] != 0 || ov[5] != 0) f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
             f->cleared = true; // the pass is drawn again from scratch (only cleared frames take the optimistic path, see render_impl)
@@ -1016,7 +1034,7 @@ crh_status settle_frame_cheaply(crh_frame* f) {
     HIP_TRY(hipStreamSynchronize(r->aux_stream));
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
-    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || sort_too_small) return settle_frame(f);
+    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small) return settle_frame(f);
     f->check_pending = false;
     return CRH_OK;
 }
@@ -1494,7 +1512,7 @@ void crh_frame_destroy(crh_frame* f) {
     f->item_upload_c.release();
     for (InstanceSlot& k : f->item_slot) k.release();
     for (crh_frame::BinSet& set : f->sets) {
-        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key};
+        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key, &set.bin_queue};
         for (DevBuf* b : bins) b->release();
         if (set.bin_done) (void)hipEventDestroy(set.bin_done);
         if (set.raster_done) (void)hipEventDestroy(set.raster_done);

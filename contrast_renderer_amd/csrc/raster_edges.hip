@@ -79,6 +79,33 @@ CRH_D ItemSlots item_slots(const SceneDev& s, const DrawItem& it) {
     k.total = k.synth_b + 28u; // 9 COVER codes, the same 9 as "the whole tile inside the hull" (kCoverHull) and as "opaque over the whole tile" (kCoverOpaque)
     return k;
 }
+// What the primitives of one draw item are set up from: gathered once per item (a wavefront's scalar registers in k_bin_edges, an LDS
+// record in k_bin_flat) instead of through the Shape's rows of shape_base per primitive.
+struct ItemCtx {
+    uint32_t shape, instance, dyn0;
+    uint32_t lv0, jn0, iq0, ic0, rq0, rc0, hull0, sv0; // the Shape's first record in every stream
+    uint32_t cb[8];                                    // shape_candidates()
+    float m0, m4, m12, m1, m5, m13;                    // the rows of the instance matrix to_framebuffer() uses
+    float col[4];                                      // straight-alpha colour of the instance
+};
+CRH_D ItemCtx item_ctx(const SceneDev& s, const RasterParams& r, const DrawItem& it, const uint32_t cb[8]) {
+    ItemCtx c;
+    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    c.shape = it.shape, c.instance = it.instance, c.dyn0 = s.shape_dyn_begin[it.shape];
+    c.lv0 = b0[CH_LINE_V], c.jn0 = b0[CH_JOINT], c.iq0 = b0[CH_IQ], c.ic0 = b0[CH_IC_V], c.rq0 = b0[CH_RQ], c.rc0 = b0[CH_RC_V], c.hull0 = b0[CH_HULL], c.sv0 = b0[CH_SOLID_V];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c.cb[i] = cb[i];
+    const float* m = r.transforms + 16u * it.instance;
+    c.m0 = m[0], c.m4 = m[4], c.m12 = m[12], c.m1 = m[1], c.m5 = m[5], c.m13 = m[13];
+    const float* color = r.colors + 4u * it.instance;
+    c.col[0] = color[0], c.col[1] = color[1], c.col[2] = color[2], c.col[3] = color[3];
+    return c;
+}
+CRH_D float2 to_framebuffer(const ItemCtx& c, float w, float h, float x, float y) { // raster_common.hpp to_framebuffer, operation for operation
+    const float cx = (c.m0 * x + c.m4 * y) + c.m12;
+    const float cy = (c.m1 * x + c.m5 * y) + c.m13;
+    return make_float2((cx * 0.5f + 0.5f) * w, (0.5f - cy * 0.5f) * h);
+}
 __global__ __launch_bounds__(256) void k_item_nslots(SceneDev s, RasterParams r, uint32_t n_items, uint32_t* out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_items) return;
@@ -87,9 +114,9 @@ __global__ __launch_bounds__(256) void k_item_nslots(SceneDev s, RasterParams r,
 
 // ---------------------------------------------------------------------------------------------- triangle setup (plain instances)
 // oracle/raster.hpp setup_triangle + setup_attribute for candidate c of the Shape (lines, joints, curve lists); false: nothing to draw
-CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const DrawItem& it, const uint32_t cb[8], uint32_t c, const float* m, PrimRec& rec) {
-    const uint32_t* b0 = s.shape_base + it.shape * NCH;
-    const uint32_t dyn0 = s.shape_dyn_begin[it.shape];
+CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const ItemCtx& ctx, uint32_t c, PrimRec& rec) {
+    const uint32_t* cb = ctx.cb;
+    const uint32_t dyn0 = ctx.dyn0;
     const float W = (float)r.width, H = (float)r.height;
     float2 p[3];
     float attr[3][4] = {};
@@ -98,7 +125,7 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
     int n_attr;
     bool valid = true;
     if (c < cb[0]) { // stroke line strips
-        const uint32_t lv0 = b0[CH_LINE_V], k = c;
+        const uint32_t lv0 = ctx.lv0, k = c;
         valid = s.line_pair_cut[(lv0 + k) >> 1] == 0;
         const uint32_t i0 = lv0 + k, i1 = lv0 + ((k & 1u) ? k + 2u : k + 1u), i2 = lv0 + ((k & 1u) ? k + 1u : k + 2u);
         const Vertex2f1i a = s.line_v[i0], b = s.line_v[i1], d = s.line_v[i2];
@@ -110,7 +137,7 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         kind = KIND_LINE;
         n_attr = 2;
     } else if (c < cb[1]) { // joint strips: 5 vertices, 3 triangles per join
-        const uint32_t q = c - cb[0], jn = q / 3u, k = q - 3u * jn, base = 5u * (b0[CH_JOINT] + jn);
+        const uint32_t q = c - cb[0], jn = q / 3u, k = q - 3u * jn, base = 5u * (ctx.jn0 + jn);
         const uint32_t i0 = base + k, i1 = base + ((k & 1u) ? k + 2u : k + 1u), i2 = base + ((k & 1u) ? k + 1u : k + 2u);
         const Vertex3f1i a = s.joint_v[i0], b = s.joint_v[i1], d = s.joint_v[i2];
         p[0] = make_float2(a.x, a.y), p[1] = make_float2(b.x, b.y), p[2] = make_float2(d.x, d.y);
@@ -120,7 +147,8 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         kind = KIND_JOINT;
         n_attr = 3;
     } else if (c < cb[3]) {
-        const uint32_t at = 3u * (b0[CH_IQ] + (c - cb[2]));
+        const uint32_t at = 3u * (ctx.iq0 + (c - cb[2]));
+#pragma unroll
         for (int v = 0; v < 3; ++v) {
             const Vertex2f a = s.iq_v[at + v];
             p[v] = make_float2(a.x, a.y);
@@ -129,7 +157,8 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         kind = KIND_IQ;
         n_attr = 2;
     } else if (c < cb[4]) {
-        const uint32_t at = b0[CH_IC_V] + 3u * (c - cb[3]);
+        const uint32_t at = ctx.ic0 + 3u * (c - cb[3]);
+#pragma unroll
         for (int v = 0; v < 3; ++v) {
             const Vertex3f a = s.ic_v[at + v];
             p[v] = make_float2(a.x, a.y);
@@ -138,7 +167,8 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         kind = KIND_IC;
         n_attr = 3;
     } else if (c < cb[5]) {
-        const uint32_t at = 3u * (b0[CH_RQ] + (c - cb[4]));
+        const uint32_t at = 3u * (ctx.rq0 + (c - cb[4]));
+#pragma unroll
         for (int v = 0; v < 3; ++v) {
             const Vertex3f a = s.rq_v[at + v];
             p[v] = make_float2(a.x, a.y);
@@ -147,7 +177,8 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         kind = KIND_RQ;
         n_attr = 3;
     } else if (c < cb[6]) {
-        const uint32_t at = b0[CH_RC_V] + 3u * (c - cb[5]);
+        const uint32_t at = ctx.rc0 + 3u * (c - cb[5]);
+#pragma unroll
         for (int v = 0; v < 3; ++v) {
             const Vertex4f a = s.rc_v[at + v];
             p[v] = make_float2(a.x, a.y);
@@ -156,14 +187,14 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         kind = KIND_RC;
         n_attr = 4;
     } else { // a triangle of the hull strip as a cover triangle (hull strips whose triangles face both ways)
-        const uint32_t k = c - cb[6], hull0 = b0[CH_HULL];
+        const uint32_t k = c - cb[6], hull0 = ctx.hull0;
         const Vertex0 a = s.hull_v[hull0 + k], b = s.hull_v[hull0 + ((k & 1u) ? k + 2u : k + 1u)], d = s.hull_v[hull0 + ((k & 1u) ? k + 1u : k + 2u)];
         p[0] = make_float2(a.x, a.y), p[1] = make_float2(b.x, b.y), p[2] = make_float2(d.x, d.y);
         kind = EK_COVER_TRI;
         n_attr = 0;
     }
 #pragma unroll
-    for (int v = 0; v < 3; ++v) p[v] = to_framebuffer(m, W, H, p[v].x, p[v].y);
+    for (int v = 0; v < 3; ++v) p[v] = to_framebuffer(ctx, W, H, p[v].x, p[v].y);
     const float d1x = p[1].x - p[0].x, d1y = p[1].y - p[0].y;
     const float d2x = p[2].x - p[0].x, d2y = p[2].y - p[0].y;
     const float det = d1x * d2y - d2x * d1y;
@@ -193,18 +224,16 @@ CRH_D bool setup_plain_triangle(const SceneDev& s, const RasterParams& r, const 
         rec.cov.nay[i] = -(eh.y - el.y) * sg;
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        if (a < n_attr) {
-            const float da1 = attr[1][a] - attr[0][a], da2 = attr[2][a] - attr[0][a];
-            rec.frag.a0[a] = attr[0][a];
-            rec.frag.gx[a] = (da1 * d2y - da2 * d1y) * inv_det;
-            rec.frag.gy[a] = (da2 * d1x - da1 * d2x) * inv_det;
-        } else {
-            rec.frag.a0[a] = rec.frag.gx[a] = rec.frag.gy[a] = 0.0f;
-        }
+    for (int a = 0; a < 4; ++a) { // selects, not branches on the run-time n_attr: those made the compiler index the record in scratch memory (40 B per lane,
+        // and every scratch access is a vector-memory operation that waits for the record stores in flight)
+        const float da1 = attr[1][a] - attr[0][a], da2 = attr[2][a] - attr[0][a];
+        const bool on = a < n_attr;
+        rec.frag.a0[a] = on ? attr[0][a] : 0.0f;
+        rec.frag.gx[a] = on ? (da1 * d2y - da2 * d1y) * inv_det : 0.0f;
+        rec.frag.gy[a] = on ? (da2 * d1x - da1 * d2x) * inv_det : 0.0f;
     }
     if (kind == EK_COVER_TRI) { // color_cover: (rgb * a, a), shaders.wgsl:304-309
-        const float* color = r.colors + 4u * it.instance;
+        const float* color = ctx.col;
         rec.frag.a0[0] = color[0] * color[3], rec.frag.a0[1] = color[1] * color[3], rec.frag.a0[2] = color[2] * color[3], rec.frag.a0[3] = color[3];
     }
     rec.frag.v0x = p[0].x;
@@ -229,6 +258,8 @@ struct Stage {
     uint32_t* key;
     uint32_t used;
     uint32_t sub; // the sub-stream of the wavefront's next block
+    uint32_t cap; // entries the wavefront's stage holds (flushed when fewer than 64 are free)
+    uint32_t at;  // k_bin_flat: where the wavefront's next block goes in the pair stream — its share of the range the workgroup reserved (0xFFFFFFFF: dropped)
 };
 CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
     if (st.used == 0u) return;
@@ -255,8 +286,28 @@ CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
     st.used = 0u;
     st.sub = (st.sub + 7u) % kSubStreams; // the next block goes to another region: one huge Shape must not fill a single region
 }
+// k_bin_flat: the wavefront's block goes to the range reserved for it (no atomic, no wait: coalesced stores only)
+CRH_D void stage_flush_reserved(Stage& st, const RasterParams& r, uint32_t lane) {
+    if (st.used == 0u) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#ifdef CRH_ABLATE
+    if (r.debug & 2097152u) st.at = 0xFFFFFFFFu; // tools/ablate_flat.sh: no pair stores
+#endif
+    if (st.at != 0xFFFFFFFFu) {
+        for (uint32_t i = lane; i < st.used; i += 64u) {
+            r.pair_tile[st.at + i] = st.tile[i];
+            r.pair_pos[st.at + i] = st.pos[i];
+            r.pair_key[st.at + i] = st.key[i];
+        }
+        st.at += st.used;
+    }
+    __builtin_amdgcn_wave_barrier();
+    st.used = 0u;
+}
 CRH_D uint32_t lanes_below(unsigned long long ballot, uint32_t lane) { return (uint32_t)__popcll(ballot & ((1ull << lane) - 1ull)); }
 // the lanes of `ballot` append one entry each
+template <bool RESERVED = false>
 CRH_D void stage_append(Stage& st, const RasterParams& r, uint32_t lane, unsigned long long ballot, uint32_t tile, uint32_t pos, uint32_t key) {
 #ifdef CRH_ABLATE
     if (r.debug & 512u) return;
@@ -268,7 +319,9 @@ CRH_D void stage_append(Stage& st, const RasterParams& r, uint32_t lane, unsigne
         st.key[at] = key;
     }
     st.used += (uint32_t)__popcll(ballot);
-    if (st.used > kStage - 64u) stage_flush(st, r, lane);
+    if (st.used > st.cap - 64u) {
+        if (RESERVED) stage_flush_reserved(st, r, lane); else stage_flush(st, r, lane);
+    }
 }
 
 CRH_D bool accepts(float e, uint32_t tl) { return e > 0.0f || (e == 0.0f && tl != 0u); }
@@ -284,17 +337,19 @@ struct BinEdge { // one boundary edge of the item, canonical orientation
 // boundary chain of a zig-zag strip (vertex.rs:28-35): the edge owned by strip position `pos` runs to position `target`
 //   pos 0 -> 1;  even pos >= 2 -> pos - 2;  odd pos -> pos + 2, or — at the end of the strip — to the other one of the last two positions
 // Edge i of an item: i < n_fe the fill chain(s), then the hull chain (n_hull_chain edges: 0 when the hull is drawn as triangles).
-CRH_D BinEdge load_edge(const SceneDev& s, const RasterParams& r, const DrawItem& it, const ItemSlots& k, uint32_t n_hull_chain, uint32_t i, const float* m) {
+// `n_fe` fill chain edges, then `n_hull_chain` hull chain edges. An endpoint that is not finite on the frame (finite vertices times a
+// finite matrix can overflow) sets *broken: the chain is not closed any more, so its backdrops mean nothing — the frame is then drawn by
+// the triangle pass, which skips exactly the strip triangles with a non-finite determinant as the reference's rasterizer would.
+CRH_D BinEdge load_edge(const SceneDev& s, const RasterParams& r, const ItemCtx& ctx, uint32_t n_fe, uint32_t n_hull_chain, uint32_t i) {
     BinEdge e = {};
     e.valid = false;
-    if (i >= k.n_fe + n_hull_chain) return e;
-    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    if (i >= n_fe + n_hull_chain) return e;
     float2 a, b;
-    if (i < k.n_fe) {
+    if (i < n_fe) {
         // Everything the edge may need is requested at once — the flags of the neighbours and the four vertices the chain can run to —
         // instead of flag -> neighbour's flag -> target vertex one after the other (the item's wavefront spent 40 % of its time in this
         // chain of dependent loads). Indices are clamped to the item's own vertices; what is selected always exists.
-        const uint32_t sv0 = b0[CH_SOLID_V], g = sv0 + i, g_last = sv0 + k.n_fe - 1u;
+        const uint32_t sv0 = ctx.sv0, g = sv0 + i, g_last = sv0 + n_fe - 1u;
         const uint32_t gm1 = i >= 1u ? g - 1u : g, gm2 = i >= 2u ? g - 2u : g, gp1 = min(g + 1u, g_last), gp2 = min(g + 2u, g_last);
         const uint32_t f = s.solid_flag[g], f_prev = s.solid_flag[gm1], f_next = s.solid_flag[gp1];
         const Vertex0 va = s.solid_v[g], vm1 = s.solid_v[gm1], vm2 = s.solid_v[gm2], vp1 = s.solid_v[gp1], vp2 = s.solid_v[gp2];
@@ -311,7 +366,7 @@ CRH_D BinEdge load_edge(const SceneDev& s, const RasterParams& r, const DrawItem
         }
         a = make_float2(va.x, va.y), b = make_float2(vb.x, vb.y);
     } else {
-        const uint32_t pos = i - k.n_fe, n = n_hull_chain, hull0 = b0[CH_HULL];
+        const uint32_t pos = i - n_fe, n = n_hull_chain, hull0 = ctx.hull0;
         uint32_t target;
         if (pos == 0u)
             target = 1u;
@@ -325,16 +380,19 @@ CRH_D BinEdge load_edge(const SceneDev& s, const RasterParams& r, const DrawItem
         if (pos + 2u < n) { // strip triangle `pos` = (pos, pos + 1, pos + 2), odd ones with the last two swapped: which way does it face?
             const float W = (float)r.width, H = (float)r.height;
             const Vertex0 v1 = s.hull_v[hull0 + ((pos & 1u) ? pos + 2u : pos + 1u)], v2 = s.hull_v[hull0 + ((pos & 1u) ? pos + 1u : pos + 2u)];
-            const float2 p0 = to_framebuffer(m, W, H, va.x, va.y), p1 = to_framebuffer(m, W, H, v1.x, v1.y), p2 = to_framebuffer(m, W, H, v2.x, v2.y);
+            const float2 p0 = to_framebuffer(ctx, W, H, va.x, va.y), p1 = to_framebuffer(ctx, W, H, v1.x, v1.y), p2 = to_framebuffer(ctx, W, H, v2.x, v2.y);
             const float d1x = p1.x - p0.x, d1y = p1.y - p0.y, d2x = p2.x - p0.x, d2y = p2.y - p0.y;
             const float det = d1x * d2y - d2x * d1y; // setup_plain_triangle's det
             e.strip_det = (det == det && is_finite(det)) ? det : 0.0f;
         }
     }
     const float W = (float)r.width, H = (float)r.height;
-    a = to_framebuffer(m, W, H, a.x, a.y);
-    b = to_framebuffer(m, W, H, b.x, b.y);
-    if (!(is_finite(a.x) && is_finite(a.y) && is_finite(b.x) && is_finite(b.y))) return e;
+    a = to_framebuffer(ctx, W, H, a.x, a.y);
+    b = to_framebuffer(ctx, W, H, b.x, b.y);
+    if (!(is_finite(a.x) && is_finite(a.y) && is_finite(b.x) && is_finite(b.y))) {
+        r.overflow[7] = 1u; // (see above; the host draws the frame again with the triangle pass)
+        return e;
+    }
     if (a.x == b.x && a.y == b.y) return e;
     const bool flip = !(a.x < b.x || (a.x == b.x && a.y < b.y)); // canonical (lexicographic) endpoint order
     const float2 lo = flip ? b : a, hi = flip ? a : b;
@@ -368,24 +426,23 @@ CRH_D uint32_t wave_max_u32(uint32_t v) {
 // The exact tile test of a set-up triangle: its best tile corner per edge decides (an edge function is monotone in x and y under fmaf).
 // A conservative superset of "some sample of the tile is covered"; the raster kernel decides per sample.
 struct TileTest {
-    float bx[3], nay[3], lo_x[3], lo_y[3], best_x[3], best_y[3];
-    uint32_t tl[3];
+    float bx[3], nay[3], lo_x[3], lo_y[3];
+    float s_lo, s_hi;  // extreme sample offsets inside a tile
+    uint32_t tl;       // bits 0-2: top-left per edge
     CRH_D void set(const PrimCoverage& cov, float lo, float hi) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            bx[i] = cov.bx[i], nay[i] = cov.nay[i], lo_x[i] = cov.lo_x[i], lo_y[i] = cov.lo_y[i];
-            best_x[i] = cov.nay[i] > 0.0f ? hi : lo;
-            best_y[i] = cov.bx[i] > 0.0f ? hi : lo;
-            tl[i] = (cov.flags >> i) & 1u;
-        }
+        for (int i = 0; i < 3; ++i) bx[i] = cov.bx[i], nay[i] = cov.nay[i], lo_x[i] = cov.lo_x[i], lo_y[i] = cov.lo_y[i];
+        s_lo = lo, s_hi = hi;
+        tl = cov.flags & 7u;
     }
     CRH_D bool hit(uint32_t tx, uint32_t ty) const {
         const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
         bool ok = true;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float e = fmaf(best_y[i], bx[i], fmaf(best_x[i], nay[i], bx[i] * (ty0 - lo_y[i]) + nay[i] * (tx0 - lo_x[i])));
-            ok = ok && accepts(e, tl[i]);
+        for (int i = 0; i < 3; ++i) { // the best corner of the tile for this edge (selected here: two registers per edge less to carry)
+            const float best_x = nay[i] > 0.0f ? s_hi : s_lo, best_y = bx[i] > 0.0f ? s_hi : s_lo;
+            const float e = fmaf(best_y, bx[i], fmaf(best_x, nay[i], bx[i] * (ty0 - lo_y[i]) + nay[i] * (tx0 - lo_x[i])));
+            ok = ok && accepts(e, (tl >> i) & 1u);
         }
         return ok;
     }
@@ -424,9 +481,10 @@ CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool d
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             wide.bx[i] = __shfl(test.bx[i], src, 64), wide.nay[i] = __shfl(test.nay[i], src, 64), wide.lo_x[i] = __shfl(test.lo_x[i], src, 64);
-            wide.lo_y[i] = __shfl(test.lo_y[i], src, 64), wide.best_x[i] = __shfl(test.best_x[i], src, 64), wide.best_y[i] = __shfl(test.best_y[i], src, 64);
-            wide.tl[i] = (uint32_t)__shfl((int)test.tl[i], src, 64);
+            wide.lo_y[i] = __shfl(test.lo_y[i], src, 64);
         }
+        wide.s_lo = test.s_lo, wide.s_hi = test.s_hi;
+        wide.tl = (uint32_t)__shfl((int)test.tl, src, 64);
         const uint32_t wx0 = (uint32_t)__shfl((int)bx0, src, 64), wy0 = (uint32_t)__shfl((int)by0, src, 64), wnx = (uint32_t)__shfl((int)nx, src, 64);
         const uint32_t wnt = (uint32_t)__shfl((int)nt, src, 64), wkey = (uint32_t)__shfl((int)key, src, 64);
         for (uint32_t base = 0; base < wnt; base += 64u) {
@@ -508,7 +566,8 @@ CRH_D bool bin_triangles_counted(Stage& st, const RasterParams& r, uint32_t lane
 // One workgroup per draw item. Wavefront 0: the stroke and curve triangles (bin_triangles). Wavefront 1: the boundary edges, transposed —
 // lane = tile of the item's rectangle (64 per pass), uniform loop over the edges (staged in LDS): every lane accumulates the backdrops of
 // its tile and the bit mask of the edges that matter inside it, then emits its entries.
-template <int S>
+// QUEUED: the items are those k_bin_flat handed on (r.bin_queue, their number in r.overflow[6]) — the ones too large for its batches.
+template <int S, bool QUEUED>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAVES))) void k_bin_edges(SceneDev s, RasterParams r) {
     __shared__ uint32_t stage_tile[2][kStage], stage_pos[2][kStage], stage_key[2][kStage];
     __shared__ float4 edge_a[64], edge_b[64];
@@ -517,14 +576,16 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     __shared__ uint32_t rect_cursor[kRectLds];                // ... and the count, then the next list position, of the edges that matter there
     __shared__ uint32_t rect_cursor_tri[kRectLds];            // the same for the triangle wavefront (its own rectangle, per chunk of 64 triangles)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, (2u * blockIdx.x + wave) % kSubStreams};
+    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, ((2u * blockIdx.x + wave) * 2654435761u) >> 26, kStage, 0u}; // (a hash: consecutive wavefronts start in unrelated sub-streams)
     // a workgroup takes items blockIdx.x, blockIdx.x + gridDim.x, ...: the pair stage carries over from one item to the next (fewer, fuller
     // flushes), and the two wavefronts never synchronise with each other
-    for (uint32_t item = blockIdx.x; item < r.n_items; item += gridDim.x) {
+    const uint32_t n_work = QUEUED ? min(r.overflow[6], r.n_items) : r.n_items;
+    for (uint32_t work = blockIdx.x; work < n_work; work += gridDim.x) {
     __builtin_amdgcn_wave_barrier(); // (the previous item's readers of the LDS tables are through)
+    const uint32_t item = QUEUED ? r.bin_queue[work] : work;
     const DrawItem it = item_of(r, item);
-    const float* m = r.transforms + 16u * it.instance;
     const ItemSlots k = item_slots(s, it);
+    const ItemCtx ctx = item_ctx(s, r, it, k.cb);
     const uint32_t slot0 = r.slot_begin[item];
     if (slot0 + k.total > r.slot_capacity) continue; // cannot happen: the capacity is the scan's total
 #ifdef CRH_ABLATE
@@ -544,7 +605,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
             CRH_PHASE(0) // item data
             if (t < k.n_tri) {
                 const uint32_t c = t < k.cb[1] ? t : t - k.cb[1] + k.cb[2]; // the Shape's candidate numbering without the solid strips
-                drawn = setup_plain_triangle(s, r, it, k.cb, c, m, rec);
+                drawn = setup_plain_triangle(s, r, ctx, c, rec);
                 if (drawn) *reinterpret_cast<PrimRec*>(r.slots + (size_t)(slot0 + 4u * t) * 32u) = rec;
             }
             CRH_PHASE(1) // triangle set-up
@@ -555,7 +616,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     } else {
         // ---------------- boundary edges: fill chain(s) then hull chain
         const uint32_t fe_slot0 = slot0 + k.fe0, synth_a = slot0 + k.synth_a, hull_slot0 = slot0 + k.hull0, synth_b = slot0 + k.synth_b;
-        const float* item_color = r.colors + 4u * it.instance;
+        const float* item_color = ctx.col;
         const bool opaque_item = item_color[3] == 1.0f && is_finite(item_color[0]) && is_finite(item_color[1]) && is_finite(item_color[2]) &&
                                  r.occlude != 0u && (r.debug & 32768u) == 0u; // debug bit 15 (tests, A/B runs): no tile is ever treated as replaced
         if (lane < 13u + kCoverOpaque) { // 4 backdrop + 27 COVER slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
@@ -576,7 +637,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
         BinEdge kept = {}; // the lane's edge of the first chunk (most items have no other)
         auto stage_chunk = [&](uint32_t i0, bool write_records) {
             const uint32_t i = i0 + lane;
-            const BinEdge e = load_edge(s, r, it, k, n_hull_chain, i, m);
+            const BinEdge e = load_edge(s, r, ctx, k.n_fe, n_hull_chain, i);
             if (write_records && i0 == 0u) kept = e;
             const uint32_t flags = (EK_EDGE << 4) | (e.tl ? kEdgeTl : 0u) | (e.sigma > 0 ? kEdgeSigmaPos : 0u) | (e.hull ? kEdgeHull : 0u);
             if (e.valid && write_records) {
@@ -638,7 +699,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                     e = kept;
                     e.valid = e.valid && i < n_edges;
                 } else {
-                    e = load_edge(s, r, it, k, n_hull_chain, i, m);
+                    e = load_edge(s, r, ctx, k.n_fe, n_hull_chain, i);
                 }
                 return e;
             };
@@ -834,7 +895,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                 PrimRec rec = {};
                 bool drawn = false;
                 if (t + 2u < k.n_hull) {
-                    drawn = setup_plain_triangle(s, r, it, k.cb, k.cb[6] + t, m, rec);
+                    drawn = setup_plain_triangle(s, r, ctx, k.cb[6] + t, rec);
                     if (drawn) *reinterpret_cast<PrimRec*>(r.slots + (size_t)(hull_slot0 + 4u * t) * 32u) = rec;
                 }
                 bin_triangles(st, r, lane, drawn, rec.cov, hull_slot0 + 4u * t, ry_first, r_last);
@@ -844,6 +905,571 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     CRH_PHASE(5) // pass 3 (edges) / nothing (triangles)
     } // items
     stage_flush(st, r, lane);
+}
+
+
+// ---------------------------------------------------------------------------------------------- k_bin_flat
+// The same binning with the lanes packed ACROSS draw items. k_bin_edges gives every item a wavefront per role and each of them walks
+// item -> ranges -> vertices -> records -> LDS passes -> returning atomics alone: 20 000 wavefronts of 33 us for the benchmark scene, a
+// third to two thirds of their lanes idle (18 triangles, 40 edges per item), and that sum of wavefront lifetimes, not arithmetic, was the
+// kernel's time. Here a 256-thread workgroup takes a batch of up to 32 consecutive items at once:
+//   0  lane = item: the item's record (ItemCtx, slot ranges, counts) into LDS — ONE round of dependent loads for the whole batch;
+//   A  lane = triangle / lane = edge over the batch (prefix sums of the items' counts in LDS, five-step search): set-up records written
+//      to the heap, the primitive kept in registers, the item's pixel box and the facing of its hull strip gathered with LDS atomics;
+//   B  lane = item: the item's tile rectangle and its share of a pool of per-tile tables in LDS;
+//   C  (pass 1) every edge adds its backdrop terms and counts, per tile of its own box, whether it matters there; every triangle
+//      counts the tiles it reaches — the triangles use the item's table too, so no primitive needs a global atomic of its own;
+//   D  (pass 2) lane = tile of the pool: ONE returning atomic on the tile's global counter reserves the list positions of everything the
+//      item has there, the synthetic entries (COVER / backdrop units) are emitted;
+//   E  (pass 3) edges and triangles walk again and take their positions from the LDS cursors.
+// A hull strip that folds (k_bin_edges) has its triangles binned the old way at the end. What does not fit a batch — more than 256
+// triangles or 512 edges in ONE item, a rectangle beyond the pool — is queued for k_bin_edges<S, true>, which has no such limits.
+// Slots, records and keys are exactly those of k_bin_edges; the order of a tile's entries in memory differs, the raster kernel sorts.
+#ifndef CRH_FLAT_WAVES
+#define CRH_FLAT_WAVES 3 // 168 registers: no scratch memory (at 4 waves = 128 registers the triangle set-up spills, and a scratch access is a vector-memory
+                         // operation that can only be waited for together with the record stores in flight); three workgroups per CU
+#endif
+constexpr uint32_t kFlatItems = 32, kFlatTris = 256, kFlatEdges = 512, kFlatPool = 1536, kFlatStage = 256; // 37 KB of LDS: four workgroups per CU
+constexpr uint32_t kFiOpaque = 1u, kFiSkip = 2u, kFiHullTris = 4u;
+struct FlatItem {
+    ItemCtx ctx;
+    uint32_t slot0, fe_slot0, synth_a, hull_slot0, synth_b; // absolute slot numbers of the item's regions
+    uint32_t n_tri, n_fe, n_hull, n_hull_chain;
+    uint32_t flags;  // kFi*
+    int box[4];      // ordered-int images of the float box of everything the item draws: min x, min y, max x, max y (LDS atomics)
+    uint32_t faces;  // bit 0: a strip triangle of the hull faces front, bit 1: one faces back
+    uint32_t tx_a, ty_a, tx_b, ty_b, nx, n_rect;
+};
+CRH_D int ordered_int(float f) { // monotone float -> int (finite values): atomicMin / atomicMax on LDS integers
+    const int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7FFFFFFF);
+}
+CRH_D float ordered_float(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7FFFFFFF)); }
+CRH_D uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+// the largest j < 32 with begin[j] <= x (begin is non-decreasing, entries behind the batch hold 0xFFFFFFFF)
+CRH_D uint32_t find_item(const uint32_t* begin, uint32_t x) {
+    uint32_t j = 0;
+#pragma unroll
+    for (uint32_t step = 16; step > 0; step >>= 1)
+        if (begin[j + step] <= x) j += step;
+    return j;
+}
+// A workgroup barrier that orders LDS accesses only. __syncthreads() also waits for the wavefront's global stores (s_waitcnt vmcnt(0):
+// gfx950 counts loads and stores with one counter), and the record stores of phase A — 46 MB per frame of the benchmark scene — took
+// 50 us to drain at the first barrier behind them, every workgroup waiting at once. Nothing here reads global memory another wavefront
+// of the workgroup wrote, so the stores may stay in flight across the barriers.
+CRH_D void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+// A boundary edge between the passes of k_bin_flat: five registers instead of BinEdge's fourteen (the rest is recomputed with the very
+// expressions load_edge used, so the values are the same bits).
+struct PackedEdge {
+    float lo_x, lo_y, hi_x, hi_y;
+    uint32_t flags; // bit 0 valid, 1 top-left, 2 hull, 3 sigma > 0, 4 down
+};
+CRH_D PackedEdge pack_edge(const BinEdge& e) {
+    return PackedEdge{e.lo_x, e.lo_y, e.hi_x, e.hi_y, (e.valid ? 1u : 0u) | (e.tl ? 2u : 0u) | (e.hull ? 4u : 0u) | (e.sigma > 0 ? 8u : 0u) | (e.down ? 16u : 0u)};
+}
+CRH_D BinEdge unpack_edge(const PackedEdge& p) {
+    BinEdge e = {};
+    e.lo_x = p.lo_x, e.lo_y = p.lo_y, e.hi_x = p.hi_x, e.hi_y = p.hi_y;
+    e.bx = p.hi_x - p.lo_x;
+    e.nay = -(p.hi_y - p.lo_y);
+    e.ymin = fminf(p.lo_y, p.hi_y), e.ymax = fmaxf(p.lo_y, p.hi_y);
+    e.valid = (p.flags & 1u) != 0u, e.tl = (p.flags >> 1) & 1u, e.hull = (p.flags >> 2) & 1u, e.sigma = (p.flags & 8u) ? 1 : -1, e.down = (int)((p.flags >> 4) & 1u);
+    return e;
+}
+struct FlatTri { // a set-up triangle between the passes: its tile test and tile box
+    TileTest test;
+    uint32_t bx0, bx1, by0, nt, key, item;
+};
+#ifdef CRH_ABLATE // tools/bin_phases.py: cycles wavefront 0 of every workgroup of k_bin_flat spends per phase (summed in overflow[80 ...])
+#define CRH_FLAT_PHASE(k)                                                                                              \
+    if ((r.debug & 65536u) && tid == 0u) {                                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+        atomicAdd(reinterpret_cast<unsigned long long*>(r.overflow + 80) + (k), now_ - phase_t);                       \
+        phase_t = __builtin_amdgcn_s_memtime();                                                                        \
+    }                                                                                                                  \
+    if ((r.debug >> 24) == (k) + 1u) return; /* tools/ablate_flat.sh: the kernel up to and including phase k */
+#else
+#define CRH_FLAT_PHASE(k)
+#endif
+template <int S>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WAVES))) void k_bin_flat(SceneDev s, RasterParams r, uint32_t items_per_group) {
+    __shared__ uint32_t stage_tile[4][kFlatStage], stage_pos[4][kFlatStage], stage_key[4][kFlatStage];
+    __shared__ FlatItem items[kFlatItems];
+    __shared__ uint32_t tri_begin[kFlatItems + 1], edge_begin[kFlatItems + 1], pool_begin[kFlatItems + 1];
+    __shared__ int pool_bd[kFlatPool], pool_hbd[kFlatPool];
+    __shared__ uint32_t pool_cursor[kFlatPool]; // pass 1: the entries the item's edges and triangles have in the tile (bits 0-19; bits 20-31: the hull edges among them), then the next list position
+    __shared__ uint32_t batch[5];               // items in the batch, its triangles, its edges, tiles of its pool, items of the batch that are binned in this turn
+    __shared__ uint32_t wave_entries[8];        // entries every wavefront appends in pass 3 ([0..3]) and in pass 2 ([4..7]); then where its share of the pair stream begins
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, 0u, kFlatStage, 0xFFFFFFFFu};
+    uint32_t turn = 0; // batches this workgroup has binned (the pair sub-stream of a batch follows from it)
+    const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
+    const float W = (float)r.width, H = (float)r.height;
+    const uint32_t first_item = blockIdx.x * items_per_group, last_item = min(r.n_items, first_item + items_per_group);
+    const bool all_queued = (r.debug & (1u | 2u | 4194304u)) != 0u; // debug bits 0, 1 (tests of k_bin_edges' own code paths), 22: every item takes that kernel
+#ifdef CRH_ABLATE
+    unsigned long long phase_t = __builtin_amdgcn_s_memtime();
+#endif
+    for (uint32_t next = first_item; next < last_item;) {
+        lds_barrier(); // (the previous batch's readers of the LDS records are through)
+        // ---------------- 0: the records of the next items
+        const uint32_t n_cand = min(kFlatItems, last_item - next);
+        if (tid < n_cand) {
+            const uint32_t item = next + tid;
+            const DrawItem it = item_of(r, item);
+            const ItemSlots k = item_slots(s, it);
+            FlatItem& fi = items[tid];
+            fi.ctx = item_ctx(s, r, it, k.cb);
+            const uint32_t slot0 = r.slot_begin[item];
+            fi.slot0 = slot0, fi.fe_slot0 = slot0 + k.fe0, fi.synth_a = slot0 + k.synth_a, fi.hull_slot0 = slot0 + k.hull0, fi.synth_b = slot0 + k.synth_b;
+            fi.n_tri = k.n_tri, fi.n_fe = k.n_fe, fi.n_hull = k.n_hull, fi.n_hull_chain = k.n_hull;
+            const float* c = fi.ctx.col;
+            const bool opaque = c[3] == 1.0f && is_finite(c[0]) && is_finite(c[1]) && is_finite(c[2]) && r.occlude != 0u && (r.debug & 32768u) == 0u;
+            const bool oversize = k.n_tri > kFlatTris || k.n_fe + k.n_hull > kFlatEdges || all_queued || slot0 + k.total > r.slot_capacity;
+            fi.flags = (opaque ? kFiOpaque : 0u) | (oversize ? kFiSkip : 0u);
+            fi.box[0] = fi.box[1] = 0x7FFFFFFF, fi.box[2] = fi.box[3] = (int)0x80000000;
+            fi.faces = 0u;
+            fi.n_rect = 0u;
+            if (oversize && slot0 + k.total <= r.slot_capacity) r.bin_queue[atomicAdd(&r.overflow[6], 1u)] = item;
+        }
+        lds_barrier();
+        if (wave == 0u) { // the batch: the longest run of items whose triangles and edges fit the lanes (an oversize item counts as empty)
+            const bool real = lane < n_cand && lane < kFlatItems, counted = real && (items[lane & 31u].flags & kFiSkip) == 0u;
+            const uint32_t nt = counted ? items[lane & 31u].n_tri : 0u, ne = counted ? items[lane & 31u].n_fe + items[lane & 31u].n_hull : 0u;
+            const uint32_t pt = wave_inclusive_scan(nt, lane), pe = wave_inclusive_scan(ne, lane);
+            const unsigned long long fits = __ballot(real && pt <= kFlatTris && pe <= kFlatEdges);
+            const uint32_t n_batch = (uint32_t)__builtin_ctzll(~fits); // leading lanes that fit (>= 1: one item alone always does)
+            if (lane <= kFlatItems) {
+                tri_begin[lane] = lane <= n_batch ? pt - nt : 0xFFFFFFFFu;
+                edge_begin[lane] = lane <= n_batch ? pe - ne : 0xFFFFFFFFu;
+            }
+            const uint32_t total_t = (uint32_t)__shfl((int)pt, (int)n_batch - 1, 64), total_e = (uint32_t)__shfl((int)pe, (int)n_batch - 1, 64);
+            if (lane == 0u) {
+                batch[0] = n_batch, batch[1] = total_t, batch[2] = total_e;
+                tri_begin[n_batch] = 0xFFFFFFFFu, edge_begin[n_batch] = 0xFFFFFFFFu; // (searches stop in front of it; the totals are in batch[])
+            }
+        }
+        lds_barrier();
+        const uint32_t n_batch = batch[0], n_tris = batch[1], n_edges = batch[2];
+        CRH_FLAT_PHASE(0) // item records + batch
+        // ---------------- A: set-up, lane = triangle and lane = edge (two edges per lane), records to the heap, boxes and hull facing to LDS.
+        // All loads first, all stores last: gfx950 counts vector loads and stores with ONE counter, in order — a load issued behind the 128-byte
+        // record stores can only be waited for together with them, and those take tens of microseconds to drain when every workgroup
+        // writes its records at once.
+        PackedEdge kept[2];
+        float strip_det[2];
+        uint32_t edge_item[2], edge_key[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t e = tid + 256u * (uint32_t)k;
+            kept[k] = PackedEdge{0.0f, 0.0f, 0.0f, 0.0f, 0u};
+            strip_det[k] = 0.0f;
+            edge_item[k] = 0u, edge_key[k] = 0u;
+            if (e < n_edges) {
+                const uint32_t j = find_item(edge_begin, e), i = e - edge_begin[j];
+                const FlatItem& fi = items[j];
+                const BinEdge loaded = load_edge(s, r, fi.ctx, fi.n_fe, fi.n_hull, i);
+                kept[k] = pack_edge(loaded), strip_det[k] = loaded.strip_det;
+                edge_item[k] = j;
+                edge_key[k] = i < fi.n_fe ? fi.fe_slot0 + i : fi.hull_slot0 + (i - fi.n_fe);
+            }
+        }
+        CRH_FLAT_PHASE(1) // edge set-up
+        FlatTri tri;
+        tri.nt = 0u, tri.item = 0u, tri.key = 0u, tri.bx0 = tri.bx1 = tri.by0 = 0u;
+        tri.test = TileTest{};
+        PrimRec rec = {};
+        bool tri_drawn = false;
+        if (tid < n_tris) {
+            const uint32_t j = find_item(tri_begin, tid), t = tid - tri_begin[j];
+            const FlatItem& fi = items[j];
+            const ItemCtx& ctx = fi.ctx;
+            const uint32_t c = t < ctx.cb[1] ? t : t - ctx.cb[1] + ctx.cb[2]; // the Shape's candidate numbering without the solid strips
+            tri_drawn = setup_plain_triangle(s, r, ctx, c, rec);
+            tri.key = fi.slot0 + 4u * t, tri.item = j;
+        }
+        // ---- stores and LDS
+#ifdef CRH_ABLATE
+        const bool store_records = (r.debug & 8388608u) == 0u; // tools/ablate_flat.sh: no record stores
+#else
+        constexpr bool store_records = true;
+#endif
+        if (tri_drawn) {
+            if (store_records) *reinterpret_cast<PrimRec*>(r.slots + (size_t)tri.key * 32u) = rec;
+            tri.test.set(rec.cov, ry_first, r_last);
+            tri.bx0 = rec.cov.box.x / kTile, tri.bx1 = rec.cov.box.y / kTile, tri.by0 = rec.cov.box.z / kTile;
+            tri.nt = (tri.bx1 - tri.bx0 + 1u) * (rec.cov.box.w / kTile - tri.by0 + 1u);
+            FlatItem& fi = items[tri.item];
+            atomicMin(&fi.box[0], ordered_int((float)rec.cov.box.x)), atomicMin(&fi.box[1], ordered_int((float)rec.cov.box.z));
+            atomicMax(&fi.box[2], ordered_int((float)rec.cov.box.y)), atomicMax(&fi.box[3], ordered_int((float)rec.cov.box.w));
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (tid + 256u * (uint32_t)k < n_edges) {
+                FlatItem& fi = items[edge_item[k]];
+                const BinEdge e = unpack_edge(kept[k]);
+                if (e.valid) {
+                    EdgeRec er;
+                    er.flags = (EK_EDGE << 4) | (e.tl ? kEdgeTl : 0u) | (e.sigma > 0 ? kEdgeSigmaPos : 0u) | (e.hull ? kEdgeHull : 0u), er.pad0 = 0u;
+                    er.lo_x = e.lo_x, er.lo_y = e.lo_y, er.hi_x = e.hi_x, er.hi_y = e.hi_y, er.bx = e.bx, er.nay = e.nay;
+                    if (store_records) *reinterpret_cast<EdgeRec*>(r.slots + (size_t)edge_key[k] * 32u) = er;
+                    atomicMin(&fi.box[0], ordered_int(e.lo_x)), atomicMin(&fi.box[1], ordered_int(e.ymin));
+                    atomicMax(&fi.box[2], ordered_int(e.hi_x)), atomicMax(&fi.box[3], ordered_int(e.ymax));
+                }
+                // (a strip triangle is judged at its first position whether or not that position's chain edge is valid)
+                if (strip_det[k] != 0.0f) atomicOr(&fi.faces, strip_det[k] < 0.0f ? 1u : 2u);
+            }
+        }
+        CRH_FLAT_PHASE(2) // triangle set-up, record stores
+        for (uint32_t q = tid; q < 31u * n_batch; q += 256u) { // the items' 4 backdrop + 27 COVER slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
+            const uint32_t j = q / 31u, l = q - 31u * j;
+            const FlatItem& fi = items[j];
+            if (fi.flags & kFiSkip) continue;
+            SynthRec sr = {};
+            sr.flags = (EK_SYNTH << 4) | (l << 8);
+            sr.first_slot = fi.slot0, sr.synth_a = fi.synth_a;
+            const float* c = fi.ctx.col;
+            if (l >= 4u) sr.r = c[0] * c[3], sr.g = c[1] * c[3], sr.b = c[2] * c[3], sr.a = c[3];
+            if (store_records) *reinterpret_cast<SynthRec*>(r.slots + (size_t)(l < 4u ? fi.synth_a + l : fi.synth_b + l - 4u) * 32u) = sr;
+        }
+        lds_barrier();
+        CRH_FLAT_PHASE(3) // synthetic records + barrier
+        // ---------------- B: lane = item: tile rectangle, its tables in the pool; does the hull strip fold?
+        if (wave == 0u) {
+            uint32_t n_rect = 0;
+            const bool mine = lane < n_batch;
+            FlatItem& fi = items[lane & 31u];
+            if (mine && (fi.flags & kFiSkip) == 0u) {
+                const float minx = ordered_float(fi.box[0]), miny = ordered_float(fi.box[1]), maxx = ordered_float(fi.box[2]), maxy = ordered_float(fi.box[3]);
+                if (fi.box[0] <= fi.box[2]) { // something is drawn
+                    const int px0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), px1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
+                    const int py0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), py1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
+                    if (px0 <= px1 && py0 <= py1) {
+                        fi.tx_a = (uint32_t)px0 / kTile, fi.tx_b = (uint32_t)px1 / kTile, fi.ty_a = (uint32_t)py0 / kTile, fi.ty_b = (uint32_t)py1 / kTile;
+                        fi.nx = fi.tx_b - fi.tx_a + 1u;
+                        n_rect = fi.nx * (fi.ty_b - fi.ty_a + 1u);
+                    }
+                }
+                if (fi.n_hull != 0u && (fi.faces == 3u || (r.debug & 4u) != 0u)) fi.flags |= kFiHullTris, fi.n_hull_chain = 0u; // debug bit 2 (tests): always
+            }
+            // Pool shares in item order. Items from the first one that does not fit are left to the workgroup's next turn (their records are
+            // written again then); an item that does not fit the pool even alone goes to k_bin_edges.
+            uint32_t end = wave_inclusive_scan(n_rect, lane);
+            uint32_t n_fit = (uint32_t)__builtin_ctzll(~__ballot(mine && end <= kFlatPool)); // leading items that fit
+            if (n_fit == 0u) {
+                if (lane == 0u) {
+                    fi.flags |= kFiSkip;
+                    r.bin_queue[atomicAdd(&r.overflow[6], 1u)] = next;
+                }
+                n_fit = 1u;
+                if (lane == 0u) n_rect = 0u, end = 0u;
+            }
+            const uint32_t pool_total = (uint32_t)__shfl((int)end, (int)n_fit - 1, 64); // (every lane takes part in the shuffle)
+            if (lane >= n_fit) n_rect = 0u, end = pool_total;
+            if (mine) fi.n_rect = n_rect;
+            if (lane <= kFlatItems) pool_begin[lane] = lane < n_batch ? end - n_rect : (lane == n_batch ? pool_total : 0xFFFFFFFFu);
+            if (lane == 0u) batch[3] = pool_total, batch[4] = n_fit;
+        }
+        lds_barrier();
+        const uint32_t n_pool = batch[3], n_turn = batch[4]; // (items n_turn .. n_batch - 1 are set up but not binned: n_rect == 0)
+        for (uint32_t q = tid; q < n_pool; q += 256u) pool_bd[q] = 0, pool_hbd[q] = 0, pool_cursor[q] = 0u;
+        lds_barrier();
+        CRH_FLAT_PHASE(4) // rectangles, pool cleared
+        // the tiles of a primitive's own box inside its item's rectangle, walked by all lanes of the wavefront together
+        // An edge visits, tile row by tile row of its own box, the columns its LINE can reach inside that row: for a long diagonal edge the
+        // box is mostly tiles the line is nowhere near (a hull edge across a 256-pixel Shape: 100 tiles in the box, 20 along the line).
+        // The column range is a float estimate with a margin (2 px + 4e-6 of the largest coordinate — the distance at which f32 rounding can
+        // still flip an edge function is about 1e-7 of it), clamped to the box; whether the edge matters in a tile is decided by the exact
+        // test as before. Coordinates beyond 1e6 (and horizontal edges, which have one row) take the whole box.
+        auto walk_edge = [&](const BinEdge& e, const FlatItem& fi, bool live, auto&& visit) {
+            int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
+            if (live) {
+                const int x_lo = (int)ceilf((e.lo_x - r_last) * (1.0f / (float)kTile) - 0.01f), x_hi = (int)floorf(e.hi_x * (1.0f / (float)kTile) + 0.01f);
+                const int y_lo = (int)ceilf((e.ymin - r_last) * (1.0f / (float)kTile) - 0.01f), y_hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
+                bx0 = max(x_lo, (int)fi.tx_a), bx1 = min(x_hi, (int)fi.tx_b), by0 = max(y_lo, (int)fi.ty_a), by1 = min(y_hi, (int)fi.ty_b);
+            }
+            const float dy = e.hi_y - e.lo_y, largest = fmaxf(fmaxf(fabsf(e.lo_x), fabsf(e.hi_x)), fmaxf(fabsf(e.lo_y), fabsf(e.hi_y)));
+            const bool by_rows = dy != 0.0f && largest < 1.0e6f;
+            const float xs = by_rows ? (e.hi_x - e.lo_x) / dy : 0.0f, pad = 2.0f + 4.0e-6f * largest;
+            auto row_range = [&](int ty, int& x0, int& x1) { // the columns of row ty worth a test
+                x0 = bx0, x1 = bx1;
+                if (by_rows) {
+                    const float ty0 = (float)(ty * kTile), ya = ty0 + ry_first - pad, yb = ty0 + r_last + pad;
+                    const float xa = e.lo_x + (ya - e.lo_y) * xs, xb = e.lo_x + (yb - e.lo_y) * xs;
+                    const float lo = fminf(xa, xb) - pad - r_last, hi = fmaxf(xa, xb) + pad;
+                    // (clamped as floats first: the estimates of a steep row can be far outside anything an int holds)
+                    x0 = (int)floorf(fmaxf(lo * (1.0f / (float)kTile), (float)bx0));
+                    x1 = (int)floorf(fminf(hi * (1.0f / (float)kTile), (float)bx1));
+                }
+            };
+            const bool up = e.nay > 0.0f; // E grows with ry (bx >= 0) and with rx iff nay > 0
+            int ty = by0, tx = 0, x1 = -1;
+            bool done = !(live && bx0 <= bx1 && by0 <= by1);
+            if (!done) row_range(ty, tx, x1);
+            while (__any(!done)) {
+                bool hit = false;
+                if (!done && tx <= x1) {
+                    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+                    const float c = e.bx * (ty0 - e.lo_y) + e.nay * (tx0 - e.lo_x);
+                    const bool gmax = accepts(fmaf(r_last, e.bx, fmaf(up ? r_last : 0.0f, e.nay, c)), e.tl), gmin = accepts(fmaf(ry_first, e.bx, fmaf(up ? 0.0f : r_last, e.nay, c)), e.tl);
+                    hit = gmax != gmin && e.ymin <= ty0 + r_last && e.ymax >= q0y && e.lo_x <= tx0 + r_last && e.hi_x >= tx0;
+                }
+                visit(hit, (uint32_t)tx, (uint32_t)ty);
+                if (!done) {
+                    if (tx < x1) {
+                        ++tx;
+                    } else if (ty < by1) {
+                        ++ty;
+                        row_range(ty, tx, x1); // (an empty row costs one idle step)
+                    } else {
+                        done = true;
+                    }
+                }
+            }
+        };
+        auto walk_tri = [&](const FlatTri& t, bool live, auto&& visit) {
+            const uint32_t nt = live ? t.nt : 0u, longest = wave_max_u32(nt);
+            uint32_t tx = t.bx0, ty = t.by0;
+            for (uint32_t w = 0; w < longest; ++w) {
+                visit(w < nt && t.test.hit(tx, ty), tx, ty);
+                if (++tx > t.bx1) tx = t.bx0, ++ty;
+            }
+        };
+        // ---------------- C: pass 1
+        uint32_t my_entries = 0; // what this lane's primitives will append in pass 3
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (256u * (uint32_t)k >= n_edges) continue; // (uniform; `continue`, not `break`: the loop must unroll or edge[] lives in scratch memory)
+            const BinEdge e = unpack_edge(kept[k]);
+            const FlatItem& fi = items[edge_item[k]];
+            // the edge takes part: valid, its item is drawn here, and — a hull edge — its hull is binned as a chain
+            const bool live = e.valid && fi.n_rect != 0u && !(e.hull && (fi.flags & kFiHullTris));
+            const uint32_t base = pool_begin[edge_item[k]], nx = fi.nx, tx_a = fi.tx_a, ty_a = fi.ty_a, ty_b = fi.ty_b;
+            // backdrop rows: the tile rows whose line q0y lies in the edge's half-open y range; a conservative integer range first
+            uint32_t row = ty_a, rows_mine = 0;
+            if (live) {
+                const int lo = (int)ceilf((e.ymin - ry_first) * (1.0f / (float)kTile) - 0.01f), hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
+                const int first = max(lo, (int)ty_a), last = min(hi, (int)ty_b);
+                if (first <= last) row = (uint32_t)first, rows_mine = (uint32_t)(last - first + 1);
+            }
+            // Along a tile row the backdrop term of an edge that crosses the row's line is 0 left of the edge and +-1 from some column on (the
+            // edge function is monotone in x under fmaf, so the very predicate a tile would evaluate switches once): that column is found
+            // by bisection — five exact evaluations instead of one per column — and the unit goes there alone; pass 2 sums along the row.
+            const uint32_t most_rows = wave_max_u32(rows_mine);
+            for (uint32_t rr = 0; rr < most_rows; ++rr) {
+                const uint32_t ty = row + rr;
+                const float ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+                const bool crosses = rr < rows_mine && e.ymin <= q0y && q0y < e.ymax; // Y_e at the backdrop row
+                const uint32_t widest = wave_max_u32(crosses ? nx : 0u);
+                if (widest == 0u) continue;
+                uint32_t lo = 0, hi = crosses ? nx : 0u; // the first column with a non-zero term lies in [lo, hi]
+                for (uint32_t span = widest; span > 0u; span >>= 1) { // (ceil(log2(widest + 1)) steps settle every lane)
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const float tx0 = (float)((tx_a + mid) * kTile);
+                    const float c = e.bx * (ty0 - e.lo_y) + e.nay * (tx0 - e.lo_x);
+                    const bool gq0 = accepts(fmaf(ry_first, e.bx, fmaf(0.0f, e.nay, c)), e.tl);
+                    const bool nonzero = ((gq0 ? 1 : 0) - e.down) != 0; // sigma * Y(q0) * (g(q0) - down)
+                    if (lo < hi) {
+                        if (nonzero) hi = mid; else lo = mid + 1u;
+                    }
+                }
+                if (crosses && lo < nx) atomicAdd(&((e.hull ? pool_hbd : pool_bd) + base + (ty - ty_a) * nx)[lo], e.down ? -e.sigma : e.sigma);
+            }
+            walk_edge(e, fi, live, [&](bool hit, uint32_t tx, uint32_t ty) {
+                if (hit) atomicAdd(&pool_cursor[base + (ty - ty_a) * nx + (tx - tx_a)], e.hull ? 0x00100001u : 1u), ++my_entries;
+            });
+        }
+        if (n_tris) {
+            const FlatItem& fi = items[tri.item];
+            const bool live = tri.nt != 0u && fi.n_rect != 0u;
+            const uint32_t base = pool_begin[tri.item], nx = fi.nx, tx_a = fi.tx_a, ty_a = fi.ty_a;
+            walk_tri(tri, live, [&](bool hit, uint32_t tx, uint32_t ty) {
+                if (hit) atomicAdd(&pool_cursor[base + (ty - ty_a) * nx + (tx - tx_a)], 1u), ++my_entries;
+            });
+        }
+        lds_barrier();
+        CRH_FLAT_PHASE(5) // pass 1
+        // ---------------- D: pass 2, lane = tile of the pool (the COVER entry carries one unit of either backdrop).
+        // Pass 1 left every edge's backdrop unit at the first column it applies to: summed along the rows first, in place (the lane of a row's
+        // first tile walks the row). 2a: what the item has in the tile — COVER entry, backdrop units — and ONE returning atomic on the tile's
+        // global counter for all of it plus the edges' and triangles' entries; the atomics of all the lane's tiles are in flight together,
+        // and the tile's verdict replaces its backdrops in the LDS tables. Then the workgroup reserves its range of the pair stream with one
+        // atomic (every wavefront knows what it will append), and 2b emits the synthetic entries.
+        constexpr uint32_t kChunks = kFlatPool / 256u;
+#pragma unroll 1
+        for (uint32_t ch = 0; ch * 256u < n_pool; ++ch) {
+            const uint32_t p = ch * 256u + tid;
+            if (p < n_pool) {
+                const uint32_t j = find_item(pool_begin, p);
+                const uint32_t q = p - pool_begin[j], nx = items[j].nx;
+                if (q % nx == 0u)
+                    for (uint32_t c = 1; c < nx; ++c) pool_bd[p + c] += pool_bd[p + c - 1u], pool_hbd[p + c] += pool_hbd[p + c - 1u];
+            }
+        }
+        lds_barrier();
+        uint32_t my_synth = 0;
+        {
+            uint32_t reserved[kChunks], lefts[kChunks];
+#pragma unroll
+            for (uint32_t ch = 0; ch < kChunks; ++ch) { // 2a
+                reserved[ch] = 0u, lefts[ch] = 0u;
+                const uint32_t p = ch * 256u + tid;
+                if (p >= n_pool) continue;
+                const uint32_t j = find_item(pool_begin, p);
+                const FlatItem& fi = items[j];
+                const uint32_t q = p - pool_begin[j], qy = q / fi.nx, qx = q - qy * fi.nx;
+                const uint32_t tile = (fi.ty_a + qy) * r.tiles_x + fi.tx_a + qx;
+                const int bd = pool_bd[p], hbd = pool_hbd[p];
+                const uint32_t counted = pool_cursor[p];
+                const uint32_t n_touching = counted & 0x000FFFFFu; // entries of the item's edges and triangles in this tile
+                const bool hull_touch = (counted >> 20) != 0u;
+                const uint32_t abd = (uint32_t)(bd < 0 ? -bd : bd), ahbd = (uint32_t)(hbd < 0 ? -hbd : hbd);
+                const bool cover = fi.n_hull_chain != 0u && (hbd != 0 || hull_touch); // the tile is inside the hull or its boundary crosses it
+                const int cbd = bd > 0 ? 1 : (bd < 0 ? -1 : 0), chbd = hbd > 0 ? 1 : (hbd < 0 ? -1 : 0);
+                const bool hull_over_tile = cover && hbd != 0 && !hull_touch;
+                const bool replaces_tile = hull_over_tile && (fi.flags & kFiOpaque) != 0u && n_touching == 0u && (bd & (int)r.winding_mask) != 0;
+                const uint32_t cover_key = fi.synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1) + (replaces_tile ? kCoverOpaque : (hull_over_tile ? kCoverHull : 0u));
+                const uint32_t n_bd = cover ? (abd ? abd - 1u : 0u) : abd, n_hbd = cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
+                const uint32_t left = (cover ? 1u : 0u) + n_bd + n_hbd;
+                lefts[ch] = left;
+                my_synth += left;
+                if (left + n_touching) reserved[ch] = atomicAdd(&r.tile_count[tile], left + n_touching);
+                // the verdict, for 2b: left (bits 0-11), backdrop units (12-23), COVER entry (24), bd > 0 (25), hbd > 0 (26) | the COVER key
+                pool_bd[p] = (int)(left | (n_bd << 12) | (cover ? 1u << 24 : 0u) | (bd > 0 ? 1u << 25 : 0u) | (hbd > 0 ? 1u << 26 : 0u));
+                pool_hbd[p] = (int)cover_key;
+            }
+#pragma unroll
+            for (uint32_t ch = 0; ch < kChunks; ++ch)
+                if (ch * 256u + tid < n_pool) pool_cursor[ch * 256u + tid] = reserved[ch] + lefts[ch]; // where the edges' and triangles' entries go
+        }
+        {
+            uint32_t a = my_entries, b = my_synth;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) a += (uint32_t)__shfl_xor((int)a, d, 64), b += (uint32_t)__shfl_xor((int)b, d, 64);
+            if (lane == 0u) wave_entries[wave] = a, wave_entries[4u + wave] = b;
+        }
+        lds_barrier();
+        if (tid == 0u) { // the workgroup's range of the pair stream: wavefront w's pass-2 entries, then its pass-3 entries
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < 8u; ++w) total += wave_entries[w];
+            const uint32_t sub = ((blockIdx.x + 40503u * turn) * 2654435761u) >> 26, region = r.pair_capacity / kSubStreams;
+            uint32_t begin = 0xFFFFFFFFu;
+            if (total) {
+                const uint32_t got = atomicAdd(&r.pair_cursor[sub], total);
+                if (got + total > region)
+                    r.overflow[5] = 1u; // this region is full: the host grows the stream and runs the pass again (nothing of this batch is written)
+                else
+                    begin = sub * region + got;
+            }
+            for (uint32_t w = 0; w < 4u; ++w) {
+                const uint32_t mine = wave_entries[4u + w] + wave_entries[w];
+                wave_entries[w] = begin;
+                if (begin != 0xFFFFFFFFu) begin += mine;
+            }
+        }
+        lds_barrier();
+        st.at = wave_entries[wave];
+#pragma unroll 1
+        for (uint32_t ch = 0; ch * 256u < n_pool; ++ch) { // 2b
+            const uint32_t p = ch * 256u + tid;
+            const bool active = p < n_pool;
+            const uint32_t j = active ? find_item(pool_begin, p) : 0u;
+            const FlatItem& fi = items[j];
+            const uint32_t q = active ? p - pool_begin[j] : 0u, row_len = max(fi.nx, 1u), qy = q / row_len, qx = q - qy * row_len;
+            const uint32_t tile = (fi.ty_a + qy) * r.tiles_x + fi.tx_a + qx;
+            const uint32_t verdict = active ? (uint32_t)pool_bd[p] : 0u, cover_key = active ? (uint32_t)pool_hbd[p] : 0u;
+            const uint32_t bd_key = fi.synth_a + ((verdict >> 25) & 1u ? 0u : 1u), hbd_key = fi.synth_a + ((verdict >> 26) & 1u ? 2u : 3u);
+            uint32_t left = verdict & 4095u, n_bd = (verdict >> 12) & 4095u, pos = active ? pool_cursor[p] - left : 0u;
+            bool cover = (verdict >> 24) & 1u;
+            for (;;) {
+                const unsigned long long ballot = __ballot(left != 0u);
+                if (!ballot) break;
+                uint32_t key = 0;
+                if (left) {
+                    if (cover)
+                        cover = false, key = cover_key;
+                    else if (n_bd)
+                        --n_bd, key = bd_key;
+                    else
+                        key = hbd_key;
+                }
+                stage_append<true>(st, r, lane, ballot, tile, pos, key);
+                if (left) ++pos, --left;
+            }
+        }
+        lds_barrier(); // (pass 3 moves the cursors 2b has just read)
+        CRH_FLAT_PHASE(6) // pass 2
+        // ---------------- E: pass 3
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (256u * (uint32_t)k >= n_edges) continue; // (uniform; `continue`, not `break`: the loop must unroll or edge[] lives in scratch memory)
+            const BinEdge e = unpack_edge(kept[k]);
+            const FlatItem& fi = items[edge_item[k]];
+            const bool live = e.valid && fi.n_rect != 0u && !(e.hull && (fi.flags & kFiHullTris));
+            const uint32_t base = pool_begin[edge_item[k]], nx = fi.nx, tx_a = fi.tx_a, ty_a = fi.ty_a, key = edge_key[k];
+            walk_edge(e, fi, live, [&](bool hit, uint32_t tx, uint32_t ty) {
+                const unsigned long long ballot = __ballot(hit);
+                if (ballot) {
+                    uint32_t pos = 0;
+                    if (hit) pos = atomicAdd(&pool_cursor[base + (ty - ty_a) * nx + (tx - tx_a)], 1u);
+                    stage_append<true>(st, r, lane, ballot, ty * r.tiles_x + tx, pos, key);
+                }
+            });
+        }
+        if (n_tris) {
+            const FlatItem& fi = items[tri.item];
+            const bool live = tri.nt != 0u && fi.n_rect != 0u;
+            const uint32_t base = pool_begin[tri.item], nx = fi.nx, tx_a = fi.tx_a, ty_a = fi.ty_a;
+            walk_tri(tri, live, [&](bool hit, uint32_t tx, uint32_t ty) {
+                const unsigned long long ballot = __ballot(hit);
+                if (ballot) {
+                    uint32_t pos = 0;
+                    if (hit) pos = atomicAdd(&pool_cursor[base + (ty - ty_a) * nx + (tx - tx_a)], 1u);
+                    stage_append<true>(st, r, lane, ballot, ty * r.tiles_x + tx, pos, tri.key);
+                }
+            });
+        }
+        stage_flush_reserved(st, r, lane); // (the batch's range is used up exactly)
+        CRH_FLAT_PHASE(7) // pass 3
+        // ---------------- hull strips that fold: triangle by triangle, as cover triangles (keys behind the fill chain and the backdrop slots);
+        // their entries take the ordinary way into the pair stream (a cursor atomic per block)
+        bool any_folded = false;
+        for (uint32_t j = 0; j < n_turn; ++j) any_folded = any_folded || (items[j].flags & (kFiHullTris | kFiSkip)) == kFiHullTris;
+        if (any_folded) { // (uniform: LDS values)
+            st.sub = ((4u * blockIdx.x + wave + 977u * turn) * 2654435761u) >> 26;
+            for (uint32_t j = 0; j < n_turn; ++j) {
+                const FlatItem& fi = items[j];
+                if ((fi.flags & (kFiHullTris | kFiSkip)) != kFiHullTris) continue;
+                const ItemCtx& ctx = fi.ctx;
+                for (uint32_t t0 = 64u * wave; t0 + 2u < fi.n_hull; t0 += 256u) { // 64 triangles per wavefront and turn
+                    const uint32_t t = t0 + lane;
+                    PrimRec rec = {};
+                    bool drawn = false;
+                    if (t + 2u < fi.n_hull) {
+                        drawn = setup_plain_triangle(s, r, ctx, ctx.cb[6] + t, rec);
+                        if (drawn) *reinterpret_cast<PrimRec*>(r.slots + (size_t)(fi.hull_slot0 + 4u * t) * 32u) = rec;
+                    }
+                    bin_triangles(st, r, lane, drawn, rec.cov, fi.hull_slot0 + 4u * t, ry_first, r_last);
+                }
+            }
+            stage_flush(st, r, lane);
+        }
+        next += n_turn;
+        ++turn;
+        CRH_FLAT_PHASE(8) // folded hulls
+    }
 }
 
 __global__ __launch_bounds__(256) void k_scatter(RasterParams r) {
@@ -1456,14 +2082,29 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
     // Items per workgroup. One is best while the grid is small (S10k: 0.169 ms; two: 0.189, four: 0.21 — an item is a chain of dependent
     // memory operations, and a wavefront that takes a second item doubles it); tens of thousands of small items are bound by workgroup
     // turnover instead (50 000 glyphs: one 0.45, two 0.31, four 0.31, eight 0.33 ms). So: about 12 000 workgroups.
-    static const uint32_t pinned = getenv("CRH_BIN_ITEMS") ? max(1, atoi(getenv("CRH_BIN_ITEMS"))) : 0u;
-    const uint32_t items_per_group = pinned ? pinned : min(8u, max(1u, (r.n_items + 12287u) / 12288u));
-    const uint32_t bin_grid = (r.n_items + items_per_group - 1u) / items_per_group;
-    if (r.n_items) {
+    const uint32_t pinned = getenv("CRH_BIN_ITEMS") ? max(1, atoi(getenv("CRH_BIN_ITEMS"))) : 0u; // (read per launch: tests and A/B runs switch it inside one process)
+    const bool itemwise = getenv("CRH_BIN_ITEMWISE") != nullptr; // k_bin_edges for every item, as in round 2
+    if (r.n_items && itemwise) {
+        const uint32_t items_per_group = pinned ? pinned : min(8u, max(1u, (r.n_items + 12287u) / 12288u));
+        const uint32_t bin_grid = (r.n_items + items_per_group - 1u) / items_per_group;
         if (samples == 4)
-            hipLaunchKernelGGL((k_bin_edges<4>), dim3(bin_grid), dim3(128), 0, stream, s, r);
+            hipLaunchKernelGGL((k_bin_edges<4, false>), dim3(bin_grid), dim3(128), 0, stream, s, r);
         else
-            hipLaunchKernelGGL((k_bin_edges<1>), dim3(bin_grid), dim3(128), 0, stream, s, r);
+            hipLaunchKernelGGL((k_bin_edges<1, false>), dim3(bin_grid), dim3(128), 0, stream, s, r);
+    } else if (r.n_items) {
+        // k_bin_flat: a batch of items per 256-thread workgroup. A workgroup lives about as long whether it holds two items or twenty (the
+        // same chain of phases), so the grid is sized to ONE round of resident workgroups — three per CU — as long as that leaves a batch
+        // within the kernel's 32 items; what a batch cannot hold is queued and binned item by item behind it.
+        const uint32_t resident = 256u * CRH_FLAT_WAVES; // workgroups the 256 CUs hold at once
+        const uint32_t items_per_group = pinned ? min(pinned, kFlatItems) : min(kFlatItems, max(1u, (r.n_items + resident - 1u) / resident));
+        const uint32_t flat_grid = (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
+        if (samples == 4) {
+            hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
+            hipLaunchKernelGGL((k_bin_edges<4, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
+        } else {
+            hipLaunchKernelGGL((k_bin_flat<1>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
+            hipLaunchKernelGGL((k_bin_edges<1, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
+        }
     }
     if (after_bin) (void)hipEventRecord(after_bin, stream);
     if (mark) mark(ctx, "raster_bin", 0);

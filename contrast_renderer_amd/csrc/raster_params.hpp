@@ -30,7 +30,8 @@ struct RasterParams {
     uint32_t* tile_offset;   // [n_tiles + 1]
     uint32_t* tile_list;     // [pair_capacity] prim ids, grouped by tile
     uint32_t pair_capacity;
-    uint32_t* overflow;      // [0] pair capacity exceeded, [1] required pairs, [2] a tile list is longer than LDS can sort, [3] longest tile list
+    uint32_t* overflow;      // [0] pair capacity exceeded, [1] required pairs, [2] a tile list is longer than LDS can sort, [3] longest tile list, [5] a region of the pair stream is full,
+                             // [6] items queued for k_bin_edges, [7] an edge with a non-finite endpoint: the edge pass cannot draw this frame
     uint32_t sort_capacity;  // primitives per tile the raster kernel's LDS sort buffer holds (a power of two)
     const uint32_t* shape_ncand;      // [n_items] candidate triangles per item
     uint32_t* shape_prim_begin;       // [n_items + 1] contiguous primitive ids per item, ascending in draw order
@@ -56,6 +57,7 @@ struct RasterParams {
     uint32_t* pair_pos;
     uint32_t* pair_key;               // ... scattered into tile_list by k_scatter once the tile offsets are known
     uint32_t* pair_cursor;            // pairs written so far (one atomic per flushed block of a wave)
+    uint32_t* bin_queue;              // [n_items] items k_bin_flat hands on to k_bin_edges (their number: overflow[6])
 };
 
 } // namespace crh

@@ -17,6 +17,15 @@ for _ in range(3):
     frame.clear(); scene.render(frame); r.synchronize()
     r.lib.crh_debug_frame_words(frame.handle, out)
 n = scene.n_shapes
+if not os.environ.get("CRH_BIN_ITEMWISE"):  # k_bin_flat: wavefront 0 of every workgroup
+    names = ["item records + batch", "edge set-up (loads)", "triangle set-up + stores", "synthetic records + barrier", "rectangles, pool cleared", "pass 1", "pass 2", "pass 3", "folded hulls", "final flush"]
+    vals = [out[80 + 2 * k] | (out[81 + 2 * k] << 32) for k in range(10)]
+    ipg = int(os.environ.get("CRH_BIN_ITEMS", 0)) or min(32, max(1, (n + 1023) // 1024))
+    groups = (n + ipg - 1) // ipg
+    for name, v in zip(names, vals):
+        print(f"{name:28s} {v / groups:10.0f} ticks per workgroup ({100.0 * v / max(1, sum(vals)):4.1f} %)")
+    print(f"total {sum(vals) / groups:.0f} ticks per workgroup of {ipg} items, {groups} workgroups")
+    sys.exit(0)
 names = [["item data", "triangle set-up", "walk", "-", "-", "-", "final flush", "-"], ["item data + synth", "edge records", "rect + clear", "pass 1", "pass 2", "pass 3", "final flush", "-"]]
 for wave in range(2):
     tot = 0
