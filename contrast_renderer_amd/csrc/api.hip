@@ -872,6 +872,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         p.slot_capacity = (uint32_t)slot_capacity;
         p.slot_begin = sc->shape_slot_begin.as<uint32_t>();
     }
+    {   // totals of the scene's tessellation (hull vertices are at most the hull candidates; on the benchmark scene about half of them)
+        const uint32_t* t = sc->totals_host;
+        const uint64_t tris = (uint64_t)t[CH_LINE_V] + 3u * (uint64_t)t[CH_JOINT] + t[CH_IQ] + t[CH_IC_V] / 3u + t[CH_RQ] + t[CH_RC_V] / 3u, edges = (uint64_t)t[CH_SOLID_V] + t[CH_HULL] / 2u;
+        const uint64_t per = std::max<uint64_t>(1, sc->d.n_shapes);
+        p.hint_tris = (uint32_t)std::min<uint64_t>(0xFFFFFFFFu, tris * p.n_items / per), p.hint_edges = (uint32_t)std::min<uint64_t>(0xFFFFFFFFu, edges * p.n_items / per);
+    }
     p.scan_scratch = set.scan_scratch.as<uint32_t>();
     p.prim_rec = static_cast<PrimRec*>(sc->prim_rec[rec].p);
     InstanceSlot& slot = recorded ? f->item_slot[item_inst] : sc->slot[inst];

@@ -929,8 +929,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
 #define CRH_FLAT_WAVES 3 // 168 registers: no scratch memory (at 4 waves = 128 registers the triangle set-up spills, and a scratch access is a vector-memory
                          // operation that can only be waited for together with the record stores in flight); three workgroups per CU
 #endif
-constexpr uint32_t kFlatItems = 32, kFlatTris = 256, kFlatEdges = 512, kFlatPool = 1536, kFlatStage = 256; // 37 KB of LDS: four workgroups per CU
-constexpr uint32_t kFiOpaque = 1u, kFiSkip = 2u, kFiHullTris = 4u;
+#ifndef CRH_FLAT_ROUNDS
+#define CRH_FLAT_ROUNDS 3
+#endif
+#ifndef CRH_FLAT_STAGE
+#define CRH_FLAT_STAGE 128
+#endif
+constexpr uint32_t kFlatItems = 32, kFlatTris = 256, kFlatEdgeRounds = CRH_FLAT_ROUNDS, kFlatEdges = 256 * kFlatEdgeRounds, kFlatPool = 1536, kFlatStage = CRH_FLAT_STAGE; // 37 KB of LDS: four workgroups per CU
+constexpr uint32_t kFiOpaque = 1u, kFiSkip = 2u, kFiHullTris = 4u, kFiQueue = 8u; // kFiQueue: not binned here but by k_bin_edges (handed on when the item's turn is over)
 struct FlatItem {
     ItemCtx ctx;
     uint32_t slot0, fe_slot0, synth_a, hull_slot0, synth_b; // absolute slot numbers of the item's regions
@@ -974,7 +980,7 @@ CRH_D void lds_barrier() {
 // expressions load_edge used, so the values are the same bits).
 struct PackedEdge {
     float lo_x, lo_y, hi_x, hi_y;
-    uint32_t flags; // bit 0 valid, 1 top-left, 2 hull, 3 sigma > 0, 4 down
+    uint32_t flags; // bit 0 valid, 1 top-left, 2 hull, 3 sigma > 0, 4 down; bits 8-12: the item of the batch (in the LDS table of k_bin_flat)
 };
 CRH_D PackedEdge pack_edge(const BinEdge& e) {
     return PackedEdge{e.lo_x, e.lo_y, e.hi_x, e.hi_y, (e.valid ? 1u : 0u) | (e.tl ? 2u : 0u) | (e.hull ? 4u : 0u) | (e.sigma > 0 ? 8u : 0u) | (e.down ? 16u : 0u)};
@@ -1010,8 +1016,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
     __shared__ uint32_t tri_begin[kFlatItems + 1], edge_begin[kFlatItems + 1], pool_begin[kFlatItems + 1];
     __shared__ int pool_bd[kFlatPool], pool_hbd[kFlatPool];
     __shared__ uint32_t pool_cursor[kFlatPool]; // pass 1: the entries the item's edges and triangles have in the tile (bits 0-19; bits 20-31: the hull edges among them), then the next list position
-    __shared__ uint32_t batch[5];               // items in the batch, its triangles, its edges, tiles of its pool, items of the batch that are binned in this turn
+    __shared__ uint32_t batch[6];               // items in the batch, its triangles, its edges, tiles of its pool, items of the batch that are binned in this turn, (edge, tile row) pairs
     __shared__ uint32_t wave_entries[8];        // entries every wavefront appends in pass 3 ([0..3]) and in pass 2 ([4..7]); then where its share of the pair stream begins
+    __shared__ PackedEdge edge_table[kFlatEdges]; // the batch's boundary edges: the walks are balanced over (edge, tile row) pairs, whoever loaded the edge
+    __shared__ uint32_t row_begin[kFlatEdges + 1]; // exclusive prefix of the tile rows every edge walks
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     Stage st = {stage_tile[wave], stage_pos[wave], stage_key[wave], 0u, 0u, kFlatStage, 0xFFFFFFFFu};
     uint32_t turn = 0; // batches this workgroup has binned (the pair sub-stream of a batch follows from it)
@@ -1038,11 +1046,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             const float* c = fi.ctx.col;
             const bool opaque = c[3] == 1.0f && is_finite(c[0]) && is_finite(c[1]) && is_finite(c[2]) && r.occlude != 0u && (r.debug & 32768u) == 0u;
             const bool oversize = k.n_tri > kFlatTris || k.n_fe + k.n_hull > kFlatEdges || all_queued || slot0 + k.total > r.slot_capacity;
-            fi.flags = (opaque ? kFiOpaque : 0u) | (oversize ? kFiSkip : 0u);
+            fi.flags = (opaque ? kFiOpaque : 0u) | (oversize ? kFiSkip : 0u) | ((oversize && slot0 + k.total <= r.slot_capacity) ? kFiQueue : 0u);
             fi.box[0] = fi.box[1] = 0x7FFFFFFF, fi.box[2] = fi.box[3] = (int)0x80000000;
             fi.faces = 0u;
             fi.n_rect = 0u;
-            if (oversize && slot0 + k.total <= r.slot_capacity) r.bin_queue[atomicAdd(&r.overflow[6], 1u)] = item;
         }
         lds_barrier();
         if (wave == 0u) { // the batch: the longest run of items whose triangles and edges fit the lanes (an oversize item counts as empty)
@@ -1068,11 +1075,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         // All loads first, all stores last: gfx950 counts vector loads and stores with ONE counter, in order — a load issued behind the 128-byte
         // record stores can only be waited for together with them, and those take tens of microseconds to drain when every workgroup
         // writes its records at once.
-        PackedEdge kept[2];
-        float strip_det[2];
-        uint32_t edge_item[2], edge_key[2];
+        PackedEdge kept[kFlatEdgeRounds];
+        float strip_det[kFlatEdgeRounds];
+        uint32_t edge_item[kFlatEdgeRounds], edge_key[kFlatEdgeRounds];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < (int)kFlatEdgeRounds; ++k) {
             const uint32_t e = tid + 256u * (uint32_t)k;
             kept[k] = PackedEdge{0.0f, 0.0f, 0.0f, 0.0f, 0u};
             strip_det[k] = 0.0f;
@@ -1116,7 +1123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             atomicMax(&fi.box[2], ordered_int((float)rec.cov.box.y)), atomicMax(&fi.box[3], ordered_int((float)rec.cov.box.w));
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < (int)kFlatEdgeRounds; ++k) {
             if (tid + 256u * (uint32_t)k < n_edges) {
                 FlatItem& fi = items[edge_item[k]];
                 const BinEdge e = unpack_edge(kept[k]);
@@ -1169,10 +1176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             uint32_t end = wave_inclusive_scan(n_rect, lane);
             uint32_t n_fit = (uint32_t)__builtin_ctzll(~__ballot(mine && end <= kFlatPool)); // leading items that fit
             if (n_fit == 0u) {
-                if (lane == 0u) {
-                    fi.flags |= kFiSkip;
-                    r.bin_queue[atomicAdd(&r.overflow[6], 1u)] = next;
-                }
+                if (lane == 0u) fi.flags |= kFiSkip | kFiQueue;
                 n_fit = 1u;
                 if (lane == 0u) n_rect = 0u, end = 0u;
             }
@@ -1181,63 +1185,102 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             if (mine) fi.n_rect = n_rect;
             if (lane <= kFlatItems) pool_begin[lane] = lane < n_batch ? end - n_rect : (lane == n_batch ? pool_total : 0xFFFFFFFFu);
             if (lane == 0u) batch[3] = pool_total, batch[4] = n_fit;
+            // (handed on exactly once: a candidate that is not part of this turn is looked at again in the next one)
+            if (lane < n_fit && (fi.flags & kFiQueue) != 0u) r.bin_queue[atomicAdd(&r.overflow[6], 1u)] = next + lane;
         }
         lds_barrier();
         const uint32_t n_pool = batch[3], n_turn = batch[4]; // (items n_turn .. n_batch - 1 are set up but not binned: n_rect == 0)
         for (uint32_t q = tid; q < n_pool; q += 256u) pool_bd[q] = 0, pool_hbd[q] = 0, pool_cursor[q] = 0u;
         lds_barrier();
         CRH_FLAT_PHASE(4) // rectangles, pool cleared
-        // the tiles of a primitive's own box inside its item's rectangle, walked by all lanes of the wavefront together
-        // An edge visits, tile row by tile row of its own box, the columns its LINE can reach inside that row: for a long diagonal edge the
-        // box is mostly tiles the line is nowhere near (a hull edge across a 256-pixel Shape: 100 tiles in the box, 20 along the line).
-        // The column range is a float estimate with a margin (2 px + 4e-6 of the largest coordinate — the distance at which f32 rounding can
-        // still flip an edge function is about 1e-7 of it), clamped to the box; whether the edge matters in a tile is decided by the exact
-        // test as before. Coordinates beyond 1e6 (and horizontal edges, which have one row) take the whole box.
-        auto walk_edge = [&](const BinEdge& e, const FlatItem& fi, bool live, auto&& visit) {
-            int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1;
-            if (live) {
-                const int x_lo = (int)ceilf((e.lo_x - r_last) * (1.0f / (float)kTile) - 0.01f), x_hi = (int)floorf(e.hi_x * (1.0f / (float)kTile) + 0.01f);
-                const int y_lo = (int)ceilf((e.ymin - r_last) * (1.0f / (float)kTile) - 0.01f), y_hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
-                bx0 = max(x_lo, (int)fi.tx_a), bx1 = min(x_hi, (int)fi.tx_b), by0 = max(y_lo, (int)fi.ty_a), by1 = min(y_hi, (int)fi.ty_b);
+        // ---------------- the edges' walks are balanced over (edge, tile row) pairs. A lane that walked ITS edge kept its wavefront in the loop
+        // for as long as the longest edge among 64 took (a hull edge across a 256-pixel Shape reaches 40 tiles, a polygon edge 3): nine
+        // tenths of the lane-steps of the walks were idle. So every edge goes to an LDS table with the number of tile rows of its own box
+        // (clamped to its item's rectangle), the counts are summed, and lane w of a pass takes pair w: the edge by a ten-step search in
+        // the prefix sums, then the row. Within its row an edge visits the columns its LINE can reach — a float estimate with a margin
+        // (2 px + 4e-6 of the largest coordinate: the distance at which f32 rounding can still flip an edge function is about 1e-7 of it),
+        // clamped to the box; whether the edge matters in a tile is decided by the exact test as ever. Coordinates beyond 1e6 and horizontal
+        // edges take the whole width of the box.
+        struct EdgeBox {
+            int bx0, bx1, by0, by1;
+        };
+        auto edge_box = [&](const BinEdge& e, const FlatItem& fi) {
+            const int x_lo = (int)ceilf((e.lo_x - r_last) * (1.0f / (float)kTile) - 0.01f), x_hi = (int)floorf(e.hi_x * (1.0f / (float)kTile) + 0.01f);
+            const int y_lo = (int)ceilf((e.ymin - r_last) * (1.0f / (float)kTile) - 0.01f), y_hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
+            return EdgeBox{max(x_lo, (int)fi.tx_a), min(x_hi, (int)fi.tx_b), max(y_lo, (int)fi.ty_a), min(y_hi, (int)fi.ty_b)};
+        };
+#pragma unroll
+        for (int k = 0; k < (int)kFlatEdgeRounds; ++k) {
+            const uint32_t e = tid + 256u * (uint32_t)k;
+            if (e < n_edges) {
+                PackedEdge pe = kept[k];
+                const FlatItem& fi = items[edge_item[k]];
+                // the edge takes part: valid, its item is drawn here, and — a hull edge — its hull is binned as a chain
+                bool live = (pe.flags & 1u) != 0u && fi.n_rect != 0u && !((pe.flags & 4u) != 0u && (fi.flags & kFiHullTris) != 0u);
+                uint32_t rows = 0;
+                if (live) {
+                    const EdgeBox box = edge_box(unpack_edge(pe), fi);
+                    live = box.by0 <= box.by1; // (an edge left of the rectangle — a Shape that sticks out of the frame — has no tile to walk but still crosses the rows' backdrop lines)
+                    if (live) rows = (uint32_t)(box.by1 - box.by0 + 1);
+                }
+                pe.flags = (pe.flags & (live ? ~0u : ~1u)) | (edge_item[k] << 8);
+                edge_table[e] = pe;
+                row_begin[e] = rows;
             }
-            const float dy = e.hi_y - e.lo_y, largest = fmaxf(fmaxf(fabsf(e.lo_x), fabsf(e.hi_x)), fmaxf(fabsf(e.lo_y), fabsf(e.hi_y)));
-            const bool by_rows = dy != 0.0f && largest < 1.0e6f;
-            const float xs = by_rows ? (e.hi_x - e.lo_x) / dy : 0.0f, pad = 2.0f + 4.0e-6f * largest;
-            auto row_range = [&](int ty, int& x0, int& x1) { // the columns of row ty worth a test
-                x0 = bx0, x1 = bx1;
-                if (by_rows) {
+        }
+        lds_barrier();
+        if (wave == 0u) { // exclusive prefix of the row counts: twelve consecutive edges per lane
+            const uint32_t per = (n_edges + 63u) / 64u, first = lane * per, last = min(n_edges, first + per);
+            uint32_t sum = 0;
+            for (uint32_t e = first; e < last; ++e) sum += row_begin[e];
+            uint32_t run = wave_inclusive_scan(sum, lane) - sum;
+            for (uint32_t e = first; e < last; ++e) {
+                const uint32_t n = row_begin[e];
+                row_begin[e] = run;
+                run += n;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)run, 63, 64);
+            if (lane == 0u) row_begin[n_edges] = total, batch[5] = total;
+        }
+        lds_barrier();
+        const uint32_t n_work = batch[5];
+        // visit(active, edge, its item, the tile row, the columns x0 .. x1 of that row worth a test, the edge's slot number)
+        auto for_edge_rows = [&](auto&& visit) {
+            for (uint32_t w0 = 0; w0 < n_work; w0 += 256u) {
+                const uint32_t w = w0 + tid;
+                const bool active = w < n_work;
+                uint32_t ei = 0; // the largest edge index with row_begin <= w (edges without rows share their successor's entry and are passed over)
+#pragma unroll
+                for (uint32_t step = 512; step > 0u; step >>= 1)
+                    if (ei + step < n_edges && row_begin[ei + step] <= w) ei += step;
+                const PackedEdge pe = edge_table[active ? ei : 0u];
+                const BinEdge e = unpack_edge(pe);
+                const uint32_t j = (pe.flags >> 8) & 31u;
+                const FlatItem& fi = items[j];
+                const EdgeBox box = edge_box(e, fi);
+                const int ty = box.by0 + (int)(w - row_begin[ei]);
+                int x0 = box.bx0, x1 = box.bx1;
+                const float dy = e.hi_y - e.lo_y, largest = fmaxf(fmaxf(fabsf(e.lo_x), fabsf(e.hi_x)), fmaxf(fabsf(e.lo_y), fabsf(e.hi_y)));
+                if (dy != 0.0f && largest < 1.0e6f) {
+                    const float xs = (e.hi_x - e.lo_x) / dy, pad = 2.0f + 4.0e-6f * largest;
                     const float ty0 = (float)(ty * kTile), ya = ty0 + ry_first - pad, yb = ty0 + r_last + pad;
                     const float xa = e.lo_x + (ya - e.lo_y) * xs, xb = e.lo_x + (yb - e.lo_y) * xs;
                     const float lo = fminf(xa, xb) - pad - r_last, hi = fmaxf(xa, xb) + pad;
                     // (clamped as floats first: the estimates of a steep row can be far outside anything an int holds)
-                    x0 = (int)floorf(fmaxf(lo * (1.0f / (float)kTile), (float)bx0));
-                    x1 = (int)floorf(fminf(hi * (1.0f / (float)kTile), (float)bx1));
+                    x0 = (int)floorf(fmaxf(lo * (1.0f / (float)kTile), (float)box.bx0));
+                    x1 = (int)floorf(fminf(hi * (1.0f / (float)kTile), (float)box.bx1));
                 }
-            };
-            const bool up = e.nay > 0.0f; // E grows with ry (bx >= 0) and with rx iff nay > 0
-            int ty = by0, tx = 0, x1 = -1;
-            bool done = !(live && bx0 <= bx1 && by0 <= by1);
-            if (!done) row_range(ty, tx, x1);
-            while (__any(!done)) {
-                bool hit = false;
-                if (!done && tx <= x1) {
-                    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
-                    const float c = e.bx * (ty0 - e.lo_y) + e.nay * (tx0 - e.lo_x);
-                    const bool gmax = accepts(fmaf(r_last, e.bx, fmaf(up ? r_last : 0.0f, e.nay, c)), e.tl), gmin = accepts(fmaf(ry_first, e.bx, fmaf(up ? 0.0f : r_last, e.nay, c)), e.tl);
-                    hit = gmax != gmin && e.ymin <= ty0 + r_last && e.ymax >= q0y && e.lo_x <= tx0 + r_last && e.hi_x >= tx0;
-                }
-                visit(hit, (uint32_t)tx, (uint32_t)ty);
-                if (!done) {
-                    if (tx < x1) {
-                        ++tx;
-                    } else if (ty < by1) {
-                        ++ty;
-                        row_range(ty, tx, x1); // (an empty row costs one idle step)
-                    } else {
-                        done = true;
-                    }
-                }
+                const uint32_t i = ei - edge_begin[j];
+                visit(active, e, j, fi, ty, x0, x1, i < fi.n_fe ? fi.fe_slot0 + i : fi.hull_slot0 + (i - fi.n_fe));
             }
+        };
+        // does the edge matter in tile (tx, ty)? (the exact test of k_bin_edges)
+        auto matters = [&](const BinEdge& e, int tx, int ty) {
+            const bool up = e.nay > 0.0f; // E grows with ry (bx >= 0) and with rx iff nay > 0
+            const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+            const float c = e.bx * (ty0 - e.lo_y) + e.nay * (tx0 - e.lo_x);
+            const bool gmax = accepts(fmaf(r_last, e.bx, fmaf(up ? r_last : 0.0f, e.nay, c)), e.tl), gmin = accepts(fmaf(ry_first, e.bx, fmaf(up ? 0.0f : r_last, e.nay, c)), e.tl);
+            return gmax != gmin && e.ymin <= ty0 + r_last && e.ymax >= q0y && e.lo_x <= tx0 + r_last && e.hi_x >= tx0;
         };
         auto walk_tri = [&](const FlatTri& t, bool live, auto&& visit) {
             const uint32_t nt = live ? t.nt : 0u, longest = wave_max_u32(nt);
@@ -1248,32 +1291,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             }
         };
         // ---------------- C: pass 1
-        uint32_t my_entries = 0; // what this lane's primitives will append in pass 3
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (256u * (uint32_t)k >= n_edges) continue; // (uniform; `continue`, not `break`: the loop must unroll or edge[] lives in scratch memory)
-            const BinEdge e = unpack_edge(kept[k]);
-            const FlatItem& fi = items[edge_item[k]];
-            // the edge takes part: valid, its item is drawn here, and — a hull edge — its hull is binned as a chain
-            const bool live = e.valid && fi.n_rect != 0u && !(e.hull && (fi.flags & kFiHullTris));
-            const uint32_t base = pool_begin[edge_item[k]], nx = fi.nx, tx_a = fi.tx_a, ty_a = fi.ty_a, ty_b = fi.ty_b;
-            // backdrop rows: the tile rows whose line q0y lies in the edge's half-open y range; a conservative integer range first
-            uint32_t row = ty_a, rows_mine = 0;
-            if (live) {
-                const int lo = (int)ceilf((e.ymin - ry_first) * (1.0f / (float)kTile) - 0.01f), hi = (int)floorf((e.ymax - ry_first) * (1.0f / (float)kTile) + 0.01f);
-                const int first = max(lo, (int)ty_a), last = min(hi, (int)ty_b);
-                if (first <= last) row = (uint32_t)first, rows_mine = (uint32_t)(last - first + 1);
-            }
+        uint32_t my_entries = 0; // what this lane will append in pass 3
+        for_edge_rows([&](bool active, const BinEdge& e, uint32_t j, const FlatItem& fi, int ty, int x0, int x1, uint32_t) {
+            const uint32_t base = pool_begin[j] + ((uint32_t)ty - fi.ty_a) * fi.nx, nx = fi.nx, tx_a = fi.tx_a;
             // Along a tile row the backdrop term of an edge that crosses the row's line is 0 left of the edge and +-1 from some column on (the
             // edge function is monotone in x under fmaf, so the very predicate a tile would evaluate switches once): that column is found
             // by bisection — five exact evaluations instead of one per column — and the unit goes there alone; pass 2 sums along the row.
-            const uint32_t most_rows = wave_max_u32(rows_mine);
-            for (uint32_t rr = 0; rr < most_rows; ++rr) {
-                const uint32_t ty = row + rr;
-                const float ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
-                const bool crosses = rr < rows_mine && e.ymin <= q0y && q0y < e.ymax; // Y_e at the backdrop row
-                const uint32_t widest = wave_max_u32(crosses ? nx : 0u);
-                if (widest == 0u) continue;
+            const float ty0 = (float)(ty * kTile), q0y = ty0 + ry_first;
+            const bool crosses = active && e.ymin <= q0y && q0y < e.ymax; // Y_e at the backdrop row
+            const uint32_t widest = wave_max_u32(crosses ? nx : 0u);
+            if (widest) {
                 uint32_t lo = 0, hi = crosses ? nx : 0u; // the first column with a non-zero term lies in [lo, hi]
                 for (uint32_t span = widest; span > 0u; span >>= 1) { // (ceil(log2(widest + 1)) steps settle every lane)
                     const uint32_t mid = (lo + hi) >> 1;
@@ -1285,12 +1312,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
                         if (nonzero) hi = mid; else lo = mid + 1u;
                     }
                 }
-                if (crosses && lo < nx) atomicAdd(&((e.hull ? pool_hbd : pool_bd) + base + (ty - ty_a) * nx)[lo], e.down ? -e.sigma : e.sigma);
+                if (crosses && lo < nx) atomicAdd(&(e.hull ? pool_hbd : pool_bd)[base + lo], e.down ? -e.sigma : e.sigma);
             }
-            walk_edge(e, fi, live, [&](bool hit, uint32_t tx, uint32_t ty) {
-                if (hit) atomicAdd(&pool_cursor[base + (ty - ty_a) * nx + (tx - tx_a)], e.hull ? 0x00100001u : 1u), ++my_entries;
-            });
-        }
+            const uint32_t cols = wave_max_u32(active && x0 <= x1 ? (uint32_t)(x1 - x0 + 1) : 0u);
+            for (uint32_t c = 0; c < cols; ++c) {
+                const int tx = x0 + (int)c;
+                if (active && tx <= x1 && matters(e, tx, ty)) atomicAdd(&pool_cursor[base + ((uint32_t)tx - tx_a)], e.hull ? 0x00100001u : 1u), ++my_entries;
+            }
+        });
         if (n_tris) {
             const FlatItem& fi = items[tri.item];
             const bool live = tri.nt != 0u && fi.n_rect != 0u;
@@ -1411,23 +1440,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         }
         lds_barrier(); // (pass 3 moves the cursors 2b has just read)
         CRH_FLAT_PHASE(6) // pass 2
-        // ---------------- E: pass 3
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (256u * (uint32_t)k >= n_edges) continue; // (uniform; `continue`, not `break`: the loop must unroll or edge[] lives in scratch memory)
-            const BinEdge e = unpack_edge(kept[k]);
-            const FlatItem& fi = items[edge_item[k]];
-            const bool live = e.valid && fi.n_rect != 0u && !(e.hull && (fi.flags & kFiHullTris));
-            const uint32_t base = pool_begin[edge_item[k]], nx = fi.nx, tx_a = fi.tx_a, ty_a = fi.ty_a, key = edge_key[k];
-            walk_edge(e, fi, live, [&](bool hit, uint32_t tx, uint32_t ty) {
+        // ---------------- E: pass 3: the same walk, every entry with its place in the tile's list
+        for_edge_rows([&](bool active, const BinEdge& e, uint32_t j, const FlatItem& fi, int ty, int x0, int x1, uint32_t key) {
+            const uint32_t base = pool_begin[j] + ((uint32_t)ty - fi.ty_a) * fi.nx, tx_a = fi.tx_a;
+            const uint32_t cols = wave_max_u32(active && x0 <= x1 ? (uint32_t)(x1 - x0 + 1) : 0u);
+            for (uint32_t c = 0; c < cols; ++c) {
+                const int tx = x0 + (int)c;
+                const bool hit = active && tx <= x1 && matters(e, tx, ty);
                 const unsigned long long ballot = __ballot(hit);
                 if (ballot) {
                     uint32_t pos = 0;
-                    if (hit) pos = atomicAdd(&pool_cursor[base + (ty - ty_a) * nx + (tx - tx_a)], 1u);
-                    stage_append<true>(st, r, lane, ballot, ty * r.tiles_x + tx, pos, key);
+                    if (hit) pos = atomicAdd(&pool_cursor[base + ((uint32_t)tx - tx_a)], 1u);
+                    stage_append<true>(st, r, lane, ballot, (uint32_t)ty * r.tiles_x + (uint32_t)tx, pos, key);
                 }
-            });
-        }
+            }
+        });
         if (n_tris) {
             const FlatItem& fi = items[tri.item];
             const bool live = tri.nt != 0u && fi.n_rect != 0u;
@@ -2083,7 +2110,10 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
     // memory operations, and a wavefront that takes a second item doubles it); tens of thousands of small items are bound by workgroup
     // turnover instead (50 000 glyphs: one 0.45, two 0.31, four 0.31, eight 0.33 ms). So: about 12 000 workgroups.
     const uint32_t pinned = getenv("CRH_BIN_ITEMS") ? max(1, atoi(getenv("CRH_BIN_ITEMS"))) : 0u; // (read per launch: tests and A/B runs switch it inside one process)
-    const bool itemwise = getenv("CRH_BIN_ITEMWISE") != nullptr; // k_bin_edges for every item, as in round 2
+    // k_bin_edges for every item: CRH_BIN_ITEMWISE (A/B runs, tests), or a pass whose AVERAGE item is beyond what a batch of k_bin_flat holds
+    // (the dashed strokes of config 5: a thousand line triangles per Shape) — every item would be queued anyway
+    const bool itemwise = getenv("CRH_BIN_ITEMWISE") != nullptr || (getenv("CRH_BIN_FLAT") == nullptr && r.n_items != 0u &&
+                                                                     (r.hint_tris / r.n_items > kFlatTris / 2u || r.hint_edges / r.n_items > kFlatEdges / 2u));
     if (r.n_items && itemwise) {
         const uint32_t items_per_group = pinned ? pinned : min(8u, max(1u, (r.n_items + 12287u) / 12288u));
         const uint32_t bin_grid = (r.n_items + items_per_group - 1u) / items_per_group;
@@ -2096,7 +2126,12 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         // same chain of phases), so the grid is sized to ONE round of resident workgroups — three per CU — as long as that leaves a batch
         // within the kernel's 32 items; what a batch cannot hold is queued and binned item by item behind it.
         const uint32_t resident = 256u * CRH_FLAT_WAVES; // workgroups the 256 CUs hold at once
-        const uint32_t items_per_group = pinned ? min(pinned, kFlatItems) : min(kFlatItems, max(1u, (r.n_items + resident - 1u) / resident));
+        // ... and within what the lanes of a batch hold (256 triangles, 768 edges): an item that does not fit is left to the workgroup's next
+        // turn, which doubles the workgroup's life — the averages of the scene keep a batch nine tenths full
+        const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)kFlatTris * 9u / 10u * r.n_items / r.hint_tris) : kFlatItems;
+        const uint32_t by_edges = r.hint_edges ? (uint32_t)((uint64_t)kFlatEdges * 9u / 10u * r.n_items / r.hint_edges) : kFlatItems;
+        const uint32_t fitting = max(1u, min(kFlatItems, min(by_tris, by_edges)));
+        const uint32_t items_per_group = pinned ? min(pinned, kFlatItems) : min(fitting, max(1u, (r.n_items + resident - 1u) / resident));
         const uint32_t flat_grid = (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
         if (samples == 4) {
             hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
