@@ -71,9 +71,42 @@ def _newest_profile(kind, workload):
     return doc, os.path.basename(files[-1])
 
 
+# ISA class (tools/isa_histogram.py) -> the class of tools/valu_rate.hip that prices it
+_RATE_OF_CLASS = {"simple": "v_fma_f32", "packed_f32": "v_pk_fma_f32", "compare": "v_cmp_ge_i32 -> sgpr pair", "cndmask": "v_cndmask_b32 (sgpr mask)", "lane": "v_readlane_b32",
+                  "quarter_rate_int": "v_mul_lo_u32", "convert": "v_cvt_i32_f32", "transcendental": "v_rcp_f32", "f64": "v_rcp_f32"}
+
+
+def _valu_cycles_per_instruction(kernel):
+    """Measured issue cost of one wave64 VALU instruction of `kernel`, in cycles of a SIMD: the chip-wide rates of profiles/rNN_valu_rate.json
+    (tools/valu_rate.hip: independent inline-asm chains, 8 wavefronts per SIMD, wall clock) weighted with the static instruction mix of the
+    kernel's ISA (profiles/rNN_isa_histogram.json, measured on THESE sources). None when either file is missing or stale."""
+    import glob
+    rates = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_rate.json")))
+    hists = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_isa_histogram.json")))
+    if not rates or not hists:
+        return None
+    with open(rates[-1]) as f:
+        rate_doc = json.load(f)
+    with open(hists[-1]) as f:
+        hist_doc = json.load(f)
+    if hist_doc.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    mix = hist_doc["kernels"].get(kernel.replace("crh::", "crh::", 1))
+    if not mix or not mix.get("valu_total"):
+        return None
+
+    def chip_rate(name):
+        c = rate_doc["classes"][name]["chip"]
+        return [v for k, v in c.items() if k.startswith("cycles_per_wave_instruction")][0]
+    cycles = sum(n * chip_rate(_RATE_OF_CLASS[c]) for c, n in mix["valu"].items())
+    return {"cycles": cycles / mix["valu_total"], "mix": mix["valu"], "rates": {c: chip_rate(_RATE_OF_CLASS[c]) for c in mix["valu"]},
+            "sources": [os.path.basename(rates[-1]), os.path.basename(hists[-1])]}
+
+
 def valu_issue(mark, avg_launch_ms, workload, triangle_pass=False):
     """Secondary roofline of the dominant kernel: VALU issue utilisation = wave-level VALU instructions (SQ_INSTS_VALU of the committed PMC
-    summary measured on THESE kernel sources) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x launch time)."""
+    summary measured on THESE kernel sources) x the MEASURED cycles per wave64 instruction of the kernel's instruction mix
+    (_valu_cycles_per_instruction; round 2 assumed 4 cycles for everything) / (1024 SIMDs x 2.4 GHz x launch time)."""
     doc, source = _newest_profile("sq_counters", workload)
     names = mark_to_kernel(workload, triangle_pass)
     if not doc or mark not in names or avg_launch_ms <= 0:
@@ -82,9 +115,13 @@ def valu_issue(mark, avg_launch_ms, workload, triangle_pass=False):
     if not k or "SQ_INSTS_VALU" not in k:
         return None
     simds, clock_hz = 256 * 4, 2.4e9
+    priced = _valu_cycles_per_instruction(names[mark])
+    cycles = priced["cycles"] if priced else 4.0
     return {"valu_wave_instructions": int(k["SQ_INSTS_VALU"]), "salu_wave_instructions": int(k.get("SQ_INSTS_SALU", 0)),
-            "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * 4.0 / (simds * clock_hz * avg_launch_ms * 1e-3), "source": source,
-            "note": "one wave64 VALU instruction per 4 cycles per SIMD; 256 CUs x 4 SIMDs at 2.4 GHz"}
+            "cycles_per_valu_instruction": cycles, "priced_by": priced if priced else "assumed 4 cycles (no current profiles/rNN_valu_rate.json + rNN_isa_histogram.json)",
+            "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * cycles / (simds * clock_hz * avg_launch_ms * 1e-3), "source": source,
+            "note": "256 CUs x 4 SIMDs at 2.4 GHz; measured per class on this part: simple f32 / int 2.5 cycles, v_pk_fma_f32 4.6, v_cmp 4.3, v_cndmask 4.2 "
+                    "(profiles/r03_valu_rate.json): the raster kernels' mix of packed fma + compare + select averages 3.3 - 3.7"}
 
 
 def measured_traffic(mark, workload, triangle_pass=False):

@@ -30,6 +30,11 @@ pub enum Error {
     TooManyNestedOpacityGroups,
     TooManyDashIntervals,
     DynamicStrokeOptionsIndexOutOfBounds,
+    /// Not a reference state (keep it last: the first five are statuses 1-5 of the C ABI). A recorded pass whose clip nesting or alpha
+    /// contexts are still open when the pass moves on to ANOTHER Shape object: the library keeps those per-sample counters for the
+    /// duration of one `crh_scene_render_draws` call over one scene, so such a pass has to be recorded against one [`Scene`] that holds
+    /// all its Shapes (`Scene::render` with real shape indices) instead of separate `Shape`s.
+    PassStateSpansShapes,
 }
 
 fn last_error() -> String {
@@ -532,6 +537,23 @@ impl Scene {
         assert!(transforms.len() == self.shape_count && colors.len() == self.shape_count);
         status(unsafe { ffi::crh_scene_render(self.raw, frame.raw, transforms.as_ptr() as *const f32, colors.as_ptr() as *const f32) })
     }
+    /// A recorded pass over the Shapes of this Scene: `draws[i]` = (index of the Shape, index into `transforms` / `colors`, operation, clip
+    /// depth and alpha layer in effect) — what a sequence of `Shape::render` calls between `Renderer::set_clip_depth` /
+    /// `save_alpha_context` calls records in the reference (renderer.rs:267-355, :932-985). Clip nesting and alpha contexts may span Shapes
+    /// here: one call is one pass.
+    pub fn render_draws(&self, frame: &mut Frame, transforms: &[[f32; 16]], colors: &[[f32; 4]], draws: &[(u32, u32, RenderOperation, u32, u32)]) -> Result<(), Error> {
+        assert!(transforms.len() == colors.len());
+        let raw_draws: Vec<ffi::crh_draw> = draws
+            .iter()
+            .map(|&(shape, instance, op, clip_depth, alpha_layer)| {
+                assert!((shape as usize) < self.shape_count && (instance as usize) < transforms.len());
+                ffi::crh_draw { shape, instance, op: op as u32, clip_depth, alpha_layer }
+            })
+            .collect();
+        status(unsafe {
+            ffi::crh_scene_render_draws(self.raw, frame.raw, transforms.as_ptr() as *const f32, colors.as_ptr() as *const f32, transforms.len() as u32, raw_draws.as_ptr(), raw_draws.len() as u32)
+        })
+    }
 }
 impl Drop for Scene {
     fn drop(&mut self) {
@@ -576,8 +598,38 @@ impl<'a> RenderPass<'a> {
         self.alpha_layer = alpha_layer as u32;
         Ok(())
     }
-    /// Runs the recorded draws, in order, as one pass per run of draws of the same Shape object (one `crh_scene_render_draws` each)
+    /// Runs the recorded draws, in order, as one pass per run of draws of the same Shape object (one `crh_scene_render_draws` each).
+    /// Clip counters and saved alpha contexts live for one such call: a run must leave them as it found them (every Clip matched by an
+    /// UnClip, every SaveAlphaContext by its RestoreAlphaContext, clip depth 0 at its borders) — otherwise `Err(PassStateSpansShapes)`,
+    /// and NOTHING of the pass is drawn. The reference's pattern "Clip shape A, Color shape B, UnClip shape A" needs A and B in one
+    /// [`Scene`].
     pub fn submit(self) -> Result<(), Error> {
+        let spans_shapes = self.draws.windows(2).any(|pair| pair[0].0 != pair[1].0);
+        if spans_shapes {
+            let mut begin = 0;
+            while begin < self.draws.len() {
+                let scene = self.draws[begin].0;
+                let (mut end, mut clips, mut saves) = (begin, 0i64, 0i64);
+                while end < self.draws.len() && self.draws[end].0 == scene {
+                    let draw = &self.draws[end].1;
+                    match draw.op {
+                        1 => clips += 1,  // RenderOperation::Clip
+                        2 => clips -= 1,  // UnClip
+                        4 => saves += 1,  // SaveAlphaContext
+                        6 => saves -= 1,  // RestoreAlphaContext
+                        _ => {}
+                    }
+                    if clips < 0 || saves < 0 || (draw.clip_depth != 0 && (end == begin || end + 1 == self.draws.len() || self.draws[end + 1].0 != scene)) {
+                        return Err(Error::PassStateSpansShapes);
+                    }
+                    end += 1;
+                }
+                if clips != 0 || saves != 0 {
+                    return Err(Error::PassStateSpansShapes);
+                }
+                begin = end;
+            }
+        }
         let mut begin = 0;
         while begin < self.draws.len() {
             let scene = self.draws[begin].0;

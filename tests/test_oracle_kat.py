@@ -341,3 +341,41 @@ def test_kat_i_stroke_dashed_interval_selection():
     assert stroke_dashed(d, 0.0, 2.3) is True       # gap_start distance 0.3: 0.09 < 0.25
     assert stroke_dashed(d, 0.0, 2.5) is False      # 0.5 from either end: 0.25 < 0.25 is false
     assert stroke_dashed(d, 0.45, 2.3) is False     # off the centre line: 0.2025 + 0.09 = 0.2925 (start cap), 0.2025 + 0.49 (end cap)
+
+
+def test_kat_j_orientation_sign_of_the_winding_contribution():
+    """path.rs:210-211: "Filled Paths increment the winding counter when they are counterclockwise and decrement it when they are clockwise."
+    What pixels can pin of that sentence is the RELATIVE sign (the stencil value itself is only ever tested against zero, renderer.rs:736-754):
+    two overlapping rectangles in one Shape — same direction of travel: the overlap carries winding +-2 and is covered under the non-zero
+    rule (winding_counter_bits = 8), not under even-odd (bits = 1); opposite directions: the contributions cancel in the overlap, which
+    stays uncovered under either rule. The absolute sign follows from the code, not from the sentence: from_rect's vertex
+    order (path.rs:736-743) is clockwise in y-up user coordinates, vertex.rs:28-35 reverses the facing of a polygon when it turns the fan
+    into a strip, front = counter-clockwise ON SCREEN (renderer.rs:477) increments (renderer.rs:577-582) — so a path that is clockwise in
+    y-up coordinates, i.e. counter-clockwise by the signed area of its y-DOWN (screen, SVG-style) coordinates, increments. Read in y-down
+    coordinates the sentence and the code agree; read in y-up coordinates the sentence has the sign backwards."""
+    from oracle import Oracle
+    W = H = 64
+    a = Path.from_rect((24.0, 32.0), (16.0, 16.0))   # x 8..40, y 16..48
+    b = Path.from_rect((40.0, 32.0), (16.0, 16.0))   # x 24..56: overlap x 24..40
+    b_reversed = Path.from_rect((40.0, 32.0), (16.0, 16.0))
+    b_reversed.reverse()
+    transform = np.zeros((1, 16), dtype=np.float32)  # user (x, y-up) in pixels -> clip space
+    transform[0, 0], transform[0, 5], transform[0, 10], transform[0, 15], transform[0, 12], transform[0, 13] = 2.0 / W, 2.0 / H, 1.0, 1.0, -1.0, -1.0
+    color = np.array([[1.0, 1.0, 1.0, 1.0]], dtype=np.float32)
+
+    def covered(paths, bits):
+        o = Oracle(batch_from_shapes([([], paths)]))
+        assert o.status() == 0
+        return o.render(W, H, 1, bits, transform, color)[..., 3] > 0
+
+    inside_a, overlap, inside_b = (slice(20, 44), slice(10, 22)), (slice(20, 44), slice(26, 38)), (slice(20, 44), slice(42, 54))  # (rows, columns), away from the edges
+    same8, same1 = covered([a, b], 8), covered([a, b], 1)
+    assert same8[inside_a].all() and same8[overlap].all() and same8[inside_b].all()          # +-1, +-2, +-1: all non-zero
+    assert same1[inside_a].all() and not same1[overlap].any() and same1[inside_b].all()      # even-odd: 2 = 0 (mod 2)
+    for bits in (8, 4, 1):
+        opposite = covered([a, b_reversed], bits)
+        assert opposite[inside_a].all() and not opposite[overlap].any() and opposite[inside_b].all()  # +1 - 1 = 0 whatever the counter width
+    # the direction of from_rect (path.rs:736-743) in y-up user coordinates: clockwise = negative signed area
+    pts = np.array([a.start] + [rec[-2:] for rec in a.records], dtype=np.float64)
+    x, y = pts[:, 0], pts[:, 1]
+    assert 0.5 * np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y) < 0.0

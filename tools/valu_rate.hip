@@ -19,11 +19,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kLoops = 512; // x 64 instructions
 
-enum Class { FMA_F32 = 0, PK_FMA_F32, CMP_CNDMASK, CMP_SGPR, MOV_B32, ADD_U32, ADD_F32, MUL_F32, AND_B32, CNDMASK_ONLY, RASTER_MIX, N_CLASSES };
+enum Class { FMA_F32 = 0, PK_FMA_F32, CMP_CNDMASK, CMP_SGPR, MOV_B32, ADD_U32, ADD_F32, MUL_F32, AND_B32, CNDMASK_ONLY, RASTER_MIX, CMP_VCC, CNDMASK_VCC, SIGN_TRICK, MUL_LO_U32, CVT_I32_F32, RCP_F32, READLANE, N_CLASSES };
 static const char* kNames[N_CLASSES] = {"v_fma_f32",       "v_pk_fma_f32",  "v_cmp_ge_i32+v_cndmask_b32 (pair, per instruction)", "v_cmp_ge_i32 -> sgpr pair", "v_mov_b32", "v_add_u32", "v_add_f32",
                                         "v_mul_f32",       "v_and_b32",     "v_cndmask_b32 (sgpr mask)",
-                                        "raster mix: 2 v_pk_fma_f32 + 4 v_cmp_ge_i32 + 4 v_cndmask_b32 + 4 v_add_u32 (per instruction)"};
-static const int kInstrPerBody[N_CLASSES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 56};
+                                        "raster mix: 2 v_pk_fma_f32 + 4 v_cmp_ge_i32 + 4 v_cndmask_b32 + 4 v_add_u32 (per instruction)",
+                                        "v_cmp_ge_i32 -> vcc (e32)", "v_cndmask_b32 (vcc, e32)", "v_sub_u32 + v_or_b32 + v_lshrrev_b32 (accept bit without a compare, per instruction)",
+                                        "v_mul_lo_u32", "v_cvt_i32_f32", "v_rcp_f32", "v_readlane_b32"};
+static const int kInstrPerBody[N_CLASSES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 56, 64, 64, 56, 64, 64, 64, 64};
 
 template <int C>
 __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float seed, unsigned lds_words) {
@@ -33,6 +35,7 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float se
     f32x2 p[8], pb = {seed, seed}, pc = {c, c};
     int ia[8], ib = (int)seed + threadIdx.x;
     unsigned long long m[4] = {0, 0, 0, 0};
+    unsigned sl[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = seed + (float)i, p[i] = f32x2{seed + (float)i, seed - (float)i}, ia[i] = (int)threadIdx.x + i;
     __builtin_amdgcn_s_barrier();
@@ -57,6 +60,17 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float se
                 if (C == MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if (C == AND_B32) asm volatile("v_and_b32 %0, %0, %1" : "+v"(ia[i]) : "v"(ib));
                 if (C == CNDMASK_ONLY) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(ia[i]) : "v"(ib), "s"(m[i & 3]));
+                if (C == CMP_VCC) asm volatile("v_cmp_ge_i32 vcc, %0, %1" : : "v"(ia[i]), "v"(ib) : "vcc");
+                if (C == CNDMASK_VCC) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(ia[i]) : "v"(ib) : "vcc");
+                if (C == SIGN_TRICK && i < 7) { // three instructions per chain step, 21 per row of seven chains
+                    if (r % 3 == 0) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(ia[i]) : "v"(ib));
+                    if (r % 3 == 1) asm volatile("v_or_b32 %0, %0, %1" : "+v"(ia[i]) : "v"(ib));
+                    if (r % 3 == 2) asm volatile("v_lshrrev_b32 %0, 31, %0" : "+v"(ia[i]));
+                }
+                if (C == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(ia[i]) : "v"(ib));
+                if (C == CVT_I32_F32) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(ia[i]) : "v"(a[i]));
+                if (C == RCP_F32) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+                if (C == READLANE) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sl[i & 3]) : "v"(ia[i]));
             }
             if (C == RASTER_MIX && r < 4) { // what one edge entry costs two sample pairs of a lane in k_raster_edges, in its proportions
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 * r]) : "v"(pb), "v"(pc));
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float se
     int si = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i] + p[i][0] + p[i][1], si += ia[i];
-    if (s == 12345.678f && si == 42 && (m[0] ^ m[1] ^ m[2] ^ m[3]) == 7ull) out[0] = 0; // keeps the results alive
+    if (s == 12345.678f && si == 42 && (m[0] ^ m[1] ^ m[2] ^ m[3]) == 7ull && (sl[0] ^ sl[1] ^ sl[2] ^ sl[3]) == 9u) out[0] = 0; // keeps the results alive
     if ((threadIdx.x & 63u) == 0u) out[1 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -85,7 +99,8 @@ static void launch(dim3 grid, dim3 block, size_t lds, unsigned long long* out) {
 }
 typedef void (*Launcher)(dim3, dim3, size_t, unsigned long long*);
 static Launcher kLaunch[N_CLASSES] = {launch<FMA_F32>, launch<PK_FMA_F32>, launch<CMP_CNDMASK>, launch<CMP_SGPR>, launch<MOV_B32>, launch<ADD_U32>,
-                                      launch<ADD_F32>, launch<MUL_F32>,    launch<AND_B32>,     launch<CNDMASK_ONLY>, launch<RASTER_MIX>};
+                                      launch<ADD_F32>, launch<MUL_F32>,    launch<AND_B32>,     launch<CNDMASK_ONLY>, launch<RASTER_MIX>, launch<CMP_VCC>, launch<CNDMASK_VCC>,
+                                      launch<SIGN_TRICK>, launch<MUL_LO_U32>, launch<CVT_I32_F32>, launch<RCP_F32>, launch<READLANE>};
 
 #define CHECK(e)                                                                         \
     do {                                                                                 \
@@ -103,9 +118,11 @@ int main() {
     unsigned long long* out = nullptr;
     const size_t slots = 1 + (size_t)cus * 2 * 16;
     CHECK(hipMalloc(&out, slots * 8));
+    unsigned long long* out_big = nullptr;
+    CHECK(hipMalloc(&out_big, (1 + (size_t)cus * 8 * 4) * 8));
     // dynamic LDS beyond 64 KiB needs the attribute
 #define ALLOW(C) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rate<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024))
-    ALLOW(FMA_F32); ALLOW(PK_FMA_F32); ALLOW(CMP_CNDMASK); ALLOW(CMP_SGPR); ALLOW(MOV_B32); ALLOW(ADD_U32); ALLOW(ADD_F32); ALLOW(MUL_F32); ALLOW(AND_B32); ALLOW(CNDMASK_ONLY); ALLOW(RASTER_MIX);
+    ALLOW(FMA_F32); ALLOW(PK_FMA_F32); ALLOW(CMP_CNDMASK); ALLOW(CMP_SGPR); ALLOW(MOV_B32); ALLOW(ADD_U32); ALLOW(ADD_F32); ALLOW(MUL_F32); ALLOW(AND_B32); ALLOW(CNDMASK_ONLY); ALLOW(RASTER_MIX); ALLOW(CMP_VCC); ALLOW(CNDMASK_VCC); ALLOW(SIGN_TRICK); ALLOW(MUL_LO_U32); ALLOW(CVT_I32_F32); ALLOW(RCP_F32); ALLOW(READLANE);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
@@ -137,6 +154,19 @@ int main() {
             std::sort(d.begin(), d.end());
             const double median = (double)d[d.size() / 2], instr = (double)kLoops * kInstrPerBody[c];
             std::printf("%s\"w%d\": {\"cycles_per_wave_instruction\": %.3f, \"median_wave_cycles\": %.0f, \"kernel_ms\": %.4f}", wi ? ", " : "", w, median / (instr * w), median, ms);
+        }
+        { // the issue rate of the whole chip: 8 wavefronts per SIMD (no LDS games: 8 x 256 CUs workgroups of 1024 threads... as many as fit), wall clock
+            const dim3 grid(8 * cus), block(256);
+            kLaunch[c](grid, block, 0, out_big);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipEventRecord(e0, 0));
+            kLaunch[c](grid, block, 0, out_big);
+            CHECK(hipEventRecord(e1, 0));
+            CHECK(hipDeviceSynchronize());
+            float ms = 0.0f;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double total = (double)grid.x * 4.0 * kLoops * kInstrPerBody[c], simds = 4.0 * cus;
+            std::printf(", \"chip\": {\"kernel_ms\": %.4f, \"wave_instructions\": %.0f, \"cycles_per_wave_instruction_at_%d_MHz\": %.3f}", ms, total, prop.clockRate / 1000, ms * 1e-3 * prop.clockRate * 1e3 * simds / total);
         }
         std::printf("}%s\n", c + 1 < N_CLASSES ? "," : "");
     }
