@@ -309,6 +309,9 @@ def main():
                     "torch.distributed statement of the same exchange (contrast_renderer_amd/distributed.py), dense slabs — validation only")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only; implies --exchange torch)")
     ap.add_argument("--check", action="store_true", help="N > 1: rank 0 also renders every shard itself and compares the composite of those layers with the gathered image")
+    ap.add_argument("--reupload", action="store_true", help="every step uploads the paths again into the existing Scene before it tessellates and renders — the "
+                    "reference's animated-path use (new geometry every frame, Shape::from_paths with existing_shape): host marshalling + PCIe are inside the "
+                    "step, so this is a host-inclusive figure, reported as such and never as the metric's `value`")
     ap.add_argument("--loopback", type=int, default=0, help="N > 1 (with --gpus 1): ONE GPU plays all N ranks of the sharded path — the N shards are rendered one after "
                     "the other into N layers and exchanged through crh_comm_local_exchange (csrc/comm.hip with device-to-device copies in place of RCCL): "
                     "the whole of BASELINE configs[3] on one box, with the exchange's per-phase GPU time and bytes on the wire")
@@ -408,7 +411,11 @@ def main():
 
     def launch(i):
         """Enqueues step i's tessellation + render (asynchronous on the renderer's streams)."""
+        nonlocal scene
         f = frames[i % len(frames)]
+        if args.reupload:
+            scene = Scene(renderer, batch, tessellate=False, existing=scene)  # crh_scene_upload into the existing Scene: validation, element stream, H2D
+            scene.set_instances(transforms, colors)
         scene.tessellate()
         f.clear()
         scene.render(f)
@@ -546,7 +553,7 @@ def main():
     # emitted bytes and writes the frame (the raster mark already carries emitted + 80 B / shape + W * H * 4); binning has none
     step_bytes = kernels.get("tess_emit", {}).get("algorithmic_bytes", 0) + kernels.get("raster_tiles", {}).get("algorithmic_bytes", 0)
     out = {
-        "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)",
+        "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)" + (" — HOST-INCLUSIVE: new geometry uploaded every step (--reupload)" if args.reupload else ""),
         "value": total_paths / step_s,
         "unit": "paths/s",
         "mpixel_per_s": size[0] * size[1] / step_s / 1e6,
@@ -628,6 +635,12 @@ def main():
                                   "untimed one (a cold run is 5x slower: arena creation and first-touch page faults); threads = the CPUs this process may "
                                   "use (affinity mask and cgroup CPU quota, not the host's core count: more threads than that only time-slice)"},
         }
+    # like for like with cpu_baseline (which is tessellation only: the reference rasterizes on a GPU): the tessellation kernels of a step, each
+    # with the GPU to itself
+    tess_alone_ms = sum(v for k, v in alone.items() if k.startswith("tess_"))
+    if tess_alone_ms > 0:
+        out["gpu_tessellation"] = {"value": batch.n_shapes / (tess_alone_ms * 1e-3), "unit": "paths/s", "ms": tess_alone_ms,
+                                   "note": "count / scan / emit / hull / range kernels of one step, stand-alone HIP-event times summed: the GPU side of what cpu_baseline times"}
     if cpu_baseline is not None:
         out["cpu_baseline"] = cpu_baseline
     if rank == 0:

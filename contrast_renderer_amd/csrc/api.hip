@@ -339,6 +339,7 @@ struct crh_scene {
     uint32_t pass_frames = 0;  // plain frames of the trial under way
     uint32_t pass_class = 0;   // size class of the target the trial / choice belongs to (log4 of its area)
     uint8_t pass_known[16] = {}; // choices already measured, by size class: a Scene drawn into a large frame and a thumbnail in turn measures twice, not for ever
+    uint32_t pass_geometry = 0; // what the choices were measured on: (log2 of the Shape count, log2 of the segment count) — an upload of geometry of the same class keeps them
     float pass_ms[2] = {0.0f, 0.0f};
     void tess_bufs(DevBuf* (&out)[kTessBufs]) {
         DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
@@ -1235,9 +1236,21 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         sc->shadow.allocated = false;
     }
     sc->tessellated_once = false;
-    sc->pass_choice = 0, sc->pass_frames = 0, sc->pass_class = 0; // new geometry: measure again
-    std::memset(sc->pass_known, 0, sizeof(sc->pass_known));
-    sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+    {   // New geometry: measure again which formulation draws it faster — unless it is geometry of the same kind (as many Shapes and segments,
+        // to a factor of two): a caller that uploads new paths every frame (the reference's animated-path use) would otherwise never leave
+        // the trial, which draws four frames on alternating passes and waits for the GPU on the fifth.
+        auto log2_of = [](uint32_t v) { uint32_t n = 0; while (v > 1u) v >>= 1, ++n; return n; };
+        const uint32_t geometry = (log2_of(b->n_shapes) << 8) | log2_of(b->n_segments);
+        if (geometry != sc->pass_geometry || !existing) {
+            sc->pass_choice = 0, sc->pass_frames = 0, sc->pass_class = 0;
+            std::memset(sc->pass_known, 0, sizeof(sc->pass_known));
+            sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+        } else if (sc->pass_choice == 0) { // (a trial under way is started over on the new geometry)
+            sc->pass_frames = 0;
+            sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+        }
+        sc->pass_geometry = geometry;
+    }
     for (bool& used : sc->rec_used) used = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;

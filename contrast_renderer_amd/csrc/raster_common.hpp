@@ -155,19 +155,31 @@ CRH_D bool cap_test(float x, float y, uint32_t cap_type) { // shaders.wgsl:165-1
 // The dashed pattern walk of shaders.wgsl:205-231 with the 48-byte descriptor in scalar registers (it is wave uniform) and the interval
 // search unrolled into selects: interval = number of leading intervals that end before the position (at most `last`). No memory access
 // and no loop per sample — the loop over global-memory descriptor fields this replaces was half of the dashed workload's raster time.
+CRH_D float wave_uniform(float v) { // v is the same in every lane: keep it in a scalar register
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
+#else
+    return v;
+#endif
+}
 CRH_D bool stroke_dashed(const crh_dynamic_stroke_descriptor& d, float tx, float ty) {
+    // The descriptor's fields as scalar VALUES first. Selected straight out of the struct ("a ? d.gap_end[1] : d.gap_end[0]"), the compiler
+    // turns the select of two loads into one load at a selected address — from a copy of the descriptor in scratch memory: 52 bytes per lane
+    // and three vector-memory round trips per sample in every kernel that draws strokes.
+    const float ge0 = wave_uniform(d.gap_end[0]), ge1 = wave_uniform(d.gap_end[1]), ge2 = wave_uniform(d.gap_end[2]), ge3 = wave_uniform(d.gap_end[3]);
+    const float gs0 = wave_uniform(d.gap_start[0]), gs1 = wave_uniform(d.gap_start[1]), gs2 = wave_uniform(d.gap_start[2]), gs3 = wave_uniform(d.gap_start[3]);
     const uint32_t last = d.count_dashed_join >> 3;
-    const float ge_last = last == 0u ? d.gap_end[0] : (last == 1u ? d.gap_end[1] : (last == 2u ? d.gap_end[2] : d.gap_end[3])); // wave uniform
+    const float ge_last = last == 0u ? ge0 : (last == 1u ? ge1 : (last == 2u ? ge2 : ge3)); // wave uniform
     const float pattern_length = ge_last;
     float position = crh_wgsl_mod(ty - d.phase, pattern_length);
     if (position < 0.0f) position = position + pattern_length;
     // for (;;) { gap_end = gap_end[interval] - position; if (gap_end >= 0 || interval >= last) break; ++interval; }
-    const bool a0 = !(d.gap_end[0] - position >= 0.0f) && 0u < last;
-    const bool a1 = a0 && !(d.gap_end[1] - position >= 0.0f) && 1u < last;
-    const bool a2 = a1 && !(d.gap_end[2] - position >= 0.0f) && 2u < last;
+    const bool a0 = !(ge0 - position >= 0.0f) && 0u < last;
+    const bool a1 = a0 && !(ge1 - position >= 0.0f) && 1u < last;
+    const bool a2 = a1 && !(ge2 - position >= 0.0f) && 2u < last;
     const uint32_t interval = (uint32_t)a0 + (uint32_t)a1 + (uint32_t)a2;
-    const float ge = a2 ? d.gap_end[3] : (a1 ? d.gap_end[2] : (a0 ? d.gap_end[1] : d.gap_end[0]));
-    const float gs = a2 ? d.gap_start[3] : (a1 ? d.gap_start[2] : (a0 ? d.gap_start[1] : d.gap_start[0]));
+    const float ge = a2 ? ge3 : (a1 ? ge2 : (a0 ? ge1 : ge0));
+    const float gs = a2 ? gs3 : (a1 ? gs2 : (a0 ? gs1 : gs0));
     const float gap_end = ge - position;
     const float gap_start = position - gs;
     if (gap_start > 0.0f) {
