@@ -133,6 +133,11 @@ struct crh_renderer {
     void* composite_table = nullptr; // device array of layer pointers (aux stream)
     uint32_t composite_table_capacity = 0;
     bool pipeline = true;     // CRH_NO_PIPELINE=1 runs everything on `stream`
+    // CRH_RASTER_EXCLUSIVE (measurement only): the raster kernel has the GPU to itself — the binning of frame i + 1 and the tessellation of
+    // frame i + 2 both start when the raster kernel of frame i has finished, and overlap each other. Slower (0.53 against 0.45 ms per step on
+    // the benchmark scene): the lanes do gain from running beside the raster kernel, however little each of them gets there.
+    bool raster_exclusive = false;
+    hipEvent_t raster_events[2] = {nullptr, nullptr}; // the raster_done events of the latest and of the previous render
     std::vector<crh_scene*> scenes; // live scenes and frames: orphaned (renderer = nullptr) when the renderer goes first, so that their own
                                     // destruction — host bindings finalise in any order — never touches a freed renderer
     std::vector<crh_frame*> frames; // live frames: a frame whose overflow check is still pending is settled before the scene it shows changes
@@ -520,6 +525,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     const hipStream_t ts = r->tessellation_stream();
     // the previous frame's k_prim_setup must have consumed the vertex streams this run overwrites; its binning and raster may still run
     if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->vertices_free, 0));
+    if (r->raster_exclusive && r->raster_events[1]) HIP_TRY(hipStreamWaitEvent(ts, r->raster_events[1], 0));
     r->begin_marks(1);
     HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, ts));
     if (d.n_elems == 0) { // nothing to tessellate: every offset is zero
@@ -810,6 +816,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     crh_frame::BinSet& set = f->sets[f->next_set];
     const int rec = sc->next_rec;
     HIP_TRY(hipStreamWaitEvent(bin, sc->tess_done, 0)); // the tessellation this frame draws (a no-op when it finished long ago)
+    if (r->raster_exclusive && r->raster_events[0]) HIP_TRY(hipStreamWaitEvent(bin, r->raster_events[0], 0));
     if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.raster_done, 0));
     if (sc->rec_used[rec]) HIP_TRY(hipStreamWaitEvent(bin, sc->rec_raster_done[rec], 0));
     RasterParams p;
@@ -984,6 +991,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
+    r->raster_events[1] = r->raster_events[0], r->raster_events[0] = sc->rec_raster_done[rec];
     if (trial) {
         HIP_TRY(hipEventRecord(trial->e[5], r->stream));
         trial->recorded = true;
@@ -1083,6 +1091,7 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
         return CRH_ERR_HIP;
     }
     r->pipeline = getenv("CRH_NO_PIPELINE") == nullptr;
+    r->raster_exclusive = getenv("CRH_RASTER_EXCLUSIVE") != nullptr;
     *out = r;
     return CRH_OK;
 }
@@ -1364,6 +1373,9 @@ void crh_scene_destroy(crh_scene* sc) {
     if (sc->renderer) {
         (void)settle_frames_of(sc, true);
         (void)sc->renderer->sync();
+        for (hipEvent_t& seen : sc->renderer->raster_events) // (the events below are about to be destroyed)
+            for (hipEvent_t mine : sc->rec_raster_done)
+                if (seen == mine) seen = nullptr;
         std::vector<crh_scene*>& live = sc->renderer->scenes;
         for (size_t i = 0; i < live.size(); ++i)
             if (live[i] == sc) {
