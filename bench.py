@@ -38,7 +38,8 @@ def mark_to_kernel(workload, triangle_pass=False):
                 "tess_emit": "crh::k_emit", "tess_count": "crh::k_count", "tess_hull": "crh::k_hull_small"}
     return {
         "raster_tiles": "crh::k_raster_edges<4, 1, true>" if msaa4_strokes else "crh::k_raster_edges<1, 4, false>",
-        "raster_bin": "crh::k_bin_edges<4>" if msaa4_strokes else "crh::k_bin_edges<1>",
+        # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
+        "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else "crh::k_bin_flat<1>",
         "raster_scatter": "crh::k_scatter",
         "tess_emit": "crh::k_emit",
         "tess_count": "crh::k_count",

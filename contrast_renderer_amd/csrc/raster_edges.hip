@@ -1539,6 +1539,12 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 #ifndef CRH_EDGE_TILE_WAVES
 #define CRH_EDGE_TILE_WAVES 5 // measured 4: 0.321, 5: 0.322, 6: 0.331 (spills), 8: 0.421 ms on the benchmark scene
 #endif
+#ifndef CRH_EDGE_TILE_WAVES_MAX
+#define CRH_EDGE_TILE_WAVES_MAX 10 // (no cap)
+#endif
+#ifndef CRH_STROKE_TILE_WAVES_MAX
+#define CRH_STROKE_TILE_WAVES_MAX 10
+#endif
 #ifndef CRH_STROKE_TILE_WAVES
 #define CRH_STROKE_TILE_WAVES 5 // dashed strokes, msaa 4 (ms): 1 (145 registers): 2.96, 4: 2.34, 5: 2.24, 6: 2.83, 8: 5.05 — the kernel waits, it does not issue
 #endif
@@ -1546,7 +1552,7 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 // msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
 // the item being drawn and the colour; entries are walked in key order (= draw order).
 template <int S, int ROWS, bool STROKES>
-__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
+__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES, (STROKES || S == 4) ? CRH_STROKE_TILE_WAVES_MAX : CRH_EDGE_TILE_WAVES_MAX))) void k_raster_edges(SceneDev s, RasterParams r) {
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
     __shared__ uint8_t compact_table[STROKES ? 4 / ROWS : 1][STROKES ? 256 : 4]; // (lane, slot) codes of the samples a stroke triangle has to decide
