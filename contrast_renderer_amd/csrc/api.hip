@@ -1082,15 +1082,26 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     crh_renderer* r = new crh_renderer;
     r->config = *config;
     r->device = device_ordinal;
-    if (!hip_ok(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->tess_stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->bin_stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->aux_stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipStreamCreateWithFlags(&r->upload_stream, hipStreamNonBlocking), "hipStreamCreate")) {
+    r->pipeline = getenv("CRH_NO_PIPELINE") == nullptr;
+    // CRH_CU_SPLIT=n (experiment): the tessellation and binning lanes get n of the device's compute units, the raster
+    // lane the others (the mask's bits are dealt round-robin to the XCDs by the driver, so both sets spread evenly over the eight dies).
+    int front_cus = 0;
+    if (const char* e = getenv("CRH_CU_SPLIT")) front_cus = atoi(e);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    const int n_cus = prop.multiProcessorCount;
+    auto make_stream = [&](hipStream_t* st, int lane) -> bool { // lane 0: unrestricted, 1: front lanes, 2: raster lane
+        if (!r->pipeline || front_cus <= 0 || front_cus >= n_cus || lane == 0) return hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
+        std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
+        for (int c = 0; c < n_cus; ++c)
+            if ((c < front_cus) == (lane == 1)) mask[(size_t)c / 32] |= 1u << (c % 32);
+        return hip_ok(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()), "hipExtStreamCreateWithCUMask");
+    };
+    if (!make_stream(&r->stream, 2) || !make_stream(&r->tess_stream, 1) || !make_stream(&r->bin_stream, 1) || !make_stream(&r->aux_stream, 0) ||
+        !make_stream(&r->upload_stream, 0)) {
         delete r;
         return CRH_ERR_HIP;
     }
-    r->pipeline = getenv("CRH_NO_PIPELINE") == nullptr;
     r->raster_exclusive = getenv("CRH_RASTER_EXCLUSIVE") != nullptr;
     *out = r;
     return CRH_OK;

@@ -191,54 +191,124 @@ __device__ __forceinline__ uint32_t pixel_zero<uint32_t>() { return 0u; }
 template <>
 __device__ __forceinline__ uint2 pixel_zero<uint2>() { return make_uint2(0u, 0u); }
 
-// bit t of `bitmap` <=> tile t of the layer holds a non-zero pixel (one workgroup per tile, one pixel per lane)
+// ---- a wavefront per 16x16 tile: lane l holds the four pixels (4 (l & 3) .. + 3, l >> 2) of the tile — 16 bytes of an RGBA8 layer, 32
+// of an RGBA16F one —, so a tile row is one 64- / 128-byte segment of the frame and a packed tile (row-major, 1 or 2 KiB) one contiguous
+// run of the pack buffer: every access of the exchange kernels is a full-width vector load or store.
 template <typename P>
-__global__ __launch_bounds__(256) void k_tile_occupancy(const P* pixels, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t* bitmap) {
-    const uint32_t tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
-    const bool any = (x < width && y < height) ? pixel_nonzero(pixels[(size_t)y * width + x]) : false;
-    if (__syncthreads_or(any) && threadIdx.x == 0) atomicOr(&bitmap[tile >> 5], 1u << (tile & 31u));
-}
-// prefix[w] = number of set bits in words [0, w) of one bitmap; one workgroup per bitmap (blockIdx.x): bitmap k starts at word
-// k * bitmap_stride of `bitmaps`, its prefix (n_words + 1 entries) at k * (n_words + 1) of `prefixes`
-__global__ __launch_bounds__(1024) void k_bit_prefix(const uint32_t* bitmaps, uint32_t bitmap_stride, uint32_t n_words, uint32_t* prefixes) {
-    __shared__ uint32_t partial[1024];
-    const uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * bitmap_stride;
-    uint32_t* prefix = prefixes + (size_t)blockIdx.x * (n_words + 1u);
-    const uint32_t per = (n_words + 1023u) / 1024u, begin = threadIdx.x * per, end = min(n_words, begin + per);
-    uint32_t sum = 0;
-    for (uint32_t w = begin; w < end; ++w) sum += (uint32_t)__popc(bitmap[w]);
-    partial[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) { // Hillis-Steele inclusive scan of the 1024 partial sums
-        const uint32_t v = threadIdx.x >= d ? partial[threadIdx.x - d] : 0u;
-        __syncthreads();
-        partial[threadIdx.x] += v;
-        __syncthreads();
+struct alignas(4 * sizeof(P)) Quad {
+    P p[4];
+};
+__device__ __forceinline__ uint32_t wave_in_block() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+template <typename P>
+__device__ __forceinline__ Quad<P> load_quad_frame(const P* pixels, uint32_t width, uint32_t height, uint32_t tx, uint32_t ty) {
+    const uint32_t lane = threadIdx.x & 63u, x = tx * 16u + (lane & 3u) * 4u, y = ty * 16u + (lane >> 2);
+    Quad<P> q;
+    for (int i = 0; i < 4; ++i) q.p[i] = pixel_zero<P>();
+    if (y >= height) return q;
+    const P* row = pixels + (size_t)y * width;
+    if ((width & 3u) == 0u) { // rows start 16-byte aligned and a quad is inside the frame or outside it
+        if (x < width) q = *reinterpret_cast<const Quad<P>*>(row + x);
+    } else {
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (x + i < width) q.p[i] = row[x + i];
     }
-    uint32_t run = partial[threadIdx.x] - sum;
+    return q;
+}
+template <typename P>
+__device__ __forceinline__ void store_quad_frame(P* pixels, uint32_t width, uint32_t height, uint32_t tx, uint32_t ty, const Quad<P>& q) {
+    const uint32_t lane = threadIdx.x & 63u, x = tx * 16u + (lane & 3u) * 4u, y = ty * 16u + (lane >> 2);
+    if (y >= height) return;
+    P* row = pixels + (size_t)y * width;
+    if ((width & 3u) == 0u) {
+        if (x < width) *reinterpret_cast<Quad<P>*>(row + x) = q;
+    } else {
+        for (uint32_t i = 0; i < 4u; ++i)
+            if (x + i < width) row[x + i] = q.p[i];
+    }
+}
+template <typename P>
+__device__ __forceinline__ Quad<P> load_quad_packed(const P* pack, size_t slot) { return reinterpret_cast<const Quad<P>*>(pack + slot * kTilePixels)[threadIdx.x & 63u]; }
+template <typename P>
+__device__ __forceinline__ void store_quad_packed(P* pack, size_t slot, const Quad<P>& q) { reinterpret_cast<Quad<P>*>(pack + slot * kTilePixels)[threadIdx.x & 63u] = q; }
+
+// bit t of `bitmap` <=> tile t of the layer holds a non-zero pixel. One workgroup per bitmap WORD (32 consecutive tiles, eight per
+// wavefront with all eight loads in flight): the word is stored whole — no atomics, no clearing pass.
+template <typename P>
+__global__ __launch_bounds__(256) void k_tile_occupancy(const P* pixels, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, uint32_t* bitmap) {
+    __shared__ uint32_t part[4];
+    const uint32_t wave = wave_in_block(), first = blockIdx.x * 32u + wave * 8u;
+    Quad<P> q[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) {
+        const uint32_t tile = first + i;
+        if (tile < n_tiles) q[i] = load_quad_frame(pixels, width, height, tile % tiles_x, tile / tiles_x);
+        else
+            for (int k = 0; k < 4; ++k) q[i].p[k] = pixel_zero<P>();
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) {
+        const bool any = pixel_nonzero(q[i].p[0]) | pixel_nonzero(q[i].p[1]) | pixel_nonzero(q[i].p[2]) | pixel_nonzero(q[i].p[3]);
+        if (__ballot(any) != 0ull) bits |= 1u << i;
+    }
+    if ((threadIdx.x & 63u) == 0u) part[wave] = bits << (wave * 8u);
+    __syncthreads();
+    if (threadIdx.x == 0u) bitmap[blockIdx.x] = part[0] | part[1] | part[2] | part[3];
+}
+// prefix[w] = number of set bits in words [0, w) of a bitmap (n_words + 1 entries). Workgroup k < world: bitmap k of `bitmaps`
+// (`bitmap_stride` words apart) -> prefixes + k (n_words + 1); workgroup `world` (launched when or_bitmap is given): the union of all
+// bitmaps -> or_bitmap, and its prefix -> or_prefix. Per thread a run of words, a shuffle scan per wavefront, sixteen totals through LDS.
+__global__ __launch_bounds__(1024) void k_bit_prefix(const uint32_t* bitmaps, uint32_t bitmap_stride, uint32_t n_words, uint32_t world, uint32_t* prefixes, uint32_t* or_bitmap,
+                                                     uint32_t* or_prefix) {
+    __shared__ uint32_t wave_total[16];
+    const bool united = blockIdx.x == world;
+    const uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * bitmap_stride;
+    uint32_t* prefix = united ? or_prefix : prefixes + (size_t)blockIdx.x * (n_words + 1u);
+    const uint32_t per = (n_words + 1023u) / 1024u, begin = threadIdx.x * per, end = min(n_words, begin + per);
+    auto word = [&](uint32_t w) -> uint32_t {
+        if (!united) return bitmap[w];
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < world; ++k) v |= bitmaps[(size_t)k * bitmap_stride + w];
+        return v;
+    };
+    uint32_t sum = 0;
+    for (uint32_t w = begin; w < end; ++w) {
+        const uint32_t v = word(w);
+        if (united) or_bitmap[w] = v;
+        sum += (uint32_t)__popc(v);
+    }
+    uint32_t scan = sum; // inclusive over the wavefront
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)scan, d, 64);
+        if (lane >= d) scan += v;
+    }
+    if (lane == 63u) wave_total[threadIdx.x >> 6] = scan;
+    __syncthreads();
+    uint32_t run = scan - sum;
+    for (uint32_t k = 0; k < (threadIdx.x >> 6); ++k) run += wave_total[k];
     for (uint32_t w = begin; w < end; ++w) {
         prefix[w] = run;
-        run += (uint32_t)__popc(bitmap[w]);
+        run += (uint32_t)__popc(united ? or_bitmap[w] : bitmap[w]); // (the thread's own stores above)
     }
-    if (threadIdx.x == 1023u) prefix[n_words] = partial[1023];
+    if (threadIdx.x == 1023u) prefix[n_words] = run;
 }
 __device__ __forceinline__ bool tile_bit(const uint32_t* bitmap, uint32_t tile) { return (bitmap[tile >> 5] >> (tile & 31u)) & 1u; }
 __device__ __forceinline__ uint32_t tile_rank(const uint32_t* bitmap, const uint32_t* prefix, uint32_t tile) { // set bits below `tile`
     return prefix[tile >> 5] + (uint32_t)__popc(bitmap[tile >> 5] & ((1u << (tile & 31u)) - 1u));
 }
-// the non-empty tiles of the layer, packed in tile order: 256 pixels (row-major inside the tile) per tile
+// the non-empty tiles of the layer, packed in tile order (row-major inside the tile); a wavefront per tile
 template <typename P>
-__global__ __launch_bounds__(256) void k_pack_tiles(const P* pixels, uint32_t width, uint32_t height, uint32_t tiles_x, const uint32_t* bitmap, const uint32_t* prefix, P* pack) {
-    const uint32_t tile = blockIdx.x;
-    if (!tile_bit(bitmap, tile)) return;
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
-    pack[(size_t)tile_rank(bitmap, prefix, tile) * kTilePixels + threadIdx.x] = (x < width && y < height) ? pixels[(size_t)y * width + x] : pixel_zero<P>();
+__global__ __launch_bounds__(256) void k_pack_tiles(const P* pixels, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, const uint32_t* bitmap,
+                                                    const uint32_t* prefix, P* pack) {
+    const uint32_t tile = blockIdx.x * 4u + wave_in_block();
+    if (tile >= n_tiles || !tile_bit(bitmap, tile)) return;
+    store_quad_packed(pack, tile_rank(bitmap, prefix, tile), load_quad_frame(pixels, width, height, tile % tiles_x, tile / tiles_x));
 }
 // Rank r's slab = tiles [slab_begin, slab_end): ordered premultiplied "over" of the `world` layers (layer k = recv[k], the non-empty tiles
 // of this slab of rank k's layer in tile order), written as the non-empty RGBA8 tiles of the result in tile order. f32 accumulation, one
 // RGBA8 quantisation — the arithmetic of k_composite (raster.hip); a tile a layer does not have is a transparent layer (exact).
+// A wavefront per tile; the tiles of up to eight layers are loaded before the first is blended.
 struct CompositeJob {
     const uint32_t* bitmaps;  // [world] bitmaps, `bitmap_stride` words apart
     const uint32_t* prefixes; // [world][n_words + 1]
@@ -250,41 +320,58 @@ struct CompositeJob {
 };
 template <typename P>
 __global__ __launch_bounds__(256) void k_composite_tiles(CompositeJob j) {
-    const uint32_t tile = j.slab_begin + blockIdx.x;
-    if (!tile_bit(j.or_bitmap, tile)) return;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (uint32_t k = 0; k < j.world; ++k) {
-        const uint32_t* bitmap = j.bitmaps + (size_t)k * j.bitmap_stride;
-        if (!tile_bit(bitmap, tile)) continue;
-        const uint32_t* prefix = j.prefixes + (size_t)k * (j.n_words + 1u);
-        const uint32_t slot = tile_rank(bitmap, prefix, tile) - tile_rank(bitmap, prefix, j.slab_begin);
-        float sr[4];
-        pixel_rgba(static_cast<const P*>(j.recv[k])[(size_t)slot * kTilePixels + threadIdx.x], sr);
-        const float keep = 1.0f - sr[3];
-        for (int c = 0; c < 4; ++c) acc[c] = sr[c] + acc[c] * keep;
+    const uint32_t tile = j.slab_begin + blockIdx.x * 4u + wave_in_block();
+    if (tile >= j.slab_end || !tile_bit(j.or_bitmap, tile)) return;
+    float acc[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int c = 0; c < 4; ++c) acc[i][c] = 0.0f;
+    for (uint32_t k0 = 0; k0 < j.world; k0 += 8u) {
+        Quad<P> q[8];
+        bool have[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+            const uint32_t k = k0 + i;
+            have[i] = false;
+            if (k < j.world) {
+                const uint32_t* bitmap = j.bitmaps + (size_t)k * j.bitmap_stride;
+                if (tile_bit(bitmap, tile)) {
+                    const uint32_t* prefix = j.prefixes + (size_t)k * (j.n_words + 1u);
+                    have[i] = true;
+                    q[i] = load_quad_packed(static_cast<const P*>(j.recv[k]), (size_t)(tile_rank(bitmap, prefix, tile) - tile_rank(bitmap, prefix, j.slab_begin)));
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+            if (!have[i]) continue;
+            for (int px = 0; px < 4; ++px) {
+                float sr[4];
+                pixel_rgba(q[i].p[px], sr);
+                const float keep = 1.0f - sr[3];
+                for (int c = 0; c < 4; ++c) acc[px][c] = sr[c] + acc[px][c] * keep;
+            }
+        }
     }
-    uint32_t packed = 0;
-    for (int c = 0; c < 4; ++c) {
-        const float x = acc[c] < 0.0f ? 0.0f : (acc[c] > 1.0f ? 1.0f : acc[c]);
-        packed |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * c);
+    Quad<uint32_t> out;
+    for (int px = 0; px < 4; ++px) {
+        uint32_t packed = 0;
+        for (int c = 0; c < 4; ++c) {
+            const float x = acc[px][c] < 0.0f ? 0.0f : (acc[px][c] > 1.0f ? 1.0f : acc[px][c]);
+            packed |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * c);
+        }
+        out.p[px] = packed;
     }
-    const uint32_t slot = tile_rank(j.or_bitmap, j.or_prefix, tile) - tile_rank(j.or_bitmap, j.or_prefix, j.slab_begin);
-    j.out[(size_t)slot * kTilePixels + threadIdx.x] = packed;
-}
-__global__ __launch_bounds__(256) void k_or_bitmaps(const uint32_t* bitmaps, uint32_t bitmap_stride, uint32_t world, uint32_t n_words, uint32_t* out) {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-    if (w >= n_words) return;
-    uint32_t v = 0;
-    for (uint32_t k = 0; k < world; ++k) v |= bitmaps[(size_t)k * bitmap_stride + w];
-    out[w] = v;
+    store_quad_packed(j.out, (size_t)(tile_rank(j.or_bitmap, j.or_prefix, tile) - tile_rank(j.or_bitmap, j.or_prefix, j.slab_begin)), out);
 }
 // rank 0: the gathered tiles -> the result frame (tiles nobody drew are cleared)
-__global__ __launch_bounds__(256) void k_unpack_tiles(uint32_t* rgba8, uint32_t width, uint32_t height, uint32_t tiles_x, const uint32_t* bitmap, const uint32_t* prefix,
-                                                      const uint32_t* pack) {
-    const uint32_t tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t x = tx * 16u + (threadIdx.x & 15u), y = ty * 16u + (threadIdx.x >> 4);
-    if (x >= width || y >= height) return;
-    rgba8[(size_t)y * width + x] = tile_bit(bitmap, tile) ? pack[(size_t)tile_rank(bitmap, prefix, tile) * kTilePixels + threadIdx.x] : 0u;
+__global__ __launch_bounds__(256) void k_unpack_tiles(uint32_t* rgba8, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles, const uint32_t* bitmap,
+                                                      const uint32_t* prefix, const uint32_t* pack) {
+    const uint32_t tile = blockIdx.x * 4u + wave_in_block();
+    if (tile >= n_tiles) return;
+    Quad<uint32_t> q;
+    for (int i = 0; i < 4; ++i) q.p[i] = 0u;
+    if (tile_bit(bitmap, tile)) q = load_quad_packed(pack, tile_rank(bitmap, prefix, tile));
+    store_quad_frame(rgba8, width, height, tile % tiles_x, tile / tiles_x, q);
 }
 } // namespace
 
@@ -309,7 +396,7 @@ struct crh_comm {
     PinnedBuf host_all, host_table, host_header;  // bitmaps_all on the host; the pointer table on its way to recv_table; this rank's header on its way to `bitmap`
     std::vector<uint32_t> or_bits;   // union of the bitmaps (host)
     hipEvent_t bitmaps_on_host = nullptr; // THE host wait of an exchange
-    hipEvent_t phase[CRH_COMM_PHASES + 1] = {}; // timing marks around the phases of the last exchange
+    hipEvent_t phase_begin[CRH_COMM_PHASES] = {}, phase_end[CRH_COMM_PHASES] = {}; // timing marks around the phases of the last exchange
     hipEvent_t packed = nullptr, composited = nullptr; // loopback: what the other communicators' streams wait for
     bool timed = false;
     // statistics of the last exchange (crh_comm_last_traffic / _peer_bytes)
@@ -359,7 +446,9 @@ crh_status ensure_buffers(crh_comm* c) {
     HIP_TRY(c->recv_table.ensure(sizeof(void*) * c->world));
     return CRH_OK;
 }
-void mark(crh_comm* c, int k) { (void)hipEventRecord(c->phase[k], c->stream); }
+enum Phase { kPack = 0, kPlan, kAllToAll, kComposite, kGather, kUnpack };
+void begin_phase(crh_comm* c, Phase k) { (void)hipEventRecord(c->phase_begin[k], c->stream); }
+void end_phase(crh_comm* c, Phase k) { (void)hipEventRecord(c->phase_end[k], c->stream); }
 
 // phase 1: [header | occupancy bitmap], its prefix sums and the packed tiles of this rank's layer (all on the communicator's stream).
 // A layer that cannot be read (its pass failed) leaves an empty bitmap and its status in the header: the rank still takes part in the
@@ -375,31 +464,34 @@ crh_status phase_pack(crh_comm* c, crh_frame* layer) {
     void* pixels = nullptr;
     const crh_status layer_status = crh_internal_frame_info(layer, &pixels, &w, &h, &device); // settles the frame: its pixels are final and visible
     HIP_TRY(hipSetDevice(c->device));
-    mark(c, 0);
+    begin_phase(c, kPack);
     uint32_t* header = c->host_header.as<uint32_t>(); // (the previous exchange's copy of it was waited for with its bitmaps)
     header[0] = kMagic, header[1] = w, header[2] = h | (format << 24), header[3] = (uint32_t)layer_status;
     HIP_TRY(hipMemcpyAsync(c->bitmap.p, header, kHeaderWords * 4, hipMemcpyHostToDevice, c->stream));
     uint32_t* bitmap = c->bitmap.as<uint32_t>() + kHeaderWords;
-    HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)c->n_words * 4, c->stream));
     if (layer_status == CRH_OK) {
         if (format == CRH_FORMAT_RGBA16F)
-            hipLaunchKernelGGL(k_tile_occupancy<uint2>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, bitmap);
+            hipLaunchKernelGGL(k_tile_occupancy<uint2>, dim3(c->n_words), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, c->n_tiles, bitmap);
         else
-            hipLaunchKernelGGL(k_tile_occupancy<uint32_t>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, bitmap);
+            hipLaunchKernelGGL(k_tile_occupancy<uint32_t>, dim3(c->n_words), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, c->n_tiles, bitmap);
+    } else {
+        HIP_TRY(hipMemsetAsync(bitmap, 0, (size_t)c->n_words * 4, c->stream));
     }
-    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, bitmap, c->n_words, c->n_words, c->prefix.as<uint32_t>());
+    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, bitmap, c->n_words, c->n_words, 1u, c->prefix.as<uint32_t>(), static_cast<uint32_t*>(nullptr),
+                       static_cast<uint32_t*>(nullptr));
     if (layer_status == CRH_OK) {
+        const dim3 grid((c->n_tiles + 3u) / 4u);
         if (format == CRH_FORMAT_RGBA16F)
-            hipLaunchKernelGGL(k_pack_tiles<uint2>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, bitmap, c->prefix.as<uint32_t>(),
+            hipLaunchKernelGGL(k_pack_tiles<uint2>, grid, dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, c->n_tiles, bitmap, c->prefix.as<uint32_t>(),
                                c->pack.as<uint2>());
         else
-            hipLaunchKernelGGL(k_pack_tiles<uint32_t>, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, bitmap,
+            hipLaunchKernelGGL(k_pack_tiles<uint32_t>, grid, dim3(256), 0, c->stream, static_cast<const uint32_t*>(pixels), w, h, c->tiles_x, c->n_tiles, bitmap,
                                c->prefix.as<uint32_t>(), c->pack.as<uint32_t>());
         st = crh_internal_frame_touched(layer, c->stream, 0); // the layer's next pass is ordered behind the packing
         if (st != CRH_OK) return st;
     }
     HIP_TRY(hipGetLastError());
-    mark(c, 1);
+    end_phase(c, kPack);
     return CRH_OK;
 }
 // phase 2 (the [header | bitmap] records of all ranks are in bitmaps_all, or on their way there on the stream): copy to the host, prefix
@@ -408,9 +500,8 @@ crh_status phase_plan(crh_comm* c) {
     HIP_TRY(hipMemcpyAsync(c->host_all.p, c->bitmaps_all.p, (size_t)c->world * c->stride() * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->bitmaps_on_host, c->stream));
     const uint32_t* first = c->bitmaps_all.as<uint32_t>() + kHeaderWords;
-    hipLaunchKernelGGL(k_bit_prefix, dim3(c->world), dim3(1024), 0, c->stream, first, c->stride(), c->n_words, c->prefixes_all.as<uint32_t>());
-    hipLaunchKernelGGL(k_or_bitmaps, dim3((c->n_words + 255u) / 256u), dim3(256), 0, c->stream, first, c->stride(), c->world, c->n_words, c->or_bitmap.as<uint32_t>());
-    hipLaunchKernelGGL(k_bit_prefix, dim3(1), dim3(1024), 0, c->stream, c->or_bitmap.as<uint32_t>(), c->n_words, c->n_words, c->or_prefix.as<uint32_t>());
+    hipLaunchKernelGGL(k_bit_prefix, dim3(c->world + 1u), dim3(1024), 0, c->stream, first, c->stride(), c->n_words, c->world, c->prefixes_all.as<uint32_t>(),
+                       c->or_bitmap.as<uint32_t>(), c->or_prefix.as<uint32_t>()); // every rank's prefix sums, the union and its prefix sums: one launch
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(c->bitmaps_on_host)); // every transfer size follows from the bitmaps
     crh_status peer = CRH_OK;
@@ -443,7 +534,7 @@ crh_status phase_plan(crh_comm* c) {
     const void** table = c->host_table.as<const void*>(); // pinned: the copy below needs no wait (the previous exchange's use of it is behind the wait above)
     for (uint32_t k = 0; k < c->world; ++k) table[k] = static_cast<uint8_t*>(c->recv.p) + offset[k];
     HIP_TRY(hipMemcpyAsync(c->recv_table.p, table, sizeof(void*) * c->world, hipMemcpyHostToDevice, c->stream));
-    mark(c, 2);
+    end_phase(c, kPlan);
     return CRH_OK;
 }
 // where rank k's tiles of slab r start inside rank k's pack buffer / how many bytes they are
@@ -457,6 +548,7 @@ void segment(const crh_comm* c, uint32_t k, uint32_t r, size_t* offset, size_t* 
 uint8_t* recv_slot(const crh_comm* c, uint32_t k) { return static_cast<uint8_t*>(const_cast<void*>(c->host_table.as<const void*>()[k])); } // where layer k's tiles of my slab are received
 // phase 4: composite my slab (after the slab tiles of every layer are in `recv`)
 crh_status phase_composite(crh_comm* c) {
+    begin_phase(c, kComposite);
     uint32_t s0, s1;
     slab_tiles(c, c->rank, &s0, &s1);
     const size_t out_tiles = host_count(c->or_bits.data(), s0, s1);
@@ -469,12 +561,12 @@ crh_status phase_composite(crh_comm* c) {
         j.world = c->world, j.n_words = c->n_words, j.bitmap_stride = c->stride(), j.slab_begin = s0, j.slab_end = s1;
         j.out = c->slab_out.as<uint32_t>();
         if (c->format == CRH_FORMAT_RGBA16F)
-            hipLaunchKernelGGL(k_composite_tiles<uint2>, dim3(s1 - s0), dim3(256), 0, c->stream, j);
+            hipLaunchKernelGGL(k_composite_tiles<uint2>, dim3((s1 - s0 + 3u) / 4u), dim3(256), 0, c->stream, j);
         else
-            hipLaunchKernelGGL(k_composite_tiles<uint32_t>, dim3(s1 - s0), dim3(256), 0, c->stream, j);
+            hipLaunchKernelGGL(k_composite_tiles<uint32_t>, dim3((s1 - s0 + 3u) / 4u), dim3(256), 0, c->stream, j);
     }
     HIP_TRY(hipGetLastError());
-    mark(c, 4);
+    end_phase(c, kComposite);
     return CRH_OK;
 }
 // phase 6 (rank 0, after every slab's tiles are in `gathered`): unpack into the result frame; no host wait — the frame is told
@@ -487,10 +579,11 @@ crh_status phase_unpack(crh_comm* c, crh_frame* result) {
     void* pixels = nullptr;
     if ((st = crh_internal_frame_info(result, &pixels, &w, &h, &device)) != CRH_OK) return st; // what the frame showed so far is settled (and discarded)
     HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_unpack_tiles, dim3(c->n_tiles), dim3(256), 0, c->stream, static_cast<uint32_t*>(pixels), w, h, c->tiles_x, c->or_bitmap.as<uint32_t>(),
-                       c->or_prefix.as<uint32_t>(), c->gathered.as<uint32_t>());
+    begin_phase(c, kUnpack);
+    hipLaunchKernelGGL(k_unpack_tiles, dim3((c->n_tiles + 3u) / 4u), dim3(256), 0, c->stream, static_cast<uint32_t*>(pixels), w, h, c->tiles_x, c->n_tiles,
+                       c->or_bitmap.as<uint32_t>(), c->or_prefix.as<uint32_t>(), c->gathered.as<uint32_t>());
     HIP_TRY(hipGetLastError());
-    mark(c, 6);
+    end_phase(c, kUnpack);
     return crh_internal_frame_touched(result, c->stream, 1);
 }
 void account(crh_comm* c) { // what this rank put on the wire vs. what dense slabs would have cost
@@ -518,7 +611,8 @@ crh_status create_common(crh_renderer* r, uint32_t rank, uint32_t world, crh_com
               hip_ok(hipEventCreateWithFlags(&c->bitmaps_on_host, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(hipEventCreateWithFlags(&c->packed, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(hipEventCreateWithFlags(&c->composited, hipEventDisableTiming), "hipEventCreate");
-    for (hipEvent_t& e : c->phase) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
+    for (hipEvent_t& e : c->phase_begin) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
+    for (hipEvent_t& e : c->phase_end) ok = ok && hip_ok(hipEventCreate(&e), "hipEventCreate");
     if (!ok) {
         crh_comm_destroy(c);
         return CRH_ERR_HIP;
@@ -603,7 +697,9 @@ void crh_comm_destroy(crh_comm* c) {
     for (PinnedBuf* b : {&c->host_all, &c->host_table, &c->host_header}) b->release();
     for (hipEvent_t e : {c->bitmaps_on_host, c->packed, c->composited})
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->phase)
+    for (hipEvent_t e : c->phase_begin)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->phase_end)
         if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -626,7 +722,7 @@ crh_status crh_comm_last_timing(crh_comm* c, float ms[CRH_COMM_PHASES]) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int last = c->rank == 0 ? CRH_COMM_PHASES : CRH_COMM_PHASES - 1; // only rank 0 unpacks
-    for (int k = 0; k < last; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], c->phase[k], c->phase[k + 1]));
+    for (int k = 0; k < last; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], c->phase_begin[k], c->phase_end[k]));
     return CRH_OK;
 }
 
@@ -639,6 +735,7 @@ crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) 
     if (st != CRH_OK) return st; // (only argument errors end here: a layer that cannot be read still takes part)
     // Sizes of the collectives follow from the frame geometry, which therefore has to be the same on every rank BEFORE a count is derived
     // from it: when it changes (the first exchange, a resized target) the headers alone are gathered and compared first, with one more wait.
+    begin_phase(c, kPlan);
     if (!c->agreed || c->agreed_width != c->width || c->agreed_height != c->height || c->agreed_format != c->format) {
         NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, kHeaderWords * 4, ncclUint8, c->nccl, c->stream));
         HIP_TRY(hipMemcpyAsync(c->host_all.p, c->bitmaps_all.p, (size_t)c->world * kHeaderWords * 4, hipMemcpyDeviceToHost, c->stream));
@@ -656,6 +753,7 @@ crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) 
     NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, (size_t)c->stride() * 4, ncclUint8, c->nccl, c->stream));
     if ((st = phase_plan(c)) != CRH_OK) return st; // (a peer's failure is seen by all ranks here: they return together, nothing is in flight)
     // all-to-all of the slab tiles: one group, so that all links are driven at once. An error inside the group still closes it.
+    begin_phase(c, kAllToAll);
     bool ok = nccl_ok(api->GroupStart(), "ncclGroupStart");
     if (!ok) return CRH_ERR_HIP;
     for (uint32_t p = 0; p < c->world && ok; ++p) {
@@ -671,10 +769,11 @@ crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) 
     }
     ok = nccl_ok(api->GroupEnd(), "ncclGroupEnd") && ok;
     if (!ok) return CRH_ERR_HIP;
-    mark(c, 3);
+    end_phase(c, kAllToAll);
     if ((st = phase_composite(c)) != CRH_OK) return st;
     // gather of the composited slabs' non-empty tiles on rank 0 (tile order = slab order)
     if (c->rank == 0) HIP_TRY(c->gathered.ensure((size_t)host_rank(c->or_bits.data(), c->n_tiles) * kResultTileBytes + kResultTileBytes));
+    begin_phase(c, kGather);
     ok = nccl_ok(api->GroupStart(), "ncclGroupStart");
     if (!ok) return CRH_ERR_HIP;
     for (uint32_t p = 0; p < c->world && ok; ++p) {
@@ -691,7 +790,7 @@ crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) 
     }
     ok = nccl_ok(api->GroupEnd(), "ncclGroupEnd") && ok;
     if (!ok) return CRH_ERR_HIP;
-    mark(c, 5);
+    end_phase(c, kGather);
     account(c);
     c->timed = true;
     if (c->rank == 0) return phase_unpack(c, result);
@@ -719,28 +818,28 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
         HIP_TRY(hipEventRecord(g[k]->packed, g[k]->stream));
     }
     CRH_SERIAL_POINT(world - 1);
-    for (uint32_t k = 0; k < world; ++k) { // "all-gather"
+    for (uint32_t k = 0; k < world; ++k)
         if (g[k]->n_tiles != g[0]->n_tiles || g[k]->width != g[0]->width || g[k]->height != g[0]->height || g[k]->format != g[0]->format) {
             set_last_error("crh_comm_local_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
             return CRH_ERR_INVALID_ARGUMENT;
         }
+    for (uint32_t k = 0; k < world; ++k) { // "all-gather" (every rank's [header | bitmap] was enqueued above), then rank k's plan
+        begin_phase(g[k], kPlan);
         for (uint32_t q = 0; q < world; ++q) {
             if (q != k) HIP_TRY(hipStreamWaitEvent(g[k]->stream, g[q]->packed, 0));
             HIP_TRY(hipMemcpyAsync(g[k]->bitmaps_all.as<uint32_t>() + (size_t)q * g[k]->stride(), g[q]->bitmap.p, (size_t)g[k]->stride() * 4, hipMemcpyDeviceToDevice, g[k]->stream));
         }
-        CRH_SERIAL_POINT(k);
-    }
-    for (uint32_t k = 0; k < world; ++k) {
         if ((st = phase_plan(g[k])) != CRH_OK) return st;
         CRH_SERIAL_POINT(k);
     }
     for (uint32_t k = 0; k < world; ++k) { // "all-to-all": rank k pulls its slab's tiles out of every rank's pack buffer (packed long ago: the plan waited)
+        begin_phase(g[k], kAllToAll);
         for (uint32_t q = 0; q < world; ++q) {
             size_t off, bytes;
             segment(g[k], q, k, &off, &bytes);
             if (bytes) HIP_TRY(hipMemcpyAsync(recv_slot(g[k], q), static_cast<uint8_t*>(g[q]->pack.p) + off, bytes, hipMemcpyDeviceToDevice, g[k]->stream));
         }
-        mark(g[k], 3);
+        end_phase(g[k], kAllToAll);
         CRH_SERIAL_POINT(k);
     }
     for (uint32_t k = 0; k < world; ++k) {
@@ -750,6 +849,7 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
     }
     crh_comm* c = g[0];
     HIP_TRY(c->gathered.ensure((size_t)host_rank(c->or_bits.data(), c->n_tiles) * kResultTileBytes + kResultTileBytes));
+    for (uint32_t k = 0; k < world; ++k) begin_phase(g[k], kGather);
     for (uint32_t p = 0; p < world; ++p) { // "gather"
         uint32_t s0, s1;
         slab_tiles(c, p, &s0, &s1);
@@ -758,7 +858,7 @@ crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, cr
         if (bytes) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(c->gathered.p) + off, g[p]->slab_out.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     }
     for (uint32_t k = 0; k < world; ++k) {
-        mark(g[k], 5);
+        end_phase(g[k], kGather);
         account(g[k]);
         g[k]->timed = true;
     }

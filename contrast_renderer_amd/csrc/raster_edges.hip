@@ -1539,12 +1539,8 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 #ifndef CRH_EDGE_TILE_WAVES
 #define CRH_EDGE_TILE_WAVES 5 // measured 4: 0.321, 5: 0.322, 6: 0.331 (spills), 8: 0.421 ms on the benchmark scene
 #endif
-#ifndef CRH_EDGE_TILE_WAVES_MAX
-#define CRH_EDGE_TILE_WAVES_MAX 10 // (no cap)
-#endif
-#ifndef CRH_STROKE_TILE_WAVES_MAX
-#define CRH_STROKE_TILE_WAVES_MAX 10
-#endif
+// (A second argument — the maximum — was tried to leave register room for the binning kernels beside this one: at a cap of four the
+// compiler takes 106 registers and nothing else fits either; and a maximum above the hardware's eight makes LLVM drop the whole attribute.)
 #ifndef CRH_STROKE_TILE_WAVES
 #define CRH_STROKE_TILE_WAVES 5 // dashed strokes, msaa 4 (ms): 1 (145 registers): 2.96, 4: 2.34, 5: 2.24, 6: 2.83, 8: 5.05 — the kernel waits, it does not issue
 #endif
@@ -1552,7 +1548,7 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 // msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
 // the item being drawn and the colour; entries are walked in key order (= draw order).
 template <int S, int ROWS, bool STROKES>
-__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES, (STROKES || S == 4) ? CRH_STROKE_TILE_WAVES_MAX : CRH_EDGE_TILE_WAVES_MAX))) void k_raster_edges(SceneDev s, RasterParams r) {
+__global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
     __shared__ uint8_t compact_table[STROKES ? 4 / ROWS : 1][STROKES ? 256 : 4]; // (lane, slot) codes of the samples a stroke triangle has to decide
@@ -2131,7 +2127,7 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         // k_bin_flat: a batch of items per 256-thread workgroup. A workgroup lives about as long whether it holds two items or twenty (the
         // same chain of phases), so the grid is sized to ONE round of resident workgroups — three per CU — as long as that leaves a batch
         // within the kernel's 32 items; what a batch cannot hold is queued and binned item by item behind it.
-        const uint32_t resident = 256u * CRH_FLAT_WAVES; // workgroups the 256 CUs hold at once
+        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * CRH_FLAT_WAVES; // workgroups the CUs of the binning lane hold at once
         // ... and within what the lanes of a batch hold (256 triangles, 768 edges): an item that does not fit is left to the workgroup's next
         // turn, which doubles the workgroup's life — the averages of the scene keep a batch nine tenths full
         const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)kFlatTris * 9u / 10u * r.n_items / r.hint_tris) : kFlatItems;

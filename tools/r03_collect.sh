@@ -2,7 +2,7 @@
 # GPU box: the round's evidence — per workload kernel stats / traffic / SQ counters / bench lines (tools/collect_all.sh), the whole of
 # config 4 on one GPU (single frame and the eight-rank loopback with its exchange), the host-inclusive mode, the parity suite.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/pytest_r03.log
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/pytest_r03.log
 for w in cubic glyphs dashed; do bash tools/collect_all.sh r03 $w > /dev/null 2>&1; done
 python bench.py --workload s100k --no-cpu-baseline > gpurun_out/bench_r03_s100k.json 2> gpurun_out/bench_r03_s100k.err
 python bench.py --workload s100k --loopback 8 --steps 5 --warmup 1 > gpurun_out/bench_r03_s100k_loop8.json 2> gpurun_out/bench_r03_s100k_loop8.err
