@@ -949,6 +949,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
         if (edges && ov[7] != 0) { // an unclosed boundary chain: this pass and the following ones of this Scene into this frame as strip triangles
+            if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] a boundary edge with a non-finite end point: this Scene goes to the triangle pass\n");
             f->triangle_pass_for = sc;
             return render_impl(sc, f, again);
         }
@@ -1023,7 +1024,10 @@ crh_status settle_frame(crh_frame* f) {
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
     const bool unclosed = ov[7] != 0 && f->last_scene && f->triangle_pass_for != f->last_scene; // (the edge pass drew it: see crh_frame::triangle_pass_for)
-    if (unclosed) f->triangle_pass_for = f->last_scene;
+    if (unclosed) {
+        if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] a boundary edge with a non-finite end point (found after the pass): this Scene goes to the triangle pass\n");
+        f->triangle_pass_for = f->last_scene;
+    }
     if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed) {
         if (ov[0] != 0 || ov[5] != 0) f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass

@@ -45,7 +45,7 @@ def _render_shards(R, scenes, world, size, n_shapes, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size", [(2, (256, 256)), (3, (200, 136)), (5, (96, 40))])
+@pytest.mark.parametrize("world,size", [(2, (256, 256)), (3, (200, 136)), (5, (96, 40)), (4, (133, 75))])
 def test_loopback_exchange_equals_the_ordered_composite_of_the_layers(world, size, oracle_lib):
     import torch
     assert torch.cuda.is_available()
@@ -114,7 +114,7 @@ def test_exchange_refuses_layers_of_different_sizes_and_formats(oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size,msaa,kind", [(4, (512, 384), 1, "cubic"), (4, (320, 256), 1, "mixed"), (3, (200, 136), 4, "mixed")])
+@pytest.mark.parametrize("world,size,msaa,kind", [(4, (512, 384), 1, "cubic"), (2, (270, 150), 1, "cubic"), (4, (320, 256), 1, "mixed"), (3, (200, 136), 4, "mixed")])
 def test_rgba16f_layers_keep_the_exchange_within_one_255th(world, size, msaa, kind, oracle_lib):
     """layers exchanged as RGBA16F -> the composite is within 1/255 of the single-GPU render of the whole scene (RGBA8
     layers: 2/255). The layer itself is the resolved colour rounded to binary16: within half a unit of the RGBA8 layer everywhere.

@@ -5,11 +5,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/pytest_r03.log
 for w in cubic glyphs dashed; do bash tools/collect_all.sh r03 $w > /dev/null 2>&1; done
 python bench.py --workload s100k --no-cpu-baseline > gpurun_out/bench_r03_s100k.json 2> gpurun_out/bench_r03_s100k.err
-python bench.py --workload s100k --loopback 8 --steps 5 --warmup 1 > gpurun_out/bench_r03_s100k_loop8.json 2> gpurun_out/bench_r03_s100k_loop8.err
-CRH_LOOPBACK_SERIAL=1 python bench.py --workload s100k --loopback 8 --steps 5 --warmup 1 > gpurun_out/bench_r03_s100k_loop8_serial.json 2>> gpurun_out/bench_r03_s100k_loop8.err
-CRH_LOOPBACK_SERIAL=1 python bench.py --workload s100k --loopback 8 --layers rgba16f --steps 5 --warmup 1 > gpurun_out/bench_r03_s100k_loop8_16f_serial.json 2>> gpurun_out/bench_r03_s100k_loop8.err
-CRH_LOOPBACK_SERIAL=1 python bench.py --loopback 8 --scaling strong --steps 10 > gpurun_out/bench_r03_s10k_strong_loop8_serial.json 2>> gpurun_out/bench_r03_s100k_loop8.err
-CRH_LOOPBACK_SERIAL=1 python bench.py --loopback 8 --scaling weak --steps 5 > gpurun_out/bench_r03_s10k_weak_loop8_serial.json 2>> gpurun_out/bench_r03_s100k_loop8.err
+bash tools/r03_loopback.sh > /dev/null 2>&1
 python bench.py --reupload --no-cpu-baseline > gpurun_out/bench_r03_reupload.json 2> gpurun_out/bench_r03_reupload.err
 cat gpurun_out/pytest_r03.log
 for f in gpurun_out/bench_r03_*.json; do echo "== $f"; python - $f <<'PY'
