@@ -266,6 +266,8 @@ struct crh_frame {
     bool cleared = true;
     bool pairs_known = false;
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
+    uint32_t opaque_covers = 0;    // ... and how many (item, tile) covers of it were opaque over the whole tile (without them there is nothing to start late behind)
+    uint32_t mean_list = 0;        // entries per tile of the last verified EDGE pass (the pairs the pass needed / tiles): long lists get k_raster_edges' LONG variant
     size_t pair_capacity_bytes = 1024 * 4; // size of a set's tile list (both sets grow to it)
     // last render, for the transparent re-run after a bin-capacity overflow
     crh_scene* last_scene = nullptr;
@@ -733,6 +735,17 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     return false; // still waiting for the trial's events: stay on the pass of the latest frames
 }
 
+// A frame whose tiles hold many entries on average has most of them in lists of several 64-entry chunks: the raster kernel then looks for
+// its late start across the chunks (k_raster_edges<.., LONG>; 100 000 paths @ 8192^2: 67 entries per tile, raster 2.34 -> 1.33 ms). For
+// short lists the plain variant is the faster one (10 000 paths @ 4096^2: 27 per tile, 0.234 against 0.255 ms), and so it is where nothing
+// covers a whole tile (50 000 glyphs @ 2048^2: long lists, no such cover: 0.56 against 0.63 ms).
+uint32_t long_lists(const crh_frame* f) {
+    const char* e = getenv("CRH_LONG_LISTS"); // A/B runs and tests: 0 never, 1 always (read per pass: they switch it inside one process)
+    const int pinned = e ? atoi(e) : -1;
+    const uint32_t n_tiles = ((f->width + 15u) / 16u) * ((f->height + 15u) / 16u);
+    return pinned >= 0 ? (uint32_t)(pinned != 0) : (uint32_t)(f->mean_list >= 40u && f->opaque_covers >= n_tiles / 2u);
+}
+
 // the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
 bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
     if (longest_list <= f->sort_capacity) return false;
@@ -914,6 +927,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.overflow = set.overflow.as<uint32_t>();
     p.pair_cursor = set.overflow.as<uint32_t>() + 8; // 64 sub-stream cursors
     p.sort_capacity = f->sort_capacity;
+    p.long_lists = long_lists(f);
     p.rgba8 = f->rgba8.as<uint8_t>();
     p.format = f->format;
     p.debug = getenv("CRH_RASTER_DEBUG") ? (uint32_t)atoi(getenv("CRH_RASTER_DEBUG")) : 0u;
@@ -948,6 +962,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(r->sync());
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
+        if (edges) f->mean_list = ov[1] / std::max(1u, p.n_tiles), f->opaque_covers = ov[4]; // (the triangle pass of the same Scene has other entries, and no such variant)
+        p.long_lists = long_lists(f);
+        if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u entries in %u tiles (longest list %u, %u opaque whole-tile covers): %s raster variant\n", ov[1], p.n_tiles, ov[3], ov[4], p.long_lists ? "long-list" : "plain");
         if (edges && ov[7] != 0) { // an unclosed boundary chain: this pass and the following ones of this Scene into this frame as strip triangles
             if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] a boundary edge with a non-finite end point: this Scene goes to the triangle pass\n");
             f->triangle_pass_for = sc;

@@ -773,6 +773,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
                 const bool hull_over_tile = n_cover != 0u && hbd != 0 && !hull_touch;
                 const bool replaces_tile = hull_over_tile && opaque_item && n_touching == 0u && (bd & (int)r.winding_mask) != 0;
                 const uint32_t cover_key = synth_b + (uint32_t)(cbd + 1) + 3u * (uint32_t)(chbd + 1) + (replaces_tile ? kCoverOpaque : (hull_over_tile ? kCoverHull : 0u));
+                if (const unsigned long long opaque = __ballot(replaces_tile)) // the host's statistic: are there tiles to start late in? (overflow[4])
+                    if (lane == 0u) atomicAdd(&r.overflow[4], (uint32_t)__popcll(opaque));
                 uint32_t n_bd = n_cover ? (abd ? abd - 1u : 0u) : abd;
                 uint32_t n_hbd = n_cover ? (ahbd ? ahbd - 1u : 0u) : 0u;
                 const uint32_t bd_key = synth_a + (bd > 0 ? 0u : 1u), hbd_key = synth_a + (hbd > 0 ? 2u : 3u);
@@ -1017,6 +1019,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
     __shared__ int pool_bd[kFlatPool], pool_hbd[kFlatPool];
     __shared__ uint32_t pool_cursor[kFlatPool]; // pass 1: the entries the item's edges and triangles have in the tile (bits 0-19; bits 20-31: the hull edges among them), then the next list position
     __shared__ uint32_t batch[6];               // items in the batch, its triangles, its edges, tiles of its pool, items of the batch that are binned in this turn, (edge, tile row) pairs
+    __shared__ uint32_t wave_opaque[4];         // opaque whole-tile covers every wavefront found in pass 2
     __shared__ uint32_t wave_entries[8];        // entries every wavefront appends in pass 3 ([0..3]) and in pass 2 ([4..7]); then where its share of the pair stream begins
     __shared__ PackedEdge edge_table[kFlatEdges]; // the batch's boundary edges: the walks are balanced over (edge, tile row) pairs, whoever loaded the edge
     __shared__ uint32_t row_begin[kFlatEdges + 1]; // exclusive prefix of the tile rows every edge walks
@@ -1348,7 +1351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             }
         }
         lds_barrier();
-        uint32_t my_synth = 0;
+        uint32_t my_synth = 0, my_opaque = 0;
         {
             uint32_t reserved[kChunks], lefts[kChunks];
 #pragma unroll
@@ -1374,6 +1377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
                 const uint32_t left = (cover ? 1u : 0u) + n_bd + n_hbd;
                 lefts[ch] = left;
                 my_synth += left;
+                my_opaque += replaces_tile ? 1u : 0u;
                 if (left + n_touching) reserved[ch] = atomicAdd(&r.tile_count[tile], left + n_touching);
                 // the verdict, for 2b: left (bits 0-11), backdrop units (12-23), COVER entry (24), bd > 0 (25), hbd > 0 (26) | the COVER key
                 pool_bd[p] = (int)(left | (n_bd << 12) | (cover ? 1u << 24 : 0u) | (bd > 0 ? 1u << 25 : 0u) | (hbd > 0 ? 1u << 26 : 0u));
@@ -1384,15 +1388,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
                 if (ch * 256u + tid < n_pool) pool_cursor[ch * 256u + tid] = reserved[ch] + lefts[ch]; // where the edges' and triangles' entries go
         }
         {
-            uint32_t a = my_entries, b = my_synth;
+            uint32_t a = my_entries, b = my_synth | (my_opaque << 22); // (6 cells per lane, < 4096 entries each: a wavefront's sums stay below 2^22 and 2^10)
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) a += (uint32_t)__shfl_xor((int)a, d, 64), b += (uint32_t)__shfl_xor((int)b, d, 64);
-            if (lane == 0u) wave_entries[wave] = a, wave_entries[4u + wave] = b;
+            if (lane == 0u) wave_entries[wave] = a, wave_entries[4u + wave] = b & 0x003FFFFFu, wave_opaque[wave] = b >> 22;
         }
         lds_barrier();
         if (tid == 0u) { // the workgroup's range of the pair stream: wavefront w's pass-2 entries, then its pass-3 entries
             uint32_t total = 0;
             for (uint32_t w = 0; w < 8u; ++w) total += wave_entries[w];
+            if (const uint32_t opaque = wave_opaque[0] + wave_opaque[1] + wave_opaque[2] + wave_opaque[3]) atomicAdd(&r.overflow[4], opaque); // the host's statistic: are there tiles to start late in?
             const uint32_t sub = ((blockIdx.x + 40503u * turn) * 2654435761u) >> 26, region = r.pair_capacity / kSubStreams;
             uint32_t begin = 0xFFFFFFFFu;
             if (total) {
@@ -1547,7 +1552,8 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 // One workgroup per 16x16 tile, laid out exactly as k_raster_tile (raster.hip): msaa 1 = one wavefront, four pixel rows per lane;
 // msaa 4 = four wavefronts, one pixel row x four samples per lane. Per sample the lane keeps the winding counter, the hull winding of
 // the item being drawn and the colour; entries are walked in key order (= draw order).
-template <int S, int ROWS, bool STROKES>
+// LONG: the late start also for lists of several chunks (selected by the host for frames whose tiles hold many entries on average).
+template <int S, int ROWS, bool STROKES, bool LONG>
 __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
@@ -1686,7 +1692,52 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     const float ry_row = lane == 16u ? (S == 1 ? 0.5f : 0.125f)
                                      : (S == 1 ? (float)row_j + 0.5f : (float)(first_row + (row_j >> 2)) + ((float)(row_j & 3u) * 0.25f + 0.125f));
     const float sy_row = ty0 + ry_row;
-    for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+    // The late start (see "Occlusion" below) of a list longer than one chunk is found before the walk: the chunks' keys and the first word
+    // of their slots from the END of the list — X, the last opaque cover over the whole tile none of whose item's triangles are in the
+    // list (keys ascend: a binary search), then R, the last cover before X that resets the whole tile. The walk begins behind R.
+    auto key_of = [&](uint32_t i) -> uint32_t { return sorted_in_place ? __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keys[i]; };
+    uint32_t walk_from = 0, verify_entry = 0xFFFFFFFFu; // absolute positions in the list
+    constexpr bool kLongLateStart = LONG; // (a variant of its own: compiled into the kernel of the 10 000 path scene — few tiles beyond one chunk — it cost 8 %: 0.234 -> 0.255 ms)
+    if (kLongLateStart && n > 64u && !r.load_existing) {
+        uint32_t x_at = 0xFFFFFFFFu;
+        for (uint32_t c0 = ((n - 1u) >> 6) << 6;; c0 -= 64u) {
+            const uint32_t k = c0 + lane < n ? key_of(c0 + lane) : 0xFFFFFFFFu;
+            uint32_t code = 0;
+            if (c0 + lane < n) {
+                const uint32_t flags = *reinterpret_cast<const uint32_t*>(slots + (size_t)k * 32u);
+                code = ((flags >> 4) & 15u) == EK_SYNTH ? (flags >> 8) & 31u : 0u;
+            }
+            unsigned long long resets = __builtin_amdgcn_ballot_w64(code >= 4u + kCoverHull);
+            if (x_at == 0xFFFFFFFFu) {
+                unsigned long long candidates = __builtin_amdgcn_ballot_w64(code >= 4u + kCoverOpaque);
+                while (candidates) {
+                    const uint32_t at = 63u - (uint32_t)__builtin_clzll(candidates);
+                    const SynthRec sr = load_uniform(reinterpret_cast<const SynthRec*>(slots + (size_t)__builtin_amdgcn_readlane(k, at) * 32u));
+                    uint32_t lo = 0, hi = n; // the number of keys below the item's synthetic slots
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (key_of(mid) < sr.synth_a) lo = mid + 1u;
+                        else hi = mid;
+                    }
+                    if (lo == 0u || key_of(lo - 1u) < sr.first_slot) {
+                        x_at = c0 + at;
+                        resets &= (1ull << at) - 1ull;
+                        break;
+                    }
+                    candidates &= ~(1ull << at);
+                }
+            }
+            if (x_at != 0xFFFFFFFFu && resets) {
+                walk_from = c0 + 64u - (uint32_t)__builtin_clzll(resets); // behind the last whole-tile reset before X
+                verify_entry = x_at;
+                break;
+            }
+            if (c0 == 0u) break;
+        }
+    }
+    uint32_t first_j = walk_from & 63u;
+    bool again_from_the_top = false;
+    for (uint32_t q0 = kLongLateStart ? walk_from & ~63u : 0u; q0 < n; q0 += 64u) {
         if (sorted_in_place)
             my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
         else if (n > 64u)
@@ -1769,7 +1820,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         // tile can leave one just outside its hull). The winding is zero everywhere behind a cover that resets the whole tile (R, the last one
         // before X): the list is started behind R with cleared counters — exact for the winding; the colours it misses are all overwritten by
         // X unless some sample fails X's stencil test, and then (verify_at) the tile is done again from the top.
-        uint32_t j = 0, verify_at = 0xFFFFFFFFu;
+        uint32_t j = kLongLateStart ? first_j : 0u, verify_at = (kLongLateStart && verify_entry - q0 < 64u) ? verify_entry - q0 : 0xFFFFFFFFu; // (a list of several chunks: found above)
+        first_j = 0;
         if (n <= 64u && !r.load_existing) { // (the whole list is in this chunk, and the tile starts from a known colour)
             unsigned long long candidates = __builtin_amdgcn_ballot_w64(replaces_tile);
             const unsigned long long resets = __builtin_amdgcn_ballot_w64(hull_over_tile);
@@ -2043,6 +2095,11 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                                 col[b][q][0] = col[b][q][1] = col[b][q][2] = col[b][q][3] = 0.0f;
                             }
                         j = 0;
+                        if (kLongLateStart && n > 64u) { // the first chunk has to be set up again
+                            verify_entry = 0xFFFFFFFFu;
+                            again_from_the_top = true;
+                            break;
+                        }
                         continue;
                     }
                 }
@@ -2073,6 +2130,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                 }
         }
         } // entries of the chunk
+        if (kLongLateStart && again_from_the_top) { // (X of the late start did not overwrite every sample: the whole list, chunk 0 first)
+            again_from_the_top = false;
+            q0 = 0u - 64u;
+        }
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
 #pragma unroll
@@ -2157,12 +2218,16 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
     constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
     const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
     const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
-#define CRH_LAUNCH_EDGES(S_, ROWS_, STROKES_) \
-    hipLaunchKernelGGL((k_raster_edges<S_, ROWS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
+#define CRH_LAUNCH_EDGES(S_, ROWS_, STROKES_, LONG_) \
+    hipLaunchKernelGGL((k_raster_edges<S_, ROWS_, STROKES_, LONG_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {
-        if (has_stroke) CRH_LAUNCH_EDGES(4, 1, true); else CRH_LAUNCH_EDGES(4, 1, false);
+        if (has_stroke) CRH_LAUNCH_EDGES(4, 1, true, false); else CRH_LAUNCH_EDGES(4, 1, false, false);
+    } else if (has_stroke) {
+        CRH_LAUNCH_EDGES(1, 4, true, false);
+    } else if (r.long_lists) {
+        CRH_LAUNCH_EDGES(1, 4, false, true);
     } else {
-        if (has_stroke) CRH_LAUNCH_EDGES(1, 4, true); else CRH_LAUNCH_EDGES(1, 4, false);
+        CRH_LAUNCH_EDGES(1, 4, false, false);
     }
 #undef CRH_LAUNCH_EDGES
     if (mark) mark(ctx, "raster_tiles", raster_bytes);
