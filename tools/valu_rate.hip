@@ -19,13 +19,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kLoops = 512; // x 64 instructions
 
-enum Class { FMA_F32 = 0, PK_FMA_F32, CMP_CNDMASK, CMP_SGPR, MOV_B32, ADD_U32, ADD_F32, MUL_F32, AND_B32, CNDMASK_ONLY, RASTER_MIX, CMP_VCC, CNDMASK_VCC, SIGN_TRICK, MUL_LO_U32, CVT_I32_F32, RCP_F32, READLANE, N_CLASSES };
+enum Class { FMA_F32 = 0, PK_FMA_F32, CMP_CNDMASK, CMP_SGPR, MOV_B32, ADD_U32, ADD_F32, MUL_F32, AND_B32, CNDMASK_ONLY, RASTER_MIX, CMP_VCC, CNDMASK_VCC, SIGN_TRICK, MUL_LO_U32, CVT_I32_F32, RCP_F32, READLANE, S_ADD_U32, S_AND_B64, S_BITREPLICATE, S_BFE_U32, MIX_FMA_SADD, CMP_SAND_CNDMASK, N_CLASSES };
 static const char* kNames[N_CLASSES] = {"v_fma_f32",       "v_pk_fma_f32",  "v_cmp_ge_i32+v_cndmask_b32 (pair, per instruction)", "v_cmp_ge_i32 -> sgpr pair", "v_mov_b32", "v_add_u32", "v_add_f32",
                                         "v_mul_f32",       "v_and_b32",     "v_cndmask_b32 (sgpr mask)",
                                         "raster mix: 2 v_pk_fma_f32 + 4 v_cmp_ge_i32 + 4 v_cndmask_b32 + 4 v_add_u32 (per instruction)",
                                         "v_cmp_ge_i32 -> vcc (e32)", "v_cndmask_b32 (vcc, e32)", "v_sub_u32 + v_or_b32 + v_lshrrev_b32 (accept bit without a compare, per instruction)",
-                                        "v_mul_lo_u32", "v_cvt_i32_f32", "v_rcp_f32", "v_readlane_b32"};
-static const int kInstrPerBody[N_CLASSES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 56, 64, 64, 56, 64, 64, 64, 64};
+                                        "v_mul_lo_u32", "v_cvt_i32_f32", "v_rcp_f32", "v_readlane_b32",
+                                        "s_add_u32", "s_and_b64", "s_bitreplicate_b64_b32", "s_bfe_u32", "v_fma_f32 + s_add_u32 alternating (per instruction)",
+                                        "v_cmp_ge_i32 -> sgpr pair, s_and_b64 on it, v_cndmask_b32 with it (the raster kernel's accept chain, per instruction)"};
+static const int kInstrPerBody[N_CLASSES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 56, 64, 64, 56, 64, 64, 64, 64, 64, 64, 64, 64, 64, 56};
 
 template <int C>
 __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float seed, unsigned lds_words) {
@@ -34,8 +36,8 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float se
     float a[8], b = seed, c = seed * 0.5f;
     f32x2 p[8], pb = {seed, seed}, pc = {c, c};
     int ia[8], ib = (int)seed + threadIdx.x;
-    unsigned long long m[4] = {0, 0, 0, 0};
-    unsigned sl[4] = {0, 0, 0, 0};
+    unsigned long long m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned sl[8] = {0, 0, 0, 0, 1, 2, 3, 4};
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = seed + (float)i, p[i] = f32x2{seed + (float)i, seed - (float)i}, ia[i] = (int)threadIdx.x + i;
     __builtin_amdgcn_s_barrier();
@@ -71,6 +73,19 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float se
                 if (C == CVT_I32_F32) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(ia[i]) : "v"(a[i]));
                 if (C == RCP_F32) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
                 if (C == READLANE) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sl[i & 3]) : "v"(ia[i]));
+                if (C == S_ADD_U32) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sl[i]) : "s"(lds_words) : "scc");
+                if (C == S_AND_B64) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m[i]) : "s"(t0) : "scc");
+                if (C == S_BITREPLICATE) asm volatile("s_bitreplicate_b64_b32 %0, %1" : "=s"(m[i]) : "s"(sl[i]));
+                if (C == S_BFE_U32) asm volatile("s_bfe_u32 %0, %0, 0x100001" : "+s"(sl[i]) : : "scc");
+                if (C == MIX_FMA_SADD) {
+                    if (i & 1) asm volatile("s_add_u32 %0, %0, %1" : "+s"(sl[i]) : "s"(lds_words) : "scc");
+                    else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+                }
+                if (C == CMP_SAND_CNDMASK && i < 7) { // three instructions per chain step, through an SGPR pair
+                    if (r % 3 == 0) asm volatile("v_cmp_ge_i32 %0, %1, %2" : "=s"(m[i]) : "v"(ia[i]), "v"(ib));
+                    if (r % 3 == 1) asm volatile("s_and_b64 %0, %0, %1" : "+s"(m[i]) : "s"(t0) : "scc");
+                    if (r % 3 == 2) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(ia[i]) : "v"(ib), "s"(m[i]));
+                }
             }
             if (C == RASTER_MIX && r < 4) { // what one edge entry costs two sample pairs of a lane in k_raster_edges, in its proportions
                 asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[2 * r]) : "v"(pb), "v"(pc));
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(1024) void k_rate(unsigned long long* out, float se
     int si = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i] + p[i][0] + p[i][1], si += ia[i];
-    if (s == 12345.678f && si == 42 && (m[0] ^ m[1] ^ m[2] ^ m[3]) == 7ull && (sl[0] ^ sl[1] ^ sl[2] ^ sl[3]) == 9u) out[0] = 0; // keeps the results alive
+    if (s == 12345.678f && si == 42 && (m[0] ^ m[1] ^ m[2] ^ m[3] ^ m[4] ^ m[5] ^ m[6] ^ m[7]) == 7ull && (sl[0] ^ sl[1] ^ sl[2] ^ sl[3] ^ sl[4] ^ sl[5] ^ sl[6] ^ sl[7]) == 9u) out[0] = 0; // keeps the results alive
     if ((threadIdx.x & 63u) == 0u) out[1 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
@@ -100,7 +115,8 @@ static void launch(dim3 grid, dim3 block, size_t lds, unsigned long long* out) {
 typedef void (*Launcher)(dim3, dim3, size_t, unsigned long long*);
 static Launcher kLaunch[N_CLASSES] = {launch<FMA_F32>, launch<PK_FMA_F32>, launch<CMP_CNDMASK>, launch<CMP_SGPR>, launch<MOV_B32>, launch<ADD_U32>,
                                       launch<ADD_F32>, launch<MUL_F32>,    launch<AND_B32>,     launch<CNDMASK_ONLY>, launch<RASTER_MIX>, launch<CMP_VCC>, launch<CNDMASK_VCC>,
-                                      launch<SIGN_TRICK>, launch<MUL_LO_U32>, launch<CVT_I32_F32>, launch<RCP_F32>, launch<READLANE>};
+                                      launch<SIGN_TRICK>, launch<MUL_LO_U32>, launch<CVT_I32_F32>, launch<RCP_F32>, launch<READLANE>,
+                                      launch<S_ADD_U32>, launch<S_AND_B64>, launch<S_BITREPLICATE>, launch<S_BFE_U32>, launch<MIX_FMA_SADD>, launch<CMP_SAND_CNDMASK>};
 
 #define CHECK(e)                                                                         \
     do {                                                                                 \
@@ -122,7 +138,7 @@ int main() {
     CHECK(hipMalloc(&out_big, (1 + (size_t)cus * 8 * 4) * 8));
     // dynamic LDS beyond 64 KiB needs the attribute
 #define ALLOW(C) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rate<C>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024))
-    ALLOW(FMA_F32); ALLOW(PK_FMA_F32); ALLOW(CMP_CNDMASK); ALLOW(CMP_SGPR); ALLOW(MOV_B32); ALLOW(ADD_U32); ALLOW(ADD_F32); ALLOW(MUL_F32); ALLOW(AND_B32); ALLOW(CNDMASK_ONLY); ALLOW(RASTER_MIX); ALLOW(CMP_VCC); ALLOW(CNDMASK_VCC); ALLOW(SIGN_TRICK); ALLOW(MUL_LO_U32); ALLOW(CVT_I32_F32); ALLOW(RCP_F32); ALLOW(READLANE);
+    ALLOW(FMA_F32); ALLOW(PK_FMA_F32); ALLOW(CMP_CNDMASK); ALLOW(CMP_SGPR); ALLOW(MOV_B32); ALLOW(ADD_U32); ALLOW(ADD_F32); ALLOW(MUL_F32); ALLOW(AND_B32); ALLOW(CNDMASK_ONLY); ALLOW(RASTER_MIX); ALLOW(CMP_VCC); ALLOW(CNDMASK_VCC); ALLOW(SIGN_TRICK); ALLOW(MUL_LO_U32); ALLOW(CVT_I32_F32); ALLOW(RCP_F32); ALLOW(READLANE); ALLOW(S_ADD_U32); ALLOW(S_AND_B64); ALLOW(S_BITREPLICATE); ALLOW(S_BFE_U32); ALLOW(MIX_FMA_SADD); ALLOW(CMP_SAND_CNDMASK);
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
