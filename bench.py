@@ -37,7 +37,9 @@ def mark_to_kernel(workload, triangle_pass=False):
                 "raster_prim_setup": "crh::k_prim_setup<4, false>" if msaa4_strokes else "crh::k_prim_setup<1, false>",
                 "tess_emit": "crh::k_emit", "tess_count": "crh::k_count", "tess_hull": "crh::k_hull_small"}
     return {
-        "raster_tiles": "crh::k_raster_edges<4, 1, true>" if msaa4_strokes else "crh::k_raster_edges<1, 4, false>",
+        # (the last argument: the variant that looks for its late start across the chunks of long tile lists — the host picks it for frames with
+        # many entries per tile and opaque whole-tile covers: the 100 000 path scene)
+        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_edges<1, 4, false, true>" if workload == "s100k" else "crh::k_raster_edges<1, 4, false, false>"),
         # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
         "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else "crh::k_bin_flat<1>",
         "raster_scatter": "crh::k_scatter",
