@@ -205,7 +205,7 @@ def run_loopback(args, size, scaling, np):
         draw()
         comms[0].local_exchange(layers, result)
 
-    for _ in range(6 + args.warmup):  # (the library's pass trial, as in the default run)
+    for _ in range(8 + args.warmup):  # (the library's pass trial, as in the default run)
         step()
     renderer.synchronize()
     t0 = time.perf_counter()
@@ -456,7 +456,7 @@ def main():
             dist.barrier()
 
     # Scene set-up, before the W warm-up steps: the library draws a Scene's first frames with both raster formulations (boundary edges /
-    # strip triangles: same pixels), times the second frame of each on the GPU and keeps the faster one from the fifth frame on
+    # strip triangles: same pixels), times two frames of each on the GPU and keeps the faster one from the seventh frame on
     watchdog = None
     if world > 1:  # the first exchanges of a multi-rank run: a rank that never answers must end the job with a message, not hang it
         import threading
@@ -468,7 +468,7 @@ def main():
         watchdog = threading.Timer(180.0, _stuck)
         watchdog.daemon = True
         watchdog.start()
-    run(6)
+    run(8)
     sync()
     if watchdog is not None:
         watchdog.cancel()
@@ -578,7 +578,7 @@ def main():
             "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} ({scaling}); {exchange_note}; the exchange of step i overlaps the rendering of step i + 1",
             "covered_fraction": covered,
         },
-        "setup": "6 untimed steps before the warm-up: the library times both raster formulations (same pixels) on this scene and keeps the faster one",
+        "setup": "8 untimed steps before the warm-up: the library times both raster formulations (same pixels) on this scene and keeps the faster one",
         "pipelining": "ms_per_step: up to three steps in flight on three HIP streams (tessellate / bin / raster); latency_ms_per_step: one step, host synchronised before and after",
         "roofline": {
             "kernel": dominant,

@@ -334,14 +334,15 @@ struct crh_scene {
     // Which formulation draws this Scene's plain passes — boundary edges + backdrops (raster_edges.hip) or the reference's strip triangles
     // (raster.hip) — is decided by MEASUREMENT: both give the same pixels, and which is faster depends on the content (long strips
     // across many tiles favour the edges, tens of thousands of glyph-sized Shapes the triangles: the edge pass pays per item and per
-    // (item, tile)). Frames 0-1 after an upload run the edge pass, frames 2-3 the triangle pass; the second frame of each is timed with
-    // events around its kernels — with the tile-list capacity verified before the raster kernel runs, since a frame that overflowed
-    // draws nothing and would win every race — and the fifth frame keeps the faster one.
+    // (item, tile)). Frames 0-2 after an upload run the edge pass, frames 3-5 the triangle pass; the second and third frame of each are
+    // timed with events around their kernels — with the tile-list capacity verified before the raster kernel runs, since a frame that
+    // overflowed draws nothing and would win every race — and the seventh frame keeps the pass whose faster timed frame was faster (one
+    // timed frame each was a cold one — caches, clocks — and the two formulations are within a few percent of each other on glyph scenes).
     // CRH_EDGE_PASS=1 / CRH_TRIANGLE_PASS=1 pin the choice.
     struct PassTrial {
         hipEvent_t e[6] = {}; // around: the binning traversal (the attempt that fitted), the list fill / scatter, the raster kernel
         bool recorded = false;
-    } pass_trial[2];
+    } pass_trial[4]; // [2 * pass + repetition]
     int pass_choice = 0;       // 0 undecided, 1 edges, 2 triangles: for targets of the size class pass_class
     uint32_t pass_frames = 0;  // plain frames of the trial under way
     uint32_t pass_class = 0;   // size class of the target the trial / choice belongs to (log4 of its area)
@@ -697,30 +698,34 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     if (cls != sc->pass_class) { // a target of another size class: its own choice, measured once
         sc->pass_class = cls;
         sc->pass_choice = sc->pass_known[cls], sc->pass_frames = 0;
-        sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+        for (crh_scene::PassTrial& t : sc->pass_trial) t.recorded = false;
     }
     if (sc->pass_choice) return sc->pass_choice == 1;
     const uint32_t n = sc->pass_frames++;
-    if (n < 2) { // the first frame of a pass sizes its buffers (and may run twice): the second one is timed
-        if (n == 1) *timed = 0;
+    if (n < 3) { // the first frame of a pass sizes its buffers (and may run twice): the second and the third one are timed
+        if (n >= 1) *timed = (int)n - 1;
         return true;
     }
-    if (n < 4) {
-        if (n == 3) *timed = 1;
+    if (n < 6) {
+        if (n >= 4) *timed = 2 + (int)n - 4;
         return false;
     }
-    if (sc->pass_trial[0].recorded && sc->pass_trial[1].recorded) {
+    if (sc->pass_trial[0].recorded && sc->pass_trial[1].recorded && sc->pass_trial[2].recorded && sc->pass_trial[3].recorded) {
         // The host runs frames ahead of the GPU: left to a query, a pipelined caller would have submitted its whole animation on the losing
-        // pass before the verdict arrived. One wait, on the fifth frame of a Scene (the two timed frames synchronised already).
+        // pass before the verdict arrived. One wait, on the seventh frame of a Scene (the four timed frames synchronised already).
         bool done = true;
         for (const crh_scene::PassTrial& t : sc->pass_trial) done = done && hipEventSynchronize(t.e[5]) == hipSuccess;
         if (done) {
             for (int k = 0; k < 2; ++k) {
-                sc->pass_ms[k] = 0.0f;
-                for (int i = 0; i < 6; i += 2) {
-                    float ms = 0.0f;
-                    (void)hipEventElapsedTime(&ms, sc->pass_trial[k].e[i], sc->pass_trial[k].e[i + 1]);
-                    sc->pass_ms[k] += ms;
+                sc->pass_ms[k] = 1.0e30f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    float sum = 0.0f;
+                    for (int i = 0; i < 6; i += 2) {
+                        float ms = 0.0f;
+                        (void)hipEventElapsedTime(&ms, sc->pass_trial[2 * k + rep].e[i], sc->pass_trial[2 * k + rep].e[i + 1]);
+                        sum += ms;
+                    }
+                    sc->pass_ms[k] = std::min(sc->pass_ms[k], sum);
                 }
             }
             sc->pass_choice = sc->pass_ms[0] <= sc->pass_ms[1] ? 1 : 2;
@@ -938,7 +943,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
     if (!f->cleared || (f->depth.p && r->config.depth_write_enabled) || trial) f->pairs_known = false; // (a timed frame must not be one that overflowed)
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
-    if (trial) HIP_TRY(r->sync()); // a timed frame has the GPU to itself (two frames per Scene, once)
+    if (trial) HIP_TRY(r->sync()); // a timed frame has the GPU to itself (four frames per Scene, once)
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
         p.tile_list = set.tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(set.tile_list.cap / 4);
@@ -1285,10 +1290,10 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         if (geometry != sc->pass_geometry || !existing) {
             sc->pass_choice = 0, sc->pass_frames = 0, sc->pass_class = 0;
             std::memset(sc->pass_known, 0, sizeof(sc->pass_known));
-            sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+            for (crh_scene::PassTrial& t : sc->pass_trial) t.recorded = false;
         } else if (sc->pass_choice == 0) { // (a trial under way is started over on the new geometry)
             sc->pass_frames = 0;
-            sc->pass_trial[0].recorded = sc->pass_trial[1].recorded = false;
+            for (crh_scene::PassTrial& t : sc->pass_trial) t.recorded = false;
         }
         sc->pass_geometry = geometry;
     }
