@@ -106,6 +106,18 @@ def _valu_cycles_per_instruction(kernel):
             "sources": [os.path.basename(rates[-1]), os.path.basename(hists[-1])]}
 
 
+def _salu_cycles_per_instruction():
+    """Measured issue cost of a scalar ALU instruction per SIMD (mean of the s_* classes of profiles/rNN_valu_rate.json), or None"""
+    import glob
+    rates = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_rate.json")))
+    if not rates:
+        return None
+    with open(rates[-1]) as f:
+        classes = json.load(f)["classes"]
+    values = [[v for k, v in c["chip"].items() if k.startswith("cycles_per_wave_instruction")][0] for name, c in classes.items() if name.startswith("s_")]
+    return sum(values) / len(values) if values else None
+
+
 def valu_issue(mark, avg_launch_ms, workload, triangle_pass=False):
     """Secondary roofline of the dominant kernel: VALU issue utilisation = wave-level VALU instructions (SQ_INSTS_VALU of the committed PMC
     summary measured on THESE kernel sources) x the MEASURED cycles per wave64 instruction of the kernel's instruction mix
@@ -120,11 +132,17 @@ def valu_issue(mark, avg_launch_ms, workload, triangle_pass=False):
     simds, clock_hz = 256 * 4, 2.4e9
     priced = _valu_cycles_per_instruction(names[mark])
     cycles = priced["cycles"] if priced else 4.0
-    return {"valu_wave_instructions": int(k["SQ_INSTS_VALU"]), "salu_wave_instructions": int(k.get("SQ_INSTS_SALU", 0)),
-            "cycles_per_valu_instruction": cycles, "priced_by": priced if priced else "assumed 4 cycles (no current profiles/rNN_valu_rate.json + rNN_isa_histogram.json)",
-            "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * cycles / (simds * clock_hz * avg_launch_ms * 1e-3), "source": source,
-            "note": "256 CUs x 4 SIMDs at 2.4 GHz; measured per class on this part: simple f32 / int 2.5 cycles, v_pk_fma_f32 4.6, v_cmp 4.3, v_cndmask 4.2 "
-                    "(profiles/r03_valu_rate.json): the raster kernels' mix of packed fma + compare + select averages 3.3 - 3.7"}
+    scalar_cycles = _salu_cycles_per_instruction()
+    out = {"valu_wave_instructions": int(k["SQ_INSTS_VALU"]), "salu_wave_instructions": int(k.get("SQ_INSTS_SALU", 0)),
+           "cycles_per_valu_instruction": cycles, "priced_by": priced if priced else "assumed 4 cycles (no current profiles/rNN_valu_rate.json + rNN_isa_histogram.json)",
+           "frac_of_valu_issue_peak": k["SQ_INSTS_VALU"] * cycles / (simds * clock_hz * avg_launch_ms * 1e-3), "source": source,
+           "note": "256 CUs x 4 SIMDs at 2.4 GHz; measured per class on this part: simple f32 / int 2.5 cycles, v_pk_fma_f32 4.6, v_cmp 4.3, v_cndmask 4.2 "
+                   "(profiles/r03_valu_rate.json): the raster kernels' mix of packed fma + compare + select averages 3.3 - 3.7; a scalar instruction issues "
+                   "every 4.3 - 4.4 cycles per SIMD (the CU's scalar unit serves its four SIMDs in turn) and overlaps the vector stream only partly"}
+    if scalar_cycles and k.get("SQ_INSTS_SALU"):
+        out["cycles_per_salu_instruction"] = scalar_cycles
+        out["frac_of_salu_issue_peak"] = k["SQ_INSTS_SALU"] * scalar_cycles / (simds * clock_hz * avg_launch_ms * 1e-3)
+    return out
 
 
 def measured_traffic(mark, workload, triangle_pass=False):
