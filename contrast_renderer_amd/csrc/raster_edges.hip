@@ -1253,6 +1253,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
                 const uint32_t w = w0 + tid;
                 const bool active = w < n_work;
                 uint32_t ei = 0; // the largest edge index with row_begin <= w (edges without rows share their successor's entry and are passed over)
+#ifdef CRH_ABLATE
+                if (r.debug & 4096u) ei = w % max(n_edges, 1u); else // what does the search cost? (the wrong edges: timing only)
+#endif
 #pragma unroll
                 for (uint32_t step = 512; step > 0u; step >>= 1)
                     if (ei + step < n_edges && row_begin[ei + step] <= w) ei += step;
