@@ -2089,7 +2089,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                         for (int q = 0; q < S; ++q) every = every && blend[b][q];
                     verify_at = 0xFFFFFFFFu;
-                    if (__builtin_amdgcn_ballot_w64(every) != ~0ull) { // no: the colours behind it matter — the whole list, from cleared state
+                    if (__builtin_amdgcn_ballot_w64(every) != ~0ull || (r.debug & 33554432u) != 0u) { // no (or debug bit 25, tests: never trusted): the colours behind it matter — the whole list, from cleared state
 #pragma unroll
                         for (int b = 0; b < ROWS; ++b)
 #pragma unroll
