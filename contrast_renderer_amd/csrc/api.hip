@@ -28,6 +28,7 @@ void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint6
 void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_items, uint32_t* item_nslots, uint32_t* slot_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_bin);
 void launch_scatter(const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
+void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, hipStream_t stream);
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
 } // namespace crh
@@ -265,6 +266,17 @@ struct crh_frame {
     DevBuf depth;                  // [height][width][samples] f32, when the configuration tests or writes depth
     bool cleared = true;
     bool pairs_known = false;
+    // Direct tile lists (RasterParams::direct): once a pass of a Scene into this frame has been verified, the places of its lists are kept
+    // — with half as much again and sixteen entries of headroom per tile — and the following passes of the same Scene store their keys
+    // straight into them (no pair stream, scan or scatter). A tile that outgrows its place is noticed like any overflow (settle_frame):
+    // the pass is drawn again the exact way and the places are taken anew; after three such misses the frame stays on the exact way.
+    DevBuf tile_base, tile_caps;
+    bool direct_ready = false;
+    crh_scene* direct_scene = nullptr;
+    uint64_t direct_generation = 0;
+    uint64_t direct_entries = 0;
+    uint32_t direct_misses = 0;
+    bool last_direct = false; // the pass pending verification was a direct one
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
     uint32_t opaque_covers = 0;    // ... and how many (item, tile) covers of it were opaque over the whole tile (without them there is nothing to start late behind)
     uint32_t mean_list = 0;        // entries per tile of the last verified EDGE pass (the pairs the pass needed / tiles): long lists get k_raster_edges' LONG variant
@@ -942,6 +954,11 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
     if (!f->cleared || (f->depth.p && r->config.depth_write_enabled) || trial) f->pairs_known = false; // (a timed frame must not be one that overflowed)
+    static const bool no_direct = getenv("CRH_NO_DIRECT_LISTS") != nullptr; // A/B runs
+    const bool direct = edges && !recorded && f->pairs_known && f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation && f->direct_misses < 3u && !no_direct;
+    p.direct = direct ? 1u : 0u;
+    p.tile_base = f->tile_base.as<uint32_t>();
+    if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     if (trial) HIP_TRY(r->sync()); // a timed frame has the GPU to itself (four frames per Scene, once)
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
@@ -977,6 +994,15 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         }
         if (ov[0] == 0 && ov[5] == 0) {
             f->pairs_known = true; // from now on this frame's passes run without the read-back (checked after the fact, settle_frame)
+            if (edges) { // ... and the edge pass keeps the places of this frame's lists (the counts are final: the stream was waited for)
+                uint32_t total = 0;
+                HIP_TRY(f->tile_caps.ensure((size_t)p.n_tiles * 4 + 4));
+                HIP_TRY(f->tile_base.ensure((size_t)p.n_tiles * 4 + 4));
+                launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), f->tile_base.as<uint32_t>(), p.scan_scratch, p.n_tiles, bin);
+                HIP_TRY(hipMemcpyAsync(&total, f->tile_base.as<uint32_t>() + p.n_tiles, 4, hipMemcpyDeviceToHost, bin));
+                HIP_TRY(hipStreamSynchronize(bin));
+                f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
+            }
             break;
         }
         if (attempt == 5) { // (six doublings of the pair stream were not enough: not a capacity problem)
@@ -1031,6 +1057,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     f->cleared = false;
     f->last_scene = sc;
     f->check_pending = true;
+    f->last_direct = direct;
     return CRH_OK;
 }
 
@@ -1049,6 +1076,10 @@ crh_status settle_frame(crh_frame* f) {
     if (unclosed) {
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] a boundary edge with a non-finite end point (found after the pass): this Scene goes to the triangle pass\n");
         f->triangle_pass_for = f->last_scene;
+    }
+    if (ov[0] != 0 && f->last_direct) { // a tile outgrew the place the earlier frame left it: the exact way again, with the read-back, and new places
+        if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] direct tile lists: a list outgrew its place, the pass is drawn again\n");
+        f->direct_ready = false, f->pairs_known = false, f->direct_misses += 1u;
     }
     if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed) {
         if (ov[0] != 0 || ov[5] != 0) f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way

@@ -261,10 +261,21 @@ struct Stage {
     uint32_t cap; // entries the wavefront's stage holds (flushed when fewer than 64 are free)
     uint32_t at;  // k_bin_flat: where the wavefront's next block goes in the pair stream — its share of the range the workgroup reserved (0xFFFFFFFF: dropped)
 };
+// direct tile lists (RasterParams::direct): the staged entries go where they belong
+CRH_D void stage_flush_direct(Stage& st, const RasterParams& r, uint32_t lane) {
+    for (uint32_t i = lane; i < st.used; i += 64u) {
+        const uint32_t t = st.tile[i], p = st.pos[i], base = r.tile_base[t];
+        if (p < r.tile_base[t + 1u] - base) r.tile_list[base + p] = st.key[i];
+        else r.overflow[0] = 1u; // the tile has outgrown the place the previous frame left it
+    }
+    __builtin_amdgcn_wave_barrier();
+    st.used = 0u;
+}
 CRH_D void stage_flush(Stage& st, const RasterParams& r, uint32_t lane) {
     if (st.used == 0u) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (r.direct) return stage_flush_direct(st, r, lane);
     const uint32_t region = r.pair_capacity / kSubStreams;
     uint32_t base = 0;
     if (lane == 0u) {
@@ -291,6 +302,7 @@ CRH_D void stage_flush_reserved(Stage& st, const RasterParams& r, uint32_t lane)
     if (st.used == 0u) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (r.direct) return stage_flush_direct(st, r, lane);
 #ifdef CRH_ABLATE
     if (r.debug & 2097152u) st.at = 0xFFFFFFFFu; // tools/ablate_flat.sh: no pair stores
 #endif
@@ -1403,7 +1415,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             if (const uint32_t opaque = wave_opaque[0] + wave_opaque[1] + wave_opaque[2] + wave_opaque[3]) atomicAdd(&r.overflow[4], opaque); // the host's statistic: are there tiles to start late in?
             const uint32_t sub = ((blockIdx.x + 40503u * turn) * 2654435761u) >> 26, region = r.pair_capacity / kSubStreams;
             uint32_t begin = 0xFFFFFFFFu;
-            if (total) {
+            if (r.direct) {
+                begin = 0u; // (no pair stream: the entries go straight into the lists)
+            } else if (total) {
                 const uint32_t got = atomicAdd(&r.pair_cursor[sub], total);
                 if (got + total > region)
                     r.overflow[5] = 1u; // this region is full: the host grows the stream and runs the pass again (nothing of this batch is written)
@@ -1610,10 +1624,13 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
-    const uint32_t list_begin = r.tile_offset[tile];
-    uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : r.tile_offset[tile + 1] - list_begin;
+    const uint32_t list_begin = r.direct ? r.tile_base[tile] : r.tile_offset[tile];
+    uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : (r.direct ? r.tile_count[tile] : r.tile_offset[tile + 1] - list_begin);
     constexpr uint32_t kLdsSortMax = kSortBytesMax / (4u * (4u / ROWS));
-    if (n > r.sort_capacity && n <= kLdsSortMax) n = 0; // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
+    if (n > r.sort_capacity && n <= kLdsSortMax) { // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
+        if (r.direct && threadIdx.x == 0u) atomicMax(&r.overflow[3], n); // (otherwise the scan of the counts has published it)
+        n = 0;
+    }
 #ifdef CRH_ABLATE
     if (r.debug & 64u) n = 0;
     if ((r.debug & 524288u) && n > 64u) n = 0;   // only the lists that fit one chunk
@@ -2209,12 +2226,21 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
     }
     if (after_bin) (void)hipEventRecord(after_bin, stream);
     if (mark) mark(ctx, "raster_bin", 0);
-    launch_scan_tiles(r, stream);
+    if (!r.direct) launch_scan_tiles(r, stream);
     if (mark) mark(ctx, "raster_tile_scan", 0);
 }
 void launch_scatter(const RasterParams& r, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
-    if (r.pair_capacity) hipLaunchKernelGGL(k_scatter, dim3((r.pair_capacity + 255u) / 256u), dim3(256), 0, stream, r);
+    if (r.pair_capacity && !r.direct) hipLaunchKernelGGL(k_scatter, dim3((r.pair_capacity + 255u) / 256u), dim3(256), 0, stream, r);
     if (mark) mark(ctx, "raster_scatter", 0);
+}
+// the places of the next frames' lists: caps[t] = count[t] + count[t] / 2 + 16, summed into tile_base[0 .. n_tiles] (tile_base[n_tiles] = all of them)
+__global__ __launch_bounds__(256) void k_tile_caps(const uint32_t* count, uint32_t* caps, uint32_t n) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n) caps[t] = count[t] + (count[t] >> 1) + 16u;
+}
+void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, tile_count, caps, n_tiles);
+    launch_scan_u32(caps, tile_base, scratch, n_tiles, stream);
 }
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
                          uint64_t raster_bytes, bool has_stroke) {

@@ -58,6 +58,12 @@ struct RasterParams {
     uint32_t* pair_key;               // ... scattered into tile_list by k_scatter once the tile offsets are known
     uint32_t* pair_cursor;            // pairs written so far (one atomic per flushed block of a wave)
     uint32_t hint_tris, hint_edges;   // about how many stroke / curve triangles and boundary edges the pass' items have in total (0: unknown) — sizes the batches of k_bin_flat
+    // Direct tile lists (edge pass, frames after the first verified one): the lists keep the places of the previous frame — tile_base[t] =
+    // exclusive prefix of (count + count / 2 + 16) of that frame — and the binning kernels store every key where it belongs, straight from
+    // their stages: no pair stream, no scan of the counts, no scatter kernel. A tile that outgrows its place sets overflow[0]; the host
+    // draws the frame again the exact way and re-bases the lists.
+    uint32_t direct;
+    const uint32_t* tile_base;        // [n_tiles + 1]
     uint32_t long_lists;              // the frame's tile lists hold many entries on average: k_raster_edges looks for its late start across chunks (host: crh_frame::mean_list)
     uint32_t* bin_queue;              // [n_items] items k_bin_flat hands on to k_bin_edges (their number: overflow[6])
 };
