@@ -142,7 +142,7 @@ struct crh_renderer {
     std::vector<crh_scene*> scenes; // live scenes and frames: orphaned (renderer = nullptr) when the renderer goes first, so that their own
                                     // destruction — host bindings finalise in any order — never touches a freed renderer
     std::vector<crh_frame*> frames; // live frames: a frame whose overflow check is still pending is settled before the scene it shows changes
-    bool timing = false;
+    unsigned timing = 0; // lanes whose kernels are bracketed by events: bit 0 raster, 1 tessellation, 2 binning (crh_renderer_enable_timing)
     std::vector<hipEvent_t> event_pool;
     std::vector<Mark> marks;
     size_t events_used = 0;
@@ -160,7 +160,7 @@ struct crh_renderer {
     hipStream_t binning_stream() const { return pipeline ? bin_stream : stream; }
     hipStream_t lane_stream(int lane) const { return lane == 1 ? tessellation_stream() : (lane == 2 ? binning_stream() : stream); }
     void begin_marks(int lane = 0) {
-        if (!timing) return;
+        if (!(timing & (1u << lane))) return;
         hipEvent_t e = next_event();
         (void)hipEventRecord(e, lane_stream(lane));
         marks.push_back({e, "", 0, lane});
@@ -171,7 +171,7 @@ struct crh_renderer {
         (void)hipEventRecord(e, r->binning_stream());
         r->marks.push_back({e, name, bytes, 2});
     }
-    MarkFn mark_fn_bin() const { return timing ? &crh_renderer::mark_cb_bin : nullptr; }
+    MarkFn mark_fn_bin() const { return (timing & 4u) ? &crh_renderer::mark_cb_bin : nullptr; }
     static void mark_cb(void* ctx, const char* name, uint64_t bytes) {
         crh_renderer* r = static_cast<crh_renderer*>(ctx);
         hipEvent_t e = r->next_event();
@@ -184,8 +184,8 @@ struct crh_renderer {
         (void)hipEventRecord(e, r->tessellation_stream());
         r->marks.push_back({e, name, bytes, 1});
     }
-    MarkFn mark_fn() const { return timing ? &crh_renderer::mark_cb : nullptr; }
-    MarkFn mark_fn_tess() const { return timing ? &crh_renderer::mark_cb_tess : nullptr; }
+    MarkFn mark_fn() const { return (timing & 1u) ? &crh_renderer::mark_cb : nullptr; }
+    MarkFn mark_fn_tess() const { return (timing & 2u) ? &crh_renderer::mark_cb_tess : nullptr; }
     hipError_t sync() { // every stream
         const hipError_t e = hipStreamSynchronize(tess_stream);
         const hipError_t b = hipStreamSynchronize(bin_stream);
@@ -568,7 +568,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
         RasterParams plain = {}; // items == nullptr: item i is Shape i, Stencil + Color
         launch_slot_ranges(d, plain, d.n_shapes, sc->shape_nslots.as<uint32_t>(), sc->shape_slot_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), ts);
     }
-    if (r->timing) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
+    if (r->timing & 2u) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
     HIP_TRY(hipEventRecord(sc->tess_done, ts));
     HIP_TRY(hipGetLastError());
     sc->layout_valid = false;
@@ -1950,7 +1950,7 @@ crh_status crh_renderer_synchronize(crh_renderer* r) {
 void* crh_renderer_stream(crh_renderer* r) { return r ? (void*)r->stream : nullptr; }
 crh_status crh_renderer_enable_timing(crh_renderer* r, int enabled) {
     if (!r) return CRH_ERR_INVALID_ARGUMENT;
-    r->timing = enabled != 0;
+    r->timing = enabled == 1 ? 7u : (enabled == 2 ? 1u : 0u); // 1: every lane, 2: the raster lane only (two events per step instead of a dozen)
     r->marks.clear();
     r->events_used = 0;
     return CRH_OK;

@@ -73,7 +73,8 @@ class Renderer:
         check(self.lib.crh_renderer_synchronize(self.handle))
 
     def enable_timing(self, enabled=True):
-        check(self.lib.crh_renderer_enable_timing(self.handle, 1 if enabled else 0))
+        """True / 1: HIP events around every kernel; 2: around the raster lane's kernels only (cheap enough for a timed loop); False / 0: off"""
+        check(self.lib.crh_renderer_enable_timing(self.handle, int(enabled)))
 
     def kernel_times(self):
         """[(kernel name, milliseconds, algorithmic bytes)] of the last tessellate / render call (HIP events on the renderer's stream)."""

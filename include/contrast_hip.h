@@ -275,7 +275,8 @@ crh_status crh_frame_synchronize(crh_frame* frame);
 /* hipStream_t of the renderer, as void* (for HIP events in bench.py). */
 void* crh_renderer_stream(crh_renderer* renderer);
 /* Milliseconds spent by the last crh_scene_tessellate / crh_scene_render* on the GPU, per kernel,
- * measured with HIP events on the renderer's stream when timing is enabled. */
+ * measured with HIP events on the renderer's streams when timing is enabled. enabled = 1: every kernel of a step (a dozen events per
+ * step: they cost a pipelined loop about 4 % of its rate); 2: the kernels of the raster lane only (two events per step); 0: off. */
 crh_status crh_renderer_enable_timing(crh_renderer* renderer, int enabled);
 typedef struct crh_kernel_time {
     char name[48];
