@@ -277,6 +277,8 @@ struct crh_frame {
     uint64_t direct_entries = 0;
     uint32_t direct_misses = 0;
     bool last_direct = false; // the pass pending verification was a direct one
+    bool queue_seen = true;       // the verified pass handed items from k_bin_flat on to k_bin_edges (until known otherwise: the queue kernel is launched)
+    bool last_skipped_queue = false;
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
     uint32_t opaque_covers = 0;    // ... and how many (item, tile) covers of it were opaque over the whole tile (without them there is nothing to start late behind)
     uint32_t mean_list = 0;        // entries per tile of the last verified EDGE pass (the pairs the pass needed / tiles): long lists get k_raster_edges' LONG variant
@@ -957,6 +959,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     static const bool no_direct = getenv("CRH_NO_DIRECT_LISTS") != nullptr; // A/B runs
     const bool direct = edges && !recorded && f->pairs_known && f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation && f->direct_misses < 3u && !no_direct;
     p.direct = direct ? 1u : 0u;
+    const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->generation;
+    p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = f->tile_base.as<uint32_t>();
     if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
@@ -1002,6 +1006,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                 HIP_TRY(hipMemcpyAsync(&total, f->tile_base.as<uint32_t>() + p.n_tiles, 4, hipMemcpyDeviceToHost, bin));
                 HIP_TRY(hipStreamSynchronize(bin));
                 f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
+                f->queue_seen = ov[6] != 0;
             }
             break;
         }
@@ -1058,6 +1063,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     f->last_scene = sc;
     f->check_pending = true;
     f->last_direct = direct;
+    f->last_skipped_queue = skip_queue;
     return CRH_OK;
 }
 
@@ -1081,7 +1087,9 @@ crh_status settle_frame(crh_frame* f) {
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] direct tile lists: a list outgrew its place, the pass is drawn again\n");
         f->direct_ready = false, f->pairs_known = false, f->direct_misses += 1u;
     }
-    if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed) {
+    const bool queue_missed = ov[6] != 0 && f->last_skipped_queue; // items were queued for a kernel that was not launched: again, with it
+    if (queue_missed) f->queue_seen = true, f->pairs_known = false;
+    if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed || queue_missed) {
         if (ov[0] != 0 || ov[5] != 0) f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
@@ -1106,7 +1114,7 @@ crh_status settle_frame_cheaply(crh_frame* f) {
     HIP_TRY(hipStreamSynchronize(r->aux_stream));
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
-    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small) return settle_frame(f);
+    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small || (ov[6] != 0 && f->last_skipped_queue)) return settle_frame(f);
     f->check_pending = false;
     return CRH_OK;
 }

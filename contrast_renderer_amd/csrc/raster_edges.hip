@@ -2218,10 +2218,10 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         const uint32_t flat_grid = (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
         if (samples == 4) {
             hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
-            hipLaunchKernelGGL((k_bin_edges<4, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
+            if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<4, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
         } else {
             hipLaunchKernelGGL((k_bin_flat<1>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
-            hipLaunchKernelGGL((k_bin_edges<1, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
+            if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<1, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
         }
     }
     if (after_bin) (void)hipEventRecord(after_bin, stream);

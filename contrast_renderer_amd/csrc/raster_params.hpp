@@ -63,6 +63,7 @@ struct RasterParams {
     // their stages: no pair stream, no scan of the counts, no scatter kernel. A tile that outgrows its place sets overflow[0]; the host
     // draws the frame again the exact way and re-bases the lists.
     uint32_t direct;
+    uint32_t skip_queue;              // the verified pass of this frame queued nothing for k_bin_edges<S, true>: its launch is left out (overflow[6] != 0 then means: draw again)
     const uint32_t* tile_base;        // [n_tiles + 1]
     uint32_t long_lists;              // the frame's tile lists hold many entries on average: k_raster_edges looks for its late start across chunks (host: crh_frame::mean_list)
     uint32_t* bin_queue;              // [n_items] items k_bin_flat hands on to k_bin_edges (their number: overflow[6])
