@@ -223,7 +223,7 @@ def run_loopback(args, size, scaling, np):
         draw()
         comms[0].local_exchange(layers, result)
 
-    for _ in range(8 + args.warmup):  # (the library's pass trial, as in the default run)
+    for _ in range(14 + args.warmup):  # (the library's pass trial, as in the default run)
         step()
     renderer.synchronize()
     t0 = time.perf_counter()
@@ -474,7 +474,7 @@ def main():
             dist.barrier()
 
     # Scene set-up, before the W warm-up steps: the library draws a Scene's first frames with both raster formulations (boundary edges /
-    # strip triangles: same pixels), times two frames of each on the GPU and keeps the faster one from the seventh frame on
+    # strip triangles: same pixels), times a group of three frames of each on the GPU and keeps the faster one from the thirteenth frame on
     watchdog = None
     if world > 1:  # the first exchanges of a multi-rank run: a rank that never answers must end the job with a message, not hang it
         import threading
@@ -486,7 +486,7 @@ def main():
         watchdog = threading.Timer(180.0, _stuck)
         watchdog.daemon = True
         watchdog.start()
-    run(8)
+    run(14)
     sync()
     if watchdog is not None:
         watchdog.cancel()
@@ -607,7 +607,7 @@ def main():
             "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} ({scaling}); {exchange_note}; the exchange of step i overlaps the rendering of step i + 1",
             "covered_fraction": covered,
         },
-        "setup": "8 untimed steps before the warm-up: the library times both raster formulations (same pixels) on this scene and keeps the faster one",
+        "setup": "14 untimed steps before the warm-up: the library times both raster formulations (same pixels) on this scene and keeps the faster one",
         "pipelining": "ms_per_step: up to three steps in flight on three HIP streams (tessellate / bin / raster); latency_ms_per_step: one step, host synchronised before and after",
         "roofline": {
             "kernel": dominant,

@@ -276,6 +276,7 @@ struct crh_frame {
     uint64_t direct_generation = 0;
     uint64_t direct_entries = 0;
     uint32_t direct_misses = 0;
+    bool last_edges = false;  // the formulation of the frame's last plain pass: the other one has other tile lists (their sizes are learned again)
     bool last_direct = false; // the pass pending verification was a direct one
     bool queue_seen = true;       // the verified pass handed items from k_bin_flat on to k_bin_edges (until known otherwise: the queue kernel is launched)
     bool last_skipped_queue = false;
@@ -348,15 +349,18 @@ struct crh_scene {
     // Which formulation draws this Scene's plain passes — boundary edges + backdrops (raster_edges.hip) or the reference's strip triangles
     // (raster.hip) — is decided by MEASUREMENT: both give the same pixels, and which is faster depends on the content (long strips
     // across many tiles favour the edges, tens of thousands of glyph-sized Shapes the triangles: the edge pass pays per item and per
-    // (item, tile)). Frames 0-2 after an upload run the edge pass, frames 3-5 the triangle pass; the second and third frame of each are
-    // timed with events around their kernels — with the tile-list capacity verified before the raster kernel runs, since a frame that
-    // overflowed draws nothing and would win every race — and the seventh frame keeps the pass whose faster timed frame was faster (one
-    // timed frame each was a cold one — caches, clocks — and the two formulations are within a few percent of each other on glyph scenes).
+    // (item, tile)). Frames 0-5 after an upload run the edge pass, frames 6-11 the triangle pass. The first frame of each is the verified
+    // one (it may run twice), the first three size the buffers of both pipeline sets (allocations: the edge pass' lists move once more
+    // when they are put in place); the three behind them run as every later frame will — pipelined as far as the caller lets them —
+    // and are timed as a GROUP: from the end of the raster kernel before them to the end of their last one (two events per pass on the
+    // raster stream). The thirteenth frame keeps the faster pass. (Rounds 2 - 3 timed single
+    // synchronised frames kernel by kernel: on glyph scenes, where the passes are within a few percent of each other alone, that put the
+    // Scene on the pass that is 14 % slower in the pipelined run.) A pass that had to be drawn again (an overflow) starts the trial over.
     // CRH_EDGE_PASS=1 / CRH_TRIANGLE_PASS=1 pin the choice.
     struct PassTrial {
-        hipEvent_t e[6] = {}; // around: the binning traversal (the attempt that fitted), the list fill / scatter, the raster kernel
-        bool recorded = false;
-    } pass_trial[4]; // [2 * pass + repetition]
+        hipEvent_t e[2] = {}; // on the raster stream: before the first timed frame is enqueued, behind the raster kernel of the last one
+        bool started = false, recorded = false;
+    } pass_trial[2];
     int pass_choice = 0;       // 0 undecided, 1 edges, 2 triangles: for targets of the size class pass_class
     uint32_t pass_frames = 0;  // plain frames of the trial under way
     uint32_t pass_class = 0;   // size class of the target the trial / choice belongs to (log4 of its area)
@@ -712,42 +716,33 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     if (cls != sc->pass_class) { // a target of another size class: its own choice, measured once
         sc->pass_class = cls;
         sc->pass_choice = sc->pass_known[cls], sc->pass_frames = 0;
-        for (crh_scene::PassTrial& t : sc->pass_trial) t.recorded = false;
+        for (crh_scene::PassTrial& t : sc->pass_trial) t.started = t.recorded = false;
     }
     if (sc->pass_choice) return sc->pass_choice == 1;
     const uint32_t n = sc->pass_frames++;
-    if (n < 3) { // the first frame of a pass sizes its buffers (and may run twice): the second and the third one are timed
-        if (n >= 1) *timed = (int)n - 1;
-        return true;
+    if (n < 12u) { // frames 0-5 edges, 6-11 triangles; *timed: 2 * pass (the group's start marker goes in front of this frame) or 2 * pass + 1 (its end marker behind it)
+        const uint32_t pass = n / 6u, k = n % 6u;
+        if (k == 3u) *timed = (int)(2u * pass);
+        if (k == 5u) *timed = (int)(2u * pass + 1u);
+        return pass == 0u;
     }
-    if (n < 6) {
-        if (n >= 4) *timed = 2 + (int)n - 4;
-        return false;
-    }
-    if (sc->pass_trial[0].recorded && sc->pass_trial[1].recorded && sc->pass_trial[2].recorded && sc->pass_trial[3].recorded) {
+    if (sc->pass_trial[0].recorded && sc->pass_trial[1].recorded) {
         // The host runs frames ahead of the GPU: left to a query, a pipelined caller would have submitted its whole animation on the losing
-        // pass before the verdict arrived. One wait, on the seventh frame of a Scene (the four timed frames synchronised already).
+        // pass before the verdict arrived. One wait, on the thirteenth frame of a Scene.
         bool done = true;
-        for (const crh_scene::PassTrial& t : sc->pass_trial) done = done && hipEventSynchronize(t.e[5]) == hipSuccess;
+        for (const crh_scene::PassTrial& t : sc->pass_trial) done = done && hipEventSynchronize(t.e[1]) == hipSuccess;
         if (done) {
             for (int k = 0; k < 2; ++k) {
-                sc->pass_ms[k] = 1.0e30f;
-                for (int rep = 0; rep < 2; ++rep) {
-                    float sum = 0.0f;
-                    for (int i = 0; i < 6; i += 2) {
-                        float ms = 0.0f;
-                        (void)hipEventElapsedTime(&ms, sc->pass_trial[2 * k + rep].e[i], sc->pass_trial[2 * k + rep].e[i + 1]);
-                        sum += ms;
-                    }
-                    sc->pass_ms[k] = std::min(sc->pass_ms[k], sum);
-                }
+                float ms = 0.0f;
+                (void)hipEventElapsedTime(&ms, sc->pass_trial[k].e[0], sc->pass_trial[k].e[1]);
+                sc->pass_ms[k] = ms / 3.0f;
             }
             sc->pass_choice = sc->pass_ms[0] <= sc->pass_ms[1] ? 1 : 2;
             sc->pass_known[sc->pass_class] = (uint8_t)sc->pass_choice;
-            if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] pass trial: edges %.3f ms, triangles %.3f ms -> %s\n", sc->pass_ms[0], sc->pass_ms[1], sc->pass_choice == 1 ? "edges" : "triangles");
+            if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] pass trial: edges %.3f ms, triangles %.3f ms per frame -> %s\n", sc->pass_ms[0], sc->pass_ms[1], sc->pass_choice == 1 ? "edges" : "triangles");
             return sc->pass_choice == 1;
         }
-    } else { // a trial frame was skipped (could not happen in sequence): start over
+    } else { // a marker was skipped (could not happen in sequence): start over
         sc->pass_frames = 0;
         return true;
     }
@@ -938,10 +933,17 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops)) ? 1u : 0u;
     int timed = -1;
     const bool edges = p.general == 0u && choose_pass(sc, f, &timed);
-    crh_scene::PassTrial* trial = (p.general == 0u && timed >= 0) ? &sc->pass_trial[timed] : nullptr;
-    if (trial)
+    if (edges != f->last_edges) f->pairs_known = false;
+    f->last_edges = edges;
+    crh_scene::PassTrial* trial = (p.general == 0u && timed >= 0) ? &sc->pass_trial[timed / 2] : nullptr;
+    if (trial) {
         for (hipEvent_t& e : trial->e)
             if (!e) HIP_TRY(hipEventCreate(&e));
+        if (timed % 2 == 0) { // (fires when the raster kernel of the frame before is through)
+            HIP_TRY(hipEventRecord(trial->e[0], r->stream));
+            trial->started = true, trial->recorded = false;
+        }
+    }
     p.slots = static_cast<uint8_t*>(sc->prim_rec[rec].p);
     p.overflow = set.overflow.as<uint32_t>();
     p.pair_cursor = set.overflow.as<uint32_t>() + 8; // 64 sub-stream cursors
@@ -955,7 +957,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
-    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled) || trial) f->pairs_known = false; // (a timed frame must not be one that overflowed)
+    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled)) f->pairs_known = false;
     static const bool no_direct = getenv("CRH_NO_DIRECT_LISTS") != nullptr; // A/B runs
     const bool direct = edges && !recorded && f->pairs_known && f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation && f->direct_misses < 3u && !no_direct;
     p.direct = direct ? 1u : 0u;
@@ -964,11 +966,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.tile_base = f->tile_base.as<uint32_t>();
     if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
-    if (trial) HIP_TRY(r->sync()); // a timed frame has the GPU to itself (four frames per Scene, once)
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
         p.tile_list = set.tile_list.as<uint32_t>();
         p.pair_capacity = (uint32_t)(set.tile_list.cap / 4);
-        if (trial) HIP_TRY(hipEventRecord(trial->e[0], bin));
         if (edges) {
             HIP_TRY(set.pair_tile.ensure(set.tile_list.cap));
             HIP_TRY(set.pair_key.ensure(set.tile_list.cap));
@@ -981,7 +981,6 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
             launch_bin_edges(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         } else
         launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
-        if (trial) HIP_TRY(hipEventRecord(trial->e[1], bin));
         if (f->pairs_known) break;
         uint32_t ov[8];
         HIP_TRY(hipMemcpyAsync(ov, p.overflow, 32, hipMemcpyDeviceToHost, bin));
@@ -1022,20 +1021,17 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(hipEventRecord(slot.read_done, bin));
         slot.was_read = true;
     }
-    if (trial) HIP_TRY(hipEventRecord(trial->e[2], bin));
     if (edges) {
         HIP_TRY(hipEventRecord(sc->ranges_free, bin)); // k_bin_edges, the only reader of the slot ranges, is behind us
         launch_scatter(p, bin, r->mark_fn_bin(), r);
     } else {
         launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
     }
-    if (trial) HIP_TRY(hipEventRecord(trial->e[3], bin));
     HIP_TRY(hipEventRecord(set.bin_done, bin));
     // ---- raster lane
     HIP_TRY(hipStreamWaitEvent(r->stream, set.bin_done, 0));
     HIP_TRY(order_after_external(f, r->stream));
     r->begin_marks(0);
-    if (trial) HIP_TRY(hipEventRecord(trial->e[4], r->stream));
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->image_bytes();
@@ -1046,8 +1042,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
     r->raster_events[1] = r->raster_events[0], r->raster_events[0] = sc->rec_raster_done[rec];
-    if (trial) {
-        HIP_TRY(hipEventRecord(trial->e[5], r->stream));
+    if (trial && timed % 2 == 1 && trial->started) {
+        HIP_TRY(hipEventRecord(trial->e[1], r->stream));
         trial->recorded = true;
     }
     set.used = true;
@@ -1094,6 +1090,10 @@ crh_status settle_frame(crh_frame* f) {
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
             f->cleared = true; // the pass is drawn again from scratch (only cleared frames take the optimistic path, see render_impl)
+            if (f->last_scene->pass_choice == 0) { // a frame of the trial that drew nothing would win every race: the trial starts over
+                f->last_scene->pass_frames = 0;
+                for (crh_scene::PassTrial& t : f->last_scene->pass_trial) t.started = t.recorded = false;
+            }
             crh_status st = render_impl(f->last_scene, f, true);
             if (st != CRH_OK) return st;
             HIP_TRY(r->sync());
@@ -1329,10 +1329,10 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         if (geometry != sc->pass_geometry || !existing) {
             sc->pass_choice = 0, sc->pass_frames = 0, sc->pass_class = 0;
             std::memset(sc->pass_known, 0, sizeof(sc->pass_known));
-            for (crh_scene::PassTrial& t : sc->pass_trial) t.recorded = false;
+            for (crh_scene::PassTrial& t : sc->pass_trial) t.started = t.recorded = false;
         } else if (sc->pass_choice == 0) { // (a trial under way is started over on the new geometry)
             sc->pass_frames = 0;
-            for (crh_scene::PassTrial& t : sc->pass_trial) t.recorded = false;
+            for (crh_scene::PassTrial& t : sc->pass_trial) t.started = t.recorded = false;
         }
         sc->pass_geometry = geometry;
     }
