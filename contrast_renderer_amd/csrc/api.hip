@@ -237,7 +237,8 @@ struct crh_frame {
     bool ext_read_set = false, ext_write_set = false;
     // Two sets of binning buffers, used alternately: frame N + 1 is binned while frame N's raster kernel still reads the other set.
     struct BinSet {
-        DevBuf tile_count_cursor, tile_offset, tile_list, overflow, scan_scratch;
+        DevBuf tile_count_cursor, tile_offset, tile_list, scan_scratch; // tile_count_cursor: [tile_cursor | tile_count | overflow words] — one memset clears what a pass needs
+        void* overflow_p = nullptr; // (inside tile_count_cursor)
         DevBuf pair_tile, pair_pos, pair_key;       // the edge pass: (tile, key) pairs as the binning waves produced them (same capacity as tile_list)
         DevBuf bin_queue;                           // the edge pass: items handed from k_bin_flat to k_bin_edges
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
@@ -276,6 +277,9 @@ struct crh_frame {
     uint64_t direct_generation = 0;
     uint64_t direct_entries = 0;
     uint32_t direct_misses = 0;
+    crh_scene* seen_scene = nullptr; // the Scene (and its geometry) of the frame's latest passes, and how many in a row
+    uint64_t seen_generation = 0;
+    uint32_t seen_passes = 0;
     bool last_edges = false;  // the formulation of the frame's last plain pass: the other one has other tile lists (their sizes are learned again)
     bool last_direct = false; // the pass pending verification was a direct one
     bool queue_seen = true;       // the verified pass handed items from k_bin_flat on to k_bin_edges (until known otherwise: the queue kernel is launched)
@@ -863,8 +867,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     if (recorded) f->item_inst_last = item_inst;
     p.transforms = recorded ? (item_inst ? f->item_transforms_b : f->item_transforms).as<float>() : (inst ? sc->transforms_b : sc->transforms).as<float>();
     p.colors = recorded ? (item_inst ? f->item_colors_b : f->item_colors).as<float>() : (inst ? sc->colors_b : sc->colors).as<float>();
-    p.tile_count = set.tile_count_cursor.as<uint32_t>();
-    p.tile_cursor = set.tile_count_cursor.as<uint32_t>() + f->n_tiles;
+    p.tile_cursor = set.tile_count_cursor.as<uint32_t>();
+    p.tile_count = set.tile_count_cursor.as<uint32_t>() + f->n_tiles;
     p.tile_offset = set.tile_offset.as<uint32_t>();
     p.shape_ncand = sc->shape_ncand.as<uint32_t>();
     p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
@@ -945,8 +949,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         }
     }
     p.slots = static_cast<uint8_t*>(sc->prim_rec[rec].p);
-    p.overflow = set.overflow.as<uint32_t>();
-    p.pair_cursor = set.overflow.as<uint32_t>() + 8; // 64 sub-stream cursors
+    p.overflow = static_cast<uint32_t*>(set.overflow_p);
+    p.pair_cursor = static_cast<uint32_t*>(set.overflow_p) + 8; // 64 sub-stream cursors
     p.sort_capacity = f->sort_capacity;
     p.long_lists = long_lists(f);
     p.rgba8 = f->rgba8.as<uint8_t>();
@@ -959,6 +963,14 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
     if (!f->cleared || (f->depth.p && r->config.depth_write_enabled)) f->pairs_known = false;
     static const bool no_direct = getenv("CRH_NO_DIRECT_LISTS") != nullptr; // A/B runs
+    // Geometry that has stayed for two passes without its lists in place (a Scene drawn into this frame after another one, paths uploaded
+    // again into the Scene): one verified pass more, which puts them in place. (Not at once: a caller that uploads new paths for every
+    // frame would pay a read-back per frame for places it never uses.)
+    if (f->seen_scene == sc && f->seen_generation == sc->generation) f->seen_passes += 1u;
+    else f->seen_scene = sc, f->seen_generation = sc->generation, f->seen_passes = 0u;
+    if (edges && !recorded && f->pairs_known && f->seen_passes == 2u && !no_direct && f->direct_misses < 3u &&
+        !(f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation))
+        f->pairs_known = false;
     const bool direct = edges && !recorded && f->pairs_known && f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation && f->direct_misses < 3u && !no_direct;
     p.direct = direct ? 1u : 0u;
     const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->generation;
@@ -1069,7 +1081,7 @@ crh_status settle_frame(crh_frame* f) {
     crh_renderer* r = f->renderer;
     uint32_t ov[8];
     HIP_TRY(r->sync());
-    HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow.p, 32, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow_p, 32, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
@@ -1110,7 +1122,7 @@ crh_status settle_frame_cheaply(crh_frame* f) {
     if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
     if (!f->check_pending) return CRH_OK;
     uint32_t ov[8];
-    HIP_TRY(hipMemcpyAsync(ov, set.overflow.p, 32, hipMemcpyDeviceToHost, r->aux_stream));
+    HIP_TRY(hipMemcpyAsync(ov, set.overflow_p, 32, hipMemcpyDeviceToHost, r->aux_stream));
     HIP_TRY(hipStreamSynchronize(r->aux_stream));
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
@@ -1579,8 +1591,8 @@ crh_status crh_frame_create_format(crh_renderer* r, uint32_t width, uint32_t hei
     bool ok = hip_ok(f->rgba8.ensure(f->image_bytes()), "hipMalloc frame") && hip_ok(hipEventCreateWithFlags(&f->ext_read, hipEventDisableTiming), "hipEventCreate") &&
               hip_ok(hipEventCreateWithFlags(&f->ext_write, hipEventDisableTiming), "hipEventCreate");
     for (crh_frame::BinSet& set : f->sets)
-        ok = ok && hip_ok(set.tile_count_cursor.ensure((size_t)f->n_tiles * 8), "hipMalloc") && hip_ok(set.tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") &&
-             hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") && hip_ok(set.overflow.ensure(512), "hipMalloc") &&
+        ok = ok && hip_ok(set.tile_count_cursor.ensure((size_t)f->n_tiles * 8 + 512), "hipMalloc") && hip_ok(set.tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") &&
+             hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") &&
              hip_ok(hipEventCreateWithFlags(&set.bin_done, hipEventDisableTiming), "hipEventCreate") &&
              hip_ok(hipEventCreateWithFlags(&set.raster_done, hipEventDisableTiming), "hipEventCreate");
     if (!ok) {
@@ -1593,7 +1605,10 @@ crh_status crh_frame_create_format(crh_renderer* r, uint32_t width, uint32_t hei
         HIP_TRY(f->depth.ensure(n * 4));
         HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(f->depth.p), 0x3f800000, n, r->stream));
     }
-    for (crh_frame::BinSet& set : f->sets) HIP_TRY(hipMemsetAsync(set.overflow.p, 0, 512, r->stream));
+    for (crh_frame::BinSet& set : f->sets) {
+        set.overflow_p = static_cast<uint8_t*>(set.tile_count_cursor.p) + (size_t)f->n_tiles * 8;
+        HIP_TRY(hipMemsetAsync(set.overflow_p, 0, 512, r->stream));
+    }
     HIP_TRY(r->sync());
     r->frames.push_back(f);
     *out = f;
@@ -1619,7 +1634,7 @@ void crh_frame_destroy(crh_frame* f) {
     f->item_upload_c.release();
     for (InstanceSlot& k : f->item_slot) k.release();
     for (crh_frame::BinSet& set : f->sets) {
-        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.overflow, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key, &set.bin_queue};
+        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key, &set.bin_queue};
         for (DevBuf* b : bins) b->release();
         if (set.bin_done) (void)hipEventDestroy(set.bin_done);
         if (set.raster_done) (void)hipEventDestroy(set.raster_done);
@@ -1839,21 +1854,21 @@ crh_status crh_frame_download_f16(crh_frame* f, void* rgba16f) { return download
 extern "C" crh_status crh_debug_frame_counters(crh_frame* f, uint32_t out[8]) { // tools only (not in the public header)
     HIP_TRY(hipSetDevice(f->renderer->device));
     HIP_TRY(f->renderer->sync());
-    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow_p, 32, hipMemcpyDeviceToHost));
     return CRH_OK;
 }
 extern "C" crh_status crh_debug_frame_counters16(crh_frame* f, uint32_t out[16]) { // tools only: + the per-class entry counts of an ablation build
     HIP_TRY(hipSetDevice(f->renderer->device));
     HIP_TRY(f->renderer->sync());
-    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 64, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow.p) + 32, 0, 32));
+    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow_p, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow_p) + 32, 0, 32));
     return CRH_OK;
 }
 extern "C" crh_status crh_debug_frame_words(crh_frame* f, uint32_t out[128]) { // tools only: the whole 512-byte flag / counter block of the last set
     HIP_TRY(hipSetDevice(f->renderer->device));
     HIP_TRY(f->renderer->sync());
-    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow.p, 512, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow.p) + 320, 0, 192));
+    HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow_p, 512, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow_p) + 320, 0, 192));
     return CRH_OK;
 }
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {

@@ -1067,8 +1067,8 @@ void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item
 }
 // `after_setup` (optional) is recorded when k_prim_setup, the last reader of the tessellated vertex streams, has been enqueued
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_setup) {
-    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
-    (void)hipMemsetAsync(r.overflow, 0, 32, stream); // [5] belongs to the edge pass (raster_edges.hip); cleared so that the host never sees a stale flag
+    // tile_cursor, tile_count and the overflow words are adjacent: one memset ([5] belongs to the edge pass (raster_edges.hip); cleared so that the host never sees a stale flag)
+    (void)hipMemsetAsync(r.tile_cursor, 0, sizeof(uint32_t) * 2u * r.n_tiles + 32, stream);
     if (r.n_items) {
         if (samples == 4) {
             if (r.prim_proj)

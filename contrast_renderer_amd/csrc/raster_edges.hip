@@ -2187,8 +2187,8 @@ void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_ite
     launch_scan_u32(item_nslots, slot_begin, scratch, n_items, stream);
 }
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
-    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * 2u * r.n_tiles, stream); // tile_count and tile_cursor are adjacent
-    (void)hipMemsetAsync(r.overflow, 0, 32 + 4 * kSubStreams, stream);                 // overflow[8 ...] are the cursors of the pair sub-streams
+    // tile_count and, right behind it, the overflow words (overflow[8 ...] are the cursors of the pair sub-streams): one memset (tile_cursor, in front, is the triangle pass')
+    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams, stream);
     // Items per workgroup. One is best while the grid is small (S10k: 0.169 ms; two: 0.189, four: 0.21 — an item is a chain of dependent
     // memory operations, and a wavefront that takes a second item doubles it); tens of thousands of small items are bound by workgroup
     // turnover instead (50 000 glyphs: one 0.45, two 0.31, four 0.31, eight 0.33 ms). So: about 12 000 workgroups.

@@ -25,7 +25,7 @@ struct RasterParams {
     uint32_t load_existing; // 0: the frame was cleared (LoadOp::Clear), 1: composite over the resolved image already there
     const float* transforms; // [n_instances][16] column-major
     const float* colors;     // [n_instances][4] straight alpha
-    uint32_t* tile_count;    // [n_tiles], immediately followed by tile_cursor (one memset clears both)
+    uint32_t* tile_count;    // [n_tiles], in one allocation [tile_cursor | tile_count | overflow]: one memset clears what a pass needs
     uint32_t* tile_cursor;   // [n_tiles]
     uint32_t* tile_offset;   // [n_tiles + 1]
     uint32_t* tile_list;     // [pair_capacity] prim ids, grouped by tile
