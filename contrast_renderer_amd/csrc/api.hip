@@ -142,6 +142,7 @@ struct crh_renderer {
     std::vector<crh_scene*> scenes; // live scenes and frames: orphaned (renderer = nullptr) when the renderer goes first, so that their own
                                     // destruction — host bindings finalise in any order — never touches a freed renderer
     std::vector<crh_frame*> frames; // live frames: a frame whose overflow check is still pending is settled before the scene it shows changes
+    uint64_t render_serial = 0; // render calls so far
     unsigned timing = 0; // lanes whose kernels are bracketed by events: bit 0 raster, 1 tessellation, 2 binning (crh_renderer_enable_timing)
     std::vector<hipEvent_t> event_pool;
     std::vector<Mark> marks;
@@ -200,6 +201,7 @@ struct crh_renderer {
 // the set (read_done) and ahead of the one that reads it next (ready), so it overlaps the binning of the frame in between.
 struct InstanceSlot {
     hipEvent_t read_done = nullptr, ready = nullptr;
+    hipEvent_t read_event = nullptr; // what the next copy into this set waits for: read_done, or (borrowed) the Scene's event behind the binning kernel that read it
     bool was_read = false, was_written = false;
     hipError_t init() {
         if (read_done) return hipSuccess;
@@ -209,7 +211,7 @@ struct InstanceSlot {
     void release() {
         if (read_done) (void)hipEventDestroy(read_done);
         if (ready) (void)hipEventDestroy(ready);
-        read_done = ready = nullptr;
+        read_done = ready = read_event = nullptr;
         was_read = was_written = false;
     }
 };
@@ -239,6 +241,7 @@ struct crh_frame {
     struct BinSet {
         DevBuf tile_count_cursor, tile_offset, tile_list, scan_scratch; // tile_count_cursor: [tile_cursor | tile_count | overflow words] — one memset clears what a pass needs
         void* overflow_p = nullptr; // (inside tile_count_cursor)
+        uint64_t raster_serial = 0; // the render call that recorded raster_done
         DevBuf pair_tile, pair_pos, pair_key;       // the edge pass: (tile, key) pairs as the binning waves produced them (same capacity as tile_list)
         DevBuf bin_queue;                           // the edge pass: items handed from k_bin_flat to k_bin_edges
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
@@ -330,6 +333,7 @@ struct crh_scene {
     bool instances_projective_of[2] = {false, false};
     bool instances_tame_of[2] = {false, false}; // all_colors_tame of that instance buffer
     hipEvent_t rec_raster_done[kPipelineDepth] = {};
+    uint64_t rec_raster_serial[kPipelineDepth] = {}; // the render call that recorded it (crh_renderer::render_serial)
     bool rec_used[kPipelineDepth] = {};
     int next_rec = 0;
     bool instances_set = false;
@@ -848,8 +852,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     const int rec = sc->next_rec;
     HIP_TRY(hipStreamWaitEvent(bin, sc->tess_done, 0)); // the tessellation this frame draws (a no-op when it finished long ago)
     if (r->raster_exclusive && r->raster_events[0]) HIP_TRY(hipStreamWaitEvent(bin, r->raster_events[0], 0));
+    // (each wait on another stream's event is a packet the binning lane — the critical one — spends 5 - 10 us on, satisfied or not: the
+    // frame's set and the Scene's record buffer were as a rule last used by the same raster kernel, and then one wait says it all)
     if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.raster_done, 0));
-    if (sc->rec_used[rec]) HIP_TRY(hipStreamWaitEvent(bin, sc->rec_raster_done[rec], 0));
+    if (sc->rec_used[rec] && !(set.used && set.raster_serial == sc->rec_raster_serial[rec])) HIP_TRY(hipStreamWaitEvent(bin, sc->rec_raster_done[rec], 0));
     RasterParams p;
     p.width = f->width;
     p.height = f->height;
@@ -1029,19 +1035,27 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
         r->begin_marks(2);
     }
-    if (slot.read_done) { // k_prim_setup, the only reader of the instance data, is behind us on this stream
+    // With the lists in place nothing runs on this lane behind the binning kernels: "the vertex streams are free", "the instance data has been
+    // read", "the slot ranges are free" and "binned" are one point in time, and the event launch_bin_edges recorded there (the Scene's
+    // vertices_free) stands for all four — three packets less on the critical lane.
+    const bool one_event = direct;
+    const hipEvent_t vertices_free_now = sc->vertices_free; // (the handle: flip_tess_set swaps the Scene's two)
+    if (one_event) {
+        if (slot.read_done) slot.read_event = vertices_free_now, slot.was_read = true;
+    } else if (slot.read_done) { // k_prim_setup, the only reader of the instance data, is behind us on this stream
         HIP_TRY(hipEventRecord(slot.read_done, bin));
+        slot.read_event = slot.read_done;
         slot.was_read = true;
     }
     if (edges) {
-        HIP_TRY(hipEventRecord(sc->ranges_free, bin)); // k_bin_edges, the only reader of the slot ranges, is behind us
+        if (!one_event) HIP_TRY(hipEventRecord(sc->ranges_free, bin)); // k_bin_edges, the only reader of the slot ranges, is behind us
         launch_scatter(p, bin, r->mark_fn_bin(), r);
     } else {
         launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
     }
-    HIP_TRY(hipEventRecord(set.bin_done, bin));
+    if (!one_event) HIP_TRY(hipEventRecord(set.bin_done, bin));
     // ---- raster lane
-    HIP_TRY(hipStreamWaitEvent(r->stream, set.bin_done, 0));
+    HIP_TRY(hipStreamWaitEvent(r->stream, one_event ? vertices_free_now : set.bin_done, 0));
     HIP_TRY(order_after_external(f, r->stream));
     r->begin_marks(0);
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
@@ -1053,6 +1067,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
+    set.raster_serial = sc->rec_raster_serial[rec] = ++r->render_serial;
     r->raster_events[1] = r->raster_events[0], r->raster_events[0] = sc->rec_raster_done[rec];
     if (trial && timed % 2 == 1 && trial->started) {
         HIP_TRY(hipEventRecord(trial->e[1], r->stream));
@@ -1714,7 +1729,7 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
         InstanceSlot& slot = sc->slot[next];
         HIP_TRY(slot.init());
         const hipStream_t up = r->pipeline ? r->upload_stream : r->stream;
-        if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_done, 0)); // the setup that read this set two updates ago
+        if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_event, 0)); // the setup that read this set two updates ago
         HIP_TRY(sc->upload_t.copy(tb.p, transforms, (size_t)sc->d.n_shapes * 64, up));
         HIP_TRY(sc->upload_c.copy(cb.p, colors, (size_t)sc->d.n_shapes * 16, up));
         HIP_TRY(hipEventRecord(slot.ready, up));
@@ -1794,7 +1809,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
         InstanceSlot& slot = f->item_slot[next];
         HIP_TRY(slot.init());
         const hipStream_t up = r->pipeline ? r->upload_stream : r->stream;
-        if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_done, 0));
+        if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_event, 0));
         HIP_TRY(f->item_upload_t.copy(tb.p, transforms, (size_t)n_instances * 64, up));
         HIP_TRY(f->item_upload_c.copy(cb.p, colors, (size_t)n_instances * 16, up));
         HIP_TRY(hipEventRecord(slot.ready, up));
