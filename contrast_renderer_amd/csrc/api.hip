@@ -28,6 +28,7 @@ void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint6
 void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_items, uint32_t* item_nslots, uint32_t* slot_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_bin);
 void launch_scatter(const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
+void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream);
 void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, hipStream_t stream);
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -333,6 +334,7 @@ struct crh_scene {
     bool instances_projective_of[2] = {false, false};
     bool instances_tame_of[2] = {false, false}; // all_colors_tame of that instance buffer
     hipEvent_t rec_raster_done[kPipelineDepth] = {};
+    unsigned one_event_history = 0; // bit k: the Scene's k-th latest render recorded one event for everything behind its binning (both bits: the tessellation need not wait for ranges_free)
     uint64_t rec_raster_serial[kPipelineDepth] = {}; // the render call that recorded it (crh_renderer::render_serial)
     bool rec_used[kPipelineDepth] = {};
     int next_rec = 0;
@@ -576,12 +578,9 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     launch_emit(d, ts, r->mark_fn_tess(), r, bytes2, sc->has_stroke, sc->big_shapes);
     // contiguous primitive ids per Shape, in draw order (transform independent, so it belongs to the tessellation); the previous
     // frame's tile walks read the old ranges until its fill pass is through
-    if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0));
-    launch_prim_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), ts);
-    {
-        RasterParams plain = {}; // items == nullptr: item i is Shape i, Stencil + Color
-        launch_slot_ranges(d, plain, d.n_shapes, sc->shape_nslots.as<uint32_t>(), sc->shape_slot_begin.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>(), ts);
-    }
+    if (sc->rendered_once && (sc->one_event_history & 3u) != 3u) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0)); // (one event stood for both: waited for above)
+    launch_plain_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->shape_nslots.as<uint32_t>(), sc->shape_slot_begin.as<uint32_t>(),
+                        sc->prim_scan_scratch.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>() + ((size_t)(d.n_shapes + 1023) / 1024 + 2), ts);
     if (r->timing & 2u) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
     HIP_TRY(hipEventRecord(sc->tess_done, ts));
     HIP_TRY(hipGetLastError());
@@ -1039,6 +1038,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // read", "the slot ranges are free" and "binned" are one point in time, and the event launch_bin_edges recorded there (the Scene's
     // vertices_free) stands for all four — three packets less on the critical lane.
     const bool one_event = direct;
+    sc->one_event_history = (sc->one_event_history << 1 | (one_event ? 1u : 0u)) & 3u;
     const hipEvent_t vertices_free_now = sc->vertices_free; // (the handle: flip_tess_set swaps the Scene's two)
     if (one_event) {
         if (slot.read_done) slot.read_event = vertices_free_now, slot.was_read = true;
@@ -1425,7 +1425,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
         !hip_ok(sc->shape_nslots.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_slot_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
-        !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 4), "hipMalloc")) {
+        !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 8), "hipMalloc")) { // (two scans side by side)
         rc = CRH_ERR_HIP;
         goto fail;
     }

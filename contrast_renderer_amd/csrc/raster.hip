@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_item_ncand(SceneDev s, RasterParams r, 
     item_candidates(s, r.items[i], cb, first, last);
     item_ncand[i] = last - first;
 }
-__global__ __launch_bounds__(256) void k_scan_local(ScanJob j) {
+CRH_D void scan_local_body(const ScanJob& j) {
     __shared__ uint32_t wave_sum[4];
     const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x * 4u;
     uint32_t v[4];
@@ -81,8 +81,11 @@ __global__ __launch_bounds__(256) void k_scan_local(ScanJob j) {
     }
     if (threadIdx.x == 255) j.block_sum[blockIdx.x] = run;
 }
+__global__ __launch_bounds__(256) void k_scan_local(ScanJob j) { scan_local_body(j); }
+// two scans of equally many items in one launch (blockIdx.y picks the job): the primitive ids and the slot ranges per Shape
+__global__ __launch_bounds__(256) void k_scan_local2(ScanJob a, ScanJob b) { scan_local_body(blockIdx.y ? b : a); }
 // mode 0: primitive ranges; mode 1: tile list offsets (also publishes the pair count and the overflow flag)
-__global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int mode) {
+CRH_D void scan_add_body(const ScanJob& j, const RasterParams& r, int mode) {
     __shared__ uint32_t partial[256];
     uint32_t sum = 0;
     for (uint32_t k = threadIdx.x; k < blockIdx.x; k += 256u) sum += j.block_sum[k];
@@ -105,6 +108,11 @@ __global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int
             r.overflow[0] = total > r.pair_capacity ? 1u : 0u;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_scan_add(ScanJob j, RasterParams r, int mode) { scan_add_body(j, r, mode); }
+__global__ __launch_bounds__(256) void k_scan_add2(ScanJob a, ScanJob b) {
+    RasterParams unused = {};
+    scan_add_body(blockIdx.y ? b : a, unused, 0);
 }
 
 // ---------------------------------------------------------------------------------------------- exact tile test
@@ -1138,6 +1146,11 @@ void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uin
     RasterParams unused = {};
     hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
     hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, unused, 0);
+}
+void launch_scan_u32_pair(const uint32_t* in0, uint32_t* out0, uint32_t* block_sum0, const uint32_t* in1, uint32_t* out1, uint32_t* block_sum1, uint32_t n, hipStream_t stream) {
+    const ScanJob a = scan_job(in0, out0, block_sum0, n), b = scan_job(in1, out1, block_sum1, n);
+    hipLaunchKernelGGL(k_scan_local2, dim3(a.blocks, 2), dim3(256), 0, stream, a, b);
+    hipLaunchKernelGGL(k_scan_add2, dim3(a.blocks, 2), dim3(256), 0, stream, a, b);
 }
 void launch_scan_tiles(const RasterParams& r, hipStream_t stream) { // tile_count -> tile_offset; publishes the pair total and the longest list
     const ScanJob j = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles, r.overflow + 3);

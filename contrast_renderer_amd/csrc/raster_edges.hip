@@ -2186,6 +2186,27 @@ void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_ite
     hipLaunchKernelGGL(k_item_nslots, dim3((n_items + 255u) / 256u), dim3(256), 0, stream, s, r, n_items, item_nslots);
     launch_scan_u32(item_nslots, slot_begin, scratch, n_items, stream);
 }
+// The plain pass' two per-Shape ranges at the end of a tessellation — contiguous primitive ids (triangle pass) and slot ranges (edge pass) —
+// in three launches instead of six (counts of both, then the two scans side by side): small kernels on a lane that starves beside the
+// binning and raster kernels pay for every launch.
+__global__ __launch_bounds__(256) void k_shape_counts(SceneDev s, uint32_t* shape_ncand, uint32_t* shape_nslots) {
+    const uint32_t shape = blockIdx.x * 256u + threadIdx.x;
+    if (shape >= s.n_shapes) return;
+    uint32_t c[8];
+    shape_ncand[shape] = shape_candidates(s, shape, c);
+    RasterParams plain = {}; // items == nullptr: item i is Shape i, Stencil + Color
+    shape_nslots[shape] = item_slots(s, item_of(plain, shape)).total;
+}
+void launch_scan_u32_pair(const uint32_t* in0, uint32_t* out0, uint32_t* block_sum0, const uint32_t* in1, uint32_t* out1, uint32_t* block_sum1, uint32_t n, hipStream_t stream); // raster.hip
+void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream) {
+    if (s.n_shapes == 0) {
+        (void)hipMemsetAsync(shape_prim_begin, 0, 4, stream);
+        (void)hipMemsetAsync(shape_slot_begin, 0, 4, stream);
+        return;
+    }
+    hipLaunchKernelGGL(k_shape_counts, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s, shape_ncand, shape_nslots);
+    launch_scan_u32_pair(shape_ncand, shape_prim_begin, scratch0, shape_nslots, shape_slot_begin, scratch1, s.n_shapes, stream);
+}
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     // tile_count and, right behind it, the overflow words (overflow[8 ...] are the cursors of the pair sub-streams): one memset (tile_cursor, in front, is the triangle pass')
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams, stream);
