@@ -64,7 +64,7 @@ def kernel_source_hash():
 def _newest_profile(kind, workload):
     """profiles/rNN_<kind>.json (the metric's workload) or profiles/rNN_<kind>_<workload>.json, newest round, if measured on these sources"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json" if workload in ("cubic", "s100k") else f"r[0-9][0-9]_{kind}_{workload}.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json" if workload == "cubic" else f"r[0-9][0-9]_{kind}_{workload}.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # container: gpurun_out/ of tools/r03_collect.sh (+ tools/r03_lines.sh, if run) -> profiles/r03_*
 cd /root/repo
-for w in cubic glyphs dashed; do python tools/collect_profiles.py r03_$w r03 gpurun_out/bench_r03_$w.json $w > /dev/null 2>&1; done
+for w in cubic glyphs dashed s100k; do python tools/collect_profiles.py r03_$w r03 gpurun_out/bench_r03_$w.json $w > /dev/null 2>&1; done
 python - <<'PY'
 import json, os
 def last(path):

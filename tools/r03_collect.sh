@@ -3,8 +3,7 @@
 # config 4 on one GPU (single frame and the eight-rank loopback with its exchange), the host-inclusive mode, the parity suite.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/pytest_r03.log
-for w in cubic glyphs dashed; do bash tools/collect_all.sh r03 $w > /dev/null 2>&1; done
-python bench.py --workload s100k --no-cpu-baseline > gpurun_out/bench_r03_s100k.json 2> gpurun_out/bench_r03_s100k.err
+for w in cubic glyphs dashed s100k; do bash tools/collect_all.sh r03 $w > /dev/null 2>&1; done
 bash tools/r03_loopback.sh > /dev/null 2>&1
 python bench.py --reupload --no-cpu-baseline > gpurun_out/bench_r03_reupload.json 2> gpurun_out/bench_r03_reupload.err
 cat gpurun_out/pytest_r03.log
