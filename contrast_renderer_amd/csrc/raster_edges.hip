@@ -1900,8 +1900,14 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     const int b0 = cmb / S, k0 = cmb % S, b1 = (cmb + 1) / S, k1 = (cmb + 1) % S;
                     const f32x2 y = {sy0[k0] + (float)(4 * b0), sy0[k1] + (float)(4 * b1)};
                     const f32x2 ev = fma2(y, splat2(ebx), f32x2{h[k0], h[k1]});
+                    if constexpr (LONG) { // the y range per sample as a bit of ym on the VECTOR unit: this variant's counters say the scalar unit is the busier one (70 % against 63 %)
+                        const uint32_t y_shift = S == 1 ? rq : 4u * rq;
+                        d[b0][k0] = (__float_as_int(ev[0]) >= thr ? unit : 0) & __builtin_amdgcn_sbfe((int)ym, y_shift + (S == 1 ? 4u * b0 : (uint32_t)k0), 1u);
+                        d[b1][k1] = (__float_as_int(ev[1]) >= thr ? unit : 0) & __builtin_amdgcn_sbfe((int)ym, y_shift + (S == 1 ? 4u * b1 : (uint32_t)k1), 1u);
+                    } else {
                     d[b0][k0] = ((__float_as_int(ev[0]) >= thr) & __builtin_amdgcn_inverse_ballot_w64(ys.m[S == 1 ? b0 : k0])) ? unit : 0;
                     d[b1][k1] = ((__float_as_int(ev[1]) >= thr) & __builtin_amdgcn_inverse_ballot_w64(ys.m[S == 1 ? b1 : k1])) ? unit : 0;
+                    }
                 }
                 if (a_plus | a_minus) { // the edge crosses the left tile boundary (or runs left of it): row constants (on the deltas, not on the state)
                     const uint32_t lane_shift = S == 1 ? rq : 4u * rq; // sample (b, q) of lane (px, rq) is row bit rq + 4b (msaa 1) / 4 rq + q (msaa 4)
