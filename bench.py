@@ -572,7 +572,7 @@ def main():
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
     # the PMC summaries under profiles/ were measured on the default invocation of each workload
-    default_workload = world == 1 and ((args.workload == "cubic" and args.paths == 10000 and args.size == 4096) or args.workload in ("glyphs", "dashed"))
+    default_workload = world == 1 and ((args.workload == "cubic" and args.paths == 10000 and args.size == 4096) or args.workload in ("glyphs", "dashed", "s100k"))
     # which formulation the library settled on for this scene (it measures both on the first frames): the marks tell
     launches_of = lambda k: kernels.get(k, {}).get("launches", 0)
     triangle_pass = launches_of("raster_prim_setup") > launches_of("raster_bin")
