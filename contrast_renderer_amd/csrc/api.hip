@@ -284,6 +284,7 @@ struct crh_frame {
     crh_scene* seen_scene = nullptr; // the Scene (and its geometry) of the frame's latest passes, and how many in a row
     uint64_t seen_generation = 0;
     uint32_t seen_passes = 0;
+    bool counts_describe_pixels = false; // the last pass drew into a cleared frame and nothing else has written the pixels since: a tile without entries is transparent (the exchange's occupancy bitmap then comes from the tile counts)
     bool last_edges = false;  // the formulation of the frame's last plain pass: the other one has other tile lists (their sizes are learned again)
     bool last_direct = false; // the pass pending verification was a direct one
     bool queue_seen = true;       // the verified pass handed items from k_bin_flat on to k_bin_edges (until known otherwise: the queue kernel is launched)
@@ -850,6 +851,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     crh_frame::BinSet& set = f->sets[f->next_set];
     const int rec = sc->next_rec;
     HIP_TRY(hipStreamWaitEvent(bin, sc->tess_done, 0)); // the tessellation this frame draws (a no-op when it finished long ago)
+    if (f->ext_read_set) HIP_TRY(hipStreamWaitEvent(bin, f->ext_read, 0)); // (the exchange reads the tile counts of the frame's passes: csrc/comm.hip)
     if (r->raster_exclusive && r->raster_events[0]) HIP_TRY(hipStreamWaitEvent(bin, r->raster_events[0], 0));
     // (each wait on another stream's event is a packet the binning lane — the critical one — spends 5 - 10 us on, satisfied or not: the
     // frame's set and the Scene's record buffer were as a rule last used by the same raster kernel, and then one wait says it all)
@@ -1087,6 +1089,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     f->check_pending = true;
     f->last_direct = direct;
     f->last_skipped_queue = skip_queue;
+    f->counts_describe_pixels = p.load_existing == 0u;
     return CRH_OK;
 }
 
@@ -1923,6 +1926,7 @@ crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written) {
     if (!f) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipEventRecord(written ? f->ext_write : f->ext_read, static_cast<hipStream_t>(stream)));
     if (written) {
+        f->counts_describe_pixels = false;
         f->ext_write_set = true;
         f->cleared = false; // it now shows an image, nothing of its own is pending
         f->check_pending = false;
@@ -1930,6 +1934,15 @@ crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written) {
     } else {
         f->ext_read_set = true;
     }
+    return CRH_OK;
+}
+// The entries per tile of the frame's last pass, on the device, when a tile without entries is a transparent tile (NULL otherwise: the
+// exchange then looks at the pixels). Valid after crh_internal_frame_info (which settles the pass).
+crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles) {
+    if (!f || !counts || !n_tiles) return CRH_ERR_INVALID_ARGUMENT;
+    const bool usable = f->counts_describe_pixels && !f->cleared && !f->check_pending && f->sets[f->last_set].used;
+    *counts = usable ? f->sets[f->last_set].tile_count_cursor.as<uint32_t>() + f->n_tiles : nullptr;
+    *n_tiles = f->n_tiles;
     return CRH_OK;
 }
 int crh_internal_renderer_device(crh_renderer* r) { return r ? r->device : -1; }

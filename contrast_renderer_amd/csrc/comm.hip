@@ -39,6 +39,7 @@ void set_last_error(const std::string& text);
 extern "C" crh_status crh_internal_frame_geometry(crh_frame* f, uint32_t* width, uint32_t* height, uint32_t* format, int* device);
 extern "C" crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device);
 extern "C" crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written);
+extern "C" crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles);
 extern "C" int crh_internal_renderer_device(crh_renderer* r);
 
 namespace {
@@ -255,6 +256,15 @@ __global__ __launch_bounds__(256) void k_tile_occupancy(const P* pixels, uint32_
     __syncthreads();
     if (threadIdx.x == 0u) bitmap[blockIdx.x] = part[0] | part[1] | part[2] | part[3];
 }
+// ... or, where the layer's last pass says how many entries every tile had (and nothing else has touched the pixels): a tile without
+// entries was written transparent by the raster kernel — the bitmap without reading the layer (a quarter of the packing at 8192^2).
+// A tile with entries that came out transparent all the same is sent as what it is.
+__global__ __launch_bounds__(256) void k_bitmap_from_counts(const uint32_t* counts, uint32_t n_tiles, uint32_t n_words, uint32_t* bitmap) {
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    const unsigned long long any = __ballot(tile < n_tiles && counts[tile] != 0u);
+    const uint32_t lane = threadIdx.x & 63u, word = tile >> 5;
+    if ((lane & 31u) == 0u && word < n_words) bitmap[word] = (uint32_t)(any >> (lane & 32u));
+}
 // prefix[w] = number of set bits in words [0, w) of a bitmap (n_words + 1 entries). Workgroup k < world: bitmap k of `bitmaps`
 // (`bitmap_stride` words apart) -> prefixes + k (n_words + 1); workgroup `world` (launched when or_bitmap is given): the union of all
 // bitmaps -> or_bitmap, and its prefix -> or_prefix. Per thread a run of words, a shuffle scan per wavefront, sixteen totals through LDS.
@@ -469,7 +479,12 @@ crh_status phase_pack(crh_comm* c, crh_frame* layer) {
     header[0] = kMagic, header[1] = w, header[2] = h | (format << 24), header[3] = (uint32_t)layer_status;
     HIP_TRY(hipMemcpyAsync(c->bitmap.p, header, kHeaderWords * 4, hipMemcpyHostToDevice, c->stream));
     uint32_t* bitmap = c->bitmap.as<uint32_t>() + kHeaderWords;
-    if (layer_status == CRH_OK) {
+    const uint32_t* counts = nullptr;
+    uint32_t counted_tiles = 0;
+    if (layer_status == CRH_OK && getenv("CRH_EXCHANGE_SCAN_PIXELS") == nullptr) (void)crh_internal_frame_tile_counts(layer, &counts, &counted_tiles);
+    if (layer_status == CRH_OK && counts && counted_tiles == c->n_tiles) {
+        hipLaunchKernelGGL(k_bitmap_from_counts, dim3((c->n_words * 32u + 255u) / 256u), dim3(256), 0, c->stream, counts, c->n_tiles, c->n_words, bitmap);
+    } else if (layer_status == CRH_OK) {
         if (format == CRH_FORMAT_RGBA16F)
             hipLaunchKernelGGL(k_tile_occupancy<uint2>, dim3(c->n_words), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, c->n_tiles, bitmap);
         else
