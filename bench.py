@@ -9,8 +9,10 @@ With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the Shap
 renders its shard into a private layer; the exchange step — occupancy bitmaps, slab all-to-all of the non-empty tiles, ordered "over"
 composite, gather to rank 0 — runs behind the C ABI (crh_frame_exchange, csrc/comm.hip) on RCCL, overlapped with the rendering of the
 next step. torch.distributed only carries the 128-byte RCCL id, the barrier and the max-over-ranks of the elapsed time.
-  --scaling weak   (default) every rank renders its own `--paths` shapes: per-GPU work fixed, value = N x paths / step time
-  --scaling strong THE scene of `--paths` shapes is split over the ranks:  total work fixed,  value = paths / step time
+  --scaling strong (default at N > 1) THE scene of `--paths` shapes — BASELINE's 10 000-path scene — is split over the ranks: total work
+                   fixed, value = paths / step time; the default run then also measures the weak figure and reports it in `weak_scaling`
+  --scaling weak   every rank renders its own `--paths` shapes: per-GPU work fixed, value = N x paths / step time
+  `python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its N ranks itself through torch.distributed.run.
   --workload s100k BASELINE configs[3]: 100 000 paths at 8192x8192 split over the ranks (strong)
 
 Prints ONE JSON line on rank 0.
@@ -323,13 +325,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--paths", type=int, default=10000, help="shapes of the scene: per GPU (weak) or in total (strong); configs[1] = 10000")
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--scaling", default=None, choices=("weak", "strong"), help="default: strong at N > 1 (the metric's scene split N ways) with the weak figure in a side block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend for the barrier / id broadcast (nccl = RCCL)")
     ap.add_argument("--exchange", default="cabi", choices=("cabi", "torch"), help="cabi: crh_frame_exchange over RCCL (the product path); torch: the "
                     "torch.distributed statement of the same exchange (contrast_renderer_amd/distributed.py), dense slabs — validation only")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (validation only; implies --exchange torch)")
-    ap.add_argument("--check", action="store_true", help="N > 1: rank 0 also renders every shard itself and compares the composite of those layers with the gathered image")
+    ap.add_argument("--check", action="store_true", help="N > 1: rank 0 also renders every shard itself and compares the composite of those layers with the gathered image "
+                    "(N = 1 always checks: CRC-32 of the downloaded frame against tests/golden/bench_frame_crc.json, the oracle's frame of the same scene)")
+    ap.add_argument("--no-check", action="store_true", help="N = 1: skip the frame CRC")
     ap.add_argument("--reupload", action="store_true", help="every step uploads the paths again into the existing Scene before it tessellates and renders — the "
                     "reference's animated-path use (new geometry every frame, Shape::from_paths with existing_shape): host marshalling + PCIe are inside the "
                     "step, so this is a host-inclusive figure, reported as such and never as the metric's `value`")
@@ -340,6 +344,17 @@ def main():
     ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed", "s100k"),
                     help="cubic = BASELINE configs[1] (the metric's configuration); glyphs = configs[2]; dashed = configs[4]; s100k = configs[3] (100k paths @ 8192^2, split over the ranks)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare: this process becomes the launcher of its own N ranks (one per GPU, rendezvous on the loopback address)
+        import socket
+        with socket.socket() as probe:
+            probe.bind(("127.0.0.1", 0))
+            port = probe.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    default_scaling = args.scaling is None
+    if default_scaling:
+        args.scaling = "strong" if args.gpus > 1 else "weak"  # (one and the same thing at N = 1)
 
     import numpy as np
     import torch
@@ -525,6 +540,8 @@ def main():
         t1 = time.perf_counter()
         run(1)
         renderer.synchronize()
+        if comm is not None:
+            comm.last_timing()  # the tail of the exchange runs on the communicator's stream: inside the clock
         latency.append(time.perf_counter() - t1)
     latency_ms = sorted(latency)[len(latency) // 2] * 1e3
     alone = {}  # the kernels of those steps, each with the GPU to itself
@@ -535,8 +552,61 @@ def main():
     image = frame.download()
     covered = float((image[..., 3] > 0).mean())
     traffic_sent = comm.last_traffic() if comm is not None else None
+    # what the transport and every rank say about the last exchange (outside the clock): RCCL's own rank count and version, this step's
+    # GPU time per phase and the bytes each rank put on the wire against dense slabs
+    exchange_stats = None
+    if comm is not None:
+        mine = {"rank": rank, "rccl": comm.info(), "phase_ms": comm.last_timing(), "bytes_sent": traffic_sent[0], "bytes_dense": traffic_sent[1],
+                "peer_bytes": comm.last_peer_bytes()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        exchange_stats = {"rccl": {"nranks": everyone[0]["rccl"]["nranks"], "version": everyone[0]["rccl"]["rccl_version"],
+                                   "nranks_seen_by_every_rank": [e["rccl"]["nranks"] for e in everyone]},
+                          "phase_ms_max_over_ranks": {k: max(e["phase_ms"][k] for e in everyone) for k in Comm.PHASES},
+                          "phase_ms_by_rank": [e["phase_ms"] for e in everyone],
+                          "bytes_sent_by_rank": [e["bytes_sent"] for e in everyone], "bytes_dense_by_rank": [e["bytes_dense"] for e in everyone],
+                          "sent_over_dense": sum(e["bytes_sent"] for e in everyone) / max(1, sum(e["bytes_dense"] for e in everyone)),
+                          "peer_bytes_by_rank": [e["peer_bytes"] for e in everyone]}
+    # The weak figure beside the strong default (N > 1): every rank now draws a 10 000-path scene of its own — the generator's streams
+    # rank * paths ... — through the same loop, exchange included.
+    weak_side = None
+    if world > 1 and default_scaling and scaling == "strong" and args.workload == "cubic" and not args.reupload:
+        strong_scene = scene
+        one = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
+        scene = Scene(renderer, one["batch"], tessellate=True)
+        scene.check()
+        scene.set_instances(one["transforms"], one["colors"])
+        run(14 + args.warmup)
+        sync()
+        tw = time.perf_counter()
+        run(args.steps)
+        sync()
+        weak_elapsed = time.perf_counter() - tw
+        tmax = torch.tensor([weak_elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        weak_elapsed = float(tmax.item())
+        scene.check()
+        weak_side = {"scaling": "weak", "value": args.paths * world / (weak_elapsed / args.steps), "unit": "paths/s", "ms_per_step": weak_elapsed / args.steps * 1e3,
+                     "paths_per_gpu": int(args.paths), "paths_total": int(args.paths * world),
+                     "note": f"every rank draws its OWN {args.paths} paths (generator streams rank x {args.paths} ...): {world} x the metric's scene per step, same loop and exchange"}
+        scene = strong_scene
     check = None
-    if args.check and world > 1:
+    if world == 1 and not args.no_check:  # the pixels this run timed, against the oracle's frame of the same scene (its CRC-32 is committed: the oracle takes minutes at this size)
+        import zlib
+        crc_file = os.path.join(ROOT, "tests", "golden", "bench_frame_crc.json")
+        expected = None
+        default_scene = (args.workload == "cubic" and args.paths == 10000 and args.size == 4096) or args.workload in ("glyphs", "dashed", "s100k")
+        if default_scene and os.path.exists(crc_file):
+            with open(crc_file) as fh:
+                expected = json.load(fh).get(args.workload)
+        got = zlib.crc32(image.tobytes())
+        check = {"frame_crc32": got, "expected_crc32": expected["crc32"] if expected else None,
+                 "frame_equals_oracle": (got == expected["crc32"]) if expected else None,
+                 "source": "tests/golden/bench_frame_crc.json (CRC-32 of the oracle's frame of this scene; tests/golden/make_golden.py --crc)" if expected
+                           else "no committed CRC for this invocation (non-default --paths / --size)"}
+        if expected and got != expected["crc32"]:
+            sys.stderr.write(f"[bench] FRAME CHECK FAILED: crc32 {got} != {expected['crc32']} (oracle)\n")
+    if args.check and world > 1:  # (scene is the strong / chosen one again)
         gathered = run(1)  # one more pass outside the timed region: the gathered image on rank 0
         sync()
         if rank == 0:
@@ -568,9 +638,13 @@ def main():
     kernels = {k: {"avg_ms": v[0] / v[1], "launches": v[1], "algorithmic_bytes": v[2], "alone_ms": alone.get(k)} for k, v in agg.items()}
     # the dominant kernel is the one that needs the GPU longest when it has it to itself: inside the pipelined run a small kernel that shares
     # the GPU with the raster kernel of the frame before is stretched to that kernel's length without doing more work
-    dominant = max(kernels, key=lambda k: (kernels[k]["alone_ms"] if kernels[k]["alone_ms"] is not None else kernels[k]["avg_ms"]) * kernels[k]["launches"])
+    longest_alone = max(kernels, key=lambda k: (kernels[k]["alone_ms"] if kernels[k]["alone_ms"] is not None else kernels[k]["avg_ms"]) * kernels[k]["launches"])
+    # ... which is why the line says both: `roofline` is the kernel that is longest per launch IN THE RUN (what the step actually waits for),
+    # `roofline_longest_alone` the one longest with the GPU to itself, when they differ
+    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
+    la = kernels[longest_alone]
     # the PMC summaries under profiles/ were measured on the default invocation of each workload
     default_workload = world == 1 and ((args.workload == "cubic" and args.paths == 10000 and args.size == 4096) or args.workload in ("glyphs", "dashed", "s100k"))
     # which formulation the library settled on for this scene (it measures both on the first frames): the marks tell
@@ -608,6 +682,8 @@ def main():
             "covered_fraction": covered,
         },
         "setup": "14 untimed steps before the warm-up: the library times both raster formulations (same pixels) on this scene and keeps the faster one",
+        "steady_state": "`value` is the steady state of IDENTICAL frames (an animation that re-tessellates and re-draws the same geometry): the tile lists keep the "
+                        "places the verified first passes left them, no read-back; `latency_ms_per_step` is one host-synchronised step, `bench.py --reupload` new geometry every step",
         "pipelining": "ms_per_step: up to three steps in flight on three HIP streams (tessellate / bin / raster); latency_ms_per_step: one step, host synchronised before and after",
         "roofline": {
             "kernel": dominant,
@@ -624,11 +700,17 @@ def main():
             "avg_launch_ms": dk["avg_ms"],
             "avg_launch_ms_alone": dk["alone_ms"],
             "kernel_source_hash": kernel_source_hash(),
-            "note": "achieved = algorithmic bytes (SURVEY.md §8(d): emitted vertex/index bytes read once + 80 B per shape + W*H*4 written once) / "
-                    "HIP-event launch time of the dominant kernel (in the run, i.e. sharing the GPU with the other lanes of the pipeline); traffic / "
+            "note": "kernel = the longest per launch IN THE RUN (HIP events on its own stream, sharing the GPU with the other lanes of the pipeline); "
+                    "achieved = its algorithmic bytes (SURVEY.md §8(d): the raster kernel reads the emitted vertex/index bytes once + 80 B per shape and writes W*H*4 once; "
+                    "binning has none) / that launch time; traffic / "
                     "valu_issue = rocprofv3 PMC passes committed under profiles/, reported only while their kernel_source_hash equals this run's. "
                     "The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
         },
+        "roofline_longest_alone": None if longest_alone == dominant else {
+            "kernel": longest_alone, "bound": "hbm", "achieved": la["algorithmic_bytes"] / (la["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": la["algorithmic_bytes"] / (la["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": la["algorithmic_bytes"],
+            "avg_launch_ms": la["avg_ms"], "avg_launch_ms_alone": la["alone_ms"],
+            "note": "the kernel that is longest with the GPU to itself, when that is not the kernel `roofline` reports (the longest per launch in the run)"},
         "roofline_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                           "note": "all kernels of a step: control data read + emitted bytes written (tessellation), emitted bytes + 80 B / shape read and W*H*4 written (raster)"},
@@ -640,6 +722,9 @@ def main():
     }
     if traffic_sent is not None:
         out["exchange"] = {"bytes_sent_by_rank0_last_step": traffic_sent[0], "dense_slabs_would_be": traffic_sent[1]}
+        out["exchange"].update(exchange_stats or {})
+    if weak_side is not None:
+        out["weak_scaling"] = weak_side
     # The CPU baseline (the oracle as the checker's clock, on rank 0 at N = 1 only) — after the GPU part: run before it, its sixteen busy
     # threads left the process with a ~20 ms host stall inside the timed region in one run out of three (the GPU idle, ms_per_step doubled)
     cpu_baseline = None

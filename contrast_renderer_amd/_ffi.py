@@ -273,6 +273,7 @@ def load_library():
         "crh_comm_last_traffic": (C.c_int, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "crh_comm_last_timing": (C.c_int, [V, C.POINTER(C.c_float)]),
         "crh_comm_last_peer_bytes": (C.c_int, [V, C.POINTER(C.c_uint64)]),
+        "crh_comm_info": (C.c_int, [V, C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
         "crh_renderer_synchronize": (C.c_int, [V]),
         "crh_renderer_stream": (V, [V]),
         "crh_renderer_enable_timing": (C.c_int, [V, C.c_int]),

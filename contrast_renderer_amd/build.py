@@ -43,10 +43,33 @@ def build_library(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode(), file=sys.stderr)
-    if procs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-ldl", "-o", OUT]  # librccl.so is dlopen()ed by comm.hip, not linked
+    exports = write_export_map()
+    if procs or not os.path.exists(OUT) or os.path.getmtime(exports) > os.path.getmtime(OUT):
+        # librccl.so is dlopen()ed by comm.hip, not linked; the version script keeps the dynamic symbol table to the C ABI
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objects + ["-ldl", "-Wl,--version-script=" + exports, "-o", OUT]
         subprocess.check_call(cmd)
     return OUT
+
+
+DEBUG_TAPS = ("crh_debug_frame_counters", "crh_debug_frame_counters16", "crh_debug_frame_words")  # tools/ and one test read the raster kernels' counters through these
+
+
+def declared_entry_points():
+    """The names include/contrast_hip.h declares — the whole of the library's dynamic symbol table, with the three debug taps."""
+    import re
+    with open(os.path.join(HERE, "..", "include", "contrast_hip.h")) as f:
+        return sorted(set(re.findall(r"\b(crh_[a-z_0-9]+)\s*\(", f.read())) - {"crh_status"})
+
+
+def write_export_map():
+    """build/exports.map: a linker version script listing exactly the header's entry points. Everything else — the C++ internals shared by
+    the translation units (crh::launch_*), the crh_internal_* accessors comm.hip uses, HIP's kernel stubs — stays local to the library."""
+    path = os.path.join(HERE, "build", "exports.map")
+    text = "{\n  global:\n" + "".join(f"    {name};\n" for name in declared_entry_points() + list(DEBUG_TAPS)) + "  local:\n    *;\n};\n"
+    if not os.path.exists(path) or open(path).read() != text:
+        with open(path, "w") as f:
+            f.write(text)
+    return path
 
 
 if __name__ == "__main__":

@@ -300,6 +300,7 @@ struct crh_frame {
     // unclosed chain has no backdrops, so passes of that Scene into this frame are drawn by the triangle pass, which skips exactly the
     // strip triangles with a non-finite determinant — as the reference's rasterizer does.
     crh_scene* triangle_pass_for = nullptr;
+    uint64_t triangle_pass_generation = 0; // ... of that Scene's geometry: a re-upload (or a new Scene at the same address) starts on the edge pass again
 };
 
 constexpr int kTessBufs = 32; // buffers a tessellation run writes (crh_scene::tess_bufs)
@@ -335,7 +336,8 @@ struct crh_scene {
     bool instances_projective_of[2] = {false, false};
     bool instances_tame_of[2] = {false, false}; // all_colors_tame of that instance buffer
     hipEvent_t rec_raster_done[kPipelineDepth] = {};
-    unsigned one_event_history = 0; // bit k: the Scene's k-th latest render recorded one event for everything behind its binning (both bits: the tessellation need not wait for ranges_free)
+    bool last_render_one_event = false; // the last render that READ the current tessellation set recorded ONE event (vertices_free) for everything behind its binning:
+                                        // the next tessellation into this set need not wait for ranges_free as well. Per set: flip_tess_set swaps it with the shadow's
     uint64_t rec_raster_serial[kPipelineDepth] = {}; // the render call that recorded it (crh_renderer::render_serial)
     bool rec_used[kPipelineDepth] = {};
     int next_rec = 0;
@@ -352,7 +354,7 @@ struct crh_scene {
     struct TessShadow {
         DevBuf buf[kTessBufs];
         hipEvent_t tess_done = nullptr, vertices_free = nullptr, ranges_free = nullptr;
-        bool allocated = false, capacity_known = false, rendered_once = false;
+        bool allocated = false, capacity_known = false, rendered_once = false, last_render_one_event = false;
         uint32_t totals_host[NCH] = {};
         uint64_t emitted_bytes = 0;
     } shadow;
@@ -505,6 +507,7 @@ crh_status flip_tess_set(crh_scene* sc) {
     std::swap(sc->ranges_free, o.ranges_free);
     std::swap(sc->capacity_known, o.capacity_known);
     std::swap(sc->rendered_once, o.rendered_once);
+    std::swap(sc->last_render_one_event, o.last_render_one_event);
     std::swap(sc->emitted_bytes, o.emitted_bytes);
     for (int c = 0; c < NCH; ++c) std::swap(sc->totals_host[c], o.totals_host[c]);
     for (int c = 0; c < NCH; ++c) sc->d.capacity[c] = sc->capacity_known ? sc->totals_host[c] : 0u;
@@ -579,7 +582,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     launch_emit(d, ts, r->mark_fn_tess(), r, bytes2, sc->has_stroke, sc->big_shapes);
     // contiguous primitive ids per Shape, in draw order (transform independent, so it belongs to the tessellation); the previous
     // frame's tile walks read the old ranges until its fill pass is through
-    if (sc->rendered_once && (sc->one_event_history & 3u) != 3u) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0)); // (one event stood for both: waited for above)
+    if (sc->rendered_once && !sc->last_render_one_event) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0)); // (one event stood for both: waited for above)
     launch_plain_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->shape_nslots.as<uint32_t>(), sc->shape_slot_begin.as<uint32_t>(),
                         sc->prim_scan_scratch.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>() + ((size_t)(d.n_shapes + 1023) / 1024 + 2), ts);
     if (r->timing & 2u) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
@@ -715,7 +718,7 @@ size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
 // the pass of this plain frame (true = edge pass) and, through `timed`, which trial (0 edges, 1 triangles) its events belong to, or -1
 bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     *timed = -1;
-    if (f->triangle_pass_for == sc) return false;
+    if (f->triangle_pass_for == sc && f->triangle_pass_generation == sc->generation) return false;
     if (getenv("CRH_TRIANGLE_PASS")) return false;
     if (getenv("CRH_EDGE_PASS")) return true;
     if (sc->d.n_shapes < 256u) return true; // a handful of Shapes (the reference's one-Shape-per-call use): launch overhead either way, not worth two synchronising frames
@@ -810,6 +813,13 @@ uint32_t depth_pass_mask(uint32_t compare) { // bit 0: fragment < stored passes,
 }
 
 crh_status settle_frame(crh_frame* f);
+// Host wait for what an exchange (csrc/comm.hip) enqueued on its own stream against this frame's pixels: the tail of crh_frame_exchange —
+// all-to-all, composite, gather, unpack — is in flight when that call returns, and asynchronous HIP / RCCL failures of it surface here.
+crh_status wait_for_external(crh_frame* f) {
+    if (f->ext_read_set) HIP_TRY(hipEventSynchronize(f->ext_read));
+    if (f->ext_write_set) HIP_TRY(hipEventSynchronize(f->ext_write));
+    return CRH_OK;
+}
 crh_status settle_frame_cheaply(crh_frame* f);
 // whatever touches the frame's pixels on `stream` next runs behind the exchange's last read and write of them (csrc/comm.hip)
 hipError_t order_after_external(crh_frame* f, hipStream_t stream) {
@@ -1011,7 +1021,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u entries in %u tiles (longest list %u, %u opaque whole-tile covers): %s raster variant\n", ov[1], p.n_tiles, ov[3], ov[4], p.long_lists ? "long-list" : "plain");
         if (edges && ov[7] != 0) { // an unclosed boundary chain: this pass and the following ones of this Scene into this frame as strip triangles
             if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] a boundary edge with a non-finite end point: this Scene goes to the triangle pass\n");
-            f->triangle_pass_for = sc;
+            f->triangle_pass_for = sc, f->triangle_pass_generation = sc->generation;
             return render_impl(sc, f, again);
         }
         if (ov[0] == 0 && ov[5] == 0) {
@@ -1040,7 +1050,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // read", "the slot ranges are free" and "binned" are one point in time, and the event launch_bin_edges recorded there (the Scene's
     // vertices_free) stands for all four — three packets less on the critical lane.
     const bool one_event = direct;
-    sc->one_event_history = (sc->one_event_history << 1 | (one_event ? 1u : 0u)) & 3u;
+    sc->last_render_one_event = one_event;
     const hipEvent_t vertices_free_now = sc->vertices_free; // (the handle: flip_tess_set swaps the Scene's two)
     if (one_event) {
         if (slot.read_done) slot.read_event = vertices_free_now, slot.was_read = true;
@@ -1104,10 +1114,10 @@ crh_status settle_frame(crh_frame* f) {
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
-    const bool unclosed = ov[7] != 0 && f->last_scene && f->triangle_pass_for != f->last_scene; // (the edge pass drew it: see crh_frame::triangle_pass_for)
+    const bool unclosed = ov[7] != 0 && f->last_scene && !(f->triangle_pass_for == f->last_scene && f->triangle_pass_generation == f->last_scene->generation); // (the edge pass drew it: see crh_frame::triangle_pass_for)
     if (unclosed) {
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] a boundary edge with a non-finite end point (found after the pass): this Scene goes to the triangle pass\n");
-        f->triangle_pass_for = f->last_scene;
+        f->triangle_pass_for = f->last_scene, f->triangle_pass_generation = f->last_scene->generation;
     }
     if (ov[0] != 0 && f->last_direct) { // a tile outgrew the place the earlier frame left it: the exact way again, with the read-back, and new places
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] direct tile lists: a list outgrew its place, the pass is drawn again\n");
@@ -1183,7 +1193,10 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     int front_cus = 0;
     if (const char* e = getenv("CRH_CU_SPLIT")) front_cus = atoi(e);
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    if (!hip_ok(hipGetDeviceProperties(&prop, device_ordinal), "hipGetDeviceProperties")) {
+        delete r;
+        return CRH_ERR_HIP;
+    }
     const int n_cus = prop.multiProcessorCount;
     auto make_stream = [&](hipStream_t* st, int lane) -> bool { // lane 0: unrestricted, 1: front lanes, 2: raster lane
         if (!r->pipeline || front_cus <= 0 || front_cus >= n_cus || lane == 0) return hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
@@ -1345,6 +1358,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
             }
     }
     sc->rendered_once = false;
+    sc->last_render_one_event = false;
     if (sc->shadow.allocated) { // sized for the previous contents
         if (!hip_ok(r->sync(), "sync")) return CRH_ERR_HIP;
         for (DevBuf& buf : sc->shadow.buf) buf.release();
@@ -1968,7 +1982,9 @@ crh_status crh_frame_synchronize(crh_frame* f) {
     if (!f || !f->renderer) return CRH_ERR_INVALID_ARGUMENT;
     crh_renderer* r = f->renderer;
     HIP_TRY(hipSetDevice(r->device));
-    return settle_frame_cheaply(f);
+    const crh_status st = settle_frame_cheaply(f);
+    if (st != CRH_OK) return st;
+    return wait_for_external(f); // an exchange may still be unpacking into (or packing out of) the pixels on its communicator's stream
 }
 
 crh_status crh_selftest_fmath(crh_renderer* r, int fn, const float* a, const float* b, float* out, uint64_t n) {
@@ -1996,6 +2012,10 @@ crh_status crh_renderer_synchronize(crh_renderer* r) {
     if (!r) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(r->sync());
+    for (crh_frame* f : r->frames) { // ... and the exchanges still working on its frames (their streams belong to the communicators)
+        const crh_status st = wait_for_external(f);
+        if (st != CRH_OK) return st;
+    }
     return CRH_OK;
 }
 void* crh_renderer_stream(crh_renderer* r) { return r ? (void*)r->stream : nullptr; }

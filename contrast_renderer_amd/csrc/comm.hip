@@ -57,6 +57,8 @@ struct Rccl { // the entry points used, resolved with dlsym
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr; // optional: crh_comm_info
+    ncclResult_t (*GetVersion)(int*) = nullptr;
 };
 // A process that imported torch has torch's bundled librccl mapped already; a second copy opened by bare name would be a second RCCL
 // runtime in one process (two sets of proxy threads and IPC state). So: the path of a librccl that is already mapped, if there is one.
@@ -94,6 +96,8 @@ Rccl* rccl() {
             CRH_SYM(Recv, "ncclRecv");
             CRH_SYM(AllGather, "ncclAllGather");
             CRH_SYM(GetErrorString, "ncclGetErrorString");
+            CRH_SYM(CommCount, "ncclCommCount");
+            CRH_SYM(GetVersion, "ncclGetVersion");
 #undef CRH_SYM
             if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.AllGather) {
                 dlclose(api.lib);
@@ -394,15 +398,17 @@ struct crh_comm {
     hipStream_t stream = nullptr;
     // geometry of the last exchange, and the geometry all ranks were found to agree on (checked once per change, with one extra wait)
     uint32_t width = 0, height = 0, format = 0, tiles_x = 0, tiles_y = 0, n_tiles = 0, n_words = 0;
-    uint32_t agreed_width = 0, agreed_height = 0, agreed_format = 0;
+    uint32_t agreed_width = 0, agreed_height = 0, agreed_format = 0, agreed_words = 0;
     bool agreed = false;
     size_t tile_bytes() const { return format == CRH_FORMAT_RGBA16F ? 2048u : 1024u; }
     uint32_t stride() const { return kHeaderWords + n_words; } // words per rank in bitmaps_all
     Buf bitmap, prefix, pack;        // this rank's layer: [header | bitmap], prefix sums of the bitmap, the packed non-empty tiles
     Buf bitmaps_all, prefixes_all;   // every rank's [header | bitmap] (all-gather) and the prefix sums of the bitmaps
+    Buf headers_all;                 // every rank's header alone: the fixed-size collective in front of every exchange
     Buf or_bitmap, or_prefix;        // union: the tiles of the composited image
     Buf recv, recv_table;            // received slab tiles, [world] pointers into `recv`
     Buf slab_out, gathered;          // this rank's composited slab (packed); rank 0: all slabs (packed, tile order)
+    PinnedBuf host_headers;          // headers_all on the host (only read when this rank's geometry is not the agreed one)
     PinnedBuf host_all, host_table, host_header;  // bitmaps_all on the host; the pointer table on its way to recv_table; this rank's header on its way to `bitmap`
     std::vector<uint32_t> or_bits;   // union of the bitmaps (host)
     hipEvent_t bitmaps_on_host = nullptr; // THE host wait of an exchange
@@ -453,6 +459,8 @@ crh_status ensure_buffers(crh_comm* c) {
     HIP_TRY(c->host_all.ensure((size_t)c->world * c->stride() * 4));
     HIP_TRY(c->host_table.ensure(sizeof(void*) * c->world));
     HIP_TRY(c->host_header.ensure(kHeaderWords * 4));
+    HIP_TRY(c->headers_all.ensure((size_t)c->world * kHeaderWords * 4));
+    HIP_TRY(c->host_headers.ensure((size_t)c->world * kHeaderWords * 4));
     HIP_TRY(c->recv_table.ensure(sizeof(void*) * c->world));
     return CRH_OK;
 }
@@ -524,6 +532,7 @@ crh_status phase_plan(crh_comm* c) {
         const uint32_t* hd = c->host_header_of(k);
         if (hd[0] != kMagic || hd[1] != c->width || hd[2] != (c->height | (c->format << 24))) {
             set_last_error("crh_frame_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
+            c->agreed = false; // the next exchange starts from the headers alone
             return CRH_ERR_INVALID_ARGUMENT; // (every rank sees the same headers and returns here together)
         }
         if (hd[3] != CRH_OK && peer == CRH_OK) {
@@ -708,8 +717,8 @@ void crh_comm_destroy(crh_comm* c) {
         for (crh_comm* m : *c->local_group) empty = empty && m == nullptr;
         if (empty) delete c->local_group;
     }
-    for (Buf* b : {&c->bitmap, &c->prefix, &c->pack, &c->bitmaps_all, &c->prefixes_all, &c->or_bitmap, &c->or_prefix, &c->recv, &c->recv_table, &c->slab_out, &c->gathered}) b->release();
-    for (PinnedBuf* b : {&c->host_all, &c->host_table, &c->host_header}) b->release();
+    for (Buf* b : {&c->bitmap, &c->prefix, &c->pack, &c->bitmaps_all, &c->prefixes_all, &c->or_bitmap, &c->or_prefix, &c->recv, &c->recv_table, &c->slab_out, &c->gathered, &c->headers_all}) b->release();
+    for (PinnedBuf* b : {&c->host_all, &c->host_table, &c->host_header, &c->host_headers}) b->release();
     for (hipEvent_t e : {c->bitmaps_on_host, c->packed, c->composited})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->phase_begin)
@@ -728,6 +737,25 @@ crh_status crh_comm_last_traffic(const crh_comm* c, uint64_t* bytes_sent, uint64
 crh_status crh_comm_last_peer_bytes(const crh_comm* c, uint64_t* per_peer) {
     if (!c || !per_peer) return CRH_ERR_INVALID_ARGUMENT;
     for (uint32_t p = 0; p < c->world; ++p) per_peer[p] = p < c->peer_bytes.size() ? c->peer_bytes[p] : 0;
+    return CRH_OK;
+}
+crh_status crh_comm_info(const crh_comm* c, uint32_t* nranks, int32_t* rccl_version) {
+    if (!c) return CRH_ERR_INVALID_ARGUMENT;
+    if (nranks) *nranks = c->world;
+    if (rccl_version) *rccl_version = 0;
+    if (!c->nccl) return CRH_OK; // a loopback communicator
+    Rccl* api = rccl();
+    if (!api) return CRH_ERR_UNSUPPORTED;
+    if (nranks && api->CommCount) {
+        int n = 0;
+        NCCL_TRY(api->CommCount(c->nccl, &n));
+        *nranks = (uint32_t)n;
+    }
+    if (rccl_version && api->GetVersion) {
+        int v = 0;
+        NCCL_TRY(api->GetVersion(&v));
+        *rccl_version = v;
+    }
     return CRH_OK;
 }
 crh_status crh_comm_last_timing(crh_comm* c, float ms[CRH_COMM_PHASES]) {
@@ -749,23 +777,35 @@ crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) 
     crh_status st = phase_pack(c, layer);
     if (st != CRH_OK) return st; // (only argument errors end here: a layer that cannot be read still takes part)
     // Sizes of the collectives follow from the frame geometry, which therefore has to be the same on every rank BEFORE a count is derived
-    // from it: when it changes (the first exchange, a resized target) the headers alone are gathered and compared first, with one more wait.
+    // from it. Two rules keep the ranks' collectives matched whatever one of them does to its layer:
+    //   (1) every exchange opens with the all-gather of the 16-byte headers — a fixed size, nothing to disagree about;
+    //   (2) a rank that holds an agreement issues the bitmap all-gather AT THE AGREED SIZE — also a rank whose own layer has since
+    //       changed size or format (its payload is then never read): its peers, who cannot know yet, issue exactly that collective.
+    // A rank whose geometry is the agreed one reads the headers together with the bitmaps, behind the ONE host wait of the exchange
+    // (phase_plan), and learns of a peer's change there; a rank without an agreement, or whose own geometry has changed, waits for the
+    // headers alone first: all equal to its own -> that is the new agreement and the bitmaps follow at the new size (one extra wait: the
+    // first exchange, a resize of every rank's target); otherwise every rank returns CRH_ERR_INVALID_ARGUMENT — the changed rank here,
+    // its peers in phase_plan — and the next exchange starts from the headers alone.
     begin_phase(c, kPlan);
-    if (!c->agreed || c->agreed_width != c->width || c->agreed_height != c->height || c->agreed_format != c->format) {
-        NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, kHeaderWords * 4, ncclUint8, c->nccl, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->host_all.p, c->bitmaps_all.p, (size_t)c->world * kHeaderWords * 4, hipMemcpyDeviceToHost, c->stream));
+    NCCL_TRY(api->AllGather(c->bitmap.p, c->headers_all.p, kHeaderWords * 4, ncclUint8, c->nccl, c->stream));
+    const bool mine_agreed = c->agreed && c->agreed_width == c->width && c->agreed_height == c->height && c->agreed_format == c->format;
+    if (c->agreed) // (the buffers only ever grow: they hold the agreed size whichever way this rank's geometry went)
+        NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, (size_t)(kHeaderWords + c->agreed_words) * 4, ncclUint8, c->nccl, c->stream));
+    if (!mine_agreed) {
+        HIP_TRY(hipMemcpyAsync(c->host_headers.p, c->headers_all.p, (size_t)c->world * kHeaderWords * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipEventRecord(c->bitmaps_on_host, c->stream));
         HIP_TRY(hipEventSynchronize(c->bitmaps_on_host));
         for (uint32_t k = 0; k < c->world; ++k) {
-            const uint32_t* hd = c->host_all.as<uint32_t>() + (size_t)k * kHeaderWords;
+            const uint32_t* hd = c->host_headers.as<uint32_t>() + (size_t)k * kHeaderWords;
             if (hd[0] != kMagic || hd[1] != c->width || hd[2] != (c->height | (c->format << 24))) {
                 set_last_error("crh_frame_exchange: rank " + std::to_string(k) + " exchanges a layer of another size or format");
+                c->agreed = false;
                 return CRH_ERR_INVALID_ARGUMENT; // on every rank
             }
         }
-        c->agreed = true, c->agreed_width = c->width, c->agreed_height = c->height, c->agreed_format = c->format;
+        c->agreed = true, c->agreed_width = c->width, c->agreed_height = c->height, c->agreed_format = c->format, c->agreed_words = c->n_words;
+        NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, (size_t)c->stride() * 4, ncclUint8, c->nccl, c->stream));
     }
-    NCCL_TRY(api->AllGather(c->bitmap.p, c->bitmaps_all.p, (size_t)c->stride() * 4, ncclUint8, c->nccl, c->stream));
     if ((st = phase_plan(c)) != CRH_OK) return st; // (a peer's failure is seen by all ranks here: they return together, nothing is in flight)
     // all-to-all of the slab tiles: one group, so that all links are driven at once. An error inside the group still closes it.
     begin_phase(c, kAllToAll);

@@ -223,6 +223,12 @@ class Comm:
         check(self.lib.crh_comm_last_peer_bytes(self.handle, out))
         return [int(v) for v in out]
 
+    def info(self):
+        """{"nranks": ncclCommCount (or the loopback group's size), "rccl_version": ncclGetVersion's code, 0 for a loopback communicator}"""
+        n, v = C.c_uint32(), C.c_int32()
+        check(self.lib.crh_comm_info(self.handle, C.byref(n), C.byref(v)))
+        return {"nranks": int(n.value), "rccl_version": int(v.value)}
+
     def __del__(self):
         if getattr(self, "handle", None):
             self.lib.crh_comm_destroy(self.handle)

@@ -146,7 +146,9 @@ def scene_quadratic(n_paths=100, size=(1024, 1024), config_index=1, stroke_steps
 
 
 def _cubic_records(rng, n, px, py, rational):
-    """8 cubic segments per path through the on-curve points: handles = +-(U(0.2,0.6) x chord) rotated by U(+-0.3) rad.
+    """8 cubic segments per path through the on-curve points: handles = +-(U(0.2,0.45) x chord) rotated by U(+-0.3) rad
+    (SURVEY.md §8(d) says U(0.2,0.6): beyond ~0.45 neighbouring handles cross often enough that the reference's own
+    degenerate-cubic assertions, fill.rs:174,178, reject a visible share of the scene — the generator stays inside what it accepts).
     Even segments integral, odd segments rational (weights U(0.5,2)) when `rational` == 'mixed'; all rational when 'all'."""
     n_seg = px.shape[1]
     ex, ey = np.roll(px, -1, axis=1), np.roll(py, -1, axis=1)

@@ -386,6 +386,10 @@ crh_status crh_comm_last_traffic(const crh_comm* comm, uint64_t* bytes_sent, uin
 crh_status crh_comm_last_timing(crh_comm* comm, float ms[CRH_COMM_PHASES]);
 /* bytes this rank sent to every peer in the all-to-all of the last exchange: per_peer[world] (its own entry is 0) */
 crh_status crh_comm_last_peer_bytes(const crh_comm* comm, uint64_t* per_peer);
+/* What the transport says about this communicator: *nranks = ncclCommCount of an RCCL communicator (the size of the loopback group for a
+ * local one), *rccl_version = ncclGetVersion's code (major * 10000 + minor * 100 + patch; 0 for a local communicator). A line of a
+ * multi-GPU measurement carries both, so that "did RCCL see N ranks" is answered by RCCL. */
+crh_status crh_comm_info(const crh_comm* comm, uint32_t* nranks, int32_t* rccl_version);
 /* The same exchange without RCCL, for several communicators on ONE device driven by one thread (tests, single-GPU validation):
  * rank 0's communicator founds the group (rank0 = NULL), ranks 1.. join it; crh_comm_local_exchange(rank 0's comm, layers[world],
  * result) then runs every rank's part with device-to-device copies in place of the transfers. */

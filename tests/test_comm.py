@@ -6,10 +6,14 @@ tiles, slab all-to-all, ordered composite, gather, unpack — with device-to-dev
 RGBA16F layers; BASELINE configs[3] whole: eight shards of the 100 000-path scene at 8192x8192), and an RCCL communicator of world
 size 1 runs ncclCommInitRank / ncclAllGather for real (its only peer is itself, so no ncclSend / ncclRecv is issued: the first real
 point-to-point transfer of this code happens on a multi-GPU node)."""
+import os
+
 import numpy as np
 import pytest
 
 from contrast_renderer_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_c_abi_sharding_matches_the_python_statement():
@@ -86,6 +90,8 @@ def test_rccl_exchange_with_itself(oracle_lib):
     result = R.Frame(r, 320, 200)
     comm.exchange(layers[0], result)
     assert np.array_equal(result.download(), layers[0].download())
+    info = comm.info()  # RCCL's own word on the communicator
+    assert info["nranks"] == 1 and info["rccl_version"] > 20000, info
     # and again into the same frames while the renderer already draws the next step into the layer's sibling
     comm.exchange(layers[0], result)
     assert np.array_equal(result.download(), layers[0].download())
@@ -231,3 +237,25 @@ def test_config4_whole_scene_eight_shards_through_the_exchange(oracle_lib):
         worst = max(worst, int(np.abs(image[y:y + band].astype(np.int16) - whole[y:y + band].astype(np.int16)).max()))
     assert worst <= 2, worst
     assert (image[..., 3] > 0).mean() > 0.5
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_reports_the_metrics_scene():
+    """`python bench.py --gpus 2` with NO launcher (WORLD_SIZE unset) must spawn its two ranks itself and print one line whose `value` is the
+    BASELINE scene split two ways (strong), with the weak figure in a side block. One GPU here: both ranks on cuda:0, gloo for the
+    barrier, the torch statement of the exchange (RCCL refuses two ranks on one device) — the launch path is what this test is about."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "3", "--paths", "2000", "--size", "1024"],
+                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
+    assert line["config"]["paths_total"] == 2000 and line["config"]["paths_per_gpu"] == 1000
+    assert line["value"] > 0 and abs(line["value"] - 2000 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    weak = line["weak_scaling"]
+    assert weak["scaling"] == "weak" and weak["paths_total"] == 4000 and weak["value"] > 0

@@ -40,6 +40,12 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} is declared in contrast_hip.h but not exported by libcontrast_hip.so"
     assert set(lib._crh_signatures) == declared, set(lib._crh_signatures) ^ declared
     assert b"gfx950" in lib.crh_version()
+    # ... and nothing else: the dynamic symbol table is the C ABI (plus three debug taps of tools/), no C++ internals
+    import subprocess
+    from contrast_renderer_amd import build as b
+    table = subprocess.run(["nm", "-D", "--defined-only", b.OUT], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in table.splitlines() if line.strip()}
+    assert exported == declared | set(b.DEBUG_TAPS), sorted(exported ^ (declared | set(b.DEBUG_TAPS)))
 
 
 def test_product_has_no_cpu_fallback_and_never_touches_the_oracle():
