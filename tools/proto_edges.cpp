@@ -2,6 +2,10 @@
 // written the way csrc/raster_edges.hip evaluates it (tile-relative f32 arithmetic, per-tile backdrop at q0, path q0 -> q_k -> p), checked
 // bit for bit against the triangle-strip specification of oracle/raster.hpp. Not shipped, not used by tests; it exists so that the sign
 // conventions and tie rules can be verified without a GPU. Build + run: tools/proto_edges.py
+// Mode 2 (round 4) states the same sum the way the row-span raster kernel accumulates it: per (edge, sample row) ONE switch column found by
+// bisection of the exact predicate (g is a step function of x along a sample row: E = fma(ry, bx, fma(rx, nay, c)) is monotone in rx under
+// round-to-nearest), two deposits into a 16 x 16 delta grid per tile — the row constant at column 0, +-1 at the switch column — and a prefix
+// sum along every row. It must equal mode 1 (and mode 0, the oracle's strips) sample for sample.
 #include <cstdio>
 
 #include "../oracle/api.cpp"
@@ -60,6 +64,16 @@ struct TileEval {
 };
 
 // winding of the chain `edges` at every sample of the frame, accumulated into acc[y][x][s] (int), the GPU way
+static bool g_rows = false; // mode 2: the row-span accumulation
+// lower bound of a monotone predicate over the 16 columns of a sample row: 5 exact evaluations (17 possible answers)
+template <class P>
+static int first_true(P pred) {
+    int lo = 0;
+    for (int step = 8; step >= 1; step >>= 1)
+        if (!pred(lo + step - 1)) lo += step;
+    if (lo == 15 && !pred(15)) lo = 16;
+    return lo;
+}
 static void chain_winding(const Frame& f, const std::vector<Edge>& edges, std::vector<int>& acc, int& tiles_touched, long& pairs) {
     if (edges.empty()) return;
     const int W = (int)f.width, H = (int)f.height;
@@ -97,6 +111,48 @@ static void chain_winding(const Frame& f, const std::vector<Edge>& edges, std::v
                 if (gmax != gmin && box) touching.push_back(&e);
             }
             pairs += (long)touching.size();
+            if (g_rows) {
+                // ---- the row-span form. Sample rows of the tile: pixel row r, sample s -> row index r * S + s; the columns of a row are the 16
+                //      pixels at that sample's x offset. Per (edge, row): d(j) = sigma * [Y_k g(j) + A_k] with the row constant
+                //      A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k); along the row g(j) = [j >= s] (nay >= 0) or [j < s] (nay < 0).
+                std::vector<int> grid((size_t)TILE * S * TILE, 0); // delta form: w(row, j) = bd + sum_{i <= j} grid[row][i]
+                for (const Edge* ep : touching) {
+                    const Edge& e = *ep;
+                    TileEval t;
+                    t.set(e, tx, ty);
+                    const float ymin = std::fmin(e.lo[1], e.hi[1]), ymax = std::fmax(e.lo[1], e.hi[1]);
+                    const bool xr = e.lo[0] <= tx0 && tx0 < e.hi[0];
+                    const int gq0 = t.g(0.0f, ry_first);
+                    for (int r = 0; r < TILE; ++r)
+                        for (uint32_t sm = 0; sm < S; ++sm) {
+                            const float ry = (float)r + soy[sm], sy = ty0 + ry;
+                            const bool Yk = ymin <= sy && sy < ymax;
+                            const int gqk = t.g(0.0f, ry);
+                            const int A = (xr ? gqk - gq0 : 0) - (Yk ? gqk : 0);
+                            int* row = &grid[((size_t)r * S + sm) * TILE];
+                            if (!Yk) {
+                                row[0] += e.sigma * A;
+                                continue;
+                            }
+                            const bool inv = e.nay < 0.0f; // g falls along the row
+                            const int sw = first_true([&](int j) { return t.g((float)j + sox[sm], ry) != inv; });
+                            const int g_left = (sw == 0) != inv ? 1 : 0; // g at column 0
+                            row[0] += e.sigma * (A + g_left);
+                            if (sw > 0 && sw < TILE) row[sw] += e.sigma * (inv ? -1 : 1);
+                        }
+                }
+                for (int py = std::max(0, ty * TILE); py < std::min(H, ty * TILE + TILE); ++py)
+                    for (uint32_t sm = 0; sm < S; ++sm) {
+                        const int* row = &grid[((size_t)(py - ty * TILE) * S + sm) * TILE];
+                        int run = bd;
+                        for (int j = 0; j < TILE; ++j) {
+                            run += row[j];
+                            const int px = tx * TILE + j;
+                            if (px >= 0 && px < W) acc[((size_t)py * f.width + px) * S + sm] += run;
+                        }
+                    }
+                continue;
+            }
             // ---- per sample: w = bd + sum over touching edges of sigma * [xr (g(qk) - g(q0)) + Yk (g(p) - g(qk))]
             for (int py = std::max(0, ty * TILE); py < std::min(H, ty * TILE + TILE); ++py)
                 for (int px = std::max(0, tx * TILE); px < std::min(W, tx * TILE + TILE); ++px)
@@ -177,7 +233,7 @@ static void render_color_edges(Frame& f, const Shape& shape, const float m[16], 
 } // namespace proto
 
 extern "C" {
-// mode 0: oracle (triangle strips), 1: edge formulation. Outputs RGBA8 and the final stencil bytes [h][w][msaa].
+// mode 0: oracle (triangle strips), 1: edge formulation per sample, 2: edge formulation as row spans (switch columns + row prefix sums). Outputs RGBA8 and the final stencil bytes [h][w][msaa].
 int proto_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, const float* transforms, const float* colors,
                  uint32_t shape_begin, uint32_t shape_end, int mode, uint8_t* rgba8, uint8_t* winding_out, long* stats) {
     Scene* sc = static_cast<Scene*>(h);
@@ -186,6 +242,7 @@ int proto_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32
     int tiles = 0;
     long pairs = 0;
     for (uint32_t s = shape_begin; s < shape_end && s < sc->shapes.size(); ++s) {
+        proto::g_rows = mode == 2;
         if (mode == 0) {
             render_stencil(f, sc->shapes[s], transforms + 16 * (size_t)s);
             render_color(f, sc->shapes[s], transforms + 16 * (size_t)s, colors + 4 * (size_t)s);

@@ -40,7 +40,7 @@ def run(lib, batch, w, h, msaa, bits, t, c, label):
     fp = C.POINTER(C.c_float)
     outs = []
     stats = (C.c_long * 2)()
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         img = np.zeros((h, w, 4), np.uint8)
         wind = np.zeros((h, w, msaa), np.uint8)
         lib.proto_render(handle, w, h, msaa, bits, t.ctypes.data_as(fp), c.ctypes.data_as(fp), 0, n, mode, img.ctypes.data, wind.ctypes.data, stats)
@@ -48,8 +48,11 @@ def run(lib, batch, w, h, msaa, bits, t, c, label):
     lib.oracle_free(handle)
     dp = int((outs[0][0] != outs[1][0]).any(axis=2).sum())
     dw = int((outs[0][1] != outs[1][1]).sum())
-    print(f"{label}: {n} shapes {w}x{h} msaa {msaa} bits {bits}: pixels differ {dp}, stencil bytes differ {dw}; tiles {stats[0]} pairs {stats[1]}")
-    return dp + dw
+    dp2 = int((outs[0][0] != outs[2][0]).any(axis=2).sum())  # the row-span form (mode 2) against the oracle's strips
+    dw2 = int((outs[0][1] != outs[2][1]).sum())
+    print(f"{label}: {n} shapes {w}x{h} msaa {msaa} bits {bits}: per sample: pixels differ {dp}, stencil bytes differ {dw}; "
+          f"row spans: pixels differ {dp2}, stencil bytes differ {dw2}; tiles {stats[0]} pairs {stats[1]}")
+    return dp + dw + dp2 + dw2
 
 
 def good_shapes(lib, shapes):
