@@ -43,6 +43,7 @@ def mark_to_kernel(workload, triangle_pass=False):
         # many entries per tile and opaque whole-tile covers: the 100 000 path scene)
         "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_edges<1, 4, false, true>" if workload == "s100k" else "crh::k_raster_edges<1, 4, false, false>"),
         # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
+        "raster_rows": "crh::k_raster_rows<true>" if workload == "s100k" else "crh::k_raster_rows<false>",  # the row-span kernel, where the library's trial picked it
         "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else "crh::k_bin_flat<1>",
         "raster_scatter": "crh::k_scatter",
         "tess_emit": "crh::k_emit",
@@ -225,7 +226,7 @@ def run_loopback(args, size, scaling, np):
         draw()
         comms[0].local_exchange(layers, result)
 
-    for _ in range(14 + args.warmup):  # (the library's pass trial, as in the default run)
+    for _ in range(20 + args.warmup):  # (the library's pass trial, as in the default run)
         step()
     renderer.synchronize()
     t0 = time.perf_counter()
@@ -501,7 +502,7 @@ def main():
         watchdog = threading.Timer(180.0, _stuck)
         watchdog.daemon = True
         watchdog.start()
-    run(14)
+    run(20)
     sync()
     if watchdog is not None:
         watchdog.cancel()
@@ -576,7 +577,7 @@ def main():
         scene = Scene(renderer, one["batch"], tessellate=True)
         scene.check()
         scene.set_instances(one["transforms"], one["colors"])
-        run(14 + args.warmup)
+        run(20 + args.warmup)
         sync()
         tw = time.perf_counter()
         run(args.steps)
@@ -657,7 +658,7 @@ def main():
     ms_per_step = step_s * 1e3
     # whole-step algorithmic bytes: the tessellation reads the control data and writes the emitted bytes, the raster reads the
     # emitted bytes and writes the frame (the raster mark already carries emitted + 80 B / shape + W * H * 4); binning has none
-    step_bytes = kernels.get("tess_emit", {}).get("algorithmic_bytes", 0) + kernels.get("raster_tiles", {}).get("algorithmic_bytes", 0)
+    step_bytes = kernels.get("tess_emit", {}).get("algorithmic_bytes", 0) + max(kernels.get("raster_tiles", {}).get("algorithmic_bytes", 0), kernels.get("raster_rows", {}).get("algorithmic_bytes", 0))
     out = {
         "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)" + (" — HOST-INCLUSIVE: new geometry uploaded every step (--reupload)" if args.reupload else ""),
         "value": total_paths / step_s,
@@ -681,7 +682,7 @@ def main():
             "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} ({scaling}); {exchange_note}; the exchange of step i overlaps the rendering of step i + 1",
             "covered_fraction": covered,
         },
-        "setup": "14 untimed steps before the warm-up: the library times both raster formulations (same pixels) on this scene and keeps the faster one",
+        "setup": "20 untimed steps before the warm-up: the library times its raster formulations (boundary edges per sample / strip triangles / boundary edges as row spans: same pixels) on this scene and keeps the fastest",
         "steady_state": "`value` is the steady state of IDENTICAL frames (an animation that re-tessellates and re-draws the same geometry): the tile lists keep the "
                         "places the verified first passes left them, no read-back; `latency_ms_per_step` is one host-synchronised step, `bench.py --reupload` new geometry every step",
         "pipelining": "ms_per_step: up to three steps in flight on three HIP streams (tessellate / bin / raster); latency_ms_per_step: one step, host synchronised before and after",
@@ -696,7 +697,7 @@ def main():
             "traffic_source": traffic_source,
             "algorithmic_bytes": dk["algorithmic_bytes"],
             "valu_issue": valu_issue(dominant, dk["avg_ms"], args.workload, triangle_pass) if default_workload else None,
-            "pass": "strip triangles (raster.hip)" if triangle_pass else "boundary edges + backdrops (raster_edges.hip)",
+            "pass": "strip triangles (raster.hip)" if triangle_pass else ("boundary edges + backdrops as row spans (raster_edges.hip, k_raster_rows)" if "raster_rows" in kernels else "boundary edges + backdrops (raster_edges.hip)"),
             "avg_launch_ms": dk["avg_ms"],
             "avg_launch_ms_alone": dk["alone_ms"],
             "kernel_source_hash": kernel_source_hash(),

@@ -373,13 +373,13 @@ struct crh_scene {
     struct PassTrial {
         hipEvent_t e[2] = {}; // on the raster stream: before the first timed frame is enqueued, behind the raster kernel of the last one
         bool started = false, recorded = false;
-    } pass_trial[2];
-    int pass_choice = 0;       // 0 undecided, 1 edges, 2 triangles: for targets of the size class pass_class
+    } pass_trial[3];
+    int pass_choice = 0;       // 0 undecided, 1 edges (per-sample raster kernel), 2 triangles, 3 edges with the row-span raster kernel: for targets of the size class pass_class
     uint32_t pass_frames = 0;  // plain frames of the trial under way
     uint32_t pass_class = 0;   // size class of the target the trial / choice belongs to (log4 of its area)
     uint8_t pass_known[16] = {}; // choices already measured, by size class: a Scene drawn into a large frame and a thumbnail in turn measures twice, not for ever
     uint32_t pass_geometry = 0; // what the choices were measured on: (log2 of the Shape count, log2 of the segment count) — an upload of geometry of the same class keeps them
-    float pass_ms[2] = {0.0f, 0.0f};
+    float pass_ms[3] = {0.0f, 0.0f, 0.0f};
     void tess_bufs(DevBuf* (&out)[kTessBufs]) {
         DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                                   &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut, &line_pair_mode,
@@ -715,13 +715,16 @@ size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
     if (ov[5] != 0) pairs = std::max(pairs, f->pair_capacity_bytes / 4 + f->pair_capacity_bytes / 8);
     return pairs * 4;
 }
-// the pass of this plain frame (true = edge pass) and, through `timed`, which trial (0 edges, 1 triangles) its events belong to, or -1
-bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
+// The pass of this plain frame — 1: boundary edges, per-sample raster kernel; 2: strip triangles; 3: boundary edges, row-span raster kernel
+// (k_raster_rows: msaa 1, no strokes) — and, through `timed`, which trial (candidate 0 edges, 1 triangles, 2 rows) its events belong to, or -1.
+int choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     *timed = -1;
-    if (f->triangle_pass_for == sc && f->triangle_pass_generation == sc->generation) return false;
-    if (getenv("CRH_TRIANGLE_PASS")) return false;
-    if (getenv("CRH_EDGE_PASS")) return true;
-    if (sc->d.n_shapes < 256u) return true; // a handful of Shapes (the reference's one-Shape-per-call use): launch overhead either way, not worth two synchronising frames
+    const bool rows_eligible = sc->renderer->config.msaa_sample_count == 1 && !sc->has_stroke && getenv("CRH_NO_ROWS") == nullptr;
+    if (f->triangle_pass_for == sc && f->triangle_pass_generation == sc->generation) return 2;
+    if (getenv("CRH_TRIANGLE_PASS")) return 2;
+    if (getenv("CRH_ROWS")) return rows_eligible ? 3 : 1;
+    if (getenv("CRH_EDGE_PASS")) return 1;
+    if (sc->d.n_shapes < 256u) return 1; // a handful of Shapes (the reference's one-Shape-per-call use): launch overhead either way, not worth synchronising frames
     uint32_t cls = 0; // size class of the target: the faster formulation depends on how many tiles a Shape spans
     for (uint64_t area = (uint64_t)f->width * f->height; area > 3u && cls < 15u; area >>= 2) ++cls;
     if (cls != sc->pass_class) { // a target of another size class: its own choice, measured once
@@ -729,35 +732,44 @@ bool choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
         sc->pass_choice = sc->pass_known[cls], sc->pass_frames = 0;
         for (crh_scene::PassTrial& t : sc->pass_trial) t.started = t.recorded = false;
     }
-    if (sc->pass_choice) return sc->pass_choice == 1;
+    if (sc->pass_choice == 3 && !rows_eligible) return 1;
+    if (sc->pass_choice) return sc->pass_choice;
+    const uint32_t candidates = rows_eligible ? 3u : 2u;
+    static const int code_of[3] = {1, 2, 3};
     const uint32_t n = sc->pass_frames++;
-    if (n < 12u) { // frames 0-5 edges, 6-11 triangles; *timed: 2 * pass (the group's start marker goes in front of this frame) or 2 * pass + 1 (its end marker behind it)
-        const uint32_t pass = n / 6u, k = n % 6u;
-        if (k == 3u) *timed = (int)(2u * pass);
-        if (k == 5u) *timed = (int)(2u * pass + 1u);
-        return pass == 0u;
+    if (n < 6u * candidates) { // six frames per candidate; *timed: 2 * candidate (the group's start marker goes in front of this frame) or 2 * candidate + 1 (its end marker behind it)
+        const uint32_t cand = n / 6u, k = n % 6u;
+        if (k == 3u) *timed = (int)(2u * cand);
+        if (k == 5u) *timed = (int)(2u * cand + 1u);
+        return code_of[cand];
     }
-    if (sc->pass_trial[0].recorded && sc->pass_trial[1].recorded) {
+    bool all_recorded = true;
+    for (uint32_t k = 0; k < candidates; ++k) all_recorded = all_recorded && sc->pass_trial[k].recorded;
+    if (all_recorded) {
         // The host runs frames ahead of the GPU: left to a query, a pipelined caller would have submitted its whole animation on the losing
-        // pass before the verdict arrived. One wait, on the thirteenth frame of a Scene.
+        // pass before the verdict arrived. One wait, on the first frame behind the trial.
         bool done = true;
-        for (const crh_scene::PassTrial& t : sc->pass_trial) done = done && hipEventSynchronize(t.e[1]) == hipSuccess;
+        for (uint32_t k = 0; k < candidates; ++k) done = done && hipEventSynchronize(sc->pass_trial[k].e[1]) == hipSuccess;
         if (done) {
-            for (int k = 0; k < 2; ++k) {
+            uint32_t best = 0;
+            for (uint32_t k = 0; k < candidates; ++k) {
                 float ms = 0.0f;
                 (void)hipEventElapsedTime(&ms, sc->pass_trial[k].e[0], sc->pass_trial[k].e[1]);
                 sc->pass_ms[k] = ms / 3.0f;
+                if (sc->pass_ms[k] < sc->pass_ms[best]) best = k;
             }
-            sc->pass_choice = sc->pass_ms[0] <= sc->pass_ms[1] ? 1 : 2;
+            sc->pass_choice = code_of[best];
             sc->pass_known[sc->pass_class] = (uint8_t)sc->pass_choice;
-            if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] pass trial: edges %.3f ms, triangles %.3f ms per frame -> %s\n", sc->pass_ms[0], sc->pass_ms[1], sc->pass_choice == 1 ? "edges" : "triangles");
-            return sc->pass_choice == 1;
+            if (getenv("CRH_PASS_VERBOSE"))
+                std::fprintf(stderr, "[contrast-hip] pass trial: edges %.3f ms, triangles %.3f ms, edges as row spans %.3f ms per frame -> %s\n", sc->pass_ms[0], sc->pass_ms[1],
+                             candidates == 3u ? sc->pass_ms[2] : 0.0f, best == 0u ? "edges" : (best == 1u ? "triangles" : "row spans"));
+            return sc->pass_choice;
         }
     } else { // a marker was skipped (could not happen in sequence): start over
         sc->pass_frames = 0;
-        return true;
+        return 1;
     }
-    return false; // still waiting for the trial's events: stay on the pass of the latest frames
+    return code_of[candidates - 1u]; // still waiting for the trial's events: stay on the pass of the latest frames
 }
 
 // A frame whose tiles hold many entries on average has most of them in lists of several 64-entry chunks: the raster kernel then looks for
@@ -953,7 +965,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // culling (a cull decision is per strip triangle). Everything else is the edge pass (raster_edges.hip).
     p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops)) ? 1u : 0u;
     int timed = -1;
-    const bool edges = p.general == 0u && choose_pass(sc, f, &timed);
+    const int pass = p.general == 0u ? choose_pass(sc, f, &timed) : 2;
+    const bool edges = pass != 2;
+    p.rows = pass == 3 ? 1u : 0u;
     if (edges != f->last_edges) f->pairs_known = false;
     f->last_edges = edges;
     crh_scene::PassTrial* trial = (p.general == 0u && timed >= 0) ? &sc->pass_trial[timed / 2] : nullptr;

@@ -2180,6 +2180,638 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+// ---------------------------------------------------------------------------------------------- k_raster_rows (round 4)
+// The same pass with the winding numbers ACCUMULATED IN LDS and the lanes spread over (entry, sample row) instead of every lane evaluating
+// every entry on its own samples (renderer.rs:304-318, 340-354, 565-582; vertex.rs:28-35; shaders.wgsl:233-266, 304-309). msaa 1, no strokes.
+//
+// Along a sample row the contribution of an edge entry is a STEP function of the column: g_e = accepts(fma(ry, bx, fma(rx, nay, c))) is monotone
+// in rx (round-to-nearest is monotone, twice), so  sigma * [Y_k g(j) + A_k]  is a row constant plus one unit from some switch column on.
+// A lane that owns (edge, row) finds the switch column with five evaluations of the EXACT predicate (a lower bound over 16 columns) and makes
+// two deposits into a 16 x 16 grid of the tile in DELTA form — the row constant at column 0, +-1 at the switch column; whole-tile backdrop
+// units deposit a constant per row; a curve triangle is evaluated by lanes laid over its own pixel box (one sample per lane, the per-sample
+// expressions of k_raster_edges) and deposits +-1 at (row, column) and -+1 at column + 1. A cell holds the fill winding in its low and the
+// hull winding in its high 16 bits as ONE integer (fill + 65536 * hull): deposits and prefix sums are linear, the two are taken apart after
+// the sum (exact while both stay below 2^15 in magnitude: a tile list of fewer than 32 768 entries cannot exceed it, longer ones go to
+// k_raster_edges). What is serial is only what the reference orders: a tile's entries are cut into GROUPS  N* C+  (N: edges, backdrop
+// units, curve triangles; C: cover entries — every item's covers follow all of its other entries in key order, and the N entries of an item
+// without a cover in this tile simply stay in the winding, exactly as the stencil buffer keeps them); the deposits of up to kRowSlots groups
+// go to as many grids at once (lanes packed across items: an item has three entries per tile on average), then the groups' cover entries are
+// committed in order: the pixel owners (lane = row, four consecutive columns) read their four cells, prefix-sum along the row (three adds
+// and two DPP steps inside the quad), add the winding left over from earlier items, test, blend, zero.
+// tools/proto_edges.cpp (mode 2) proves the row form against oracle/raster.hpp on the CPU; the GPU parity suite checks this kernel.
+#ifndef CRH_ROW_SLOTS
+#define CRH_ROW_SLOTS 2
+#endif
+#ifndef CRH_ROW_TILE_WAVES
+#define CRH_ROW_TILE_WAVES 6
+#endif
+constexpr uint32_t kRowSlots = CRH_ROW_SLOTS; // a power of two
+CRH_D int quad_from(int v, int ctrl_0012_or_0101, bool shift_two) { // lane c of a quad <- lane c - 1 (c - 2); lanes without a source get their own value (masked by the caller)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return shift_two ? __builtin_amdgcn_mov_dpp(v, 0x44, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(v, 0x90, 0xF, 0xF, true);
+#else
+    return v;
+#endif
+}
+// inclusive prefix sum over the wavefront with DPP modifiers (no LDS): Hillis-Steele inside the 16-lane rows (lanes without a source keep the
+// identity 0), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRH_DPP(v_, ctrl_, rows_) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v_), ctrl_, rows_, 0xF, false))
+#else
+#define CRH_DPP(v_, ctrl_, rows_) (v_)
+#endif
+CRH_D uint32_t dpp_scan_add(uint32_t v) {
+    v += CRH_DPP(v, 0x111, 0xF), v += CRH_DPP(v, 0x112, 0xF), v += CRH_DPP(v, 0x114, 0xF), v += CRH_DPP(v, 0x118, 0xF);
+    v += CRH_DPP(v, 0x142, 0xA), v += CRH_DPP(v, 0x143, 0xC);
+    return v;
+}
+// RGBA8 unorm of a resolved colour, store_pixel's arithmetic (clamp to [0, 1] with NaN -> 0, x * 255 + 0.5 truncated) in four instructions per channel
+CRH_D uint32_t pack_unorm8(float c0, float c1, float c2, float c3) {
+    const float v[4] = {c0, c1, c2, c3};
+    uint32_t out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float x = __builtin_amdgcn_fmed3f(v[ch], 0.0f, 1.0f); // a NaN operand makes v_med3_f32 return the minimum of the others: 0
+#else
+        const float x = v[ch];
+#endif
+        out |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+    }
+    return out;
+}
+// the first of the 16 columns of sample row y (x_j = j + 0.5) at which  accepts(E_j) != inv  — E = fma(y, bx, fma(x, nay, c)) is monotone in x,
+// so the predicate switches at most once —, 16 if there is none: five evaluations of the exact predicate
+CRH_D uint32_t switch_column(float y, float c, float bx, float nay, int thr, bool inv) {
+    float lo = 0.0f;
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1) {
+        const float x = lo + ((float)step - 0.5f);
+        const bool g = __float_as_int(fmaf(y, bx, fmaf(x, nay, c))) >= thr;
+        lo = (g != inv) ? lo : lo + (float)step;
+    }
+    const bool g15 = __float_as_int(fmaf(y, bx, fmaf(15.5f, nay, c))) >= thr;
+    return (lo == 15.0f && g15 == inv) ? 16u : (uint32_t)(int)lo;
+}
+template <bool LONG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE_WAVES))) void k_raster_rows(SceneDev s, RasterParams r) {
+    extern __shared__ uint32_t sort_buffer[];
+    __shared__ float4 entry_buffer[64 * 3];
+    __shared__ uint32_t grid[kRowSlots][16][16]; // [group slot][sample row][column], delta form, fill + 65536 * hull
+    __shared__ float4 frag_buffer[64 * 3];       // a curve triangle's attribute planes relative to the tile: constants, x gradients, y gradients
+    __shared__ uint8_t edge_list[64], tri_list[64], slot_of[64];
+    __shared__ uint16_t pair_start[66];          // [rank of a triangle in the chunk] its first (triangle, row) pair; [number of triangles] all pairs
+    constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
+    const uint32_t turn = blockIdx.x >> 3;
+    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
+    const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    const uint32_t tile = ty * r.tiles_x + tx;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* __restrict__ keys = sort_buffer;
+    // pixel owners: lane = (row k, quad c) owns the pixels (4c .. 4c + 3, k) of the tile: 16 bytes of a frame row
+    const uint32_t row_k = lane >> 2, quad_c = lane & 3u;
+    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+    const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
+    const uint32_t gx0 = tx * kTile + 4u * quad_c, gy = ty * kTile + row_k;
+    const int quad_m1 = quad_c >= 1u ? -1 : 0, quad_m2 = quad_c >= 2u ? -1 : 0;
+    int left[4]; // the winding the stencil buffer still holds from earlier items (non-zero only where an item's fill pokes out of its hull)
+    bool left_any = false; // ... on some sample of the tile
+    float col[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        left[i] = 0;
+        col[i][0] = col[i][1] = col[i][2] = col[i][3] = 0.0f;
+    }
+    if (r.load_existing && gy < r.height) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (gx0 + (uint32_t)i < r.width) {
+                const float4 d = load_pixel(r, gx0 + (uint32_t)i, gy);
+                col[i][0] = d.x, col[i][1] = d.y, col[i][2] = d.z, col[i][3] = d.w;
+            }
+    }
+    uint4* const my_cells = reinterpret_cast<uint4*>(&grid[0][row_k][4u * quad_c]); // + slot * 64 (uint4 units)
+#pragma unroll
+    for (uint32_t g = 0; g < kRowSlots; ++g) my_cells[g * 64u] = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t list_begin = r.direct ? r.tile_base[tile] : r.tile_offset[tile];
+    uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : (r.direct ? r.tile_count[tile] : r.tile_offset[tile + 1] - list_begin);
+    constexpr uint32_t kLdsSortMax = kSortBytesMax / 4u;
+    if (n > r.sort_capacity && n <= kLdsSortMax) { // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
+        if (r.direct && threadIdx.x == 0u) atomicMax(&r.overflow[3], n);
+        n = 0;
+    }
+    uint32_t my_key = 0xFFFFFFFFu;
+    const bool sorted_in_place = n > kLdsSortMax;
+    uint32_t* const segment = r.tile_list + list_begin;
+    if (sorted_in_place) { // as k_raster_edges: a normalised bitonic network over the tile's segment of the list, in global memory
+        const uint32_t tid = threadIdx.x, n_threads = 64u;
+        uint32_t padded = 1;
+        while (padded < n) padded <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t partner) {
+            if (partner < n) {
+                const uint32_t a = __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b = __hip_atomic_load(segment + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a > b) {
+                    __hip_atomic_store(segment + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(segment + partner, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        for (uint32_t kk = 2; kk <= padded; kk <<= 1) {
+            const uint32_t half = kk >> 1;
+            for (uint32_t p = tid; p < (padded >> 1); p += n_threads) {
+                const uint32_t blk = p / half, t = p - blk * half;
+                exchange(blk * kk + t, blk * kk + kk - 1u - t);
+            }
+            __threadfence();
+            __syncthreads();
+            for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+                for (uint32_t p = tid; p < (padded >> 1); p += n_threads) {
+                    const uint32_t i = 2u * j * (p / j) + (p % j);
+                    exchange(i, i + j);
+                }
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    } else if (n <= 64u) {
+        if (lane < n) my_key = r.tile_list[list_begin + lane];
+        // (a network as deep as the list needs: most tiles hold fewer than 32 entries)
+        const uint32_t depth = n <= 2u ? 2u : (n <= 4u ? 4u : (n <= 8u ? 8u : (n <= 16u ? 16u : (n <= 32u ? 32u : 64u))));
+        if (n > 1u) {
+#pragma unroll
+            for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
+                if (kk > depth) break;
+#pragma unroll
+                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                    const uint32_t other = __shfl_xor(my_key, j, 64);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                    my_key = keep_min ? min(my_key, other) : max(my_key, other);
+                }
+            }
+        }
+    } else {
+        uint32_t padded = 128;
+        while (padded < n) padded <<= 1;
+        for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < n ? r.tile_list[list_begin + i] : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t kk = 2; kk <= padded; kk <<= 1)
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = lane; i < padded; i += 64u) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const uint32_t a = keys[i], b = keys[partner];
+                        if (((i & kk) == 0) ? (a > b) : (a < b)) {
+                            keys[i] = b;
+                            keys[partner] = a;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+
+    const uint8_t* slots = r.slots;
+    const int wmask = (int)r.winding_mask;
+    auto key_of = [&](uint32_t i) -> uint32_t { return sorted_in_place ? __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keys[i]; };
+    // the late start of a list of several chunks: as k_raster_edges<.., LONG>
+    uint32_t walk_from = 0, verify_entry = 0xFFFFFFFFu;
+    if (LONG && n > 64u && !r.load_existing) {
+        uint32_t x_at = 0xFFFFFFFFu;
+        for (uint32_t c0 = ((n - 1u) >> 6) << 6;; c0 -= 64u) {
+            const uint32_t k = c0 + lane < n ? key_of(c0 + lane) : 0xFFFFFFFFu;
+            uint32_t code = 0;
+            if (c0 + lane < n) {
+                const uint32_t flags = *reinterpret_cast<const uint32_t*>(slots + (size_t)k * 32u);
+                code = ((flags >> 4) & 15u) == EK_SYNTH ? (flags >> 8) & 31u : 0u;
+            }
+            unsigned long long resets = __builtin_amdgcn_ballot_w64(code >= 4u + kCoverHull);
+            if (x_at == 0xFFFFFFFFu) {
+                unsigned long long candidates = __builtin_amdgcn_ballot_w64(code >= 4u + kCoverOpaque);
+                while (candidates) {
+                    const uint32_t at = 63u - (uint32_t)__builtin_clzll(candidates);
+                    const SynthRec sr = load_uniform(reinterpret_cast<const SynthRec*>(slots + (size_t)__builtin_amdgcn_readlane(k, at) * 32u));
+                    uint32_t lo = 0, hi = n;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (key_of(mid) < sr.synth_a) lo = mid + 1u;
+                        else hi = mid;
+                    }
+                    if (lo == 0u || key_of(lo - 1u) < sr.first_slot) {
+                        x_at = c0 + at;
+                        resets &= (1ull << at) - 1ull;
+                        break;
+                    }
+                    candidates &= ~(1ull << at);
+                }
+            }
+            if (x_at != 0xFFFFFFFFu && resets) {
+                walk_from = c0 + 64u - (uint32_t)__builtin_clzll(resets);
+                verify_entry = x_at;
+                break;
+            }
+            if (c0 == 0u) break;
+        }
+    }
+    uint32_t first_j = walk_from & 63u;
+    bool again_from_the_top = false;
+    bool prev_cover = true; // the entry in front of the chunk's first one was a cover (or there was none): the first entry opens a group
+    uint32_t group_base = 0; // the group of the chunk's first entry (groups are numbered along the list; slot = group % kRowSlots)
+    // what a lane of the deposit phases is: one of four entries of an iteration (e4) x one of the tile's 16 sample rows (row16)
+    const uint32_t e4 = lane >> 4, row16 = lane & 15u;
+    const float ry_row = (float)row16 + 0.5f, sy_row = ty0 + ry_row;
+    for (uint32_t q0 = LONG ? walk_from & ~63u : 0u; q0 < n; q0 += 64u) {
+        if (sorted_in_place)
+            my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        else if (n > 64u)
+            my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
+        const uint32_t count = min(64u, n - q0);
+        // ---- entry setup, vectorised across the chunk: lane j prepares entry j (as k_raster_edges)
+        float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0;
+        bool hull_over_tile = false, replaces_tile = false;
+        uint32_t item_first = 0, item_synth_a = 0;
+        uint32_t cls = 0; // 1: edge-like (a boundary edge or a backdrop unit), 2: curve triangle, 3: cover
+        float4 f0 = e0, f1 = e0, f2 = e0;
+        uint32_t my_rows = 0; // a curve triangle: the sample rows of its box inside the tile
+        if (lane < count) {
+            const uint8_t* slot = slots + (size_t)my_key * 32u;
+            const uint32_t flags = *reinterpret_cast<const uint32_t*>(slot);
+            const uint32_t kind = (flags >> 4) & 15u;
+            if (kind == EK_EDGE) {
+                const EdgeRec er = *reinterpret_cast<const EdgeRec*>(slot);
+                const float c = er.bx * (ty0 - er.lo_y) + er.nay * (tx0 - er.lo_x);
+                const bool xr = er.lo_x <= tx0 && tx0 < er.hi_x; // the edge crosses the line of the left tile boundary
+                e0 = make_float4(c, er.bx, er.nay, 0.0f);
+                e1 = make_float4(fminf(er.lo_y, er.hi_y), fmaxf(er.lo_y, er.hi_y), 0.0f, __uint_as_float(flags | (xr ? 0x1000u : 0u)));
+                cls = 1u;
+            } else if (kind == EK_SYNTH) {
+                const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
+                e0 = make_float4(sr.r, sr.g, sr.b, sr.a);
+                e1.w = __uint_as_float(flags);
+                const uint32_t code_all = (flags >> 8) & 31u;
+                hull_over_tile = code_all >= 4u + kCoverHull;
+                replaces_tile = code_all >= 4u + kCoverOpaque;
+                item_first = sr.first_slot, item_synth_a = sr.synth_a;
+                cls = code_all >= 4u ? 3u : 1u;
+            } else {
+                const PrimCoverage mine = *reinterpret_cast<const PrimCoverage*>(slot);
+                const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
+                const int by0 = max((int)mine.box.z, tpy) - tpy, by1 = min((int)mine.box.w, tpy + kTile - 1) - tpy;
+                const uint32_t col_bits = bx1 >= bx0 ? (2u << bx1) - (1u << bx0) : 0u, row_bits = by1 >= by0 ? (2u << by1) - (1u << by0) : 0u;
+                float cc[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cc[i] = mine.bx[i] * (ty0 - mine.lo_y[i]) + mine.nay[i] * (tx0 - mine.lo_x[i]);
+                e0 = make_float4(cc[0], cc[1], cc[2], __uint_as_float(col_bits | (row_bits << 16)));
+                e1 = make_float4(mine.bx[0], mine.bx[1], mine.bx[2], __uint_as_float(flags));
+                e2 = make_float4(mine.nay[0], mine.nay[1], mine.nay[2], 0.0f);
+                cls = kind == EK_COVER_TRI ? 3u : (kind <= KIND_RC ? 2u : 0u); // (stroke triangles: not in a pass this kernel draws)
+                if (cls == 2u) { // the fragment half: attribute planes through vertex 0 -> relative to the tile (the expressions of k_raster_edges)
+                    const PrimFragment* frag = reinterpret_cast<const PrimFragment*>(slot + 64);
+                    const float4 a0 = *reinterpret_cast<const float4*>(frag->a0), gxv = *reinterpret_cast<const float4*>(frag->gx), gyv = *reinterpret_cast<const float4*>(frag->gy);
+                    const float dx0 = tx0 - frag->v0x, dy0 = ty0 - frag->v0y;
+                    f0 = make_float4(fmaf(dy0, gyv.x, fmaf(dx0, gxv.x, a0.x)), fmaf(dy0, gyv.y, fmaf(dx0, gxv.y, a0.y)), fmaf(dy0, gyv.z, fmaf(dx0, gxv.z, a0.z)),
+                                     fmaf(dy0, gyv.w, fmaf(dx0, gxv.w, a0.w)));
+                    f1 = gxv, f2 = gyv;
+                    my_rows = col_bits ? (uint32_t)__popc(row_bits) : 0u;
+                }
+            }
+        }
+        float4* __restrict__ entries = entry_buffer;
+        __builtin_amdgcn_wave_barrier();
+        entries[lane * 3u + 0u] = e0;
+        entries[lane * 3u + 1u] = e1;
+        entries[lane * 3u + 2u] = e2;
+        if (cls == 2u) frag_buffer[lane * 3u + 0u] = f0, frag_buffer[lane * 3u + 1u] = f1, frag_buffer[lane * 3u + 2u] = f2;
+        // ---- where the walk starts (the late start of k_raster_edges, found the same way) ...
+        uint32_t j_start = LONG ? first_j : 0u, verify_at = (LONG && verify_entry - q0 < 64u) ? verify_entry - q0 : 0xFFFFFFFFu;
+        first_j = 0;
+        if (n <= 64u && !r.load_existing) {
+            unsigned long long candidates = __builtin_amdgcn_ballot_w64(replaces_tile);
+            const unsigned long long resets = __builtin_amdgcn_ballot_w64(hull_over_tile);
+            while (candidates) {
+                const uint32_t at = 63u - (uint32_t)__builtin_clzll(candidates);
+                const uint32_t first_slot = __builtin_amdgcn_readlane(item_first, at), synth_a = __builtin_amdgcn_readlane(item_synth_a, at);
+                const uint32_t below = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(lane < count && my_key < synth_a));
+                if (below == 0u || __builtin_amdgcn_readlane(my_key, below - 1u) < first_slot) {
+                    const unsigned long long before = resets & ((1ull << at) - 1ull);
+                    j_start = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u;
+                    verify_at = j_start ? at : 0xFFFFFFFFu;
+                    break;
+                }
+                candidates &= ~(1ull << at);
+            }
+        }
+        const unsigned long long edge_all = __builtin_amdgcn_ballot_w64(cls == 1u), tri_all = __builtin_amdgcn_ballot_w64(cls == 2u), cover_all = __builtin_amdgcn_ballot_w64(cls == 3u);
+        { // the chunk's edge-like entries and its triangles in list order, and where each triangle's (triangle, row) pairs begin
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (cls == 1u) edge_list[__popcll(edge_all & below)] = (uint8_t)lane;
+            const uint32_t pairs_end = tri_all ? dpp_scan_add(my_rows) : 0u;
+            if (cls == 2u) {
+                const uint32_t rank = (uint32_t)__popcll(tri_all & below);
+                tri_list[rank] = (uint8_t)lane;
+                pair_start[rank] = (uint16_t)(pairs_end - my_rows);
+            }
+            if (lane == 63u) pair_start[__popcll(tri_all)] = (uint16_t)pairs_end;
+        }
+        bool chunk_again;
+        do { // (run once; twice when X of the late start turns out not to overwrite every sample)
+            chunk_again = false;
+            // ---- ... which entries take part, their groups  N* C+  and the slot of each group's grid
+            const unsigned long long live = j_start ? ~((1ull << j_start) - 1ull) : ~0ull; // (j_start < 64: a reset lies in front of it)
+            const unsigned long long cover_mask = cover_all & live;
+            const unsigned long long in_walk = (count == 64u ? ~0ull : (1ull << count) - 1ull) & live;
+            // a group begins at an entry that is no cover and follows a cover (the chunk's first entry: follows the previous chunk's last)
+            const unsigned long long after_cover = (cover_all << 1) | (((j_start == 0u && !prev_cover) ? 0ull : 1ull) << j_start);
+            const unsigned long long begins = after_cover & ~cover_all & in_walk;
+            {
+                const unsigned long long upto = lane == 63u ? ~0ull : (2ull << lane) - 1ull;
+                const uint32_t group = group_base + (uint32_t)__popcll(begins & upto);
+                slot_of[lane] = (uint8_t)(group & (kRowSlots - 1u));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t pos = j_start;
+            while (pos < count) {
+                // ---- a round: the entries of the next kRowSlots groups
+                uint32_t round_end = count;
+                {
+                    unsigned long long later = pos >= 63u ? 0ull : begins & ~((2ull << pos) - 1ull); // groups that begin behind `pos`
+#pragma unroll
+                    for (uint32_t g = 1; g < kRowSlots; ++g) later &= later - 1ull; // drop kRowSlots - 1 of them (0 & -1 stays 0)
+                    if (later) round_end = (uint32_t)__builtin_ctzll(later);
+                }
+                const unsigned long long below_pos = (1ull << pos) - 1ull, below_end = round_end == 64u ? ~0ull : (1ull << round_end) - 1ull;
+#ifdef CRH_ABLATE // tools/count_rows.py: how often does each part of the kernel run?
+                if ((r.debug & 256u) && lane == 0u) {
+                    atomicAdd(&r.overflow[8], 1u);
+                    atomicAdd(&r.overflow[10], (uint32_t)__popcll(edge_all & below_end & ~below_pos));
+                    atomicAdd(&r.overflow[9], ((uint32_t)__popcll(edge_all & below_end & ~below_pos) + 3u) / 4u);
+                    atomicAdd(&r.overflow[11], (uint32_t)__popcll(tri_all & below_end & ~below_pos));
+                    atomicAdd(&r.overflow[13], (uint32_t)__popcll(cover_mask & below_end & ~below_pos));
+                    if (pos == j_start && q0 == 0u) atomicAdd(&r.overflow[14], 1u);
+                }
+#endif
+                // ---- deposits of the edge-like entries: lane = (one of four entries, sample row)
+                const uint32_t e_lo = (uint32_t)__popcll(edge_all & below_pos), e_hi = (uint32_t)__popcll(edge_all & below_end); // (pos >= j_start: ranks among all of the chunk's)
+                for (uint32_t t = e_lo; t < e_hi; t += 4u) {
+                    const uint32_t me = t + e4;
+                    if (me < e_hi) {
+                        const uint32_t idx = edge_list[me];
+                        const float4 ea4 = entries[idx * 3u + 0u], eb4 = entries[idx * 3u + 1u];
+                        const uint32_t flags = __float_as_uint(eb4.w);
+                        uint32_t* const cells = &grid[slot_of[idx]][row16][0];
+                        if (((flags >> 4) & 15u) == EK_SYNTH) { // a whole-tile backdrop unit of the fill (codes 0, 1) or hull (2, 3) winding
+                            const uint32_t code = (flags >> 8) & 31u;
+                            const int unit = (code & 1u) ? -1 : 1;
+                            __hip_atomic_fetch_add(cells, (uint32_t)(code < 2u ? unit : unit * 65536), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            // d(j) = sigma * [Y_k g(j) + A_k],  A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k)   (the header of this file; q_k = the left tile boundary in row k)
+                            const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z, ymin = eb4.x, ymax = eb4.y;
+                            const int thr = 1 - (int)(flags & kEdgeTl);
+                            const float at_left = fmaf(0.0f, enay, c0);
+                            const int gqk = __float_as_int(fmaf(ry_row, ebx, at_left)) >= thr ? 1 : 0, gq0 = __float_as_int(fmaf(0.5f, ebx, at_left)) >= thr ? 1 : 0;
+                            const bool yk = (ymin <= sy_row) & (sy_row < ymax);
+                            const int xr = (flags & 0x1000u) ? 1 : 0;
+                            const int a_k = xr * (gqk - gq0) - (yk ? gqk : 0);
+                            const bool inv = enay < 0.0f; // g falls along the row: search the first column where it is 0
+                            const uint32_t sw = switch_column(ry_row, c0, ebx, enay, thr, inv);
+                            const int g_left = ((sw == 0u) != inv) ? 1 : 0;
+                            const int sigma = (flags & kEdgeSigmaPos) ? 1 : -1;
+                            const int field = (flags & kEdgeHull) ? 65536 : 1;
+                            const int at0 = sigma * (a_k + (yk ? g_left : 0)) * field;
+                            if (at0 != 0) __hip_atomic_fetch_add(cells, (uint32_t)at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (yk && sw > 0u && sw < 16u) __hip_atomic_fetch_add(cells + sw, (uint32_t)((inv ? -sigma : sigma) * field), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+                // ---- deposits of the curve triangles: lane = (triangle, sample row of its box). The columns of the row that lie inside the triangle
+                //      are an interval — each edge function switches once along the row —, found with three searches; the lane then walks the
+                //      interval, decides every sample with the implicit-curve test (shaders.wgsl:236-266, the expressions of k_raster_edges)
+                //      and deposits +-delta where a run of accepted samples begins and ends. (Measured against the samples of all intervals laid
+                //      end to end as tasks, one per lane: fewer instructions on large triangles, more phases — slower where this kernel is used.)
+                const uint32_t t_lo = (uint32_t)__popcll(tri_all & below_pos), t_hi = (uint32_t)__popcll(tri_all & below_end);
+                if (t_lo < t_hi) {
+                    const uint32_t p_lo = __builtin_amdgcn_readfirstlane((uint32_t)pair_start[t_lo]), p_hi = __builtin_amdgcn_readfirstlane((uint32_t)pair_start[t_hi]);
+                    uint32_t first_step = 1;
+                    while (first_step * 2u < t_hi - t_lo) first_step *= 2u;
+                    for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 64u) {
+#ifdef CRH_ABLATE
+                        if ((r.debug & 256u) && lane == 0u) atomicAdd(&r.overflow[12], 1u), atomicAdd(&r.overflow[15], min(64u, p_hi - p0));
+#endif
+                        const uint32_t pair = p0 + lane;
+                        const bool valid = pair < p_hi;
+                        uint32_t rank = t_lo; // the last triangle of the round whose pairs begin at or before `pair`
+                        for (uint32_t step = first_step; step >= 1u; step >>= 1) {
+                            const uint32_t cand = rank + step;
+                            if (cand < t_hi && (uint32_t)pair_start[min(cand, 64u)] <= pair) rank = cand;
+                        }
+                        const uint32_t idx = tri_list[rank];
+                        const float4 ea4 = entries[idx * 3u + 0u], eb4 = entries[idx * 3u + 1u], ec4 = entries[idx * 3u + 2u];
+                        const uint32_t flags = __float_as_uint(eb4.w), bits = __float_as_uint(ea4.w);
+                        const uint32_t col_bits = bits & 0xFFFFu, row_bits = bits >> 16;
+                        const uint32_t row = ((uint32_t)__builtin_ctz(row_bits | 0x10000u) + (pair - (uint32_t)pair_start[rank])) & 15u;
+                        const float y = (float)row + 0.5f;
+                        uint32_t c_lo = (uint32_t)__builtin_ctz(col_bits | 0x10000u), c_hi = c_lo + (uint32_t)__popc(col_bits);
+                        {
+                            const bool i0 = ec4.x < 0.0f, i1 = ec4.y < 0.0f, i2 = ec4.z < 0.0f;
+                            const uint32_t s0 = switch_column(y, ea4.x, eb4.x, ec4.x, 1 - (int)(flags & 1u), i0);
+                            const uint32_t s1 = switch_column(y, ea4.y, eb4.y, ec4.y, 1 - (int)((flags >> 1) & 1u), i1);
+                            const uint32_t s2 = switch_column(y, ea4.z, eb4.z, ec4.z, 1 - (int)((flags >> 2) & 1u), i2);
+                            c_lo = max(c_lo, max(i0 ? 0u : s0, max(i1 ? 0u : s1, i2 ? 0u : s2)));
+                            c_hi = min(c_hi, min(i0 ? s0 : 16u, min(i1 ? s1 : 16u, i2 ? s2 : 16u)));
+                        }
+                        if (!valid || c_lo >= c_hi) c_lo = 1u, c_hi = 0u; // nothing to walk
+                        const float4 fc = frag_buffer[idx * 3u + 0u], fx = frag_buffer[idx * 3u + 1u], fy = frag_buffer[idx * 3u + 2u];
+                        const uint32_t kind = (flags >> 4) & 15u;
+                        const bool square = kind == KIND_IQ || kind == KIND_RQ;
+                        const int delta = (flags & 8u) ? 1 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+                        uint32_t* const cells = &grid[slot_of[idx]][row][0];
+                        uint32_t j = c_lo;
+                        float x = (float)c_lo + 0.5f;
+                        bool prev = false;
+                        while (__builtin_amdgcn_ballot_w64(j <= c_hi) != 0ull) { // (one column past the interval: a run that reaches its end is closed there)
+                            if (j <= c_hi) {
+                                const float a0 = fmaf(y, fy.x, fmaf(x, fx.x, fc.x)), a1 = fmaf(y, fy.y, fmaf(x, fx.y, fc.y));
+                                const float a2 = fmaf(y, fy.z, fmaf(x, fx.z, fc.z)), a3 = fmaf(y, fy.w, fmaf(x, fx.w, fc.w));
+                                const float sq = a0 * a0, m12 = a1 * a2;
+                                const float lhs = square ? sq : sq * a0;
+                                const float rhs = kind == KIND_IQ ? a1 : (kind == KIND_RC ? m12 * a3 : m12);
+                                const bool acc = j < c_hi && lhs - rhs <= 0.0f;
+                                if (acc != prev && j < 16u) __hip_atomic_fetch_add(cells + j, (uint32_t)(acc ? delta : -delta), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                prev = acc;
+                            }
+                            j += 1u;
+                            x += 1.0f;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // ---- the covers of the round, in order: commit the group's grid, color_cover (renderer.rs:340-354, 736-754; shaders.wgsl:304-309)
+                unsigned long long covers = cover_mask & below_end & ~below_pos;
+                // a cover finds deposits in its group's grid iff the entry in front of it is no cover (the group's later covers find it committed)
+                const unsigned long long dirty_covers = cover_all & ((~cover_all << 1) | ((j_start == 0u && !prev_cover) ? 1ull : 0ull));
+                bool restart = false;
+                while (covers) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(covers);
+                    covers &= covers - 1ull;
+                    const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
+                    const uint32_t flags = __builtin_amdgcn_readfirstlane(__float_as_uint(eb4.w));
+                    const uint32_t kind = (flags >> 4) & 15u;
+                    const bool dirty = ((dirty_covers >> j) & 1ull) != 0ull;
+                    bool blend[4];
+                    float cs0, cs1, cs2, cs3;
+                    if (!dirty && !left_any && kind == EK_SYNTH) {
+                        // Nothing was deposited for this cover and no sample carries a winding: fill = hull = 0 on the whole tile, so the hull test is
+                        // "hbd != 0" and the stencil test "bd != 0 under the winding rule" for every sample alike (an item over the whole tile)
+                        const uint32_t code = 4u + (((flags >> 8) & 31u) - 4u) % 9u;
+                        const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
+                        const bool all = hbd != 0 && (bd & wmask) != 0;
+                        if (j == verify_at) {
+                            verify_at = 0xFFFFFFFFu;
+                            if (!all || (r.debug & 33554432u) != 0u) {
+                                restart = true;
+                                break;
+                            }
+                        }
+                        if (!all) continue; // (the winding stays zero either way)
+                        cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
+                        const bool replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
+                        const float one_minus_a = 1.0f - cs3;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            col[i][0] = replace ? cs0 : cs0 + col[i][0] * one_minus_a, col[i][1] = replace ? cs1 : cs1 + col[i][1] * one_minus_a;
+                            col[i][2] = replace ? cs2 : cs2 + col[i][2] * one_minus_a, col[i][3] = replace ? cs3 : cs3 + col[i][3] * one_minus_a;
+                        }
+                        continue;
+                    }
+                    int p[4] = {0, 0, 0, 0};
+                    if (dirty) {
+                        uint4* const mine = my_cells + (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)slot_of[j]) * 64u;
+                        const uint4 d = *mine;
+                        *mine = make_uint4(0u, 0u, 0u, 0u);
+                        // prefix sum along the row: inside the lane, then over the four lanes of the row
+                        const int total = (int)(d.x + d.y + d.z + d.w);
+                        int scan = total + (quad_from(total, 0, false) & quad_m1);
+                        scan = scan + (quad_from(scan, 0, true) & quad_m2);
+                        p[0] = scan - total + (int)d.x, p[1] = p[0] + (int)d.y, p[2] = p[1] + (int)d.z, p[3] = p[2] + (int)d.w;
+                    }
+                    if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
+                        const uint32_t code = 4u + (((flags >> 8) & 31u) - 4u) % 9u;
+                        const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
+                        cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int fill = __builtin_amdgcn_sbfe(p[i], 0u, 16u), hull = (p[i] - fill) >> 16;
+                            const int w = left[i] + fill + bd;
+                            const bool in_hull = hull + hbd != 0;
+                            blend[i] = in_hull && (w & wmask) != 0;
+                            left[i] = in_hull ? 0 : w;
+                        }
+                        if (j == verify_at) { // X of the late start: does it overwrite every sample? (it does unless a sample inherited a winding)
+                            const bool every = blend[0] && blend[1] && blend[2] && blend[3];
+                            verify_at = 0xFFFFFFFFu;
+                            if (__builtin_amdgcn_ballot_w64(every) != ~0ull || (r.debug & 33554432u) != 0u) { // no (or debug bit 25): the colours behind it matter — the whole list, from cleared state
+                                restart = true;
+                                break;
+                            }
+                        }
+                    } else { // a triangle of a folded hull strip, drawn as the reference draws it
+                        const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
+                        const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
+                        const uint32_t bits = __builtin_amdgcn_readfirstlane(__float_as_uint(ea4.w));
+                        const int thr0 = 1 - (int)(flags & 1u), thr1 = 1 - (int)((flags >> 1) & 1u), thr2 = 1 - (int)((flags >> 2) & 1u);
+                        const float y = (float)row_k + 0.5f;
+                        const bool row_in = ((bits >> (16u + row_k)) & 1u) != 0u;
+                        cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t px = 4u * quad_c + (uint32_t)i;
+                            const float x = (float)px + 0.5f;
+                            const float ea = fmaf(y, eb4.x, fmaf(x, ec4.x, ea4.x)), eb = fmaf(y, eb4.y, fmaf(x, ec4.y, ea4.y)), ec = fmaf(y, eb4.z, fmaf(x, ec4.z, ea4.z));
+                            const bool inside = row_in && ((bits >> px) & 1u) != 0u && (__float_as_int(ea) >= thr0) & (__float_as_int(eb) >= thr1) & (__float_as_int(ec) >= thr2);
+                            const int w = left[i] + __builtin_amdgcn_sbfe(p[i], 0u, 16u);
+                            blend[i] = inside && (w & wmask) != 0;
+                            left[i] = inside ? 0 : w;
+                        }
+                    }
+                    left_any = __builtin_amdgcn_ballot_w64((left[0] | left[1] | left[2] | left[3]) != 0) != 0ull;
+                    // an opaque source over finite colours: src + dst * (1 - 1) is the source (r.occlude: every colour of the pass is tame; a
+                    // source component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic)
+                    const bool replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
+                    if (replace) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            col[i][0] = blend[i] ? cs0 : col[i][0];
+                            col[i][1] = blend[i] ? cs1 : col[i][1];
+                            col[i][2] = blend[i] ? cs2 : col[i][2];
+                            col[i][3] = blend[i] ? cs3 : col[i][3];
+                        }
+                    } else {
+                        const float one_minus_a = 1.0f - cs3;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float n0 = cs0 + col[i][0] * one_minus_a, n1 = cs1 + col[i][1] * one_minus_a;
+                            const float n2 = cs2 + col[i][2] * one_minus_a, n3 = cs3 + col[i][3] * one_minus_a;
+                            col[i][0] = blend[i] ? n0 : col[i][0];
+                            col[i][1] = blend[i] ? n1 : col[i][1];
+                            col[i][2] = blend[i] ? n2 : col[i][2];
+                            col[i][3] = blend[i] ? n3 : col[i][3];
+                        }
+                    }
+                }
+                if (restart) { // (X of the late start did not overwrite every sample: everything again, from cleared state, the shortcut off)
+                    left_any = false;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        left[i] = 0;
+                        col[i][0] = col[i][1] = col[i][2] = col[i][3] = 0.0f;
+                    }
+#pragma unroll
+                    for (uint32_t g = 0; g < kRowSlots; ++g) my_cells[g * 64u] = make_uint4(0u, 0u, 0u, 0u);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    prev_cover = true, group_base = 0;
+                    if (LONG && n > 64u) {
+                        verify_entry = 0xFFFFFFFFu;
+                        again_from_the_top = true;
+                    } else {
+                        j_start = 0;
+                        chunk_again = true;
+                    }
+                    break;
+                }
+                pos = round_end;
+            }
+            if (!chunk_again && !again_from_the_top) {
+                group_base += (uint32_t)__popcll(begins); // = the group of the chunk's last entry: it may go on in the next chunk
+                prev_cover = ((cover_all >> (count - 1u)) & 1ull) != 0ull;
+            }
+            __builtin_amdgcn_wave_barrier(); // the lists and slots of this pass over the chunk are read: they may be rewritten
+        } while (chunk_again);
+        if (LONG && again_from_the_top) { // the whole list, chunk 0 first
+            again_from_the_top = false;
+            q0 = 0u - 64u;
+        }
+    }
+    // ---- RGBA8 unorm / RGBA16F store: 16 (32) bytes of a frame row per lane
+    if (gy < r.height) {
+        if (r.format != CRH_FORMAT_RGBA16F && gx0 + 3u < r.width) {
+            uint4 px;
+            px.x = pack_unorm8(col[0][0], col[0][1], col[0][2], col[0][3]), px.y = pack_unorm8(col[1][0], col[1][1], col[1][2], col[1][3]);
+            px.z = pack_unorm8(col[2][0], col[2][1], col[2][2], col[2][3]), px.w = pack_unorm8(col[3][0], col[3][1], col[3][2], col[3][3]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(r.rgba8) + (size_t)gy * r.width + gx0) = px;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (gx0 + (uint32_t)i < r.width) store_pixel(r, gx0 + (uint32_t)i, gy, col[i][0], col[i][1], col[i][2], col[i][3]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uint32_t n, hipStream_t stream); // raster.hip
 
@@ -2276,7 +2908,12 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
     const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
 #define CRH_LAUNCH_EDGES(S_, ROWS_, STROKES_, LONG_) \
     hipLaunchKernelGGL((k_raster_edges<S_, ROWS_, STROKES_, LONG_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
-    if (samples == 4) {
+    if (samples == 1 && !has_stroke && r.rows) { // the row-span kernel: winding numbers accumulated in LDS, lanes over (entry, sample row)
+        if (r.long_lists)
+            hipLaunchKernelGGL((k_raster_rows<true>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
+        else
+            hipLaunchKernelGGL((k_raster_rows<false>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
+    } else if (samples == 4) {
         if (has_stroke) CRH_LAUNCH_EDGES(4, 1, true, false); else CRH_LAUNCH_EDGES(4, 1, false, false);
     } else if (has_stroke) {
         CRH_LAUNCH_EDGES(1, 4, true, false);
@@ -2286,7 +2923,7 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
         CRH_LAUNCH_EDGES(1, 4, false, false);
     }
 #undef CRH_LAUNCH_EDGES
-    if (mark) mark(ctx, "raster_tiles", raster_bytes);
+    if (mark) mark(ctx, (samples == 1 && !has_stroke && r.rows) ? "raster_rows" : "raster_tiles", raster_bytes);
 }
 
 } // namespace crh

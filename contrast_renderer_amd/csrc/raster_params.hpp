@@ -67,6 +67,7 @@ struct RasterParams {
     const uint32_t* tile_base;        // [n_tiles + 1]
     uint32_t long_lists;              // the frame's tile lists hold many entries on average: k_raster_edges looks for its late start across chunks (host: crh_frame::mean_list)
     uint32_t* bin_queue;              // [n_items] items k_bin_flat hands on to k_bin_edges (their number: overflow[6])
+    uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
 };
 
 } // namespace crh
