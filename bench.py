@@ -705,7 +705,7 @@ def main():
                     "achieved = its algorithmic bytes (SURVEY.md §8(d): the raster kernel reads the emitted vertex/index bytes once + 80 B per shape and writes W*H*4 once; "
                     "binning has none) / that launch time; traffic / "
                     "valu_issue = rocprofv3 PMC passes committed under profiles/, reported only while their kernel_source_hash equals this run's. "
-                    "The kernel is VALU-issue bound (per-sample edge functions), not HBM bound: see DESIGN.md",
+                    "The raster kernels are issue- and latency-bound (per-sample edge functions, tiny algorithmic traffic), not HBM bound: see DESIGN.md §4",
         },
         "roofline_longest_alone": None if longest_alone == dominant else {
             "kernel": longest_alone, "bound": "hbm", "achieved": la["algorithmic_bytes"] / (la["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -29,27 +29,39 @@ CRH_D float2 to_framebuffer(const float* m, float w, float h, float x, float y) 
     return make_float2((cx * 0.5f + 0.5f) * w, (0.5f - cy * 0.5f) * h);
 }
 
+// RGBA8 unorm of a resolved colour: clamp to [0, 1] with NaN -> 0, x * 255 + 0.5 truncated (oracle/raster.hpp resolve_rgba8) — four instructions per channel
+CRH_D uint32_t pack_unorm8(float c0, float c1, float c2, float c3) {
+    const float v[4] = {c0, c1, c2, c3};
+    uint32_t out = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float x = __builtin_amdgcn_fmed3f(v[ch], 0.0f, 1.0f); // a NaN operand makes v_med3_f32 return the minimum of the others: 0
+#else
+        const float x = v[ch];
+#endif
+        out |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
+    }
+    return out;
+}
 // The target's pixel (gx, gy): the resolved premultiplied colour, clamped to [0, 1] (NaN -> 0) and stored as RGBA8 unorm or — the layers
 // of the multi-GPU exchange — as four binary16 values (round to nearest even; the clamp is the same, so a 16F layer holds what the RGBA8
 // target would have quantised).
 CRH_D void store_pixel(const RasterParams& r, uint32_t gx, uint32_t gy, float c0, float c1, float c2, float c3) {
-    float v[4] = {c0, c1, c2, c3};
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-        float x = v[ch];
-        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
-        if (!(x == x)) x = 0.0f;
-        v[ch] = x;
-    }
     const size_t at = (size_t)gy * r.width + gx;
     if (r.format == CRH_FORMAT_RGBA16F) {
+        float v[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float x = v[ch];
+            x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+            if (!(x == x)) x = 0.0f;
+            v[ch] = x;
+        }
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         reinterpret_cast<h4*>(r.rgba8)[at] = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     } else {
-        uint32_t packed_px = 0;
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) packed_px |= (uint32_t)(int)(v[ch] * 255.0f + 0.5f) << (8 * ch);
-        reinterpret_cast<uint32_t*>(r.rgba8)[at] = packed_px;
+        reinterpret_cast<uint32_t*>(r.rgba8)[at] = pack_unorm8(c0, c1, c2, c3);
     }
 }
 CRH_D float4 load_pixel(const RasterParams& r, uint32_t gx, uint32_t gy) {

@@ -1672,13 +1672,17 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         }
     } else if (n <= 64u) {
         if (lane < n) my_key = r.tile_list[list_begin + lane];
+        if (n > 1u) {
+            const uint32_t depth = n <= 8u ? 8u : (n <= 16u ? 16u : (n <= 32u ? 32u : 64u)); // a network as deep as the list needs (the keys sit in the leading lanes)
 #pragma unroll
-        for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
+            for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
+                if (kk > depth) break;
 #pragma unroll
-            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-                const uint32_t other = __shfl_xor(my_key, j, 64);
-                const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
-                my_key = keep_min ? min(my_key, other) : max(my_key, other);
+                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                    const uint32_t other = __shfl_xor(my_key, j, 64);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                    my_key = keep_min ? min(my_key, other) : max(my_key, other);
+                }
             }
         }
     } else {
@@ -2142,6 +2146,20 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         winding[b][q] = inside[b][q] ? 0 : winding[b][q];
                     }
             }
+            // an opaque source over finite colours: src + dst * (1 - 1) is the source (r.occlude: every colour of the pass is tame; a source
+            // component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic): a select per channel, no multiply-add
+            const bool replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
+            if (replace) {
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q) {
+                        col[b][q][0] = blend[b][q] ? cs0 : col[b][q][0];
+                        col[b][q][1] = blend[b][q] ? cs1 : col[b][q][1];
+                        col[b][q][2] = blend[b][q] ? cs2 : col[b][q][2];
+                        col[b][q][3] = blend[b][q] ? cs3 : col[b][q][3];
+                    }
+            } else {
             const float one_minus_a = 1.0f - cs3;
 #pragma unroll
             for (int b = 0; b < ROWS; ++b)
@@ -2154,6 +2172,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     col[b][q][2] = blend[b][q] ? n2 : col[b][q][2];
                     col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
                 }
+            }
         }
         } // entries of the chunk
         if (kLongLateStart && again_from_the_top) { // (X of the late start did not overwrite every sample: the whole list, chunk 0 first)
@@ -2224,21 +2243,6 @@ CRH_D uint32_t dpp_scan_add(uint32_t v) {
     v += CRH_DPP(v, 0x111, 0xF), v += CRH_DPP(v, 0x112, 0xF), v += CRH_DPP(v, 0x114, 0xF), v += CRH_DPP(v, 0x118, 0xF);
     v += CRH_DPP(v, 0x142, 0xA), v += CRH_DPP(v, 0x143, 0xC);
     return v;
-}
-// RGBA8 unorm of a resolved colour, store_pixel's arithmetic (clamp to [0, 1] with NaN -> 0, x * 255 + 0.5 truncated) in four instructions per channel
-CRH_D uint32_t pack_unorm8(float c0, float c1, float c2, float c3) {
-    const float v[4] = {c0, c1, c2, c3};
-    uint32_t out = 0;
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        const float x = __builtin_amdgcn_fmed3f(v[ch], 0.0f, 1.0f); // a NaN operand makes v_med3_f32 return the minimum of the others: 0
-#else
-        const float x = v[ch];
-#endif
-        out |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * ch);
-    }
-    return out;
 }
 // the first of the 16 columns of sample row y (x_j = j + 0.5) at which  accepts(E_j) != inv  — E = fma(y, bx, fma(x, nay, c)) is monotone in x,
 // so the predicate switches at most once —, 16 if there is none: five evaluations of the exact predicate

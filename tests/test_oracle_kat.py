@@ -379,3 +379,47 @@ def test_kat_j_orientation_sign_of_the_winding_contribution():
     pts = np.array([a.start] + [rec[-2:] for rec in a.records], dtype=np.float64)
     x, y = pts[:, 0], pts[:, 1]
     assert 0.5 * np.sum(x * np.roll(y, -1) - np.roll(x, -1) * y) < 0.0
+
+
+def _stroke_over_fill_case():
+    """One Shape: a stroked horizontal line (width 8) crossed by a filled rectangle — clockwise in y-up user coordinates as from_rect makes
+    it (path.rs:736-743), or reverse()d. Returns (paths builder, transform, colour, regions) for a 64 x 64 frame."""
+    W = H = 64
+    line = Path(start=(8.0, 32.0))
+    line.push_line((56.0, 32.0))
+    line.stroke_options = StrokeOptions(8.0, 0.0, 4.0, False, 0, CurveApproximation.UniformlySpacedParameters(1))
+    dynamic = [DynamicStrokeOptions.Solid(Join.Miter, Cap.Butt, Cap.Butt)]
+    transform = np.zeros((1, 16), dtype=np.float32)  # user (x, y-up) in pixels -> clip space
+    transform[0, 0], transform[0, 5], transform[0, 10], transform[0, 15], transform[0, 12], transform[0, 13] = 2.0 / W, 2.0 / H, 1.0, 1.0, -1.0, -1.0
+    color = np.array([[1.0, 1.0, 1.0, 1.0]], dtype=np.float32)
+
+    def shape(reverse_fill):
+        rect = Path.from_rect((32.0, 32.0), (8.0, 16.0))  # x 24..40, y 16..48: crosses the stroke band y 28..36
+        if reverse_fill:
+            rect.reverse()
+        return batch_from_shapes([(dynamic, [line, rect])])
+    # (rows, columns) well inside: the stroke alone, the fill alone (above the band), stroke and fill together; rows count from the top, y is up
+    regions = dict(stroke_only=(slice(29, 35), slice(10, 22)), fill_only=(slice(18, 26), slice(26, 38)), both=(slice(29, 35), slice(26, 38)))
+    return shape, transform, color, regions, W, H
+
+
+def test_kat_k_a_stroke_and_a_fill_overlapping_in_one_shape_show_the_absolute_sign():
+    """The ONE place where the absolute sign of a filled path's winding contribution reaches a pixel. Shape::render(Stencil) draws the
+    strokes first — stencil Equal(0) -> IncrementWrap on both faces, i.e. "set to 1 once" (renderer.rs:275-303, 571-576) — and the fills
+    behind them with IncrementWrap / DecrementWrap by facing (renderer.rs:304-336, 577-582); the cover keeps a sample iff the counter is not
+    zero (renderer.rs:736-754). Where a stroke and a fill of the same Shape overlap the counter is 1 + 1 = 2 for a fill that increments
+    (covered under the non-zero rule; 0 under even-odd, bits = 1) and 1 - 1 = 0 for a fill that decrements (a HOLE under every rule).
+    By the chain of facts in KAT-J / DESIGN.md §2 a rectangle as from_rect emits it — clockwise in y-up user coordinates — increments when
+    the instance transform preserves orientation, so the restatement covers the overlap at bits 4 and 8 and punches it out at bits 1,
+    and the reverse()d rectangle punches it out at every width. If the real crate behaved by the y-up reading of path.rs:210-211
+    ("increment when counterclockwise") these two rows would swap — which is what showcase/main.rs:82-84 (every glyph path reverse()d
+    in a Shape that also strokes a rounded rectangle) suggests its author expects; DESIGN.md §2 says which un-vendored conventions decide."""
+    from oracle import Oracle
+    shape, transform, color, regions, W, H = _stroke_over_fill_case()
+    for reverse_fill, expect_both in ((False, {8: True, 4: True, 1: False}), (True, {8: False, 4: False, 1: False})):
+        for bits, both_covered in expect_both.items():
+            o = Oracle(shape(reverse_fill))
+            assert o.status() == 0
+            covered = o.render(W, H, 1, bits, transform, color)[..., 3] > 0
+            assert covered[regions["stroke_only"]].all() and covered[regions["fill_only"]].all(), (reverse_fill, bits)
+            assert covered[regions["both"]].all() == both_covered and covered[regions["both"]].any() == both_covered, (reverse_fill, bits)

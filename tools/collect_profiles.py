@@ -30,7 +30,8 @@ traffic = {
     "kernel_source_hash": kernel_source_hash(),
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline" + ("" if workload == "cubic" else " --workload " + workload),
     "units": "FETCH_SIZE / WRITE_SIZE are KiB per launch; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the x2 is the gfx950 FETCH_SIZE "
-             "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE calibrates 1:1 here (k_raster_tile writes exactly 4096*4096*4 B = 65536 KiB)",
+             "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE is taken 1:1 (KiB). A raster kernel's WRITE_SIZE is the frame (W * H * 4 B = 65536 KiB at 4096^2) "
+             "PLUS its scratch stores: a build that spills writes more than the frame, which is how the spills show",
     "kernels": {},
 }
 for name, v in summary.items():
