@@ -2257,6 +2257,14 @@ CRH_D uint32_t switch_column(float y, float c, float bx, float nay, int thr, boo
     const bool g15 = __float_as_int(fmaf(y, bx, fmaf(15.5f, nay, c))) >= thr;
     return (lo == 15.0f && g15 == inv) ? 16u : (uint32_t)(int)lo;
 }
+// the first of 16 indices (as a float, 0 .. 15) at which a predicate that is monotone (false ... false true ... true) holds, 16 if none: five evaluations
+template <class P>
+CRH_D uint32_t first_of_16(P holds) {
+    float lo = 0.0f;
+#pragma unroll
+    for (int step = 8; step >= 1; step >>= 1) lo = holds(lo + (float)(step - 1)) ? lo : lo + (float)step;
+    return (lo == 15.0f && !holds(15.0f)) ? 16u : (uint32_t)(int)lo;
+}
 template <bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE_WAVES))) void k_raster_rows(SceneDev s, RasterParams r) {
     extern __shared__ uint32_t sort_buffer[];
@@ -2265,6 +2273,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
     __shared__ float4 frag_buffer[64 * 3];       // a curve triangle's attribute planes relative to the tile: constants, x gradients, y gradients
     __shared__ uint8_t edge_list[64], tri_list[64], slot_of[64];
     __shared__ uint16_t pair_start[66];          // [rank of a triangle in the chunk] its first (triangle, row) pair; [number of triangles] all pairs
+    __shared__ uint16_t edge_pair_start[66];     // the same for the boundary edges: their (edge, row) pairs — the rows of the edge's half-open y range
+    __shared__ uint32_t vgrid[kRowSlots][16];    // [group slot][sample row] what begins at that row and holds for every column of it and of the rows below (delta form down the tile)
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
     const uint32_t turn = blockIdx.x >> 3;
     const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
@@ -2298,6 +2308,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
     uint4* const my_cells = reinterpret_cast<uint4*>(&grid[0][row_k][4u * quad_c]); // + slot * 64 (uint4 units)
 #pragma unroll
     for (uint32_t g = 0; g < kRowSlots; ++g) my_cells[g * 64u] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < kRowSlots * 16u) (&vgrid[0][0])[lane] = 0u;
     const uint32_t list_begin = r.direct ? r.tile_base[tile] : r.tile_offset[tile];
     uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : (r.direct ? r.tile_count[tile] : r.tile_offset[tile + 1] - list_begin);
     constexpr uint32_t kLdsSortMax = kSortBytesMax / 4u;
@@ -2424,9 +2435,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
     bool again_from_the_top = false;
     bool prev_cover = true; // the entry in front of the chunk's first one was a cover (or there was none): the first entry opens a group
     uint32_t group_base = 0; // the group of the chunk's first entry (groups are numbered along the list; slot = group % kRowSlots)
-    // what a lane of the deposit phases is: one of four entries of an iteration (e4) x one of the tile's 16 sample rows (row16)
-    const uint32_t e4 = lane >> 4, row16 = lane & 15u;
-    const float ry_row = (float)row16 + 0.5f, sy_row = ty0 + ry_row;
     for (uint32_t q0 = LONG ? walk_from & ~63u : 0u; q0 < n; q0 += 64u) {
         if (sorted_in_place)
             my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
@@ -2439,7 +2447,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
         uint32_t item_first = 0, item_synth_a = 0;
         uint32_t cls = 0; // 1: edge-like (a boundary edge or a backdrop unit), 2: curve triangle, 3: cover
         float4 f0 = e0, f1 = e0, f2 = e0;
-        uint32_t my_rows = 0; // a curve triangle: the sample rows of its box inside the tile
+        uint32_t my_rows = 0; // a curve triangle: the sample rows of its box inside the tile; a boundary edge: the rows of its y range
+        uint32_t v_row = 16u; // an edge-like entry: the row from which on it adds v_value to every sample of the tile (16: none)
+        int v_value = 0;
         if (lane < count) {
             const uint8_t* slot = slots + (size_t)my_key * 32u;
             const uint32_t flags = *reinterpret_cast<const uint32_t*>(slot);
@@ -2448,8 +2458,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                 const EdgeRec er = *reinterpret_cast<const EdgeRec*>(slot);
                 const float c = er.bx * (ty0 - er.lo_y) + er.nay * (tx0 - er.lo_x);
                 const bool xr = er.lo_x <= tx0 && tx0 < er.hi_x; // the edge crosses the line of the left tile boundary
+                // The edge's contribution to sample (row k, column j), sigma * [Y_k g(k, j) + xr (g(q_k) - g(q_0)) - Y_k g(q_k)], in two parts:
+                //   sigma Y_k (g(k, j) - g(q_k))   lives in the rows of the edge's half-open y range [ky0, ky1): one (edge, row) lane each, below;
+                //   sigma xr (g(q_k) - g(q_0))     is the same for every column, and g(q_k) is monotone in k (bx >= 0): a unit from the row on at
+                //                                  which the edge function at the left tile boundary switches — ONE deposit down the tile.
+                const float ymin = fminf(er.lo_y, er.hi_y), ymax = fmaxf(er.lo_y, er.hi_y);
+                const uint32_t ky0 = first_of_16([&](float k) { return ymin <= ty0 + (k + 0.5f); }), ky1 = first_of_16([&](float k) { return !(ty0 + (k + 0.5f) < ymax); });
+                my_rows = ky1 > ky0 ? ky1 - ky0 : 0u;
+                const int thr = 1 - (int)(flags & kEdgeTl);
+                const float at_left = fmaf(0.0f, er.nay, c);
+                const int sigma_field = ((flags & kEdgeSigmaPos) ? 1 : -1) * ((flags & kEdgeHull) ? 65536 : 1);
+                if (xr && !(__float_as_int(fmaf(0.5f, er.bx, at_left)) >= thr)) { // g(q_0) = 0: the unit begins at the first row with g(q_k) = 1
+                    v_row = first_of_16([&](float k) { return __float_as_int(fmaf(k + 0.5f, er.bx, at_left)) >= thr; });
+                    v_value = sigma_field;
+                }
                 e0 = make_float4(c, er.bx, er.nay, 0.0f);
-                e1 = make_float4(fminf(er.lo_y, er.hi_y), fmaxf(er.lo_y, er.hi_y), 0.0f, __uint_as_float(flags | (xr ? 0x1000u : 0u)));
+                e1 = make_float4(ymin, ymax, __uint_as_float(ky0), __uint_as_float(flags | (xr ? 0x1000u : 0u)));
                 cls = 1u;
             } else if (kind == EK_SYNTH) {
                 const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
@@ -2460,6 +2484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                 replaces_tile = code_all >= 4u + kCoverOpaque;
                 item_first = sr.first_slot, item_synth_a = sr.synth_a;
                 cls = code_all >= 4u ? 3u : 1u;
+                if (code_all < 4u) v_row = 0u, v_value = ((code_all & 1u) ? -1 : 1) * (code_all < 2u ? 1 : 65536); // a whole-tile backdrop unit of the fill (codes 0, 1) or hull (2, 3) winding
             } else {
                 const PrimCoverage mine = *reinterpret_cast<const PrimCoverage*>(slot);
                 const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
@@ -2511,8 +2536,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
         const unsigned long long edge_all = __builtin_amdgcn_ballot_w64(cls == 1u), tri_all = __builtin_amdgcn_ballot_w64(cls == 2u), cover_all = __builtin_amdgcn_ballot_w64(cls == 3u);
         { // the chunk's edge-like entries and its triangles in list order, and where each triangle's (triangle, row) pairs begin
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (cls == 1u) edge_list[__popcll(edge_all & below)] = (uint8_t)lane;
-            const uint32_t pairs_end = tri_all ? dpp_scan_add(my_rows) : 0u;
+            const uint32_t edge_pairs_end = edge_all ? dpp_scan_add(cls == 1u ? my_rows : 0u) : 0u;
+            if (cls == 1u) {
+                const uint32_t rank = (uint32_t)__popcll(edge_all & below);
+                edge_list[rank] = (uint8_t)lane;
+                edge_pair_start[rank] = (uint16_t)(edge_pairs_end - my_rows);
+            }
+            if (lane == 63u) edge_pair_start[__popcll(edge_all)] = (uint16_t)edge_pairs_end;
+            const uint32_t pairs_end = tri_all ? dpp_scan_add(cls == 2u ? my_rows : 0u) : 0u;
             if (cls == 2u) {
                 const uint32_t rank = (uint32_t)__popcll(tri_all & below);
                 tri_list[rank] = (uint8_t)lane;
@@ -2558,36 +2589,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                     if (pos == j_start && q0 == 0u) atomicAdd(&r.overflow[14], 1u);
                 }
 #endif
-                // ---- deposits of the edge-like entries: lane = (one of four entries, sample row)
+                // ---- deposits of the edge-like entries. (a) lane = entry: what an entry adds to whole rows (a backdrop unit; an edge's switch at the
+                //      left tile boundary) goes down the tile in delta form; (b) lane = (edge, row of its y range), the pairs of the round's edges
+                //      laid end to end: the switch column of the row, two deposits along it.
+                if (v_row < 16u && ((below_end & ~below_pos) >> lane) & 1ull)
+                    __hip_atomic_fetch_add(&vgrid[slot_of[lane]][v_row], (uint32_t)v_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const uint32_t e_lo = (uint32_t)__popcll(edge_all & below_pos), e_hi = (uint32_t)__popcll(edge_all & below_end); // (pos >= j_start: ranks among all of the chunk's)
-                for (uint32_t t = e_lo; t < e_hi; t += 4u) {
-                    const uint32_t me = t + e4;
-                    if (me < e_hi) {
-                        const uint32_t idx = edge_list[me];
-                        const float4 ea4 = entries[idx * 3u + 0u], eb4 = entries[idx * 3u + 1u];
-                        const uint32_t flags = __float_as_uint(eb4.w);
-                        uint32_t* const cells = &grid[slot_of[idx]][row16][0];
-                        if (((flags >> 4) & 15u) == EK_SYNTH) { // a whole-tile backdrop unit of the fill (codes 0, 1) or hull (2, 3) winding
-                            const uint32_t code = (flags >> 8) & 31u;
-                            const int unit = (code & 1u) ? -1 : 1;
-                            __hip_atomic_fetch_add(cells, (uint32_t)(code < 2u ? unit : unit * 65536), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        } else {
-                            // d(j) = sigma * [Y_k g(j) + A_k],  A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k)   (the header of this file; q_k = the left tile boundary in row k)
-                            const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z, ymin = eb4.x, ymax = eb4.y;
+                if (e_lo < e_hi) {
+                    const uint32_t p_lo = __builtin_amdgcn_readfirstlane((uint32_t)edge_pair_start[e_lo]), p_hi = __builtin_amdgcn_readfirstlane((uint32_t)edge_pair_start[e_hi]);
+                    uint32_t first_step = 1;
+                    while (first_step * 2u < e_hi - e_lo) first_step *= 2u;
+                    for (uint32_t p0 = p_lo; p0 < p_hi; p0 += 64u) {
+#ifdef CRH_ABLATE
+                        if ((r.debug & 256u) && lane == 0u) atomicAdd(&r.overflow[9], 1u);
+#endif
+                        const uint32_t pair = p0 + lane;
+                        if (pair < p_hi) {
+                            uint32_t rank = e_lo; // the last edge of the round whose pairs begin at or before `pair`
+                            for (uint32_t step = first_step; step >= 1u; step >>= 1) {
+                                const uint32_t cand = rank + step;
+                                if (cand < e_hi && (uint32_t)edge_pair_start[min(cand, 64u)] <= pair) rank = cand;
+                            }
+                            const uint32_t idx = edge_list[rank];
+                            const float4 ea4 = entries[idx * 3u + 0u], eb4 = entries[idx * 3u + 1u];
+                            const uint32_t flags = __float_as_uint(eb4.w);
+                            const uint32_t row = (__float_as_uint(eb4.z) + (pair - (uint32_t)edge_pair_start[rank])) & 15u;
+                            const float ry = (float)row + 0.5f;
+                            const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z;
                             const int thr = 1 - (int)(flags & kEdgeTl);
-                            const float at_left = fmaf(0.0f, enay, c0);
-                            const int gqk = __float_as_int(fmaf(ry_row, ebx, at_left)) >= thr ? 1 : 0, gq0 = __float_as_int(fmaf(0.5f, ebx, at_left)) >= thr ? 1 : 0;
-                            const bool yk = (ymin <= sy_row) & (sy_row < ymax);
-                            const int xr = (flags & 0x1000u) ? 1 : 0;
-                            const int a_k = xr * (gqk - gq0) - (yk ? gqk : 0);
+                            const int gqk = __float_as_int(fmaf(ry, ebx, fmaf(0.0f, enay, c0))) >= thr ? 1 : 0;
                             const bool inv = enay < 0.0f; // g falls along the row: search the first column where it is 0
-                            const uint32_t sw = switch_column(ry_row, c0, ebx, enay, thr, inv);
+                            const uint32_t sw = switch_column(ry, c0, ebx, enay, thr, inv);
                             const int g_left = ((sw == 0u) != inv) ? 1 : 0;
-                            const int sigma = (flags & kEdgeSigmaPos) ? 1 : -1;
-                            const int field = (flags & kEdgeHull) ? 65536 : 1;
-                            const int at0 = sigma * (a_k + (yk ? g_left : 0)) * field;
-                            if (at0 != 0) __hip_atomic_fetch_add(cells, (uint32_t)at0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (yk && sw > 0u && sw < 16u) __hip_atomic_fetch_add(cells + sw, (uint32_t)((inv ? -sigma : sigma) * field), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int sigma_field = ((flags & kEdgeSigmaPos) ? 1 : -1) * ((flags & kEdgeHull) ? 65536 : 1);
+                            uint32_t* const cells = &grid[slot_of[idx]][row][0];
+                            if (g_left != gqk) __hip_atomic_fetch_add(cells, (uint32_t)((g_left - gqk) * sigma_field), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (sw > 0u && sw < 16u) __hip_atomic_fetch_add(cells + sw, (uint32_t)(inv ? -sigma_field : sigma_field), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                 }
@@ -2697,11 +2734,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                         uint4* const mine = my_cells + (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)slot_of[j]) * 64u;
                         const uint4 d = *mine;
                         *mine = make_uint4(0u, 0u, 0u, 0u);
+                        uint32_t* const my_down = &vgrid[0][row_k] + (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)slot_of[j]) * 16u;
+                        uint32_t down = *my_down; // what begins at this row for all columns: summed down the tile (the four lanes of a row hold the same)
+                        *my_down = 0u;
+                        down += CRH_DPP(down, 0x114, 0xF), down += CRH_DPP(down, 0x118, 0xF), down += CRH_DPP(down, 0x142, 0xA), down += CRH_DPP(down, 0x143, 0xC);
                         // prefix sum along the row: inside the lane, then over the four lanes of the row
                         const int total = (int)(d.x + d.y + d.z + d.w);
                         int scan = total + (quad_from(total, 0, false) & quad_m1);
                         scan = scan + (quad_from(scan, 0, true) & quad_m2);
-                        p[0] = scan - total + (int)d.x, p[1] = p[0] + (int)d.y, p[2] = p[1] + (int)d.z, p[3] = p[2] + (int)d.w;
+                        p[0] = scan - total + (int)d.x + (int)down, p[1] = p[0] + (int)d.y, p[2] = p[1] + (int)d.z, p[3] = p[2] + (int)d.w;
                     }
                     if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
                         const uint32_t code = 4u + (((flags >> 8) & 31u) - 4u) % 9u;
@@ -2776,6 +2817,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                     }
 #pragma unroll
                     for (uint32_t g = 0; g < kRowSlots; ++g) my_cells[g * 64u] = make_uint4(0u, 0u, 0u, 0u);
+                    if (lane < kRowSlots * 16u) (&vgrid[0][0])[lane] = 0u;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     prev_cover = true, group_base = 0;
