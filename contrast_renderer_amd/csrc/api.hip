@@ -116,6 +116,43 @@ struct PinnedUpload {
     }
 };
 
+// Pinned staging memory a caller fills in place (crh_scene_upload builds the element stream straight into it): two arenas in turn, each guarded
+// by the event behind the copies that read it, so the call that filled it need not wait for them.
+struct PinnedArena {
+    void* host[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+    hipEvent_t sent[2] = {nullptr, nullptr};
+    int next = 0, cur = 0;
+    hipError_t begin(size_t bytes, uint8_t** out) {
+        const int k = next;
+        next ^= 1;
+        cur = k;
+        hipError_t e;
+        if (!sent[k] && (e = hipEventCreateWithFlags(&sent[k], hipEventDisableTiming)) != hipSuccess) return e;
+        if (cap[k] && (e = hipEventSynchronize(sent[k])) != hipSuccess) return e; // (the copies out of it two uploads ago: long done)
+        if (cap[k] < bytes) {
+            if (host[k]) (void)hipHostFree(host[k]);
+            host[k] = nullptr, cap[k] = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            if ((e = hipHostMalloc(&host[k], want, hipHostMallocDefault)) != hipSuccess) return e;
+            cap[k] = want;
+        }
+        *out = static_cast<uint8_t*>(host[k]);
+        return hipSuccess;
+    }
+    hipError_t done(hipStream_t stream) { return hipEventRecord(sent[cur], stream); }
+    void release() {
+        for (int k = 0; k < 2; ++k) {
+            if (sent[k]) {
+                (void)hipEventSynchronize(sent[k]);
+                (void)hipEventDestroy(sent[k]);
+            }
+            if (host[k]) (void)hipHostFree(host[k]);
+            host[k] = nullptr, sent[k] = nullptr, cap[k] = 0;
+        }
+    }
+};
+
 struct Mark {
     hipEvent_t event;
     std::string name;
@@ -330,6 +367,9 @@ struct crh_scene {
     // deferred tile-list check may still ask for it to be drawn again — needs no wait; only a frame two updates old is settled first.
     DevBuf transforms_b, colors_b;
     PinnedUpload upload_t, upload_c;
+    PinnedArena geometry_stage;          // crh_scene_upload's element stream on its way to the device
+    hipEvent_t geometry_ready = nullptr; // behind those copies (on the renderer's stream); the next tessellation waits for it once
+    bool geometry_pending = false, tessellated_once_before_upload = false;
     InstanceSlot slot[2];
     int instances_cur = 0;
     uint64_t generation = 0;            // bumped by every upload: what a frame's cached recorded pass was built against
@@ -402,6 +442,7 @@ struct crh_scene {
         for (DevBuf& b : prim_proj) b.release();
         upload_t.release();
         upload_c.release();
+        geometry_stage.release();
         for (InstanceSlot& k : slot) k.release();
     }
 };
@@ -560,6 +601,10 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     const hipStream_t ts = r->tessellation_stream();
     // the previous frame's k_prim_setup must have consumed the vertex streams this run overwrites; its binning and raster may still run
     if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->vertices_free, 0));
+    if (sc->geometry_pending) { // the element stream of the last crh_scene_upload is still on its way (asynchronous copies out of pinned staging memory)
+        HIP_TRY(hipStreamWaitEvent(ts, sc->geometry_ready, 0));
+        sc->geometry_pending = false;
+    }
     if (r->raster_exclusive && r->raster_events[1]) HIP_TRY(hipStreamWaitEvent(ts, r->raster_events[1], 0));
     r->begin_marks(1);
     HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, ts));
@@ -1303,57 +1348,93 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         }
     }
     if ((uint64_t)b->n_segments + 2ull * b->n_paths >= 0xFFFFFFF0ull || (uint64_t)b->n_control_floats + 2ull * b->n_paths >= 0xFFFFFFF0ull) return CRH_ERR_UNSUPPORTED; // 32-bit element / pool offsets
-    // ---- element stream: MOVE, segments..., END per path; pool = start point + records, -0 canonicalised (safe_float.rs:44-52)
     const uint32_t n_elems = b->n_segments + 2u * b->n_paths;
-    std::vector<uint8_t> elem_type(n_elems);
-    std::vector<uint32_t> elem_off(n_elems), elem_path(n_elems), path_elem_begin(b->n_paths + 1), path_shape(b->n_paths), shape_elem_begin(b->n_shapes + 1);
-    std::vector<float> pool;
-    pool.reserve((size_t)b->n_control_floats + 2u * b->n_paths);
-    auto push = [&](float v) -> bool {
-        if (!std::isfinite(v)) return false;
-        pool.push_back(v == 0.0f ? 0.0f : v);
-        return true;
-    };
-    uint32_t e = 0;
-    size_t cursor = 0;
-    bool finite = true;
-    for (uint32_t s = 0; s < b->n_shapes; ++s) {
-        shape_elem_begin[s] = e;
-        for (uint32_t p = b->shape_path_begin[s]; p < b->shape_path_begin[s + 1]; ++p) {
-            path_elem_begin[p] = e;
-            path_shape[p] = s;
-            elem_type[e] = ELEM_MOVE;
-            elem_off[e] = (uint32_t)pool.size();
-            elem_path[e] = p;
-            ++e;
-            finite &= push(b->path_start[2 * (size_t)p]);
-            finite &= push(b->path_start[2 * (size_t)p + 1]);
-            for (uint32_t g = b->path_segment_begin[p]; g < b->path_segment_begin[p + 1]; ++g) {
-                const uint8_t t = b->segment_types[g];
-                if (t > 4) return CRH_ERR_INVALID_ARGUMENT;
-                elem_type[e] = t;
-                elem_off[e] = (uint32_t)pool.size();
-                elem_path[e] = p;
-                ++e;
-                for (int k = 0; k < kSegmentFloats[t]; ++k) finite &= push(b->control_data[cursor++]);
-            }
-            elem_type[e] = ELEM_END;
-            elem_off[e] = (uint32_t)pool.size();
-            elem_path[e] = p;
-            ++e;
-        }
-    }
-    if (!finite) return CRH_ERR_NON_FINITE; // the reference panics in SafeFloat::from (safe_float.rs:46,114)
-    if (cursor != b->n_control_floats || e != n_elems) return CRH_ERR_INVALID_ARGUMENT;
-    path_elem_begin[b->n_paths] = e;
-    shape_elem_begin[b->n_shapes] = e;
-
     HIP_TRY(hipSetDevice(r->device));
     if (existing) {
         const crh_status st = settle_frames_of(existing, false);
         if (st != CRH_OK) return st;
     }
     crh_scene* sc = existing ? existing : new crh_scene;
+    // ---- element stream: MOVE, segments..., END per path; pool = start point + records, -0 canonicalised (safe_float.rs:44-52) — built straight
+    //      into pinned staging memory (one arena for all thirteen arrays; the copies to the device are asynchronous, the tessellation waits
+    //      for them through an event). Nothing of the Scene is touched before the geometry is known to be finite.
+    const size_t n_pool = (size_t)b->n_control_floats + 2u * (size_t)b->n_paths;
+    struct Part { size_t at, bytes; };
+    Part part[12];
+    size_t arena_bytes = 0;
+    {
+        const size_t sizes[12] = {(size_t)n_elems, (size_t)n_elems * 4, (size_t)n_elems * 4, (size_t)n_elems * 4, n_pool * 4, ((size_t)b->n_paths + 1) * 4, (size_t)b->n_paths * 4,
+                                  (size_t)b->n_paths * 4, ((size_t)b->n_shapes + 1) * 4, ((size_t)b->n_shapes + 1) * 4, (size_t)b->n_stroke_options * sizeof(crh_stroke_options),
+                                  (size_t)b->n_dynamic_stroke_options * sizeof(crh_dynamic_stroke_descriptor)};
+        for (int k = 0; k < 12; ++k) {
+            part[k] = Part{arena_bytes, sizes[k]};
+            arena_bytes += (sizes[k] + 255u) & ~(size_t)255u;
+        }
+    }
+    enum { P_TYPE, P_OFF, P_PREV, P_PATH, P_POOL, P_PATH_BEGIN, P_PATH_SHAPE, P_PATH_STROKE, P_SHAPE_BEGIN, P_DYN_BEGIN, P_OPTIONS, P_DESCRIPTORS };
+    uint8_t* arena = nullptr;
+    if (!hip_ok(sc->geometry_stage.begin(arena_bytes + 256u, &arena), "hipHostMalloc")) {
+        if (!existing) delete sc;
+        return CRH_ERR_HIP;
+    }
+    {
+        uint8_t* const elem_type = arena + part[P_TYPE].at;
+        uint32_t* const elem_off = reinterpret_cast<uint32_t*>(arena + part[P_OFF].at);
+        uint32_t* const elem_prev_off = reinterpret_cast<uint32_t*>(arena + part[P_PREV].at); // the point stored just before the record: end of the previous segment, or Path::start
+        uint32_t* const elem_path = reinterpret_cast<uint32_t*>(arena + part[P_PATH].at);
+        float* const pool = reinterpret_cast<float*>(arena + part[P_POOL].at);
+        uint32_t* const path_elem_begin = reinterpret_cast<uint32_t*>(arena + part[P_PATH_BEGIN].at);
+        uint32_t* const path_shape = reinterpret_cast<uint32_t*>(arena + part[P_PATH_SHAPE].at);
+        uint32_t* const shape_elem_begin = reinterpret_cast<uint32_t*>(arena + part[P_SHAPE_BEGIN].at);
+        uint32_t e = 0, at = 0; // element, float of the pool
+        size_t cursor = 0;      // float of control_data
+        for (uint32_t sh = 0; sh < b->n_shapes; ++sh) {
+            shape_elem_begin[sh] = e;
+            for (uint32_t p = b->shape_path_begin[sh]; p < b->shape_path_begin[sh + 1]; ++p) {
+                path_elem_begin[p] = e;
+                path_shape[p] = sh;
+                elem_type[e] = ELEM_MOVE, elem_off[e] = at, elem_prev_off[e] = at >= 2u ? at - 2u : 0u, elem_path[e] = p;
+                ++e;
+                pool[at] = b->path_start[2 * (size_t)p], pool[at + 1] = b->path_start[2 * (size_t)p + 1];
+                at += 2u;
+                const uint32_t g0 = b->path_segment_begin[p], g1 = b->path_segment_begin[p + 1];
+                const uint32_t first = at;
+                for (uint32_t g = g0; g < g1; ++g) {
+                    const uint8_t t = b->segment_types[g]; // (<= 4: checked above)
+                    elem_type[e] = t, elem_off[e] = at, elem_prev_off[e] = at - 2u, elem_path[e] = p;
+                    ++e;
+                    at += (uint32_t)kSegmentFloats[t];
+                }
+                if (at != first) std::memcpy(pool + first, b->control_data + cursor, (size_t)(at - first) * 4); // a path's records are contiguous in the batch
+                cursor += at - first;
+                elem_type[e] = ELEM_END, elem_off[e] = at, elem_prev_off[e] = at - 2u, elem_path[e] = p;
+                ++e;
+            }
+        }
+        path_elem_begin[b->n_paths] = e;
+        shape_elem_begin[b->n_shapes] = e;
+        uint32_t bad = 0; // SafeFloat::from (safe_float.rs:44-52): finite, and -0 -> +0 (x + 0 is x for every x but -0)
+        for (size_t i = 0; i < n_pool; ++i) {
+            uint32_t u;
+            std::memcpy(&u, &pool[i], 4);
+            bad |= (uint32_t)((u & 0x7F800000u) == 0x7F800000u);
+            pool[i] = pool[i] + 0.0f;
+        }
+        if (bad != 0u || cursor != b->n_control_floats || e != n_elems || at != n_pool) {
+            if (!existing) {
+                sc->geometry_stage.release();
+                delete sc;
+            }
+            return bad ? CRH_ERR_NON_FINITE : CRH_ERR_INVALID_ARGUMENT; // the reference panics in SafeFloat::from (safe_float.rs:46,114)
+        }
+        if (b->n_paths) std::memcpy(arena + part[P_PATH_STROKE].at, b->path_stroke_options, (size_t)b->n_paths * 4);
+        uint32_t* const dyn_begin = reinterpret_cast<uint32_t*>(arena + part[P_DYN_BEGIN].at);
+        if (b->shape_dynamic_begin) std::memcpy(dyn_begin, b->shape_dynamic_begin, ((size_t)b->n_shapes + 1) * 4);
+        else std::memset(dyn_begin, 0, ((size_t)b->n_shapes + 1) * 4);
+        sc->shape_dyn_begin_host.assign(dyn_begin, dyn_begin + b->n_shapes + 1);
+        if (b->n_stroke_options) std::memcpy(arena + part[P_OPTIONS].at, b->stroke_options, part[P_OPTIONS].bytes);
+        if (!descriptors.empty()) std::memcpy(arena + part[P_DESCRIPTORS].at, descriptors.data(), part[P_DESCRIPTORS].bytes);
+    }
     sc->renderer = r;
     sc->device = r->device;
     static std::atomic<uint64_t> next_generation{1}; // unique across scenes (and threads): a new Scene at a recycled address is not mistaken for the old one
@@ -1378,6 +1459,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         for (DevBuf& buf : sc->shadow.buf) buf.release();
         sc->shadow.allocated = false;
     }
+    sc->tessellated_once_before_upload = sc->tessellated_once;
     sc->tessellated_once = false;
     {   // New geometry: measure again which formulation draws it faster — unless it is geometry of the same kind (as many Shapes and segments,
         // to a factor of two): a caller that uploads new paths every frame (the reference's animated-path use) would otherwise never leave
@@ -1419,36 +1501,28 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.n_wg = (n_elems + kTessBlock - 1) / kTessBlock;
     hipStream_t st = r->stream;
     crh_status rc;
-#define UP(buf, vec)                                                  \
-    if ((rc = upload_vector(sc->buf, vec, st)) != CRH_OK) goto fail;
-    {
-        std::vector<int32_t> path_stroke(b->path_stroke_options, b->path_stroke_options + b->n_paths);
-        std::vector<crh_stroke_options> options(b->stroke_options, b->stroke_options + b->n_stroke_options);
-        std::vector<uint32_t> dyn_begin(b->n_shapes + 1, 0u);
-        if (b->shape_dynamic_begin) dyn_begin.assign(b->shape_dynamic_begin, b->shape_dynamic_begin + b->n_shapes + 1);
-        sc->shape_dyn_begin_host = dyn_begin;
-        UP(elem_type, elem_type)
-        std::vector<uint32_t> elem_prev_off(n_elems); // the point stored just before the record: end of the previous segment, or Path::start
-        for (size_t i = 0; i < n_elems; ++i) elem_prev_off[i] = elem_off[i] >= 2u ? elem_off[i] - 2u : 0u;
-        UP(elem_off0, elem_off)
-        UP(elem_off, elem_off)
-        UP(elem_prev_off, elem_prev_off)
-        UP(elem_path, elem_path)
-        UP(pool, pool)
-        UP(path_elem_begin, path_elem_begin)
-        UP(path_shape, path_shape)
-        UP(path_stroke, path_stroke)
-        UP(shape_elem_begin, shape_elem_begin)
-        UP(shape_dyn_begin, dyn_begin)
-        UP(stroke_options, options)
-        UP(descriptors, descriptors)
-        // the staging vectors must outlive the async copies
-        if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) {
+    {   // thirteen asynchronous copies out of the arena, behind whatever still reads the old geometry; no host wait
+        if (!sc->geometry_ready && !hip_ok(hipEventCreateWithFlags(&sc->geometry_ready, hipEventDisableTiming), "hipEventCreate")) {
             rc = CRH_ERR_HIP;
             goto fail;
         }
+        bool ok = true;
+        if (existing && sc->tess_done && sc->tessellated_once_before_upload) ok = hip_ok(hipStreamWaitEvent(st, sc->tess_done, 0), "hipStreamWaitEvent"); // a tessellation of the old paths may still run
+        auto up = [&](DevBuf& buf, int k) {
+            if (!ok) return;
+            ok = hip_ok(buf.ensure(part[k].bytes), "hipMalloc");
+            if (ok && part[k].bytes) ok = hip_ok(hipMemcpyAsync(buf.p, arena + part[k].at, part[k].bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        };
+        up(sc->elem_type, P_TYPE), up(sc->elem_off0, P_OFF), up(sc->elem_off, P_OFF), up(sc->elem_prev_off, P_PREV), up(sc->elem_path, P_PATH), up(sc->pool, P_POOL);
+        up(sc->path_elem_begin, P_PATH_BEGIN), up(sc->path_shape, P_PATH_SHAPE), up(sc->path_stroke, P_PATH_STROKE), up(sc->shape_elem_begin, P_SHAPE_BEGIN);
+        up(sc->shape_dyn_begin, P_DYN_BEGIN), up(sc->stroke_options, P_OPTIONS), up(sc->descriptors, P_DESCRIPTORS);
+        if (ok) ok = hip_ok(sc->geometry_stage.done(st), "hipEventRecord") && hip_ok(hipEventRecord(sc->geometry_ready, st), "hipEventRecord");
+        if (!ok) {
+            rc = CRH_ERR_HIP;
+            goto fail;
+        }
+        sc->geometry_pending = true;
     }
-#undef UP
     if (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
         !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->group_base.ensure(((size_t)d.n_wg / 64 + 2) * NCH * 4), "hipMalloc") ||
         !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
@@ -1518,7 +1592,8 @@ void crh_scene_destroy(crh_scene* sc) {
             }
     }
     sc->release_all();
-    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free, sc->shadow.tess_done, sc->shadow.vertices_free, sc->shadow.ranges_free})
+    if (sc->geometry_ready) (void)hipEventSynchronize(sc->geometry_ready);
+    for (hipEvent_t e : {sc->tess_done, sc->vertices_free, sc->ranges_free, sc->shadow.tess_done, sc->shadow.vertices_free, sc->shadow.ranges_free, sc->geometry_ready})
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : sc->rec_raster_done)
         if (e) (void)hipEventDestroy(e);
