@@ -162,6 +162,7 @@ struct Mark {
 } // namespace
 
 struct crh_renderer {
+    int n_cus = 256; // compute units of the device (sizes the resident raster grid)
     crh_config config;
     int device;
     hipStream_t stream;       // raster kernel, copies
@@ -336,6 +337,8 @@ struct crh_frame {
     // The edge pass met a boundary edge with a non-finite endpoint on this frame (finite vertices times a finite matrix can overflow): an
     // unclosed chain has no backdrops, so passes of that Scene into this frame are drawn by the triangle pass, which skips exactly the
     // strip triangles with a non-finite determinant — as the reference's rasterizer does.
+    DevBuf tile_order;             // [workgroups of the edge pass' raster grid] the tile each one draws (order_tiles_heavy_first), or not ready: the kernels' own order
+    bool tile_order_ready = false;
     crh_scene* triangle_pass_for = nullptr;
     uint64_t triangle_pass_generation = 0; // ... of that Scene's geometry: a re-upload (or a new Scene at the same address) starts on the edge pass again
 };
@@ -817,6 +820,65 @@ int choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     return code_of[candidates - 1u]; // still waiting for the trial's events: stay on the pass of the latest frames
 }
 
+// The order in which the edge pass' raster kernels take a frame's tiles. One wavefront draws one tile, tile times spread over an order of
+// magnitude (entries per tile), and a long tile that starts late ends after everything else: the tail. The kernels' own order deals 8 x 8-tile
+// blocks to the eight XCDs (workgroup b runs on XCD b mod 8; neighbouring tiles share records in one L2). This keeps every tile on the XCD its
+// block belongs to and lets every XCD take its HEAVY tiles — more than `factor` x the mean number of entries in the verified pass — first,
+// the others in block order behind them. Any permutation draws the same image; the counts of one verified pass order all later passes.
+crh_status order_tiles_heavy_first(crh_frame* f, const uint32_t* tile_count_dev, hipStream_t stream) {
+    const char* e = getenv("CRH_HEAVY_FIRST"); // the factor; 0 switches the re-ordering off (A/B runs)
+    const bool sort_all = !e || std::strcmp(e, "sort") == 0; // the default: every XCD's tiles by falling count (a threshold factor keeps block order below it: measured slower)
+    const double factor = sort_all ? 1.0 : atof(e);
+    f->tile_order_ready = false;
+    if (!(factor > 0.0)) return CRH_OK;
+    const uint32_t n_tiles = f->n_tiles, tiles_x = f->tiles_x, tiles_y = f->tiles_y;
+    std::vector<uint32_t> count(n_tiles);
+    HIP_TRY(hipMemcpyAsync(count.data(), tile_count_dev, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    uint64_t sum = 0;
+    for (uint32_t c : count) sum += c;
+    const double threshold = factor * (double)sum / (double)std::max(1u, n_tiles);
+    constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
+    const uint32_t blocks_x = (tiles_x + kBlock - 1u) >> kB, blocks = blocks_x * ((tiles_y + kBlock - 1u) >> kB);
+    const uint32_t grid = ((blocks + 7u) / 8u) * kBlock * kBlock * 8u, turns = grid / 8u;
+    std::vector<uint32_t> order(grid), rest;
+    rest.reserve(turns);
+    for (uint32_t x = 0; x < 8u; ++x) { // XCD x: its workgroups in launch order
+        uint32_t at = 0;
+        rest.clear();
+        for (uint32_t turn = 0; turn < turns; ++turn) {
+            const uint32_t block = (turn >> (2u * kB)) * 8u + x;
+            const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+            if (tx >= tiles_x || ty >= tiles_y) continue;
+            const uint32_t tile = ty * tiles_x + tx;
+            if ((double)count[tile] > threshold) order[(at++) * 8u + x] = tile;
+            else rest.push_back(tile);
+        }
+        if (sort_all) { // (experiment: every XCD's tiles by falling count, block order lost)
+            std::vector<uint32_t> all;
+            for (uint32_t k = 0; k < at; ++k) all.push_back(order[k * 8u + x]);
+            all.insert(all.end(), rest.begin(), rest.end());
+            std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
+            at = 0;
+            rest.clear();
+            for (uint32_t tile : all) order[(at++) * 8u + x] = tile;
+        }
+        for (uint32_t tile : rest) order[(at++) * 8u + x] = tile;
+        for (; at < turns; ++at) order[at * 8u + x] = 0xFFFFFFFFu; // (workgroups beyond the frame: nothing to draw)
+    }
+    if (e && std::strcmp(e, "global") == 0) { // (experiment: all tiles by falling count, dealt to the XCDs in turn)
+        std::vector<uint32_t> all(n_tiles);
+        for (uint32_t t = 0; t < n_tiles; ++t) all[t] = t;
+        std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
+        for (uint32_t i = 0; i < grid; ++i) order[i] = i < n_tiles ? all[i] : 0xFFFFFFFFu;
+    }
+    HIP_TRY(f->tile_order.ensure((size_t)grid * 4));
+    HIP_TRY(hipMemcpyAsync(f->tile_order.p, order.data(), (size_t)grid * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    f->tile_order_ready = true;
+    return CRH_OK;
+}
+
 // A frame whose tiles hold many entries on average has most of them in lists of several 64-entry chunks: the raster kernel then looks for
 // its late start across the chunks (k_raster_edges<.., LONG>; 100 000 paths @ 8192^2: 67 entries per tile, raster 2.34 -> 1.33 ms). For
 // short lists the plain variant is the faster one (10 000 paths @ 4096^2: 27 per tile, 0.234 against 0.255 ms), and so it is where nothing
@@ -1052,6 +1114,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->generation;
     p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = f->tile_base.as<uint32_t>();
+    p.tile_order = (edges && f->tile_order_ready) ? f->tile_order.as<uint32_t>() : nullptr;
     if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
@@ -1094,6 +1157,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                 HIP_TRY(hipStreamSynchronize(bin));
                 f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
                 f->queue_seen = ov[6] != 0;
+                const crh_status ordered = order_tiles_heavy_first(f, p.tile_count, bin);
+                if (ordered != CRH_OK) return ordered;
             }
             break;
         }
@@ -1257,6 +1322,7 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
         return CRH_ERR_HIP;
     }
     const int n_cus = prop.multiProcessorCount;
+    r->n_cus = n_cus;
     auto make_stream = [&](hipStream_t* st, int lane) -> bool { // lane 0: unrestricted, 1: front lanes, 2: raster lane
         if (!r->pipeline || front_cus <= 0 || front_cus >= n_cus || lane == 0) return hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
         std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
@@ -1748,7 +1814,7 @@ void crh_frame_destroy(crh_frame* f) {
                 break;
             }
     }
-    DevBuf* all[] = {&f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
+    DevBuf* all[] = {&f->tile_order, &f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
                      &f->item_nslots, &f->item_slot_begin};
     for (DevBuf* b : all) b->release();
     f->item_upload_t.release();

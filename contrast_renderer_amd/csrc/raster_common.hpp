@@ -10,9 +10,6 @@
 #ifndef CRH_TILE_WAVES
 #define CRH_TILE_WAVES 6
 #endif
-#ifndef CRH_XCD_BLOCK_LOG2
-#define CRH_XCD_BLOCK_LOG2 3 // the raster kernel's XCD blocks are 8x8 tiles
-#endif
 #ifndef CRH_WALK_WAVES
 #define CRH_WALK_WAVES 2
 #endif

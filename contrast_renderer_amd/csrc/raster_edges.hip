@@ -1572,13 +1572,19 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 // LONG: the late start also for lists of several chunks (selected by the host for frames whose tiles hold many entries on average).
 template <int S, int ROWS, bool STROKES, bool LONG>
 __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu((STROKES || S == 4) ? CRH_STROKE_TILE_WAVES : CRH_EDGE_TILE_WAVES))) void k_raster_edges(SceneDev s, RasterParams r) {
+    const uint32_t bid = blockIdx.x; // the workgroup's place in the frame's tile order
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
     __shared__ uint8_t compact_table[STROKES ? 4 / ROWS : 1][STROKES ? 256 : 4]; // (lane, slot) codes of the samples a stroke triangle has to decide
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
-    const uint32_t turn = blockIdx.x >> 3;
-    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
-    const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    const uint32_t turn = bid >> 3;
+    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (bid & 7u);
+    uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    if (r.tile_order) { // the host's order for this frame: every XCD's heavy tiles first (api.hip order_tiles_heavy_first)
+        const uint32_t mine = r.tile_order[bid];
+        if (mine == 0xFFFFFFFFu) return;
+        ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
+    }
     if (tx >= r.tiles_x || ty >= r.tiles_y) return;
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2198,6 +2204,10 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         }
     }
 }
+// (A RESIDENT grid — as many workgroups as stay on the machine at four wavefronts per SIMD, each looping over the places bid, bid + gridDim.x, ...
+// of a falling tile order, so that the next frame's binning and tessellation workgroups find room beside it — was measured in round 4: dealt
+// statically, the tiles balance worse than under the hardware's dynamic dispatch (0.29 - 0.31 against 0.22 ms), the loop around the kernel
+// body costs 5 - 12 % by itself, and the front lanes gain nothing. Not kept.)
 
 // ---------------------------------------------------------------------------------------------- k_raster_rows (round 4)
 // The same pass with the winding numbers ACCUMULATED IN LDS and the lanes spread over (entry, sample row) instead of every lane evaluating
@@ -2267,6 +2277,7 @@ CRH_D uint32_t first_of_16(P holds) {
 }
 template <bool LONG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE_WAVES))) void k_raster_rows(SceneDev s, RasterParams r) {
+    const uint32_t bid = blockIdx.x;
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[64 * 3];
     __shared__ uint32_t grid[kRowSlots][16][16]; // [group slot][sample row][column], delta form, fill + 65536 * hull
@@ -2276,9 +2287,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
     __shared__ uint16_t edge_pair_start[66];     // the same for the boundary edges: their (edge, row) pairs — the rows of the edge's half-open y range
     __shared__ uint32_t vgrid[kRowSlots][16];    // [group slot][sample row] what begins at that row and holds for every column of it and of the rows below (delta form down the tile)
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
-    const uint32_t turn = blockIdx.x >> 3;
-    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
-    const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    const uint32_t turn = bid >> 3;
+    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (bid & 7u);
+    uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    if (r.tile_order) { // the host's order for this frame: every XCD's heavy tiles first (api.hip order_tiles_heavy_first)
+        const uint32_t mine = r.tile_order[bid];
+        if (mine == 0xFFFFFFFFu) return;
+        ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
+    }
     if (tx >= r.tiles_x || ty >= r.tiles_y) return;
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u;
@@ -2857,7 +2873,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
         }
     }
 }
-
 // ---------------------------------------------------------------------------------------------- launchers
 void launch_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* block_sum, uint32_t n, hipStream_t stream); // raster.hip
 
@@ -2951,7 +2966,7 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
                          uint64_t raster_bytes, bool has_stroke) {
     constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
     const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
-    const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
+    const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u); // the places of the tile order (a multiple of 8: place b is drawn on XCD b mod 8)
 #define CRH_LAUNCH_EDGES(S_, ROWS_, STROKES_, LONG_) \
     hipLaunchKernelGGL((k_raster_edges<S_, ROWS_, STROKES_, LONG_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 1 && !has_stroke && r.rows) { // the row-span kernel: winding numbers accumulated in LDS, lanes over (entry, sample row)

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef CRH_XCD_BLOCK_LOG2
+#define CRH_XCD_BLOCK_LOG2 3 // the raster kernels' XCD blocks are 8x8 tiles (the host mirrors the mapping: api.hip order_tiles_heavy_first)
+#endif
+
 namespace crh {
 
 struct PrimRec;
@@ -67,6 +71,7 @@ struct RasterParams {
     const uint32_t* tile_base;        // [n_tiles + 1]
     uint32_t long_lists;              // the frame's tile lists hold many entries on average: k_raster_edges looks for its late start across chunks (host: crh_frame::mean_list)
     uint32_t* bin_queue;              // [n_items] items k_bin_flat hands on to k_bin_edges (their number: overflow[6])
+    const uint32_t* tile_order;       // [workgroups of the raster grid] the tile each workgroup of the edge pass' raster kernels draws (0xFFFFFFFF: none), or nullptr: the kernels' own XCD-aware order
     uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
 };
 

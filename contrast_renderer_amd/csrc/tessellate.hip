@@ -133,7 +133,12 @@ CRH_D void count_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint
     }
 }
 
-__global__ __launch_bounds__(kTessBlock) void k_count(SceneDev s) {
+#ifdef CRH_TESS_WAVES
+#define CRH_TESS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(CRH_TESS_WAVES)))
+#else
+#define CRH_TESS_OCCUPANCY
+#endif
+__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_count(SceneDev s) {
     __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
     const uint32_t e = blockIdx.x * kTessBlock + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -314,7 +319,7 @@ CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint3
     }
 }
 
-__global__ __launch_bounds__(kTessBlock) void k_emit(SceneDev s) {
+__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_emit(SceneDev s) {
     const uint32_t e = blockIdx.x * kTessBlock + threadIdx.x;
     if (e >= s.n_elems) return;
     if (!fits(s)) {
