@@ -949,7 +949,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
 #ifndef CRH_FLAT_STAGE
 #define CRH_FLAT_STAGE 128
 #endif
-constexpr uint32_t kFlatItems = 32, kFlatTris = 256, kFlatEdgeRounds = CRH_FLAT_ROUNDS, kFlatEdges = 256 * kFlatEdgeRounds, kFlatPool = 1536, kFlatStage = CRH_FLAT_STAGE; // 37 KB of LDS: four workgroups per CU
+#ifndef CRH_FLAT_THREADS
+#define CRH_FLAT_THREADS 256 // threads of a workgroup of k_bin_flat: 256 (four wavefronts, a batch of up to 32 items) or 64 (ONE wavefront, a quarter of every table)
+#endif
+constexpr uint32_t kFlatThreads = CRH_FLAT_THREADS, kFlatWaveCount = kFlatThreads / 64u;
+static_assert(kFlatThreads == 64u || kFlatThreads == 128u || kFlatThreads == kFlatThreads, "CRH_FLAT_THREADS");
+#ifndef CRH_FLAT_POOL
+#define CRH_FLAT_POOL 6 // tile cells of the batch's rectangles per thread
+#endif
+#ifndef CRH_FLAT_BATCH
+#define CRH_FLAT_BATCH (CRH_FLAT_THREADS / 8) // items of a batch at most
+#endif
+// kFlatItems: entries of the index tables (find_item searches 32); kFlatBatch: items a batch holds (their LDS records)
+constexpr uint32_t kFlatItems = 32, kFlatBatch = CRH_FLAT_BATCH, kFlatTris = kFlatThreads, kFlatEdgeRounds = CRH_FLAT_ROUNDS, kFlatEdges = kFlatThreads * kFlatEdgeRounds, kFlatPool = CRH_FLAT_POOL * kFlatThreads, kFlatStage = CRH_FLAT_STAGE; // 256 threads: 37 KB of LDS
+static_assert(kFlatBatch >= 1u && kFlatBatch <= kFlatItems, "CRH_FLAT_BATCH");
 constexpr uint32_t kFiOpaque = 1u, kFiSkip = 2u, kFiHullTris = 4u, kFiQueue = 8u; // kFiQueue: not binned here but by k_bin_edges (handed on when the item's turn is over)
 struct FlatItem {
     ItemCtx ctx;
@@ -1024,15 +1037,20 @@ struct FlatTri { // a set-up triangle between the passes: its tile test and tile
 #define CRH_FLAT_PHASE(k)
 #endif
 template <int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WAVES))) void k_bin_flat(SceneDev s, RasterParams r, uint32_t items_per_group) {
-    __shared__ uint32_t stage_tile[4][kFlatStage], stage_pos[4][kFlatStage], stage_key[4][kFlatStage];
-    __shared__ FlatItem items[kFlatItems];
+#ifdef CRH_FLAT_VGPRS
+#define CRH_FLAT_BUDGET __attribute__((amdgpu_num_vgpr(CRH_FLAT_VGPRS)))
+#else
+#define CRH_FLAT_BUDGET
+#endif
+__global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WAVES))) CRH_FLAT_BUDGET void k_bin_flat(SceneDev s, RasterParams r, uint32_t items_per_group) {
+    __shared__ uint32_t stage_tile[kFlatWaveCount][kFlatStage], stage_pos[kFlatWaveCount][kFlatStage], stage_key[kFlatWaveCount][kFlatStage];
+    __shared__ FlatItem items[kFlatBatch];
     __shared__ uint32_t tri_begin[kFlatItems + 1], edge_begin[kFlatItems + 1], pool_begin[kFlatItems + 1];
     __shared__ int pool_bd[kFlatPool], pool_hbd[kFlatPool];
     __shared__ uint32_t pool_cursor[kFlatPool]; // pass 1: the entries the item's edges and triangles have in the tile (bits 0-19; bits 20-31: the hull edges among them), then the next list position
     __shared__ uint32_t batch[6];               // items in the batch, its triangles, its edges, tiles of its pool, items of the batch that are binned in this turn, (edge, tile row) pairs
-    __shared__ uint32_t wave_opaque[4];         // opaque whole-tile covers every wavefront found in pass 2
-    __shared__ uint32_t wave_entries[8];        // entries every wavefront appends in pass 3 ([0..3]) and in pass 2 ([4..7]); then where its share of the pair stream begins
+    __shared__ uint32_t wave_opaque[kFlatWaveCount];         // opaque whole-tile covers every wavefront found in pass 2
+    __shared__ uint32_t wave_entries[2u * kFlatWaveCount];        // entries every wavefront appends in pass 3 ([0..3]) and in pass 2 ([4..7]); then where its share of the pair stream begins
     __shared__ PackedEdge edge_table[kFlatEdges]; // the batch's boundary edges: the walks are balanced over (edge, tile row) pairs, whoever loaded the edge
     __shared__ uint32_t row_begin[kFlatEdges + 1]; // exclusive prefix of the tile rows every edge walks
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1048,7 +1066,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
     for (uint32_t next = first_item; next < last_item;) {
         lds_barrier(); // (the previous batch's readers of the LDS records are through)
         // ---------------- 0: the records of the next items
-        const uint32_t n_cand = min(kFlatItems, last_item - next);
+        const uint32_t n_cand = min(kFlatBatch, last_item - next);
         if (tid < n_cand) {
             const uint32_t item = next + tid;
             const DrawItem it = item_of(r, item);
@@ -1068,8 +1086,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         }
         lds_barrier();
         if (wave == 0u) { // the batch: the longest run of items whose triangles and edges fit the lanes (an oversize item counts as empty)
-            const bool real = lane < n_cand && lane < kFlatItems, counted = real && (items[lane & 31u].flags & kFiSkip) == 0u;
-            const uint32_t nt = counted ? items[lane & 31u].n_tri : 0u, ne = counted ? items[lane & 31u].n_fe + items[lane & 31u].n_hull : 0u;
+            const FlatItem& mine_ = items[min(lane, kFlatBatch - 1u)];
+            const bool real = lane < n_cand && lane < kFlatBatch, counted = real && (mine_.flags & kFiSkip) == 0u;
+            const uint32_t nt = counted ? mine_.n_tri : 0u, ne = counted ? mine_.n_fe + mine_.n_hull : 0u;
             const uint32_t pt = wave_inclusive_scan(nt, lane), pe = wave_inclusive_scan(ne, lane);
             const unsigned long long fits = __ballot(real && pt <= kFlatTris && pe <= kFlatEdges);
             const uint32_t n_batch = (uint32_t)__builtin_ctzll(~fits); // leading lanes that fit (>= 1: one item alone always does)
@@ -1095,7 +1114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         uint32_t edge_item[kFlatEdgeRounds], edge_key[kFlatEdgeRounds];
 #pragma unroll
         for (int k = 0; k < (int)kFlatEdgeRounds; ++k) {
-            const uint32_t e = tid + 256u * (uint32_t)k;
+            const uint32_t e = tid + kFlatThreads * (uint32_t)k;
             kept[k] = PackedEdge{0.0f, 0.0f, 0.0f, 0.0f, 0u};
             strip_det[k] = 0.0f;
             edge_item[k] = 0u, edge_key[k] = 0u;
@@ -1139,7 +1158,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         }
 #pragma unroll
         for (int k = 0; k < (int)kFlatEdgeRounds; ++k) {
-            if (tid + 256u * (uint32_t)k < n_edges) {
+            if (tid + kFlatThreads * (uint32_t)k < n_edges) {
                 FlatItem& fi = items[edge_item[k]];
                 const BinEdge e = unpack_edge(kept[k]);
                 if (e.valid) {
@@ -1155,7 +1174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             }
         }
         CRH_FLAT_PHASE(2) // triangle set-up, record stores
-        for (uint32_t q = tid; q < 31u * n_batch; q += 256u) { // the items' 4 backdrop + 27 COVER slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
+        for (uint32_t q = tid; q < 31u * n_batch; q += kFlatThreads) { // the items' 4 backdrop + 27 COVER slots (the COVER ones carry the premultiplied source colour, shaders.wgsl:304-309)
             const uint32_t j = q / 31u, l = q - 31u * j;
             const FlatItem& fi = items[j];
             if (fi.flags & kFiSkip) continue;
@@ -1172,7 +1191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         if (wave == 0u) {
             uint32_t n_rect = 0;
             const bool mine = lane < n_batch;
-            FlatItem& fi = items[lane & 31u];
+            FlatItem& fi = items[min(lane, kFlatBatch - 1u)];
             if (mine && (fi.flags & kFiSkip) == 0u) {
                 const float minx = ordered_float(fi.box[0]), miny = ordered_float(fi.box[1]), maxx = ordered_float(fi.box[2]), maxy = ordered_float(fi.box[3]);
                 if (fi.box[0] <= fi.box[2]) { // something is drawn
@@ -1205,7 +1224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         }
         lds_barrier();
         const uint32_t n_pool = batch[3], n_turn = batch[4]; // (items n_turn .. n_batch - 1 are set up but not binned: n_rect == 0)
-        for (uint32_t q = tid; q < n_pool; q += 256u) pool_bd[q] = 0, pool_hbd[q] = 0, pool_cursor[q] = 0u;
+        for (uint32_t q = tid; q < n_pool; q += kFlatThreads) pool_bd[q] = 0, pool_hbd[q] = 0, pool_cursor[q] = 0u;
         lds_barrier();
         CRH_FLAT_PHASE(4) // rectangles, pool cleared
         // ---------------- the edges' walks are balanced over (edge, tile row) pairs. A lane that walked ITS edge kept its wavefront in the loop
@@ -1226,7 +1245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         };
 #pragma unroll
         for (int k = 0; k < (int)kFlatEdgeRounds; ++k) {
-            const uint32_t e = tid + 256u * (uint32_t)k;
+            const uint32_t e = tid + kFlatThreads * (uint32_t)k;
             if (e < n_edges) {
                 PackedEdge pe = kept[k];
                 const FlatItem& fi = items[edge_item[k]];
@@ -1261,7 +1280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         const uint32_t n_work = batch[5];
         // visit(active, edge, its item, the tile row, the columns x0 .. x1 of that row worth a test, the edge's slot number)
         auto for_edge_rows = [&](auto&& visit) {
-            for (uint32_t w0 = 0; w0 < n_work; w0 += 256u) {
+            for (uint32_t w0 = 0; w0 < n_work; w0 += kFlatThreads) {
                 const uint32_t w = w0 + tid;
                 const bool active = w < n_work;
                 uint32_t ei = 0; // the largest edge index with row_begin <= w (edges without rows share their successor's entry and are passed over)
@@ -1269,7 +1288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
                 if (r.debug & 4096u) ei = w % max(n_edges, 1u); else // what does the search cost? (the wrong edges: timing only)
 #endif
 #pragma unroll
-                for (uint32_t step = 512; step > 0u; step >>= 1)
+                for (uint32_t step = kFlatEdges >= 512u ? 512u : (kFlatEdges >= 256u ? 256u : 128u); step > 0u; step >>= 1)
                     if (ei + step < n_edges && row_begin[ei + step] <= w) ei += step;
                 const PackedEdge pe = edge_table[active ? ei : 0u];
                 const BinEdge e = unpack_edge(pe);
@@ -1354,10 +1373,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         // global counter for all of it plus the edges' and triangles' entries; the atomics of all the lane's tiles are in flight together,
         // and the tile's verdict replaces its backdrops in the LDS tables. Then the workgroup reserves its range of the pair stream with one
         // atomic (every wavefront knows what it will append), and 2b emits the synthetic entries.
-        constexpr uint32_t kChunks = kFlatPool / 256u;
+        constexpr uint32_t kChunks = kFlatPool / kFlatThreads;
 #pragma unroll 1
-        for (uint32_t ch = 0; ch * 256u < n_pool; ++ch) {
-            const uint32_t p = ch * 256u + tid;
+        for (uint32_t ch = 0; ch * kFlatThreads < n_pool; ++ch) {
+            const uint32_t p = ch * kFlatThreads + tid;
             if (p < n_pool) {
                 const uint32_t j = find_item(pool_begin, p);
                 const uint32_t q = p - pool_begin[j], nx = items[j].nx;
@@ -1372,7 +1391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
 #pragma unroll
             for (uint32_t ch = 0; ch < kChunks; ++ch) { // 2a
                 reserved[ch] = 0u, lefts[ch] = 0u;
-                const uint32_t p = ch * 256u + tid;
+                const uint32_t p = ch * kFlatThreads + tid;
                 if (p >= n_pool) continue;
                 const uint32_t j = find_item(pool_begin, p);
                 const FlatItem& fi = items[j];
@@ -1400,19 +1419,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
             }
 #pragma unroll
             for (uint32_t ch = 0; ch < kChunks; ++ch)
-                if (ch * 256u + tid < n_pool) pool_cursor[ch * 256u + tid] = reserved[ch] + lefts[ch]; // where the edges' and triangles' entries go
+                if (ch * kFlatThreads + tid < n_pool) pool_cursor[ch * kFlatThreads + tid] = reserved[ch] + lefts[ch]; // where the edges' and triangles' entries go
         }
         {
             uint32_t a = my_entries, b = my_synth | (my_opaque << 22); // (6 cells per lane, < 4096 entries each: a wavefront's sums stay below 2^22 and 2^10)
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) a += (uint32_t)__shfl_xor((int)a, d, 64), b += (uint32_t)__shfl_xor((int)b, d, 64);
-            if (lane == 0u) wave_entries[wave] = a, wave_entries[4u + wave] = b & 0x003FFFFFu, wave_opaque[wave] = b >> 22;
+            if (lane == 0u) wave_entries[wave] = a, wave_entries[kFlatWaveCount + wave] = b & 0x003FFFFFu, wave_opaque[wave] = b >> 22;
         }
         lds_barrier();
         if (tid == 0u) { // the workgroup's range of the pair stream: wavefront w's pass-2 entries, then its pass-3 entries
             uint32_t total = 0;
-            for (uint32_t w = 0; w < 8u; ++w) total += wave_entries[w];
-            if (const uint32_t opaque = wave_opaque[0] + wave_opaque[1] + wave_opaque[2] + wave_opaque[3]) atomicAdd(&r.overflow[4], opaque); // the host's statistic: are there tiles to start late in?
+            for (uint32_t w = 0; w < 2u * kFlatWaveCount; ++w) total += wave_entries[w];
+            uint32_t opaque = 0;
+            for (uint32_t w = 0; w < kFlatWaveCount; ++w) opaque += wave_opaque[w];
+            if (opaque) atomicAdd(&r.overflow[4], opaque); // the host's statistic: are there tiles to start late in?
             const uint32_t sub = ((blockIdx.x + 40503u * turn) * 2654435761u) >> 26, region = r.pair_capacity / kSubStreams;
             uint32_t begin = 0xFFFFFFFFu;
             if (r.direct) {
@@ -1424,8 +1445,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
                 else
                     begin = sub * region + got;
             }
-            for (uint32_t w = 0; w < 4u; ++w) {
-                const uint32_t mine = wave_entries[4u + w] + wave_entries[w];
+            for (uint32_t w = 0; w < kFlatWaveCount; ++w) {
+                const uint32_t mine = wave_entries[kFlatWaveCount + w] + wave_entries[w];
                 wave_entries[w] = begin;
                 if (begin != 0xFFFFFFFFu) begin += mine;
             }
@@ -1433,8 +1454,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         lds_barrier();
         st.at = wave_entries[wave];
 #pragma unroll 1
-        for (uint32_t ch = 0; ch * 256u < n_pool; ++ch) { // 2b
-            const uint32_t p = ch * 256u + tid;
+        for (uint32_t ch = 0; ch * kFlatThreads < n_pool; ++ch) { // 2b
+            const uint32_t p = ch * kFlatThreads + tid;
             const bool active = p < n_pool;
             const uint32_t j = active ? find_item(pool_begin, p) : 0u;
             const FlatItem& fi = items[j];
@@ -1497,12 +1518,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WA
         bool any_folded = false;
         for (uint32_t j = 0; j < n_turn; ++j) any_folded = any_folded || (items[j].flags & (kFiHullTris | kFiSkip)) == kFiHullTris;
         if (any_folded) { // (uniform: LDS values)
-            st.sub = ((4u * blockIdx.x + wave + 977u * turn) * 2654435761u) >> 26;
+            st.sub = ((kFlatWaveCount * blockIdx.x + wave + 977u * turn) * 2654435761u) >> 26;
             for (uint32_t j = 0; j < n_turn; ++j) {
                 const FlatItem& fi = items[j];
                 if ((fi.flags & (kFiHullTris | kFiSkip)) != kFiHullTris) continue;
                 const ItemCtx& ctx = fi.ctx;
-                for (uint32_t t0 = 64u * wave; t0 + 2u < fi.n_hull; t0 += 256u) { // 64 triangles per wavefront and turn
+                for (uint32_t t0 = 64u * wave; t0 + 2u < fi.n_hull; t0 += kFlatThreads) { // 64 triangles per wavefront and turn
                     const uint32_t t = t0 + lane;
                     PrimRec rec = {};
                     bool drawn = false;
@@ -2928,19 +2949,19 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         // k_bin_flat: a batch of items per 256-thread workgroup. A workgroup lives about as long whether it holds two items or twenty (the
         // same chain of phases), so the grid is sized to ONE round of resident workgroups — three per CU — as long as that leaves a batch
         // within the kernel's 32 items; what a batch cannot hold is queued and binned item by item behind it.
-        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * CRH_FLAT_WAVES; // workgroups the CUs of the binning lane hold at once
+        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * CRH_FLAT_WAVES * (4u / kFlatWaveCount); // workgroups the CUs of the binning lane hold at once
         // ... and within what the lanes of a batch hold (256 triangles, 768 edges): an item that does not fit is left to the workgroup's next
         // turn, which doubles the workgroup's life — the averages of the scene keep a batch nine tenths full
-        const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)kFlatTris * 9u / 10u * r.n_items / r.hint_tris) : kFlatItems;
-        const uint32_t by_edges = r.hint_edges ? (uint32_t)((uint64_t)kFlatEdges * 9u / 10u * r.n_items / r.hint_edges) : kFlatItems;
-        const uint32_t fitting = max(1u, min(kFlatItems, min(by_tris, by_edges)));
-        const uint32_t items_per_group = pinned ? min(pinned, kFlatItems) : min(fitting, max(1u, (r.n_items + resident - 1u) / resident));
+        const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)kFlatTris * 9u / 10u * r.n_items / r.hint_tris) : kFlatBatch;
+        const uint32_t by_edges = r.hint_edges ? (uint32_t)((uint64_t)kFlatEdges * 9u / 10u * r.n_items / r.hint_edges) : kFlatBatch;
+        const uint32_t fitting = max(1u, min(kFlatBatch, min(by_tris, by_edges)));
+        const uint32_t items_per_group = pinned ? min(pinned, kFlatBatch) : min(fitting, max(1u, (r.n_items + resident - 1u) / resident));
         const uint32_t flat_grid = (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
         if (samples == 4) {
-            hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
+            hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
             if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<4, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
         } else {
-            hipLaunchKernelGGL((k_bin_flat<1>), dim3(flat_grid), dim3(256), 0, stream, s, r, items_per_group);
+            hipLaunchKernelGGL((k_bin_flat<1>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
             if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<1, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
         }
     }
