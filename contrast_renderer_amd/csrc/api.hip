@@ -1764,7 +1764,7 @@ crh_status crh_frame_format(const crh_frame* f, uint32_t* format) {
 }
 crh_status crh_frame_create_format(crh_renderer* r, uint32_t width, uint32_t height, uint32_t format, crh_frame** out) {
     // pixel boxes are 16-bit (0xFFFF = nothing to draw), so a frame is at most 65 535 pixels wide and high
-    if (!r || !out || width == 0 || height == 0 || width > 65535u || height > 65535u || format > CRH_FORMAT_RGBA16F) return CRH_ERR_INVALID_ARGUMENT;
+    if (!r || !out || width == 0 || height == 0 || width > 65535u || height > 65535u || format > CRH_FORMAT_RGBA8_ATTACHMENT) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipSetDevice(r->device));
     crh_frame* f = new crh_frame;
     f->renderer = r;
@@ -2021,7 +2021,7 @@ crh_status crh_scene_render(crh_scene* sc, crh_frame* f, const float* transforms
 }
 namespace {
 crh_status download_pixels(crh_frame* f, void* out, uint32_t format) {
-    if (!f || !out || f->format != format) return CRH_ERR_INVALID_ARGUMENT;
+    if (!f || !out || (f->format == CRH_FORMAT_RGBA16F) != (format == CRH_FORMAT_RGBA16F)) return CRH_ERR_INVALID_ARGUMENT; // (both RGBA8 formats store RGBA8)
     crh_renderer* r = f->renderer;
     HIP_TRY(hipSetDevice(r->device));
     crh_status st = settle_frame(f);

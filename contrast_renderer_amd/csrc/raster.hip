@@ -896,7 +896,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                             for (int l = 0; l < kMaxAlphaLayers; ++l) mine = (uint32_t)l == layer ? saved[cb_][ck_][l] : mine;
                             const float scaled = scale_src + alpha * (1.0f - scale_src);      // alpha' = src.a * One + dst.a * (1 - src.a), renderer.rs:803-828
                             const float restored = alpha - (1.0f - mine) * (1.0f - ca);        // alpha' = dst.a - (1 - saved)(1 - a), renderer.rs:829-861
-                            const float next = is_scale ? scaled : (is_restore ? restored : alpha);
+                            float next = is_scale ? scaled : (is_restore ? restored : alpha);
+                            if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) next = attachment_unorm8(next); // an Rgba8Unorm attachment keeps 8 bits of what the blender writes
                             col[b][k][3] = pass ? next : alpha;
 #pragma unroll
                             for (int l = 0; l < kMaxAlphaLayers; ++l) // save_alpha_context_cover: the layer receives the frame's alpha, shaders.wgsl:326-331
@@ -997,6 +998,14 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         col[b][k][2] = blend[b][k] ? n2 : col[b][k][2];
                         col[b][k][3] = blend[b][k] ? n3 : col[b][k][3];
                     }
+                if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) { // an Rgba8Unorm attachment keeps 8 bits of what the blender writes (idempotent on the others)
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                        for (int k = 0; k < S; ++k)
+#pragma unroll
+                            for (int ch = 0; ch < 4; ++ch) col[b][k][ch] = attachment_unorm8(col[b][k][ch]);
+                }
             }
         }
     }

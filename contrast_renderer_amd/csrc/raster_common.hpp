@@ -41,6 +41,16 @@ CRH_D uint32_t pack_unorm8(float c0, float c1, float c2, float c3) {
     }
     return out;
 }
+// What an Rgba8Unorm attachment keeps of a colour component a blend wrote (CRH_FORMAT_RGBA8_ATTACHMENT): pack_unorm8's rounding, read back as
+// load_pixel reads it — idempotent, so it may be applied to components the blend left alone
+CRH_D float attachment_unorm8(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float x = __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f);
+#else
+    const float x = v;
+#endif
+    return (float)(uint32_t)(int)(x * 255.0f + 0.5f) * (1.0f / 255.0f);
+}
 // The target's pixel (gx, gy): the resolved premultiplied colour, clamped to [0, 1] (NaN -> 0) and stored as RGBA8 unorm or — the layers
 // of the multi-GPU exchange — as four binary16 values (round to nearest even; the clamp is the same, so a 16F layer holds what the RGBA8
 // target would have quantised).

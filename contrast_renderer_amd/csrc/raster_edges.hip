@@ -2200,6 +2200,14 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                     col[b][q][3] = blend[b][q] ? n3 : col[b][q][3];
                 }
             }
+            if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) { // an Rgba8Unorm attachment keeps 8 bits of what the blender writes (idempotent on the others)
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int q = 0; q < S; ++q)
+#pragma unroll
+                        for (int ch = 0; ch < 4; ++ch) col[b][q][ch] = attachment_unorm8(col[b][q][ch]);
+            }
         }
         } // entries of the chunk
         if (kLongLateStart && again_from_the_top) { // (X of the late start did not overwrite every sample: the whole list, chunk 0 first)
@@ -2764,6 +2772,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                             col[i][0] = replace ? cs0 : cs0 + col[i][0] * one_minus_a, col[i][1] = replace ? cs1 : cs1 + col[i][1] * one_minus_a;
                             col[i][2] = replace ? cs2 : cs2 + col[i][2] * one_minus_a, col[i][3] = replace ? cs3 : cs3 + col[i][3] * one_minus_a;
                         }
+                        if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int ch = 0; ch < 4; ++ch) col[i][ch] = attachment_unorm8(col[i][ch]);
+                        }
                         continue;
                     }
                     int p[4] = {0, 0, 0, 0};
@@ -2843,6 +2857,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
                             col[i][2] = blend[i] ? n2 : col[i][2];
                             col[i][3] = blend[i] ? n3 : col[i][3];
                         }
+                    }
+                    if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) { // an Rgba8Unorm attachment keeps 8 bits of what the blender writes (idempotent on the others)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int ch = 0; ch < 4; ++ch) col[i][ch] = attachment_unorm8(col[i][ch]);
                     }
                 }
                 if (restart) { // (X of the late start did not overwrite every sample: everything again, from cleared state, the shortcut off)

@@ -98,7 +98,7 @@ class Renderer:
             self.handle = None
 
 
-FORMAT_RGBA8, FORMAT_RGBA16F = 0, 1
+FORMAT_RGBA8, FORMAT_RGBA16F, FORMAT_RGBA8_ATTACHMENT = 0, 1, 2  # (2: RGBA8 storage, every blend rounded to 8 bits like an Rgba8Unorm attachment)
 
 
 class Frame:

@@ -212,7 +212,12 @@ crh_status crh_frame_create(crh_renderer* renderer, uint32_t width, uint32_t hei
 /* The same with the storage format of the resolved image named. CRH_FORMAT_RGBA8 is the reference's target (main.rs:205-215 renders to
  * the surface format, 8 bits per channel). CRH_FORMAT_RGBA16F keeps four binary16 values per pixel — the per-rank LAYERS of the multi-GPU
  * exchange (layers exchanged as RGBA16F keep the composite within 1/255 of a single-GPU render, RGBA8 layers within 2/255). */
-enum { CRH_FORMAT_RGBA8 = 0, CRH_FORMAT_RGBA16F = 1 };
+enum { CRH_FORMAT_RGBA8 = 0, CRH_FORMAT_RGBA16F = 1, CRH_FORMAT_RGBA8_ATTACHMENT = 2 };
+/* CRH_FORMAT_RGBA8_ATTACHMENT: RGBA8 storage like CRH_FORMAT_RGBA8, and the frame behaves like the wgpu::TextureFormat::Rgba8Unorm colour
+ * ATTACHMENT the reference blends into (renderer.rs:736-754, examples/showcase/main.rs:32-43,205-215): every colour write of a cover — the
+ * premultiplied "over" of Color, the alpha writes of Scale / RestoreAlphaContext — is rounded to 8 bits per channel where it happens, as a
+ * hardware blender reads and writes the texture. CRH_FORMAT_RGBA8 keeps f32 colours for the whole pass and rounds once at the end: up to a
+ * few 1/255 closer to the exact composite where many translucent Shapes overlap. Same download / upload entry points as CRH_FORMAT_RGBA8. */
 crh_status crh_frame_create_format(crh_renderer* renderer, uint32_t width, uint32_t height, uint32_t format, crh_frame** out);
 crh_status crh_frame_format(const crh_frame* frame, uint32_t* format);
 void crh_frame_destroy(crh_frame* frame);

@@ -438,8 +438,10 @@ class Renderer { // renderer.rs:408-435
 // The caller-owned colour + depth/stencil attachments of the render pass (examples/showcase/main.rs:217-230).
 class Frame {
   public:
-    Frame(Renderer& renderer, uint32_t width, uint32_t height) : width_(width), height_(height), samples_(renderer.msaa_sample_count()) {
-        check(crh_frame_create(renderer.raw(), width, height, &handle_));
+    // `format`: CRH_FORMAT_RGBA8 (f32 colours during a pass, one rounding at the end) or CRH_FORMAT_RGBA8_ATTACHMENT (every blend rounded to 8 bits, as
+    // the wgpu Rgba8Unorm attachment of main.rs:205-215 would)
+    Frame(Renderer& renderer, uint32_t width, uint32_t height, uint32_t format = CRH_FORMAT_RGBA8) : width_(width), height_(height), samples_(renderer.msaa_sample_count()) {
+        check(crh_frame_create_format(renderer.raw(), width, height, format, &handle_));
     }
     ~Frame() { crh_frame_destroy(handle_); }
     Frame(const Frame&) = delete;

@@ -111,6 +111,9 @@ int oracle_convert_dynamic_stroke_options(const crh_dynamic_stroke_options* o, c
 }
 
 // The loop of examples/showcase/main.rs:236-250 over shapes [shape_begin, shape_end) into a cleared frame.
+// frames created after this call behave as Rgba8Unorm attachments (per-blend rounding) or not: see oracle/raster.hpp Frame::attachment8
+void oracle_set_attachment8(int on) { Frame::attachment8_default() = on != 0; }
+
 int oracle_render(void* h, uint32_t width, uint32_t height, uint32_t msaa, uint32_t winding_bits, const float* transforms, const float* colors,
                   uint32_t shape_begin, uint32_t shape_end, uint8_t* rgba8) {
     Scene* sc = static_cast<Scene*>(h);

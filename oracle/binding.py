@@ -117,14 +117,17 @@ class Oracle:
         n = self.lib.oracle_shape_descriptors(self.handle, shape, out, 64)
         return [out[i] for i in range(n)]
 
-    def render(self, width, height, msaa, winding_bits, transforms, colors, shape_begin=0, shape_end=None):
-        """Stencil + Color of shapes [begin, end) in index order into a cleared frame -> RGBA8 [h, w, 4] premultiplied."""
+    def render(self, width, height, msaa, winding_bits, transforms, colors, shape_begin=0, shape_end=None, attachment8=False):
+        """Stencil + Color of shapes [begin, end) in index order into a cleared frame -> RGBA8 [h, w, 4] premultiplied.
+        attachment8: the target is an Rgba8Unorm attachment — every blend rounds to 8 bits (CRH_FORMAT_RGBA8_ATTACHMENT)."""
+        self.lib.oracle_set_attachment8(1 if attachment8 else 0)
         shape_end = self.n_shapes if shape_end is None else shape_end
         t = np.ascontiguousarray(transforms, dtype=np.float32)
         c = np.ascontiguousarray(colors, dtype=np.float32)
         out = np.zeros((height, width, 4), dtype=np.uint8)
         rc = self.lib.oracle_render(self.handle, width, height, msaa, winding_bits, t.ctypes.data_as(C.POINTER(C.c_float)),
                                     c.ctypes.data_as(C.POINTER(C.c_float)), shape_begin, shape_end, out.ctypes.data)
+        self.lib.oracle_set_attachment8(0)
         if rc != 0:
             raise RuntimeError(f"oracle_render failed: {rc}")
         return out
@@ -144,7 +147,7 @@ def render_draws(oracle, width, height, msaa, winding_bits, clip_bits, alpha_lay
 
 
 def render_pass(oracle, width, height, msaa, winding_bits, clip_bits, alpha_layers, transforms, colors, draws, cull_mode=0, depth_compare=0,
-                depth_write=0, depth=None, load=None):
+                depth_write=0, depth=None, load=None, attachment8=False):
     """render_draws with the colour cover's depth / cull state (renderer.rs:383-390). `depth` = the depth attachment [h, w, msaa] the pass
     starts from (None: no depth attachment) -> (RGBA8 [h, w, 4], depth after the pass or None)."""
     t = np.ascontiguousarray(transforms, dtype=np.float32)
@@ -155,9 +158,11 @@ def render_pass(oracle, width, height, msaa, winding_bits, clip_bits, alpha_laye
     z = None if depth is None else np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float32).reshape(height, width, -1), (height, width, msaa))).copy()
     fp = C.POINTER(C.c_float)
     start = None if load is None else np.ascontiguousarray(load, dtype=np.uint8).reshape(height, width, 4)  # LoadOp::Load: the image the pass starts from
+    oracle.lib.oracle_set_attachment8(1 if attachment8 else 0)
     rc = oracle.lib.oracle_render_pass_over(oracle.handle, width, height, msaa, winding_bits, clip_bits, alpha_layers, state.ctypes.data_as(C.POINTER(C.c_uint32)),
                                             None if z is None else z.ctypes.data_as(fp), t.ctypes.data_as(fp), c.ctypes.data_as(fp),
                                             d.ctypes.data_as(C.POINTER(C.c_uint32)), len(d), None if start is None else start.ctypes.data, out.ctypes.data)
+    oracle.lib.oracle_set_attachment8(0)
     if rc != 0:
         raise RuntimeError(f"oracle_render_pass failed: {rc}")
     return out, z

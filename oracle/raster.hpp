@@ -47,6 +47,19 @@ struct Frame {
     // Configuration::{cull_mode, depth_compare, depth_write_enabled} (renderer.rs:383-390) of the colour cover; depth attachment [y][x][s]
     uint32_t cull_mode = CRH_CULL_NONE, depth_compare = CRH_COMPARE_ALWAYS, depth_write = 0;
     std::vector<float> depth;
+    // The colour attachment is an Rgba8Unorm texture the blender reads and writes (CRH_FORMAT_RGBA8_ATTACHMENT; renderer.rs:736-754 blends into the
+    // caller's target, examples/showcase/main.rs:205-215): every component a cover writes is rounded to 8 bits where it is written. false: f32 colours
+    // for the whole pass, one rounding at resolve (CRH_FORMAT_RGBA8).
+    bool attachment8 = attachment8_default();
+    static bool& attachment8_default() {
+        static bool value = false; // (set by oracle_set_attachment8 for the frames created afterwards: test infrastructure)
+        return value;
+    }
+    static float unorm8(float v) { // resolve_rgba8's rounding, read back as value / 255
+        float x = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        if (!(x == x)) x = 0.0f;
+        return (float)(uint32_t)(int)(x * 255.0f + 0.5f) * (1.0f / 255.0f);
+    }
     void create_depth(float clear_value) { depth.assign((size_t)width * height * samples, clear_value); }
     void create(uint32_t w, uint32_t h, uint32_t s, uint32_t winding_bits, uint32_t clip_bits = 0, uint32_t n_alpha_layers = 0) {
         width = w;
@@ -625,6 +638,8 @@ inline void render_cover(Frame& f, const Shape& shape, const float m[16], const 
                             // the depth test follows the stencil test; depth_fail_op = Keep (renderer.rs:442): the winding survives
                             if (!f.depth.empty() && !depth_test(f.depth_compare, z, f.depth[si])) break;
                             for (int c = 0; c < 4; ++c) dst[c] = src[c] + dst[c] * one_minus_a;
+                            if (f.attachment8)
+                                for (int c = 0; c < 4; ++c) dst[c] = Frame::unorm8(dst[c]);
                             if (!f.depth.empty() && f.depth_write) f.depth[si] = z;
                         }
                         f.winding[si] = (uint8_t)(st & ~f.winding_mask);
@@ -642,9 +657,11 @@ inline void render_cover(Frame& f, const Shape& shape, const float m[16], const 
                             } else if (op == CRH_OP_SCALE_ALPHA_CONTEXT) { // src = (0,0,0,1-a): alpha' = src.a * One + dst.a * (1 - src.a), renderer.rs:803-828
                                 const float sa = 1.0f - rgba[3];
                                 dst[3] = sa + dst[3] * (1.0f - sa);
+                                if (f.attachment8) dst[3] = Frame::unorm8(dst[3]);
                             } else { // RestoreAlphaContext: src.a = (1 - saved)(1 - a); alpha' = dst.a * One - src.a * One, renderer.rs:829-861
                                 const float sa = (1.0f - (*layer)[si]) * (1.0f - rgba[3]);
                                 dst[3] = dst[3] - sa;
+                                if (f.attachment8) dst[3] = Frame::unorm8(dst[3]);
                             }
                         }
                         break;

@@ -1,6 +1,8 @@
 """RenderOperation::{Clip, UnClip, SaveAlphaContext, ScaleAlphaContext, RestoreAlphaContext} and instancing:
 the oracle's statement of renderer.rs:692-729,761-861 + shaders.wgsl:311-355 (CPU tests, hand-checkable), and the HIP tile rasterizer
 against it through crh_scene_render_draws (GPU tests, bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -185,3 +187,45 @@ def test_an_opaque_cover_that_does_not_overwrite_its_tiles(msaa, pin, oracle_lib
         assert np.array_equal(image, expect), f"{(image != expect).any(axis=2).sum()} pixels differ"
         inside_hole, outside = image[128 + 6, 128 + 13], image[128 + 90, 128]  # (y down) a pixel inside the hole, one below it inside the foreground
         assert tuple(outside[:3]) == (230, 51, 26) and tuple(inside_hole[:3]) != (230, 51, 26)  # the hole shows what lies under the foreground
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_rgba8_attachment_rounds_at_every_blend(msaa, oracle_lib):
+    """CRH_FORMAT_RGBA8_ATTACHMENT: the frame behaves like the Rgba8Unorm colour attachment the reference blends into (renderer.rs:736-754,
+    examples/showcase/main.rs:32-43,205-215) — every blend reads and writes 8-bit components — where CRH_FORMAT_RGBA8 keeps f32 colours for
+    the pass and rounds once. A stack of translucent Shapes: (a) the device equals the oracle run the same way, on all three raster
+    formulations; (b) at msaa 1 it is EXACTLY what Shape-by-Shape passes over existing content give on a plain RGBA8 frame (each pass loads
+    the rounded pixels and stores them rounded); (c) it differs from the single-rounding frame by a few 1/255 at most, somewhere."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from contrast_renderer_amd import scenes
+    sc = scenes.scene_cubic_fill(300, (256, 192), r_lo=10.0, r_hi=70.0, config_index=13)
+    colors = np.asarray(sc["colors"], np.float32).copy()
+    colors[:, 3] = np.random.RandomState(3).uniform(0.15, 0.6, len(colors))  # all translucent: deep stacks of blends
+    oracle = oracle_lib.Oracle(sc["batch"], 4)
+    expect = oracle.render(256, 192, msaa, 4, sc["transforms"], colors, attachment8=True)
+    once = oracle.render(256, 192, msaa, 4, sc["transforms"], colors)
+    worst = np.abs(expect.astype(int) - once.astype(int)).max()
+    assert 1 <= worst <= 12, worst
+    r = R.Renderer(R.Configuration(msaa_sample_count=msaa, winding_counter_bits=4), device=0)
+    scene = R.Scene(r, sc["batch"])
+    for pin in ("CRH_EDGE_PASS", "CRH_TRIANGLE_PASS", "CRH_ROWS"):
+        os.environ[pin] = "1"
+        try:
+            frame = R.Frame(r, 256, 192, R.FORMAT_RGBA8_ATTACHMENT)
+            frame.clear()
+            scene.render(frame, sc["transforms"], colors)
+            got = frame.download()
+        finally:
+            del os.environ[pin]
+        assert np.array_equal(got, expect), f"{pin}: {(got != expect).any(axis=2).sum()} pixels differ, max {np.abs(got.astype(int) - expect.astype(int)).max()}"
+    if msaa == 1:  # Shape by Shape over existing content, plain RGBA8: the same bytes
+        plain = R.Frame(r, 256, 192)
+        plain.clear()
+        n = sc["batch"].n_shapes
+        for k in range(n):
+            one = R.Scene(r, sc["batch"].slice_shapes(k, k + 1))
+            one.render(plain, sc["transforms"][k:k + 1], colors[k:k + 1])
+        assert np.array_equal(plain.download(), expect)
