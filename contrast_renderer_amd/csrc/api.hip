@@ -827,7 +827,10 @@ int choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
 // the others in block order behind them. Any permutation draws the same image; the counts of one verified pass order all later passes.
 crh_status order_tiles_heavy_first(crh_frame* f, const uint32_t* tile_count_dev, hipStream_t stream) {
     const char* e = getenv("CRH_HEAVY_FIRST"); // the factor; 0 switches the re-ordering off (A/B runs)
-    const bool sort_all = !e || std::strcmp(e, "sort") == 0; // the default: every XCD's tiles by falling count (a threshold factor keeps block order below it: measured slower)
+    // the default: every XCD's tiles by falling count, in buckets of 2^bucket_shift entries — tiles of one bucket keep their block order (the sort is
+    // stable), i.e. some of the L2 locality of neighbouring tiles ("b<shift>" pins the bucket; a threshold factor keeps block order below it)
+    const bool sort_all = !e || std::strcmp(e, "sort") == 0 || e[0] == 'b';
+    const uint32_t bucket_shift = (e && e[0] == 'b') ? (uint32_t)atoi(e + 1) : 0u;
     const double factor = sort_all ? 1.0 : atof(e);
     f->tile_order_ready = false;
     if (!(factor > 0.0)) return CRH_OK;
@@ -858,19 +861,13 @@ crh_status order_tiles_heavy_first(crh_frame* f, const uint32_t* tile_count_dev,
             std::vector<uint32_t> all;
             for (uint32_t k = 0; k < at; ++k) all.push_back(order[k * 8u + x]);
             all.insert(all.end(), rest.begin(), rest.end());
-            std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
+            std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return (count[a] >> bucket_shift) > (count[b] >> bucket_shift); });
             at = 0;
             rest.clear();
             for (uint32_t tile : all) order[(at++) * 8u + x] = tile;
         }
         for (uint32_t tile : rest) order[(at++) * 8u + x] = tile;
         for (; at < turns; ++at) order[at * 8u + x] = 0xFFFFFFFFu; // (workgroups beyond the frame: nothing to draw)
-    }
-    if (e && std::strcmp(e, "global") == 0) { // (experiment: all tiles by falling count, dealt to the XCDs in turn)
-        std::vector<uint32_t> all(n_tiles);
-        for (uint32_t t = 0; t < n_tiles; ++t) all[t] = t;
-        std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
-        for (uint32_t i = 0; i < grid; ++i) order[i] = i < n_tiles ? all[i] : 0xFFFFFFFFu;
     }
     HIP_TRY(f->tile_order.ensure((size_t)grid * 4));
     HIP_TRY(hipMemcpyAsync(f->tile_order.p, order.data(), (size_t)grid * 4, hipMemcpyHostToDevice, stream));
