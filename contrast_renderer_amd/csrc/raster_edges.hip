@@ -1062,6 +1062,7 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
     const bool all_queued = (r.debug & (1u | 2u | 4194304u)) != 0u; // debug bits 0, 1 (tests of k_bin_edges' own code paths), 22: every item takes that kernel
 #ifdef CRH_ABLATE
     unsigned long long phase_t = __builtin_amdgcn_s_memtime();
+    const unsigned long long born_t = phase_t; // (tools/bin_phases.py: the longest-lived workgroup, overflow[120..121], and the sum, [122..123])
 #endif
     for (uint32_t next = first_item; next < last_item;) {
         lds_barrier(); // (the previous batch's readers of the LDS records are through)
@@ -1540,6 +1541,14 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
         ++turn;
         CRH_FLAT_PHASE(8) // folded hulls
     }
+#ifdef CRH_ABLATE
+    if ((r.debug & 65536u) && tid == 0u) {
+        const unsigned long long life = __builtin_amdgcn_s_memtime() - born_t;
+        atomicMax(reinterpret_cast<unsigned long long*>(r.overflow + 120), life);
+        atomicAdd(reinterpret_cast<unsigned long long*>(r.overflow + 122), life);
+        atomicAdd(r.overflow + 124, 1u);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(256) void k_scatter(RasterParams r) {

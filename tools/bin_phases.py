@@ -25,6 +25,9 @@ if not os.environ.get("CRH_BIN_ITEMWISE"):  # k_bin_flat: wavefront 0 of every w
     for name, v in zip(names, vals):
         print(f"{name:28s} {v / groups:10.0f} ticks per workgroup ({100.0 * v / max(1, sum(vals)):4.1f} %)")
     print(f"total {sum(vals) / groups:.0f} ticks per workgroup of {ipg} items, {groups} workgroups")
+    longest, total, n_wg = out[120] | (out[121] << 32), out[122] | (out[123] << 32), out[124]
+    if n_wg:
+        print(f"workgroup lifetimes: {n_wg} workgroups, mean {total / n_wg:.0f} ticks, longest {longest} ticks = {longest * n_wg / max(1, total):.2f} x the mean")
     sys.exit(0)
 names = [["item data", "triangle set-up", "walk", "-", "-", "-", "final flush", "-"], ["item data + synth", "edge records", "rect + clear", "pass 1", "pass 2", "pass 3", "final flush", "-"]]
 for wave in range(2):
