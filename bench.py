@@ -640,12 +640,14 @@ def main():
     # the dominant kernel is the one that needs the GPU longest when it has it to itself: inside the pipelined run a small kernel that shares
     # the GPU with the raster kernel of the frame before is stretched to that kernel's length without doing more work
     longest_alone = max(kernels, key=lambda k: (kernels[k]["alone_ms"] if kernels[k]["alone_ms"] is not None else kernels[k]["avg_ms"]) * kernels[k]["launches"])
-    # ... which is why the line says both: `roofline` is the kernel that is longest per launch IN THE RUN (what the step actually waits for),
-    # `roofline_longest_alone` the one longest with the GPU to itself, when they differ
-    dominant = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    # ... which is why the line says both: `roofline` is the kernel that needs the GPU longest when it has it to itself (its launch time in the run is
+    # what `achieved` is computed from), `roofline_longest_in_run` the one whose launches last longest inside the pipelined run (waiting for wave
+    # slots beside the others included) when that is another one — the binning kernel, which has no algorithmic bytes at all
+    in_run_longest = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    dominant = longest_alone
     dk = kernels[dominant]
     achieved = dk["algorithmic_bytes"] / (dk["avg_ms"] * 1e-3) / 1e9 if dk["avg_ms"] > 0 else 0.0
-    la = kernels[longest_alone]
+    la = kernels[in_run_longest]
     # the PMC summaries under profiles/ were measured on the default invocation of each workload
     default_workload = world == 1 and ((args.workload == "cubic" and args.paths == 10000 and args.size == 4096) or args.workload in ("glyphs", "dashed", "s100k"))
     # which formulation the library settled on for this scene (it measures both on the first frames): the marks tell
@@ -701,17 +703,19 @@ def main():
             "avg_launch_ms": dk["avg_ms"],
             "avg_launch_ms_alone": dk["alone_ms"],
             "kernel_source_hash": kernel_source_hash(),
-            "note": "kernel = the longest per launch IN THE RUN (HIP events on its own stream, sharing the GPU with the other lanes of the pipeline); "
+            "note": "kernel = the one that needs the GPU longest per launch with the GPU to itself (avg_launch_ms_alone); avg_launch_ms = its launches in the timed run "
+                    "(HIP events on its own stream, sharing the GPU with the other lanes of the pipeline); "
                     "achieved = its algorithmic bytes (SURVEY.md §8(d): the raster kernel reads the emitted vertex/index bytes once + 80 B per shape and writes W*H*4 once; "
                     "binning has none) / that launch time; traffic / "
                     "valu_issue = rocprofv3 PMC passes committed under profiles/, reported only while their kernel_source_hash equals this run's. "
                     "The raster kernels are issue- and latency-bound (per-sample edge functions, tiny algorithmic traffic), not HBM bound: see DESIGN.md §4",
         },
-        "roofline_longest_alone": None if longest_alone == dominant else {
-            "kernel": longest_alone, "bound": "hbm", "achieved": la["algorithmic_bytes"] / (la["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline_longest_in_run": None if in_run_longest == dominant else {
+            "kernel": in_run_longest, "bound": "hbm", "achieved": la["algorithmic_bytes"] / (la["avg_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": la["algorithmic_bytes"] / (la["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": la["algorithmic_bytes"],
             "avg_launch_ms": la["avg_ms"], "avg_launch_ms_alone": la["alone_ms"],
-            "note": "the kernel that is longest with the GPU to itself, when that is not the kernel `roofline` reports (the longest per launch in the run)"},
+            "note": "the kernel whose launches last longest INSIDE the pipelined run (HIP events on its stream: the time it waits for wave slots beside the other "
+                    "lanes is in it), when that is not the kernel `roofline` reports (the longest with the GPU to itself); binning has no algorithmic bytes"},
         "roofline_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                           "note": "all kernels of a step: control data read + emitted bytes written (tessellation), emitted bytes + 80 B / shape read and W*H*4 written (raster)"},

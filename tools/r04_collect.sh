@@ -16,7 +16,7 @@ try:
 except Exception as e:
     print("unreadable:", e); sys.exit(0)
 print("ms/step %.3f value %.3e latency %s check %s" % (d["ms_per_step"], d["value"], d.get("latency_ms_per_step"), (d.get("check") or {}).get("frame_equals_oracle")))
-if d.get("roofline"): print({k: d["roofline"][k] for k in ("kernel", "frac", "traffic", "avg_launch_ms", "avg_launch_ms_alone", "pass")}, d.get("roofline_longest_alone") and {k: d["roofline_longest_alone"][k] for k in ("kernel", "frac", "avg_launch_ms")})
+if d.get("roofline"): print({k: d["roofline"][k] for k in ("kernel", "frac", "traffic", "avg_launch_ms", "avg_launch_ms_alone", "pass")}, (d.get("roofline_longest_in_run") or d.get("roofline_longest_alone")) and {k: (d.get("roofline_longest_in_run") or d.get("roofline_longest_alone"))[k] for k in ("kernel", "frac", "avg_launch_ms")})
 if d.get("weak_scaling"): print("weak:", d["weak_scaling"]["value"], d["weak_scaling"]["ms_per_step"])
 PY
 done
