@@ -1111,7 +1111,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->generation;
     p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = f->tile_base.as<uint32_t>();
-    p.tile_order = (edges && f->tile_order_ready) ? f->tile_order.as<uint32_t>() : nullptr;
+    p.tile_order = f->tile_order_ready ? f->tile_order.as<uint32_t>() : nullptr;
     if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
@@ -1154,6 +1154,8 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                 HIP_TRY(hipStreamSynchronize(bin));
                 f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
                 f->queue_seen = ov[6] != 0;
+            }
+            { // (both passes: the counts of this verified pass order the frame's later ones — the triangle pass' lists go with its strip triangles)
                 const crh_status ordered = order_tiles_heavy_first(f, p.tile_count, bin);
                 if (ordered != CRH_OK) return ordered;
             }

@@ -564,7 +564,12 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
     const uint32_t turn = blockIdx.x >> 3;
     const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (blockIdx.x & 7u);
-    const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    if (r.tile_order) { // the host's order for this frame: every XCD's heavy tiles first (api.hip order_tiles_heavy_first)
+        const uint32_t mine = r.tile_order[blockIdx.x];
+        if (mine == 0xFFFFFFFFu) return;
+        ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
+    }
     if (tx >= r.tiles_x || ty >= r.tiles_y) return;
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
