@@ -51,11 +51,11 @@ def build_library(force=False, verbose=False):
     return OUT
 
 
-DEBUG_TAPS = ("crh_debug_frame_counters", "crh_debug_frame_counters16", "crh_debug_frame_words")  # tools/ and one test read the raster kernels' counters through these
+DEBUG_TAPS = ("crh_debug_frame_counters", "crh_debug_frame_counters16", "crh_debug_frame_words", "crh_debug_frame_bin_dump")  # tools/ and one test read the raster kernels' counters through these
 
 
 def declared_entry_points():
-    """The names include/contrast_hip.h declares — the whole of the library's dynamic symbol table, with the three debug taps."""
+    """The names include/contrast_hip.h declares — the whole of the library's dynamic symbol table, with the debug taps."""
     import re
     with open(os.path.join(HERE, "..", "include", "contrast_hip.h")) as f:
         return sorted(set(re.findall(r"\b(crh_[a-z_0-9]+)\s*\(", f.read())) - {"crh_status"})

@@ -29,6 +29,8 @@ void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_ite
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_bin);
 void launch_scatter(const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
 void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream);
+bool bin_itemwise(const RasterParams& r);
+void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs);
 void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, hipStream_t stream);
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -339,6 +341,12 @@ struct crh_frame {
     // strip triangles with a non-finite determinant — as the reference's rasterizer does.
     DevBuf tile_order;             // [workgroups of the edge pass' raster grid] the tile each one draws (order_tiles_heavy_first), or not ready: the kernels' own order
     bool tile_order_ready = false;
+    // k_bin_flat's batches by cost (RasterParams::item_cost / bin_batches): built at a verified edge pass, used by the later passes of the same
+    // geometry with the same number of items (any partition of the items bins the same lists: stale costs only cost time)
+    DevBuf item_cost, bin_batches;
+    uint32_t n_bin_batches = 0, batches_items = 0;
+    crh_scene* batches_scene = nullptr;
+    uint64_t batches_generation = 0;
     crh_scene* triangle_pass_for = nullptr;
     uint64_t triangle_pass_generation = 0; // ... of that Scene's geometry: a re-upload (or a new Scene at the same address) starts on the edge pass again
 };
@@ -1112,6 +1120,15 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = f->tile_base.as<uint32_t>();
     p.tile_order = f->tile_order_ready ? f->tile_order.as<uint32_t>() : nullptr;
+    static const bool no_batches = getenv("CRH_NO_BIN_BATCHES") != nullptr; // A/B runs
+    const bool batches = edges && !no_batches && f->n_bin_batches != 0u && f->batches_scene == sc && f->batches_generation == sc->generation && f->batches_items == p.n_items;
+    p.bin_batches = batches ? f->bin_batches.as<uint32_t>() : nullptr, p.n_bin_batches = batches ? f->n_bin_batches : 0u;
+    p.item_cost = nullptr;
+    static const bool bin_dump = getenv("CRH_BIN_DUMP") != nullptr; // tools/bin_phases.py (a library built with -DCRH_ABLATE): a record per workgroup behind the costs
+    if (edges && (!f->pairs_known || bin_dump) && !no_batches) { // (a verified pass: it says what every item takes of a batch)
+        HIP_TRY(f->item_cost.ensure((size_t)p.n_items * (bin_dump ? 40 : 8) + 48));
+        p.item_cost = f->item_cost.as<uint32_t>();
+    }
     if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
@@ -1154,6 +1171,18 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                 HIP_TRY(hipStreamSynchronize(bin));
                 f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
                 f->queue_seen = ov[6] != 0;
+                f->n_bin_batches = 0;
+                if (p.item_cost && !bin_itemwise(p) && p.n_items != 0u) { // k_bin_flat wrote every item's cost: the later passes' batches
+                    std::vector<uint32_t> cost((size_t)p.n_items * 2), starts;
+                    HIP_TRY(hipMemcpyAsync(cost.data(), p.item_cost, cost.size() * 4, hipMemcpyDeviceToHost, bin));
+                    HIP_TRY(hipStreamSynchronize(bin));
+                    flat_batches(cost.data(), p.n_items, starts);
+                    HIP_TRY(f->bin_batches.ensure(starts.size() * 4));
+                    HIP_TRY(hipMemcpyAsync(f->bin_batches.p, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, bin));
+                    HIP_TRY(hipStreamSynchronize(bin));
+                    f->n_bin_batches = (uint32_t)(starts.size() / 2), f->batches_items = p.n_items, f->batches_scene = sc, f->batches_generation = sc->generation;
+                    if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u items in %u batches of k_bin_flat\n", p.n_items, f->n_bin_batches);
+                }
             }
             { // (both passes: the counts of this verified pass order the frame's later ones — the triangle pass' lists go with its strip triangles)
                 const crh_status ordered = order_tiles_heavy_first(f, p.tile_count, bin);
@@ -1813,7 +1842,7 @@ void crh_frame_destroy(crh_frame* f) {
                 break;
             }
     }
-    DevBuf* all[] = {&f->tile_order, &f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
+    DevBuf* all[] = {&f->tile_order, &f->item_cost, &f->bin_batches, &f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
                      &f->item_nslots, &f->item_slot_begin};
     for (DevBuf* b : all) b->release();
     f->item_upload_t.release();
@@ -2055,6 +2084,13 @@ extern "C" crh_status crh_debug_frame_words(crh_frame* f, uint32_t out[128]) { /
     HIP_TRY(f->renderer->sync());
     HIP_TRY(hipMemcpy(out, f->sets[f->last_set].overflow_p, 512, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(static_cast<uint8_t*>(f->sets[f->last_set].overflow_p) + 320, 0, 192));
+    return CRH_OK;
+}
+extern "C" crh_status crh_debug_frame_bin_dump(crh_frame* f, uint32_t* out, uint32_t n_words) { // tools only (CRH_BIN_DUMP): the items' costs and k_bin_flat's workgroup records
+    HIP_TRY(hipSetDevice(f->renderer->device));
+    HIP_TRY(f->renderer->sync());
+    if ((size_t)n_words * 4 > f->item_cost.cap) return CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipMemcpy(out, f->item_cost.p, (size_t)n_words * 4, hipMemcpyDeviceToHost));
     return CRH_OK;
 }
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {

@@ -24,7 +24,9 @@
 //   k_scatter          pair -> its slot in the tile's list (offsets from the scan of the counts).
 //   k_raster_edges<..> one wavefront per tile as in raster.hip; entries are triangles, edges and one COVER entry per (item, tile).
 // Keys are slot numbers of a 32-byte primitive heap (a triangle owns four slots = its 128-byte record); they ascend in draw order.
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "raster_common.hpp"
 
@@ -1058,11 +1060,13 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
     uint32_t turn = 0; // batches this workgroup has binned (the pair sub-stream of a batch follows from it)
     const float ry_first = S == 1 ? 0.5f : 0.125f, r_last = (float)(kTile - 1) + (S == 1 ? 0.5f : 0.875f); // extreme sample offsets inside a tile
     const float W = (float)r.width, H = (float)r.height;
-    const uint32_t first_item = blockIdx.x * items_per_group, last_item = min(r.n_items, first_item + items_per_group);
+    const uint32_t first_item = r.bin_batches ? r.bin_batches[2u * blockIdx.x] : blockIdx.x * items_per_group;
+    const uint32_t last_item = r.bin_batches ? r.bin_batches[2u * blockIdx.x + 1u] : min(r.n_items, first_item + items_per_group);
     const bool all_queued = (r.debug & (1u | 2u | 4194304u)) != 0u; // debug bits 0, 1 (tests of k_bin_edges' own code paths), 22: every item takes that kernel
 #ifdef CRH_ABLATE
     unsigned long long phase_t = __builtin_amdgcn_s_memtime();
     const unsigned long long born_t = phase_t; // (tools/bin_phases.py: the longest-lived workgroup, overflow[120..121], and the sum, [122..123])
+    uint32_t dump_items = 0, dump_tris = 0, dump_edges = 0, dump_pool = 0, dump_work = 0, dump_walk = 0; // (... and what every workgroup held, CRH_BIN_DUMP)
 #endif
     for (uint32_t next = first_item; next < last_item;) {
         lds_barrier(); // (the previous batch's readers of the LDS records are through)
@@ -1205,6 +1209,12 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
                     }
                 }
                 if (fi.n_hull != 0u && (fi.faces == 3u || (r.debug & 4u) != 0u)) fi.flags |= kFiHullTris, fi.n_hull_chain = 0u; // debug bit 2 (tests): always
+            }
+            // (a verified pass: what the item takes of a batch — the host sizes later passes' batches with it)
+            if (r.item_cost && mine) {
+                const bool skipped = (fi.flags & kFiSkip) != 0u, too_wide = n_rect > kFlatPool; // (too wide: queued once it is the first of a batch — a run of its own)
+                r.item_cost[2u * (next + lane)] = skipped ? 0u : (too_wide ? 0xFFFFFFFFu : n_rect);
+                r.item_cost[2u * (next + lane) + 1u] = (skipped || too_wide) ? 0x80000000u : (fi.n_tri | ((fi.n_fe + fi.n_hull) << 9) | ((fi.flags & kFiHullTris) ? 1u << 29 : 0u));
             }
             // Pool shares in item order. Items from the first one that does not fit are left to the workgroup's next turn (their records are
             // written again then); an item that does not fit the pool even alone goes to k_bin_edges.
@@ -1537,6 +1547,9 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
             }
             stage_flush(st, r, lane);
         }
+#ifdef CRH_ABLATE
+        dump_items += n_turn, dump_tris += n_tris, dump_edges += n_edges, dump_pool += n_pool, dump_work += n_work, dump_walk += wave_max_u32(tri.nt);
+#endif
         next += n_turn;
         ++turn;
         CRH_FLAT_PHASE(8) // folded hulls
@@ -1547,6 +1560,10 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
         atomicMax(reinterpret_cast<unsigned long long*>(r.overflow + 120), life);
         atomicAdd(reinterpret_cast<unsigned long long*>(r.overflow + 122), life);
         atomicAdd(r.overflow + 124, 1u);
+    }
+    if ((r.debug & 65536u) && r.item_cost && lane == 0u && wave == 0u) { // CRH_BIN_DUMP: the workgroup's record behind the items' costs
+        uint32_t* rec = r.item_cost + 2u * (size_t)(r.n_items + 1u) + 8u * (size_t)blockIdx.x;
+        rec[0] = (uint32_t)(__builtin_amdgcn_s_memtime() - born_t), rec[1] = turn, rec[2] = dump_items, rec[3] = dump_tris, rec[4] = dump_edges, rec[5] = dump_pool, rec[6] = dump_work, rec[7] = dump_walk;
     }
 #endif
 }
@@ -2956,6 +2973,45 @@ void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* sha
     hipLaunchKernelGGL(k_shape_counts, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s, shape_ncand, shape_nslots);
     launch_scan_u32_pair(shape_ncand, shape_prim_begin, scratch0, shape_nslots, shape_slot_begin, scratch1, s.n_shapes, stream);
 }
+// The items of a pass cut into runs of consecutive items that fill ONE batch of k_bin_flat each (cost: what a verified pass wrote to
+// RasterParams::item_cost). A workgroup's life is a chain of barrier-separated phases per batch, whatever the batch holds: with equal
+// NUMBERS of items per workgroup the ones with large Shapes took two to four batches (10 000 Shapes of 16-256 px: the longest workgroup
+// lived 1.84 x the mean, and the kernel lasts as long as that one); with one full batch per workgroup every workgroup lives one chain and
+// the hardware's dispatch balances the rest. runs[2 k], runs[2 k + 1] = the first item of run k and the one behind its last.
+bool bin_itemwise(const RasterParams& r) { // (read per launch: tests and A/B runs switch it inside one process)
+    return getenv("CRH_BIN_ITEMWISE") != nullptr ||
+           (getenv("CRH_BIN_FLAT") == nullptr && r.n_items != 0u && (r.hint_tris / r.n_items > kFlatTris / 2u || r.hint_edges / r.n_items > kFlatEdges / 2u));
+}
+void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs) {
+    struct Run {
+        uint32_t first, last;
+        float ticks;
+    };
+    std::vector<Run> all;
+    static const float cap = getenv("CRH_BIN_BATCH_TICKS") ? (float)atof(getenv("CRH_BIN_BATCH_TICKS")) : 0.0f; // A/B runs: close a run at this predicted life as well
+    uint32_t n = 0, tris = 0, edges = 0, cells = 0, widest = 0, folded = 0, first = 0;
+    // a workgroup's life in shader clocks, fitted to the lifetimes tools/bin_phases.py dumps (10 000 Shapes / 50 000 glyphs): the chain of
+    // phases, then what grows with the batch — the walks over (edge, tile row) pairs, the pool's cells, the longest triangle's tile box
+    // (it goes with the widest rectangle), hull strips that fold (item by item)
+    auto ticks = [&]() { return 76000.0f + 2000.0f * (float)n + 40.0f * (float)tris + 250.0f * (float)edges + 60.0f * (float)cells + 45.0f * (float)widest + 8000.0f * (float)folded; };
+    for (uint32_t i = 0; i < n_items; ++i) {
+        const uint32_t c = cost[2u * i], w = cost[2u * i + 1u];
+        const bool alone = c == 0xFFFFFFFFu; // wider than the pool: k_bin_flat hands it on when it is the first of a batch
+        const uint32_t t = (w >> 31) ? 0u : (w & 0x1FFu), e = (w >> 31) ? 0u : ((w >> 9) & 0x3FFu);
+        if (n != 0u && (alone || n == kFlatBatch || tris + t > kFlatTris || edges + e > kFlatEdges || cells + c > kFlatPool || (cap > 0.0f && ticks() > cap))) {
+            all.push_back(Run{first, i, ticks()});
+            n = tris = edges = cells = widest = folded = 0u, first = i;
+        }
+        n += 1u, tris += t, edges += e, cells += alone ? 0u : c, widest = std::max(widest, alone ? 0u : c), folded += (w >> 29) & 1u;
+        if (alone) n = kFlatBatch; // (the next item opens a run)
+    }
+    if (n_items) all.push_back(Run{first, n_items, ticks()});
+    // the long runs first: the hardware starts workgroups in grid order, and a long one that starts late ends after everything else
+    static const bool in_order = getenv("CRH_BIN_BATCH_ORDER") != nullptr; // A/B runs: the runs in item order
+    if (!in_order) std::stable_sort(all.begin(), all.end(), [](const Run& a, const Run& b) { return a.ticks > b.ticks; });
+    runs.clear();
+    for (const Run& run : all) runs.push_back(run.first), runs.push_back(run.last);
+}
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     // tile_count and, right behind it, the overflow words (overflow[8 ...] are the cursors of the pair sub-streams): one memset (tile_cursor, in front, is the triangle pass')
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams, stream);
@@ -2965,8 +3021,7 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
     const uint32_t pinned = getenv("CRH_BIN_ITEMS") ? max(1, atoi(getenv("CRH_BIN_ITEMS"))) : 0u; // (read per launch: tests and A/B runs switch it inside one process)
     // k_bin_edges for every item: CRH_BIN_ITEMWISE (A/B runs, tests), or a pass whose AVERAGE item is beyond what a batch of k_bin_flat holds
     // (the dashed strokes of config 5: a thousand line triangles per Shape) — every item would be queued anyway
-    const bool itemwise = getenv("CRH_BIN_ITEMWISE") != nullptr || (getenv("CRH_BIN_FLAT") == nullptr && r.n_items != 0u &&
-                                                                     (r.hint_tris / r.n_items > kFlatTris / 2u || r.hint_edges / r.n_items > kFlatEdges / 2u));
+    const bool itemwise = bin_itemwise(r);
     if (r.n_items && itemwise) {
         const uint32_t items_per_group = pinned ? pinned : min(8u, max(1u, (r.n_items + 12287u) / 12288u));
         const uint32_t bin_grid = (r.n_items + items_per_group - 1u) / items_per_group;
@@ -2985,7 +3040,7 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         const uint32_t by_edges = r.hint_edges ? (uint32_t)((uint64_t)kFlatEdges * 9u / 10u * r.n_items / r.hint_edges) : kFlatBatch;
         const uint32_t fitting = max(1u, min(kFlatBatch, min(by_tris, by_edges)));
         const uint32_t items_per_group = pinned ? min(pinned, kFlatBatch) : min(fitting, max(1u, (r.n_items + resident - 1u) / resident));
-        const uint32_t flat_grid = (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
+        const uint32_t flat_grid = r.bin_batches ? r.n_bin_batches : (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
         if (samples == 4) {
             hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
             if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<4, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);

@@ -72,6 +72,12 @@ struct RasterParams {
     uint32_t long_lists;              // the frame's tile lists hold many entries on average: k_raster_edges looks for its late start across chunks (host: crh_frame::mean_list)
     uint32_t* bin_queue;              // [n_items] items k_bin_flat hands on to k_bin_edges (their number: overflow[6])
     const uint32_t* tile_order;       // [workgroups of the raster grid] the tile each workgroup of the edge pass' raster kernels draws (0xFFFFFFFF: none), or nullptr: the kernels' own XCD-aware order
+    // k_bin_flat's batches by what they cost (round 4): a verified pass writes, per item, what the item takes of a batch's tables
+    // (item_cost[2 i] = tile cells of its rectangle, [2 i + 1] = triangles | edges << 9 | 1 << 29 if its hull strip folds | 1 << 31 if it is not binned there at all); the
+    // host cuts the items into runs that fill ONE batch each (flat_batches, raster_edges.hip) and later passes start one workgroup per run.
+    uint32_t* item_cost;              // [2 n_items] or nullptr
+    const uint32_t* bin_batches;      // [2 n_bin_batches] first item of every run and the one behind its last, the long runs first, or nullptr: equal numbers of items
+    uint32_t n_bin_batches;
     uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
 };
 

@@ -28,6 +28,23 @@ if not os.environ.get("CRH_BIN_ITEMWISE"):  # k_bin_flat: wavefront 0 of every w
     longest, total, n_wg = out[120] | (out[121] << 32), out[122] | (out[123] << 32), out[124]
     if n_wg:
         print(f"workgroup lifetimes: {n_wg} workgroups, mean {total / n_wg:.0f} ticks, longest {longest} ticks = {longest * n_wg / max(1, total):.2f} x the mean")
+    if os.environ.get("CRH_BIN_DUMP"):  # what every workgroup held, and a least-squares fit of its lifetime to it
+        import numpy as np
+        words = 2 * (n + 1) + 8 * n
+        buf = (C.c_uint32 * words)()
+        r.lib.crh_debug_frame_bin_dump.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+        assert r.lib.crh_debug_frame_bin_dump(frame.handle, buf, words) == 0
+        rec = np.frombuffer(buf, dtype=np.uint32)[2 * (n + 1):].reshape(-1, 8)[:n_wg].astype(np.float64)
+        names = ["life", "turns", "items", "tris", "edges", "cells", "edge rows", "longest tri walk"]
+        print("per workgroup: " + ", ".join(f"{nm} mean {rec[:, k].mean():.0f} max {rec[:, k].max():.0f}" for k, nm in enumerate(names)))
+        A = np.concatenate([np.ones((len(rec), 1)), rec[:, 1:]], axis=1)
+        coef, *_ = np.linalg.lstsq(A, rec[:, 0], rcond=None)
+        fit = A @ coef
+        print("life ~ " + " + ".join(f"{c:.1f} x {nm}" for c, nm in zip(coef, ["1"] + names[1:])), f"(residual rms {np.sqrt(((fit - rec[:, 0]) ** 2).mean()):.0f} ticks)")
+        for k in np.argsort(-rec[:, 0])[:8]:
+            print("  longest:", {nm: int(v) for nm, v in zip(names, rec[k])})
+        for k in np.argsort(rec[:, 0])[:4]:
+            print("  shortest:", {nm: int(v) for nm, v in zip(names, rec[k])})
     sys.exit(0)
 names = [["item data", "triangle set-up", "walk", "-", "-", "-", "final flush", "-"], ["item data + synth", "edge records", "rect + clear", "pass 1", "pass 2", "pass 3", "final flush", "-"]]
 for wave in range(2):
