@@ -2989,6 +2989,7 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
     };
     std::vector<Run> all;
     static const float cap = getenv("CRH_BIN_BATCH_TICKS") ? (float)atof(getenv("CRH_BIN_BATCH_TICKS")) : 0.0f; // A/B runs: close a run at this predicted life as well
+    static const uint32_t most = getenv("CRH_BIN_BATCH_ITEMS") ? (uint32_t)std::max(1, atoi(getenv("CRH_BIN_BATCH_ITEMS"))) : kFlatBatch; // ... or at this many items
     uint32_t n = 0, tris = 0, edges = 0, cells = 0, widest = 0, folded = 0, first = 0;
     // a workgroup's life in shader clocks, fitted to the lifetimes tools/bin_phases.py dumps (10 000 Shapes / 50 000 glyphs): the chain of
     // phases, then what grows with the batch — the walks over (edge, tile row) pairs, the pool's cells, the longest triangle's tile box
@@ -2998,7 +2999,7 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
         const uint32_t c = cost[2u * i], w = cost[2u * i + 1u];
         const bool alone = c == 0xFFFFFFFFu; // wider than the pool: k_bin_flat hands it on when it is the first of a batch
         const uint32_t t = (w >> 31) ? 0u : (w & 0x1FFu), e = (w >> 31) ? 0u : ((w >> 9) & 0x3FFu);
-        if (n != 0u && (alone || n == kFlatBatch || tris + t > kFlatTris || edges + e > kFlatEdges || cells + c > kFlatPool || (cap > 0.0f && ticks() > cap))) {
+        if (n != 0u && (alone || n >= std::min(most, kFlatBatch) || tris + t > kFlatTris || edges + e > kFlatEdges || cells + c > kFlatPool || (cap > 0.0f && ticks() > cap))) {
             all.push_back(Run{first, i, ticks()});
             n = tris = edges = cells = widest = folded = 0u, first = i;
         }
