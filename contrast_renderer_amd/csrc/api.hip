@@ -1120,7 +1120,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = f->tile_base.as<uint32_t>();
     p.tile_order = f->tile_order_ready ? f->tile_order.as<uint32_t>() : nullptr;
-    static const bool no_batches = getenv("CRH_NO_BIN_BATCHES") != nullptr; // A/B runs
+    const bool no_batches = getenv("CRH_NO_BIN_BATCHES") != nullptr; // A/B runs and tests (read per pass: they switch it inside one process)
     const bool batches = edges && !no_batches && f->n_bin_batches != 0u && f->batches_scene == sc && f->batches_generation == sc->generation && f->batches_items == p.n_items;
     p.bin_batches = batches ? f->bin_batches.as<uint32_t>() : nullptr, p.n_bin_batches = batches ? f->n_bin_batches : 0u;
     p.item_cost = nullptr;

@@ -2988,8 +2988,8 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
         float ticks;
     };
     std::vector<Run> all;
-    static const float cap = getenv("CRH_BIN_BATCH_TICKS") ? (float)atof(getenv("CRH_BIN_BATCH_TICKS")) : 0.0f; // A/B runs: close a run at this predicted life as well
-    static const uint32_t most = getenv("CRH_BIN_BATCH_ITEMS") ? (uint32_t)std::max(1, atoi(getenv("CRH_BIN_BATCH_ITEMS"))) : kFlatBatch; // ... or at this many items
+    const float cap = getenv("CRH_BIN_BATCH_TICKS") ? (float)atof(getenv("CRH_BIN_BATCH_TICKS")) : 0.0f; // A/B runs: close a run at this predicted life as well
+    const uint32_t most = getenv("CRH_BIN_BATCH_ITEMS") ? (uint32_t)std::max(1, atoi(getenv("CRH_BIN_BATCH_ITEMS"))) : kFlatBatch; // ... or at this many items
     uint32_t n = 0, tris = 0, edges = 0, cells = 0, widest = 0, folded = 0, first = 0;
     // a workgroup's life in shader clocks, fitted to the lifetimes tools/bin_phases.py dumps (10 000 Shapes / 50 000 glyphs): the chain of
     // phases, then what grows with the batch — the walks over (edge, tile row) pairs, the pool's cells, the longest triangle's tile box
@@ -3008,7 +3008,7 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
     }
     if (n_items) all.push_back(Run{first, n_items, ticks()});
     // the long runs first: the hardware starts workgroups in grid order, and a long one that starts late ends after everything else
-    static const bool in_order = getenv("CRH_BIN_BATCH_ORDER") != nullptr; // A/B runs: the runs in item order
+    const bool in_order = getenv("CRH_BIN_BATCH_ORDER") != nullptr; // A/B runs: the runs in item order
     if (!in_order) std::stable_sort(all.begin(), all.end(), [](const Run& a, const Run& b) { return a.ticks > b.ticks; });
     runs.clear();
     for (const Run& run : all) runs.push_back(run.first), runs.push_back(run.last);
