@@ -18,12 +18,12 @@ for _ in range(3):
     r.lib.crh_debug_frame_words(frame.handle, out)
 n = scene.n_shapes
 if not os.environ.get("CRH_BIN_ITEMWISE"):  # k_bin_flat: wavefront 0 of every workgroup
-    names = ["item records + batch", "edge set-up (loads)", "triangle set-up + stores", "synthetic records + barrier", "rectangles, pool cleared", "pass 1 (the walk)", "row sums", "pass 2", "folded hulls", "final flush"]
+    names = ["item records + batch", "edge set-up (loads)", "triangle set-up + stores", "synthetic records + barrier", "rectangles, pool cleared", "pass 1 (edge table, row sums, the walk)", "pass 2", "pass 3", "folded hulls", "final flush"]
     vals = [out[80 + 2 * k] | (out[81 + 2 * k] << 32) for k in range(10)]
     ipg = int(os.environ.get("CRH_BIN_ITEMS", 0)) or min(32, max(1, (n + 1023) // 1024))
     groups = (n + ipg - 1) // ipg
     for name, v in zip(names, vals):
-        print(f"{name:28s} {v / groups:10.0f} ticks per workgroup ({100.0 * v / max(1, sum(vals)):4.1f} %)")
+        print(f"{name:40s} {v / groups:10.0f} ticks per workgroup ({100.0 * v / max(1, sum(vals)):4.1f} %)")
     print(f"total {sum(vals) / groups:.0f} ticks per workgroup of {ipg} items, {groups} workgroups")
     longest, total, n_wg = out[120] | (out[121] << 32), out[122] | (out[123] << 32), out[124]
     if n_wg:
