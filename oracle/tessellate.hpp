@@ -740,6 +740,7 @@ struct Shape {
     StrokeBuilder stroke;
     FillBuilder fill;
     std::vector<Vertex0> convex_hull;
+    std::vector<Safe2> hull_candidates; // what andrew() was given, in emission order (tools/proto_hull.cpp, tests/test_hull_formulations.py)
     int status = CRH_OK;
 };
 
@@ -765,6 +766,7 @@ inline void shape_from_paths(Shape& shape, const crh_dynamic_stroke_options* dyn
         }
     }
     shape.convex_hull = triangle_fan_to_strip(andrew(proto_hull));
+    shape.hull_candidates = std::move(proto_hull);
     // concat_buffers! (renderer.rs:121-141, :198-209)
     auto& vb = shape.vertex_buffer;
     append_bytes(vb, shape.stroke.line_vertices);
