@@ -2062,6 +2062,9 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                         base[b * S + q] = total;
                         total += (uint32_t)__popcll(cand[b * S + q]);
                     }
+#ifdef CRH_ABLATE
+                if (r.debug & 512u) total = 0u; // tools/ablate_edges.sh: the stroke triangles' coverage without their fragment stages
+#endif
                 if (total != 0u) {
                     uint8_t* const table = compact_table[wave];
                     uint32_t rank[ROWS * S];
