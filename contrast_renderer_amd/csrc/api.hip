@@ -31,6 +31,7 @@ void launch_scatter(const RasterParams& r, hipStream_t stream, MarkFn mark, void
 void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream);
 bool bin_itemwise(const RasterParams& r);
 void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs);
+void flat_batch_limits(uint32_t limits[4]);
 void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, hipStream_t stream);
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -2092,6 +2093,16 @@ extern "C" crh_status crh_debug_frame_bin_dump(crh_frame* f, uint32_t* out, uint
     if ((size_t)n_words * 4 > f->item_cost.cap) return CRH_ERR_INVALID_ARGUMENT;
     HIP_TRY(hipMemcpy(out, f->item_cost.p, (size_t)n_words * 4, hipMemcpyDeviceToHost));
     return CRH_OK;
+}
+// tests only (host code, no device): the runs flat_batches cuts `n_items` items of the given costs into — runs[2 k], runs[2 k + 1] — and
+// the limits of a batch (items, triangles, edges, tile cells) in limits[4]; returns the number of runs, or -1 if `cap_runs` is too small
+extern "C" int crh_debug_flat_batches(const uint32_t* cost, uint32_t n_items, uint32_t* runs, uint32_t cap_runs, uint32_t limits[4]) {
+    std::vector<uint32_t> out;
+    flat_batches(cost, n_items, out);
+    flat_batch_limits(limits);
+    if (out.size() / 2 > cap_runs) return -1;
+    std::copy(out.begin(), out.end(), runs);
+    return (int)(out.size() / 2);
 }
 crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
     if (!f || !out) return CRH_ERR_INVALID_ARGUMENT;

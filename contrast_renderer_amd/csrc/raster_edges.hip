@@ -2994,6 +2994,7 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
     const float cap = getenv("CRH_BIN_BATCH_TICKS") ? (float)atof(getenv("CRH_BIN_BATCH_TICKS")) : 0.0f; // A/B runs: close a run at this predicted life as well
     const uint32_t most = getenv("CRH_BIN_BATCH_ITEMS") ? (uint32_t)std::max(1, atoi(getenv("CRH_BIN_BATCH_ITEMS"))) : kFlatBatch; // ... or at this many items
     uint32_t n = 0, tris = 0, edges = 0, cells = 0, widest = 0, folded = 0, first = 0;
+    bool closed = false;
     // a workgroup's life in shader clocks, fitted to the lifetimes tools/bin_phases.py dumps (10 000 Shapes / 50 000 glyphs): the chain of
     // phases, then what grows with the batch — the walks over (edge, tile row) pairs, the pool's cells, the longest triangle's tile box
     // (it goes with the widest rectangle), hull strips that fold (item by item)
@@ -3002,12 +3003,12 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
         const uint32_t c = cost[2u * i], w = cost[2u * i + 1u];
         const bool alone = c == 0xFFFFFFFFu; // wider than the pool: k_bin_flat hands it on when it is the first of a batch
         const uint32_t t = (w >> 31) ? 0u : (w & 0x1FFu), e = (w >> 31) ? 0u : ((w >> 9) & 0x3FFu);
-        if (n != 0u && (alone || n >= std::min(most, kFlatBatch) || tris + t > kFlatTris || edges + e > kFlatEdges || cells + c > kFlatPool || (cap > 0.0f && ticks() > cap))) {
+        if (n != 0u && (alone || closed || n >= std::min(most, kFlatBatch) || tris + t > kFlatTris || edges + e > kFlatEdges || cells + c > kFlatPool || (cap > 0.0f && ticks() > cap))) {
             all.push_back(Run{first, i, ticks()});
-            n = tris = edges = cells = widest = folded = 0u, first = i;
+            n = tris = edges = cells = widest = folded = 0u, first = i, closed = false;
         }
         n += 1u, tris += t, edges += e, cells += alone ? 0u : c, widest = std::max(widest, alone ? 0u : c), folded += (w >> 29) & 1u;
-        if (alone) n = kFlatBatch; // (the next item opens a run)
+        if (alone) closed = true; // (the next item opens a run)
     }
     if (n_items) all.push_back(Run{first, n_items, ticks()});
     // the long runs first: the hardware starts workgroups in grid order, and a long one that starts late ends after everything else
@@ -3016,6 +3017,7 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
     runs.clear();
     for (const Run& run : all) runs.push_back(run.first), runs.push_back(run.last);
 }
+void flat_batch_limits(uint32_t limits[4]) { limits[0] = kFlatBatch, limits[1] = kFlatTris, limits[2] = kFlatEdges, limits[3] = kFlatPool; }
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     // tile_count and, right behind it, the overflow words (overflow[8 ...] are the cursors of the pair sub-streams): one memset (tile_cursor, in front, is the triangle pass')
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams, stream);

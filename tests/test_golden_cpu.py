@@ -109,3 +109,50 @@ def test_header_is_plain_c():
             run = subprocess.run(["gcc", f"-std={std}", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", src],
                                  capture_output=True, text=True)
             assert run.returncode == 0, run.stderr
+
+
+def test_binning_runs_partition_the_items_within_a_batch_and_start_with_the_long_ones(monkeypatch):
+    """Host logic of the binning kernel's batches by cost (csrc/raster_edges.hip flat_batches; no device involved): whatever the items cost,
+    the runs partition 0 .. n in order, every run fits ONE batch (items, triangles, edges, tile cells), an item wider than the pool is a run
+    of its own, an item that is not binned there takes a place but nothing else, and the runs come longest predicted life first."""
+    import ctypes as C
+    import numpy as np
+    import __graft_entry__ as entry
+    entry.build()
+    from contrast_renderer_amd import _ffi
+    lib = _ffi.load_library()
+    lib.crh_debug_flat_batches.restype = C.c_int
+    lib.crh_debug_flat_batches.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+    for var in ("CRH_BIN_BATCH_TICKS", "CRH_BIN_BATCH_ITEMS", "CRH_BIN_BATCH_ORDER"):
+        monkeypatch.delenv(var, raising=False)
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 31, 33, 1000, 20000):
+        tris = rng.integers(0, 60, n).astype(np.uint32)
+        edges = rng.integers(0, 200, n).astype(np.uint32)
+        cells = np.minimum(rng.lognormal(3.0, 1.5, n), 1400).astype(np.uint32)
+        folded = (rng.uniform(size=n) < 0.1).astype(np.uint32)
+        kind = rng.uniform(size=n)  # 3 %: wider than the pool, 3 %: not binned by this kernel
+        cost = np.zeros((n, 2), dtype=np.uint32)
+        cost[:, 0] = np.where(kind < 0.03, 0xFFFFFFFF, np.where(kind < 0.06, 0, cells))
+        cost[:, 1] = np.where(kind < 0.06, 0x80000000, tris | (edges << 9) | (folded << 29))
+        runs = np.zeros((max(1, n), 2), dtype=np.uint32)
+        limits = (C.c_uint32 * 4)()
+        k = lib.crh_debug_flat_batches(cost.ctypes.data_as(C.POINTER(C.c_uint32)), n, runs.ctypes.data_as(C.POINTER(C.c_uint32)), max(1, n), limits)
+        assert k >= 0 and (k == 0) == (n == 0)
+        max_items, max_tris, max_edges, max_cells = limits[:]
+        runs = runs[:k]
+        in_order = runs[np.argsort(runs[:, 0], kind="stable")]
+        assert n == 0 or (in_order[0, 0] == 0 and in_order[-1, 1] == n and (in_order[1:, 0] == in_order[:-1, 1]).all() and (runs[:, 1] > runs[:, 0]).all())
+        predicted = []
+        for a, b in runs:
+            c = cost[a:b]
+            alone = c[:, 0] == 0xFFFFFFFF
+            skipped = (c[:, 1] >> 31) != 0
+            assert not alone.any() or b - a == 1, "an item wider than the pool shares a run"
+            t = np.where(skipped, 0, c[:, 1] & 0x1FF).sum()
+            e = np.where(skipped, 0, (c[:, 1] >> 9) & 0x3FF).sum()
+            cl = np.where(alone, 0, c[:, 0]).astype(np.uint64)
+            f = np.where(skipped, 0, (c[:, 1] >> 29) & 1).sum()
+            assert b - a <= max_items and t <= max_tris and e <= max_edges and cl.sum() <= max_cells
+            predicted.append(76000.0 + 2000.0 * (b - a) + 40.0 * t + 250.0 * e + 60.0 * float(cl.sum()) + 45.0 * float(cl.max()) + 8000.0 * f)
+        assert all(x >= y - 1.0 for x, y in zip(predicted, predicted[1:])), "the runs are not in falling order of their predicted life"
