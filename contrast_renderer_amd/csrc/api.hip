@@ -330,6 +330,7 @@ struct crh_frame {
     bool last_direct = false; // the pass pending verification was a direct one
     bool queue_seen = true;       // the verified pass handed items from k_bin_flat on to k_bin_edges (until known otherwise: the queue kernel is launched)
     bool last_skipped_queue = false;
+    bool last_used_batches = false; // the pass pending verification took k_bin_flat's runs by cost (stale_batches)
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
     uint32_t opaque_covers = 0;    // ... and how many (item, tile) covers of it were opaque over the whole tile (without them there is nothing to start late behind)
     uint32_t mean_list = 0;        // entries per tile of the last verified EDGE pass (the pairs the pass needed / tiles): long lists get k_raster_edges' LONG variant
@@ -345,7 +346,7 @@ struct crh_frame {
     // k_bin_flat's batches by cost (RasterParams::item_cost / bin_batches): built at a verified edge pass, used by the later passes of the same
     // geometry with the same number of items (any partition of the items bins the same lists: stale costs only cost time)
     DevBuf item_cost, bin_batches;
-    uint32_t n_bin_batches = 0, batches_items = 0;
+    uint32_t n_bin_batches = 0, batches_items = 0, batches_age = 0; // (age: passes drawn with these runs)
     crh_scene* batches_scene = nullptr;
     uint64_t batches_generation = 0;
     crh_scene* triangle_pass_for = nullptr;
@@ -1181,7 +1182,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                     HIP_TRY(f->bin_batches.ensure(starts.size() * 4));
                     HIP_TRY(hipMemcpyAsync(f->bin_batches.p, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, bin));
                     HIP_TRY(hipStreamSynchronize(bin));
-                    f->n_bin_batches = (uint32_t)(starts.size() / 2), f->batches_items = p.n_items, f->batches_scene = sc, f->batches_generation = sc->generation;
+                    f->n_bin_batches = (uint32_t)(starts.size() / 2), f->batches_items = p.n_items, f->batches_scene = sc, f->batches_generation = sc->generation, f->batches_age = 0;
                     if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u items in %u batches of k_bin_flat\n", p.n_items, f->n_bin_batches);
                 }
             }
@@ -1252,11 +1253,27 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     f->check_pending = true;
     f->last_direct = direct;
     f->last_skipped_queue = skip_queue;
+    f->last_used_batches = batches;
+    if (batches) f->batches_age += 1u;
     f->counts_describe_pixels = p.load_existing == 0u;
     return CRH_OK;
 }
 
 // after a sync: if the optimistic bin capacity was too small, grow it and render again (the frame content is recomputed from scratch)
+// The runs of k_bin_flat are cut by what the items cost in the frame's verified pass; when the instances move (a zoom), a run no longer fits
+// one batch and its workgroup takes several turns — correct, but the balance is gone. A quarter of the workgroups in that state: the
+// runs are dropped and the next pass is a verified one, which measures again. (Called where the frame's flags are read anyway.)
+crh_status stale_batches(crh_frame* f, hipStream_t stream) {
+    if (!f->last_used_batches || f->n_bin_batches == 0u) return CRH_OK;
+    uint32_t extra = 0;
+    HIP_TRY(hipMemcpyAsync(&extra, static_cast<const uint32_t*>(f->sets[f->last_set].overflow_p) + kExtraTurnsWord, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if ((uint64_t)extra * 4u > f->n_bin_batches && f->batches_age >= 16u) { // (not more often than every sixteen passes: a verified pass drains the pipeline)
+        if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u of %u runs of k_bin_flat needed more than one turn: the costs are measured again\n", extra, f->n_bin_batches);
+        f->n_bin_batches = 0, f->pairs_known = false;
+    }
+    return CRH_OK;
+}
 crh_status settle_frame(crh_frame* f) {
     if (!f->check_pending) return CRH_OK;
     crh_renderer* r = f->renderer;
@@ -1264,6 +1281,10 @@ crh_status settle_frame(crh_frame* f) {
     HIP_TRY(r->sync());
     HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow_p, 32, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
+    {
+        const crh_status stale = stale_batches(f, r->stream);
+        if (stale != CRH_OK) return stale;
+    }
     f->check_pending = false;
     if (ov[2] != 0) return CRH_ERR_UNSUPPORTED; // a tile list longer than the LDS sort can hold (documented limit)
     const bool sort_overflow = grow_sort_capacity(f, ov[3]);
@@ -1308,6 +1329,8 @@ crh_status settle_frame_cheaply(crh_frame* f) {
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
     if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small || (ov[6] != 0 && f->last_skipped_queue)) return settle_frame(f);
+    const crh_status stale = stale_batches(f, r->aux_stream);
+    if (stale != CRH_OK) return stale;
     f->check_pending = false;
     return CRH_OK;
 }

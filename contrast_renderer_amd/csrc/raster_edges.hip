@@ -1554,6 +1554,8 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
         ++turn;
         CRH_FLAT_PHASE(8) // folded hulls
     }
+    // (a run the host cut for one turn needed more: the costs it was cut by are stale — the host counts these and measures again, api.hip)
+    if (r.bin_batches && turn > 1u && tid == 0u) atomicAdd(&r.overflow[kExtraTurnsWord], turn - 1u);
 #ifdef CRH_ABLATE
     if ((r.debug & 65536u) && tid == 0u) {
         const unsigned long long life = __builtin_amdgcn_s_memtime() - born_t;
@@ -3020,7 +3022,7 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
 void flat_batch_limits(uint32_t limits[4]) { limits[0] = kFlatBatch, limits[1] = kFlatTris, limits[2] = kFlatEdges, limits[3] = kFlatPool; }
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     // tile_count and, right behind it, the overflow words (overflow[8 ...] are the cursors of the pair sub-streams): one memset (tile_cursor, in front, is the triangle pass')
-    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams, stream);
+    (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams + 32, stream); // (... and kExtraTurnsWord behind them)
     // Items per workgroup. One is best while the grid is small (S10k: 0.169 ms; two: 0.189, four: 0.21 — an item is a chain of dependent
     // memory operations, and a wavefront that takes a second item doubles it); tens of thousands of small items are bound by workgroup
     // turnover instead (50 000 glyphs: one 0.45, two 0.31, four 0.31, eight 0.33 ms). So: about 12 000 workgroups.

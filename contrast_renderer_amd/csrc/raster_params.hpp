@@ -20,6 +20,7 @@ struct DrawItem {
     uint32_t refs; // bits 0-7 clip depth of the stencil phase, 8-15 clip depth of the cover phase, 16-23 alpha layer
 };
 
+constexpr uint32_t kExtraTurnsWord = 76; // of RasterParams::overflow: behind the 8 flag words and the 64 cursors of the pair sub-streams
 struct RasterParams {
     uint32_t width, height, tiles_x, tiles_y, n_tiles; // 16x16-pixel tiles
     uint32_t winding_mask;
@@ -77,7 +78,7 @@ struct RasterParams {
     // host cuts the items into runs that fill ONE batch each (flat_batches, raster_edges.hip) and later passes start one workgroup per run.
     uint32_t* item_cost;              // [2 n_items] or nullptr
     const uint32_t* bin_batches;      // [2 n_bin_batches] first item of every run and the one behind its last, the long runs first, or nullptr: equal numbers of items
-    uint32_t n_bin_batches;
+    uint32_t n_bin_batches;           // (overflow[kExtraTurnsWord]: turns beyond the first that the runs' workgroups needed — stale costs)
     uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
 };
 
