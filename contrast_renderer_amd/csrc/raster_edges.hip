@@ -1979,16 +1979,16 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                             d[b][q] += (int)((psh >> p) & 1u) - (int)((nsh >> p) & 1u);
                         }
                 }
-                if (flags & kEdgeHull) {
+                { // both sets of counters, each with its (scalar) share of the delta — one multiply-add per counter: a branch on the edge's
+                  // kind around the additions left the compiler a dozen register copies per entry where the two sides meet
+                    const int to_hull = (flags & kEdgeHull) ? 1 : 0, to_fill = 1 - to_hull;
 #pragma unroll
                     for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                        for (int q = 0; q < S; ++q) hullw[b][q] += d[b][q];
-                } else {
-#pragma unroll
-                    for (int b = 0; b < ROWS; ++b)
-#pragma unroll
-                        for (int q = 0; q < S; ++q) winding[b][q] += d[b][q];
+                        for (int q = 0; q < S; ++q) {
+                            hullw[b][q] = __mul24(d[b][q], to_hull) + hullw[b][q];
+                            winding[b][q] = __mul24(d[b][q], to_fill) + winding[b][q];
+                        }
                 }
             } else if (kind == EK_SYNTH) { // a whole-tile backdrop of the fill (codes 0, 1) or hull (2, 3) winding
                 const uint32_t code = (flags >> 8) & 31u;
