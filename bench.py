@@ -440,11 +440,21 @@ def main():
         except Exception as e:  # reported, never silent: the line then says which path produced the number
             comm = None
             exchange_note = f"FALLBACK to torch.distributed (crh_comm_create failed: {e})"
-    if world > 1 and comm is None:
-        exchange_note = exchange_note or "torch.distributed statement of the exchange (dense slabs, validation only)"
+    if world > 1 and os.environ.get("CRH_BENCH_FAIL_FIRST_EXCHANGE") is not None:  # (tests: every rank holds a communicator whose exchange fails)
+        class _Failing:
+            def exchange(self, *a):
+                raise RuntimeError("injected failure of the first exchange")
+        comm = _Failing()
+
+    def torch_path():
+        nonlocal layer_views, slab
         layer_views = [torch.as_tensor(_DeviceArray(f.device_pointer(), (size[1], size[0], 4)), device=f"cuda:{local_rank}") for f in frames]
         r0, r1 = D.slab_rows(size[1], world)[rank]
         slab = torch.empty((r1 - r0, size[0], 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
+
+    if world > 1 and comm is None:
+        exchange_note = exchange_note or "torch.distributed statement of the exchange (dense slabs, validation only)"
+        torch_path()
 
     def launch(i):
         """Enqueues step i's tessellation + render (asynchronous on the renderer's streams)."""
@@ -502,6 +512,25 @@ def main():
         watchdog = threading.Timer(180.0, _stuck)
         watchdog.daemon = True
         watchdog.start()
+    if world > 1 and comm is not None:
+        # The first exchange through the C ABI, by itself: if it FAILS on any rank (an RCCL error — the point-to-point path has never run on
+        # real links), every rank hears of it and the run goes on with the torch.distributed statement of the exchange; the line says so.
+        # (A rank that HANGS in it is the watchdog's business.)
+        failure = ""
+        try:
+            launch(0)
+            finish(0)
+            renderer.synchronize()
+            comm.last_timing()
+        except Exception as e:
+            failure = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([0 if failure else 1], dtype=torch.int32, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            sys.stderr.write(f"[bench] rank {rank}: the first crh_frame_exchange failed on some rank ({failure or 'not this one'}): continuing with torch.distributed\n")
+            comm, result = None, None
+            exchange_note = "FALLBACK to torch.distributed (the first crh_frame_exchange failed" + (f": {failure}" if failure else " on another rank") + ")"
+            torch_path()
     run(20)
     sync()
     if watchdog is not None:

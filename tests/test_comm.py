@@ -259,3 +259,23 @@ def test_bench_starts_its_own_ranks_and_reports_the_metrics_scene():
     assert line["value"] > 0 and abs(line["value"] - 2000 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     weak = line["weak_scaling"]
     assert weak["scaling"] == "weak" and weak["paths_total"] == 4000 and weak["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_goes_on_with_the_torch_exchange_when_the_first_c_abi_exchange_fails():
+    """The first multi-GPU run on real links is the first execution of the RCCL point-to-point path: if crh_frame_exchange FAILS there, every
+    rank must hear of it (one all-reduce of a flag) and the run must go on with the torch.distributed statement of the exchange, the
+    line saying which path produced the number. Injected here: both ranks hold a communicator whose exchange raises."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["CRH_BENCH_FAIL_FIRST_EXCHANGE"] = "1"
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "3", "--paths", "2000", "--size", "1024"],
+                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [l for l in done.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert "FALLBACK to torch.distributed (the first crh_frame_exchange failed" in line["config"]["parallelism"], line["config"]["parallelism"]
+    assert line["n_gpus"] == 2 and line["value"] > 0
