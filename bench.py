@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--scaling", default=None, choices=("weak", "strong"), help="default: strong at N > 1 (the metric's scene split N ways) with the weak figure in a side block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="blocks of --steps steps timed again behind the timed region (never `value`): their min / median / max ms per step go to `spread`")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend for the barrier / id broadcast (nccl = RCCL)")
     ap.add_argument("--exchange", default="cabi", choices=("cabi", "torch"), help="cabi: crh_frame_exchange over RCCL (the product path); torch: the "
                     "torch.distributed statement of the same exchange (contrast_renderer_amd/distributed.py), dense slabs — validation only")
@@ -355,7 +356,7 @@ def main():
                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     default_scaling = args.scaling is None
     if default_scaling:
-        args.scaling = "strong" if args.gpus > 1 else "weak"  # (one and the same thing at N = 1)
+        args.scaling = "strong" if args.gpus > 1 else "single"  # (N = 1: nothing is split; the scene generator treats it as weak, which is the same thing)
 
     import numpy as np
     import torch
@@ -387,6 +388,8 @@ def main():
     scaling = args.scaling
     if args.workload == "s100k":
         args.paths, size, scaling = 100000, (8192, 8192), "strong"
+    if world == 1 and args.loopback <= 1:
+        scaling = "single"  # nothing is split
     if args.loopback > 1:
         if world != 1 or args.workload not in ("cubic", "s100k"):
             raise SystemExit("--loopback N runs in one process on one GPU (--gpus 1), workloads cubic / s100k")
@@ -440,6 +443,13 @@ def main():
         except Exception as e:  # reported, never silent: the line then says which path produced the number
             comm = None
             exchange_note = f"FALLBACK to torch.distributed (crh_comm_create failed: {e})"
+        # every rank takes the same branch from here on: a communicator that only SOME ranks hold would leave those in the first exchange's
+        # collectives while the others are already in the torch statement of it
+        created = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+        dist.all_reduce(created, op=dist.ReduceOp.MIN)
+        if int(created.item()) == 0 and comm is not None:
+            comm, result = None, None
+            exchange_note = "FALLBACK to torch.distributed (crh_comm_create failed on another rank)"
     if world > 1 and os.environ.get("CRH_BENCH_FAIL_FIRST_EXCHANGE") is not None:  # (tests: every rank holds a communicator whose exchange fails)
         class _Failing:
             def exchange(self, *a):
@@ -554,6 +564,20 @@ def main():
     if os.environ.get("CRH_BENCH_NO_MARKS") is not None:  # (measurement of the measurement: what do the timing marks cost the timed region?)
         raise SystemExit(f"[bench] without timing marks: {elapsed / args.steps * 1e3:.4f} ms/step")
     kernel_times = renderer.kernel_times()  # the raster lane of the timed steps
+    # the spread of the timed region: the same block of K steps again, R times, each bracketed like the timed one (never `value`)
+    blocks = []
+    for _ in range(max(0, args.repeats)):
+        renderer.kernel_times()  # (drained: the marks of these blocks are not reported)
+        sync()
+        tb = time.perf_counter()
+        run(args.steps)
+        sync()
+        blocks.append(time.perf_counter() - tb)
+    if dist is not None and blocks:
+        tb = torch.tensor(blocks, dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+        dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        blocks = [float(x) for x in tb.tolist()]
+    renderer.kernel_times()
     renderer.enable_timing(1)
     sync()
     run(args.steps)
@@ -700,6 +724,10 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "latency_ms_per_step": latency_ms,
+        "spread": None if not blocks else {"blocks": len(blocks), "steps_per_block": args.steps,
+                                           "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_median": sorted(blocks)[len(blocks) // 2] / args.steps * 1e3,
+                                           "ms_per_step_max": max(blocks) / args.steps * 1e3,
+                                           "note": "the timed block of K steps run again R times behind the timed region, each between barrier + synchronize (max over ranks); `value` is the first block alone"},
         "higher_is_better": True,
         "scaling": scaling,
         "vs_baseline": None,
@@ -794,10 +822,17 @@ def main():
                                    "note": "count / scan / emit / hull / range kernels of one step, stand-alone HIP-event times summed: the GPU side of what cpu_baseline times"}
     if cpu_baseline is not None:
         out["cpu_baseline"] = cpu_baseline
+    wrong_pixels = bool(check) and check.get("frame_equals_oracle") is False
+    if wrong_pixels:  # a run whose pixels differ from the oracle's frame is not a result: the line says so and the process fails
+        out["invalid"] = True
+        out["invalid_reason"] = "check.frame_equals_oracle is false: the timed frame is not the oracle's frame of this scene"
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if wrong_pixels:
+        sys.stdout.flush()
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

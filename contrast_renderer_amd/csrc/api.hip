@@ -332,6 +332,7 @@ struct crh_frame {
     bool last_skipped_queue = false;
     bool last_used_batches = false; // the pass pending verification took k_bin_flat's runs by cost (stale_batches)
     uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
+    uint32_t longest_list = 0;     // the longest tile list any pass into this frame has reported (overflow[3]); gates k_raster_rows
     uint32_t opaque_covers = 0;    // ... and how many (item, tile) covers of it were opaque over the whole tile (without them there is nothing to start late behind)
     uint32_t mean_list = 0;        // entries per tile of the last verified EDGE pass (the pairs the pass needed / tiles): long lists get k_raster_edges' LONG variant
     size_t pair_capacity_bytes = 1024 * 4; // size of a set's tile list (both sets grow to it)
@@ -899,6 +900,7 @@ uint32_t long_lists(const crh_frame* f) {
 
 // the raster kernel sorts a tile's list in LDS: size that buffer (a power of two) from the longest list seen; true when it had to grow
 bool grow_sort_capacity(crh_frame* f, uint32_t longest_list) {
+    f->longest_list = std::max(f->longest_list, longest_list);
     if (longest_list <= f->sort_capacity) return false;
     const uint32_t limit = 32768u / (4u * (f->renderer->config.msaa_sample_count == 4 ? 4u : 1u)); // 32 KiB of dynamic LDS per workgroup (kSortBytesMax)
     uint32_t capacity = f->sort_capacity;
@@ -1081,7 +1083,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     int timed = -1;
     const int pass = p.general == 0u ? choose_pass(sc, f, &timed) : 2;
     const bool edges = pass != 2;
-    p.rows = pass == 3 ? 1u : 0u;
+    // k_raster_rows keeps fill + 65536 * hull in one cell: exact below 2^15 entries per tile. Lists in place grow by half at most between two
+    // verified passes, so a frame that has ever shown a list of 16 384 entries keeps the per-sample kernel.
+    p.rows = (pass == 3 && f->longest_list < 16384u) ? 1u : 0u;
     if (edges != f->last_edges) f->pairs_known = false;
     f->last_edges = edges;
     crh_scene::PassTrial* trial = (p.general == 0u && timed >= 0) ? &sc->pass_trial[timed / 2] : nullptr;
@@ -1154,6 +1158,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(r->sync());
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
+        if (f->longest_list >= 16384u) p.rows = 0u;
         if (edges) f->mean_list = ov[1] / std::max(1u, p.n_tiles), f->opaque_covers = ov[4]; // (the triangle pass of the same Scene has other entries, and no such variant)
         p.long_lists = long_lists(f);
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u entries in %u tiles (longest list %u, %u opaque whole-tile covers): %s raster variant\n", ov[1], p.n_tiles, ov[3], ov[4], p.long_lists ? "long-list" : "plain");
@@ -1634,6 +1639,9 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         up(sc->elem_type, P_TYPE), up(sc->elem_off0, P_OFF), up(sc->elem_off, P_OFF), up(sc->elem_prev_off, P_PREV), up(sc->elem_path, P_PATH), up(sc->pool, P_POOL);
         up(sc->path_elem_begin, P_PATH_BEGIN), up(sc->path_shape, P_PATH_SHAPE), up(sc->path_stroke, P_PATH_STROKE), up(sc->shape_elem_begin, P_SHAPE_BEGIN);
         up(sc->shape_dyn_begin, P_DYN_BEGIN), up(sc->stroke_options, P_OPTIONS), up(sc->descriptors, P_DESCRIPTORS);
+        // the status word: cleared IN FRONT of geometry_ready — the tessellation stream waits for that event only, then clears the word itself and
+        // lets its kernels write error codes; a memset enqueued behind the event would be unordered against those writes
+        if (ok) ok = hip_ok(sc->status.ensure(4), "hipMalloc") && hip_ok(hipMemsetAsync(sc->status.p, 0xFF, 4, st), "hipMemset");
         if (ok) ok = hip_ok(sc->geometry_stage.done(st), "hipEventRecord") && hip_ok(hipEventRecord(sc->geometry_ready, st), "hipEventRecord");
         if (!ok) {
             rc = CRH_ERR_HIP;
@@ -1666,10 +1674,6 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.stroke_options = sc->stroke_options.as<crh_stroke_options>();
     d.descriptors = sc->descriptors.as<crh_dynamic_stroke_descriptor>();
     bind_tess_pointers(sc);
-    if (!hip_ok(hipMemsetAsync(d.status, 0xFF, 4, st), "hipMemset")) {
-        rc = CRH_ERR_HIP;
-        goto fail;
-    }
     if (!existing) r->scenes.push_back(sc);
     *out = sc;
     return CRH_OK;

@@ -599,7 +599,7 @@ crh_status phase_unpack(crh_comm* c, crh_frame* result) {
     int device = 0;
     crh_status st = crh_internal_frame_geometry(result, &w, &h, &format, &device);
     if (st != CRH_OK) return st;
-    if (w != c->width || h != c->height || device != c->device || format != CRH_FORMAT_RGBA8) return CRH_ERR_INVALID_ARGUMENT;
+    if (w != c->width || h != c->height || device != c->device || format == CRH_FORMAT_RGBA16F) return CRH_ERR_INVALID_ARGUMENT; // (either RGBA8 storage format: the result is the gathered bytes)
     void* pixels = nullptr;
     if ((st = crh_internal_frame_info(result, &pixels, &w, &h, &device)) != CRH_OK) return st; // what the frame showed so far is settled (and discarded)
     HIP_TRY(hipSetDevice(c->device));

@@ -1685,6 +1685,8 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     if (n > r.sort_capacity && n <= kLdsSortMax) { // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
         if (r.direct && threadIdx.x == 0u) atomicMax(&r.overflow[3], n); // (otherwise the scan of the counts has published it)
         n = 0;
+    } else if (n > kLdsSortMax && r.direct && threadIdx.x == 0u) {
+        atomicMax(&r.overflow[3], n); // (sorted in place below; the host keeps the longest list it has heard of: crh_frame::longest_list)
     }
 #ifdef CRH_ABLATE
     if (r.debug & 64u) n = 0;
@@ -2391,6 +2393,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
     if (n > r.sort_capacity && n <= kLdsSortMax) { // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
         if (r.direct && threadIdx.x == 0u) atomicMax(&r.overflow[3], n);
         n = 0;
+    } else if (n > kLdsSortMax && r.direct && threadIdx.x == 0u) {
+        atomicMax(&r.overflow[3], n); // (the host takes frames with lists of 16 384 entries and more away from this kernel: its cells hold two 16-bit fields)
     }
     uint32_t my_key = 0xFFFFFFFFu;
     const bool sorted_in_place = n > kLdsSortMax;
