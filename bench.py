@@ -41,7 +41,7 @@ def mark_to_kernel(workload, triangle_pass=False):
     return {
         # (the last argument: the variant that looks for its late start across the chunks of long tile lists — the host picks it for frames with
         # many entries per tile and opaque whole-tile covers: the 100 000 path scene)
-        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_edges<1, 4, false, true>" if workload == "s100k" else "crh::k_raster_edges<1, 4, false, false>"),
+        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_fill<true>" if workload == "s100k" else "crh::k_raster_fill<false>"),
         # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
         "raster_rows": "crh::k_raster_rows<true>" if workload == "s100k" else "crh::k_raster_rows<false>",  # the row-span kernel, where the library's trial picked it
         "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else "crh::k_bin_flat<1>",

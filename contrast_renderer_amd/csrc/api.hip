@@ -1086,6 +1086,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // k_raster_rows keeps fill + 65536 * hull in one cell: exact below 2^15 entries per tile. Lists in place grow by half at most between two
     // verified passes, so a frame that has ever shown a list of 16 384 entries keeps the per-sample kernel.
     p.rows = (pass == 3 && f->longest_list < 16384u) ? 1u : 0u;
+    p.fill_cells = f->longest_list < 16384u ? 1u : 0u; // (k_raster_fill keeps the same cell)
     if (edges != f->last_edges) f->pairs_known = false;
     f->last_edges = edges;
     crh_scene::PassTrial* trial = (p.general == 0u && timed >= 0) ? &sc->pass_trial[timed / 2] : nullptr;
@@ -1158,7 +1159,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(r->sync());
         grow_sort_capacity(f, ov[3]);
         p.sort_capacity = f->sort_capacity;
-        if (f->longest_list >= 16384u) p.rows = 0u;
+        if (f->longest_list >= 16384u) p.rows = 0u, p.fill_cells = 0u;
         if (edges) f->mean_list = ov[1] / std::max(1u, p.n_tiles), f->opaque_covers = ov[4]; // (the triangle pass of the same Scene has other entries, and no such variant)
         p.long_lists = long_lists(f);
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u entries in %u tiles (longest list %u, %u opaque whole-tile covers): %s raster variant\n", ov[1], p.n_tiles, ov[3], ov[4], p.long_lists ? "long-list" : "plain");

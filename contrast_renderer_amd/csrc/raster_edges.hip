@@ -2271,6 +2271,546 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 // statically, the tiles balance worse than under the hardware's dynamic dispatch (0.29 - 0.31 against 0.22 ms), the loop around the kernel
 // body costs 5 - 12 % by itself, and the front lanes gain nothing. Not kept.)
 
+// ---------------------------------------------------------------------------------------------- k_raster_fill (round 5)
+// The per-sample kernel of fill scenes at msaa 1 (no stroke triangles), with the walk re-stated (renderer.rs:304-318, 340-354, 565-582;
+// shaders.wgsl:233-266, 304-309; vertex.rs:28-35): what k_raster_edges<1, 4, false, *> draws, entry for entry and bit for bit, but
+//   * CLASS-BATCHED: a chunk's sorted entries are cut into groups  N* C  (N: edges, backdrop units, curve triangles; C: one cover). Inside a
+//     group the N entries only add integers to the winding counters, so they commute: one ballot per class for the whole chunk, then per
+//     group a homogeneous loop per class over the class mask (scalar bit scans) — no per-entry read of the entry's flags through LDS into a
+//     scalar register and no chain of uniform branches per entry (round 4's ablation priced that dispatch at 15 vector + 45 scalar
+//     instructions per walked entry, half of the kernel's scalar work). A group's backdrop units are summed on the scalar unit (population
+//     counts of their masks) and applied with one add per sample row.
+//   * PACKED COUNTERS: a sample keeps  fill + 65536 * hull  in ONE register (k_raster_rows' cell; exact while a tile's list has fewer than
+//     16 384 entries — every entry moves a counter by two at most —, the host keeps frames with longer lists on k_raster_edges). A fill
+//     edge or a curve triangle adds its accept bit with ONE add-with-carry (the compare's lane mask is the carry), four registers less per lane.
+//   * The sample rows an edge's y range or a triangle's box leaves out are folded into the compare as a sign bit (two cheap vector
+//     instructions per row) instead of lane masks built on the scalar unit (fifteen scalar instructions per entry: by the measured issue
+//     rates, tools/valu_rate.hip, a scalar instruction costs a SIMD as much as a compare); a triangle's three edge tests are one saturating
+//     subtract each, a three-way minimum and ONE compare.
+// LONG: as k_raster_edges (the late start found across the chunks of a long list).
+CRH_D int add_lane_bit(int v, unsigned long long mask) { // v + (this lane's bit of mask): the mask is the carry-in
+#if defined(__HIP_DEVICE_COMPILE__)
+    int out;
+    unsigned long long carry;
+    asm("v_addc_co_u32 %0, %1, %2, 0, %3" : "=v"(out), "=s"(carry) : "v"(v), "s"(mask));
+    return out;
+#else
+    return v;
+#endif
+}
+CRH_D int sub_lane_bit(int v, unsigned long long mask) { // v - (this lane's bit of mask)
+#if defined(__HIP_DEVICE_COMPILE__)
+    int out;
+    unsigned long long carry;
+    asm("v_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(out), "=s"(carry) : "v"(v), "s"(mask));
+    return out;
+#else
+    return v;
+#endif
+}
+// bit `bit` of `rows` clear -> the sign bit set in x (a sample row that is left out fails every  x >= 0 / x >= 1  test): v_lshlrev_b32 + v_and_or_b32
+CRH_D int reject_unless_row(int x, uint32_t not_rows, int bit) { return (int)(((not_rows << (31 - bit)) & 0x80000000u) | (uint32_t)x); }
+template <bool LONG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TILE_WAVES))) void k_raster_fill(SceneDev s, RasterParams r) {
+    constexpr int ROWS = 4;
+    const uint32_t bid = blockIdx.x; // the workgroup's place in the frame's tile order
+    extern __shared__ uint32_t sort_buffer[];
+    __shared__ float4 entry_buffer[64 * 3];
+    constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
+    const uint32_t turn = bid >> 3;
+    const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (bid & 7u);
+    uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
+    if (r.tile_order) { // the host's order for this frame: every XCD's heavy tiles first (api.hip order_tiles_heavy_first)
+        const uint32_t mine = r.tile_order[bid];
+        if (mine == 0xFFFFFFFFu) return;
+        ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
+    }
+    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    const uint32_t tile = ty * r.tiles_x + tx;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* __restrict__ keys = sort_buffer;
+    const uint32_t px = lane & 15u, rq = lane >> 4;
+    const uint32_t gx = tx * kTile + px;
+    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+    const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
+    const float sx = (float)px + 0.5f, sy0 = (float)rq + 0.5f; // the lane's samples: column px, rows rq + 4 b
+    int cell[ROWS];        // fill winding + 65536 * hull winding of sample row rq + 4 b
+    float col[ROWS][4];
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b) {
+        cell[b] = 0;
+        col[b][0] = col[b][1] = col[b][2] = col[b][3] = 0.0f;
+    }
+    if (r.load_existing) {
+#pragma unroll
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + 4u * b + rq;
+            if (gx < r.width && gy < r.height) {
+                const float4 d = load_pixel(r, gx, gy);
+                col[b][0] = d.x, col[b][1] = d.y, col[b][2] = d.z, col[b][3] = d.w;
+            }
+        }
+    }
+    const uint32_t list_begin = r.direct ? r.tile_base[tile] : r.tile_offset[tile];
+    uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : (r.direct ? r.tile_count[tile] : r.tile_offset[tile + 1] - list_begin);
+    constexpr uint32_t kLdsSortMax = kSortBytesMax / 4u;
+    if (n > r.sort_capacity && n <= kLdsSortMax) { // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
+        if (r.direct && threadIdx.x == 0u) atomicMax(&r.overflow[3], n); // (otherwise the scan of the counts has published it)
+        n = 0;
+    } else if (n > kLdsSortMax && r.direct && threadIdx.x == 0u) {
+        atomicMax(&r.overflow[3], n);
+    }
+#ifdef CRH_ABLATE
+    if (r.debug & 64u) n = 0;
+#endif
+    uint32_t my_key = 0xFFFFFFFFu;
+    const bool sorted_in_place = n > kLdsSortMax;
+    uint32_t* const segment = r.tile_list + list_begin;
+    if (sorted_in_place) { // as k_raster_edges: a normalised bitonic network over the tile's segment of the list, in global memory
+        uint32_t padded = 1;
+        while (padded < n) padded <<= 1;
+        auto exchange = [&](uint32_t i, uint32_t partner) {
+            if (partner < n) {
+                const uint32_t a = __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b = __hip_atomic_load(segment + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a > b) {
+                    __hip_atomic_store(segment + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(segment + partner, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        for (uint32_t kk = 2; kk <= padded; kk <<= 1) {
+            const uint32_t half = kk >> 1;
+            for (uint32_t p = lane; p < (padded >> 1); p += 64u) {
+                const uint32_t blk = p / half, t = p - blk * half;
+                exchange(blk * kk + t, blk * kk + kk - 1u - t);
+            }
+            __threadfence();
+            __syncthreads();
+            for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+                for (uint32_t p = lane; p < (padded >> 1); p += 64u) {
+                    const uint32_t i = 2u * j * (p / j) + (p % j);
+                    exchange(i, i + j);
+                }
+                __threadfence();
+                __syncthreads();
+            }
+        }
+    } else if (n <= 64u) {
+        if (lane < n) my_key = r.tile_list[list_begin + lane];
+        if (n > 1u) {
+            const uint32_t depth = n <= 8u ? 8u : (n <= 16u ? 16u : (n <= 32u ? 32u : 64u)); // a network as deep as the list needs (the keys sit in the leading lanes)
+#pragma unroll
+            for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
+                if (kk > depth) break;
+#pragma unroll
+                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                    const uint32_t other = __shfl_xor(my_key, j, 64);
+                    const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
+                    my_key = keep_min ? min(my_key, other) : max(my_key, other);
+                }
+            }
+        }
+    } else {
+        uint32_t padded = 128;
+        while (padded < n) padded <<= 1;
+        for (uint32_t i = lane; i < padded; i += 64u) keys[i] = i < n ? r.tile_list[list_begin + i] : 0xFFFFFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t kk = 2; kk <= padded; kk <<= 1)
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = lane; i < padded; i += 64u) {
+                    const uint32_t partner = i ^ j;
+                    if (partner > i) {
+                        const uint32_t a = keys[i], b = keys[partner];
+                        if (((i & kk) == 0) ? (a > b) : (a < b)) {
+                            keys[i] = b;
+                            keys[partner] = a;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+
+    const uint8_t* slots = r.slots;
+    const uint32_t wmask = r.winding_mask;
+    // Cooperative row evaluation of an edge entry: lane j < 16 evaluates sample row j at the left tile boundary, lane 16 the backdrop row q0
+    const uint32_t row_j = lane & 15u;
+    const float ry_row = lane == 16u ? 0.5f : (float)row_j + 0.5f;
+    const float sy_row = ty0 + ry_row;
+    auto key_of = [&](uint32_t i) -> uint32_t { return sorted_in_place ? __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keys[i]; };
+    uint32_t walk_from = 0, verify_entry = 0xFFFFFFFFu; // absolute positions in the list
+    if (LONG && n > 64u && !r.load_existing) { // the late start of a list of several chunks (k_raster_edges: X, the last opaque whole-tile cover; R, the last whole-tile reset before it)
+        uint32_t x_at = 0xFFFFFFFFu;
+        for (uint32_t c0 = ((n - 1u) >> 6) << 6;; c0 -= 64u) {
+            const uint32_t k = c0 + lane < n ? key_of(c0 + lane) : 0xFFFFFFFFu;
+            uint32_t code = 0;
+            if (c0 + lane < n) {
+                const uint32_t flags = *reinterpret_cast<const uint32_t*>(slots + (size_t)k * 32u);
+                code = ((flags >> 4) & 15u) == EK_SYNTH ? (flags >> 8) & 31u : 0u;
+            }
+            unsigned long long resets = __builtin_amdgcn_ballot_w64(code >= 4u + kCoverHull);
+            if (x_at == 0xFFFFFFFFu) {
+                unsigned long long candidates = __builtin_amdgcn_ballot_w64(code >= 4u + kCoverOpaque);
+                while (candidates) {
+                    const uint32_t at = 63u - (uint32_t)__builtin_clzll(candidates);
+                    const SynthRec sr = load_uniform(reinterpret_cast<const SynthRec*>(slots + (size_t)__builtin_amdgcn_readlane(k, at) * 32u));
+                    uint32_t lo = 0, hi = n; // the number of keys below the item's synthetic slots
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (key_of(mid) < sr.synth_a) lo = mid + 1u;
+                        else hi = mid;
+                    }
+                    if (lo == 0u || key_of(lo - 1u) < sr.first_slot) {
+                        x_at = c0 + at;
+                        resets &= (1ull << at) - 1ull;
+                        break;
+                    }
+                    candidates &= ~(1ull << at);
+                }
+            }
+            if (x_at != 0xFFFFFFFFu && resets) {
+                walk_from = c0 + 64u - (uint32_t)__builtin_clzll(resets); // behind the last whole-tile reset before X
+                verify_entry = x_at;
+                break;
+            }
+            if (c0 == 0u) break;
+        }
+    }
+    uint32_t first_j = walk_from & 63u;
+    bool again_from_the_top = false;
+    for (uint32_t q0 = LONG ? walk_from & ~63u : 0u; q0 < n; q0 += 64u) {
+        if (sorted_in_place)
+            my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+        else if (n > 64u)
+            my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
+        const uint32_t count = min(64u, n - q0);
+        // ---- entry set-up, vectorised across the chunk: lane j prepares entry j (the records of k_raster_edges) and says what class it is
+        float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0;
+        uint32_t eflags = 15u << 4; // (no entry: no class)
+        uint32_t item_first = 0, item_synth_a = 0;
+        if (lane < count) {
+            const uint8_t* slot = slots + (size_t)my_key * 32u;
+            const uint32_t flags = *reinterpret_cast<const uint32_t*>(slot);
+            const uint32_t kind = (flags >> 4) & 15u;
+            eflags = flags;
+            if (kind == EK_EDGE) {
+                const EdgeRec er = *reinterpret_cast<const EdgeRec*>(slot);
+                const float c = er.bx * (ty0 - er.lo_y) + er.nay * (tx0 - er.lo_x);
+                const bool xr = er.lo_x <= tx0 && tx0 < er.hi_x; // the edge crosses the line of the left tile boundary
+                eflags = flags | (xr ? 0x1000u : 0u);
+                e0 = make_float4(c, er.bx, er.nay, 0.0f);
+                e1 = make_float4(fminf(er.lo_y, er.hi_y), fmaxf(er.lo_y, er.hi_y), 0.0f, 0.0f);
+            } else if (kind == EK_SYNTH) {
+                const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
+                e0 = make_float4(sr.r, sr.g, sr.b, sr.a);
+                item_first = sr.first_slot, item_synth_a = sr.synth_a;
+            } else {
+                const PrimCoverage mine = *reinterpret_cast<const PrimCoverage*>(slot);
+                const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
+                const int by0 = max((int)mine.box.z, tpy) - tpy, by1 = min((int)mine.box.w, tpy + kTile - 1) - tpy;
+                const uint32_t col_bits = bx1 >= bx0 ? (2u << bx1) - (1u << bx0) : 0u, row_bits = by1 >= by0 ? (2u << by1) - (1u << by0) : 0u;
+                float cc[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cc[i] = mine.bx[i] * (ty0 - mine.lo_y[i]) + mine.nay[i] * (tx0 - mine.lo_x[i]);
+                e0 = make_float4(cc[0], cc[1], cc[2], __uint_as_float(col_bits | (row_bits << 16)));
+                e1 = make_float4(mine.bx[0], mine.bx[1], mine.bx[2], 0.0f);
+                e2 = make_float4(mine.nay[0], mine.nay[1], mine.nay[2], 0.0f);
+            }
+        }
+        float4* __restrict__ entries = entry_buffer;
+        __builtin_amdgcn_wave_barrier();
+        entries[lane * 3u + 0u] = e0;
+        entries[lane * 3u + 1u] = e1;
+        entries[lane * 3u + 2u] = e2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- the chunk's classes, one ballot each
+        const uint32_t ekind = (eflags >> 4) & 15u, ecode = (eflags >> 8) & 31u;
+        const bool synth = ekind == EK_SYNTH;
+        const unsigned long long m_cover = __builtin_amdgcn_ballot_w64(ekind == EK_COVER_TRI || (synth && ecode >= 4u));
+        const unsigned long long m_edge = __builtin_amdgcn_ballot_w64(ekind == EK_EDGE);
+        const unsigned long long m_tri = __builtin_amdgcn_ballot_w64(ekind >= KIND_IQ && ekind <= KIND_RC);
+        const unsigned long long m_units = __builtin_amdgcn_ballot_w64(synth && ecode < 4u);       // backdrop units: fill +1 / -1 (codes 0, 1), hull +1 / -1 (2, 3)
+        const unsigned long long m_odd = __builtin_amdgcn_ballot_w64(synth && (ecode & 1u) != 0u); // ... the -1 ones
+        const unsigned long long m_hullu = __builtin_amdgcn_ballot_w64(synth && (ecode & 2u) != 0u); // ... the hull's
+#ifdef CRH_ABLATE
+        if (r.debug & 128u) continue;
+#endif
+        // sample row b of this lane inside a set-up triangle? (k_raster_tile's coverage — E_i = fma(y, bx_i, fma(x, nay_i, c_i)) accepted as
+        // an integer >= 1 - top_left_i — as the lane mask of the samples inside: a saturating subtract per edge, a three-way minimum, the box
+        // rows folded in as a sign bit, ONE compare)
+        struct TriCoverage {
+            float ha, hb, hc, bxa, bxb, bxc;
+            int thr0, thr1, thr2;
+            uint32_t not_rows; // bit 4 b clear: the lane's sample row b is inside the triangle's pixel box
+        };
+        auto tri_coverage = [&](const float4& ea4, const float4& eb4, const float4& ec4, uint32_t flags) {
+            const uint32_t bits = __float_as_uint(ea4.w);
+            TriCoverage t;
+            t.not_rows = ((bits >> px) & 1u) ? ~((bits >> 16) >> rq) : ~0u;
+            t.thr0 = 1 - (int)(flags & 1u), t.thr1 = 1 - (int)((flags >> 1) & 1u), t.thr2 = 1 - (int)((flags >> 2) & 1u);
+            t.ha = fmaf(sx, ec4.x, ea4.x), t.hb = fmaf(sx, ec4.y, ea4.y), t.hc = fmaf(sx, ec4.z, ea4.z);
+            t.bxa = eb4.x, t.bxb = eb4.y, t.bxc = eb4.z;
+            return t;
+        };
+        auto inside_row = [&](const TriCoverage& t, int b) -> unsigned long long {
+            const float y = sy0 + (float)(4 * b);
+            const int xa = __builtin_elementwise_sub_sat(__float_as_int(fmaf(y, t.bxa, t.ha)), t.thr0);
+            const int xb = __builtin_elementwise_sub_sat(__float_as_int(fmaf(y, t.bxb, t.hb)), t.thr1);
+            const int xc = __builtin_elementwise_sub_sat(__float_as_int(fmaf(y, t.bxc, t.hc)), t.thr2);
+            return __builtin_amdgcn_ballot_w64(reject_unless_row(min(xa, min(xb, xc)), t.not_rows, 4 * b) >= 0);
+        };
+        // Occlusion (k_raster_edges): X = the last opaque cover over the whole tile none of whose item's triangles are in the list; the walk starts
+        // behind R, the last whole-tile reset in front of it, and X verifies that it overwrites every sample.
+        uint32_t j0 = LONG ? first_j : 0u, verify_at = (LONG && verify_entry - q0 < 64u) ? verify_entry - q0 : 0xFFFFFFFFu;
+        first_j = 0;
+        if (n <= 64u && !r.load_existing) { // (the whole list is in this chunk, and the tile starts from a known colour)
+            unsigned long long candidates = __builtin_amdgcn_ballot_w64(synth && ecode >= 4u + kCoverOpaque);
+            const unsigned long long resets = __builtin_amdgcn_ballot_w64(synth && ecode >= 4u + kCoverHull);
+            while (candidates) {
+                const uint32_t at = 63u - (uint32_t)__builtin_clzll(candidates);
+                const uint32_t first_slot = __builtin_amdgcn_readlane(item_first, at), synth_a = __builtin_amdgcn_readlane(item_synth_a, at);
+                const uint32_t below = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(lane < count && my_key < synth_a));
+                if (below == 0u || __builtin_amdgcn_readlane(my_key, below - 1u) < first_slot) {
+                    const unsigned long long before = resets & ((1ull << at) - 1ull);
+                    j0 = before ? 64u - (uint32_t)__builtin_clzll(before) : 0u; // behind the last whole-tile reset before X
+                    verify_at = j0 ? at : 0xFFFFFFFFu;
+                    break;
+                }
+                candidates &= ~(1ull << at);
+            }
+        }
+        const unsigned long long all = count >= 64u ? ~0ull : (1ull << count) - 1ull;
+        unsigned long long rest = j0 >= 64u ? 0ull : all & (~0ull << j0);
+        while (rest) {
+            const unsigned long long covers = m_cover & rest;
+            const uint32_t end = covers ? (uint32_t)__builtin_ctzll(covers) : 64u;
+            const unsigned long long group = end >= 64u ? rest : rest & ((1ull << end) - 1ull); // the N entries in front of the next cover
+            // ---- backdrop units of the group: summed on the scalar unit
+            const unsigned long long units = group & m_units;
+            if (units) {
+                const int fill_units = (int)__popcll(units & ~m_hullu & ~m_odd) - (int)__popcll(units & ~m_hullu & m_odd);
+                const int hull_units = (int)__popcll(units & m_hullu & ~m_odd) - (int)__popcll(units & m_hullu & m_odd);
+                int add = fill_units + hull_units * 65536;
+#ifdef CRH_ABLATE
+                if (r.debug & 16u) add = 0;
+#endif
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) cell[b] += add;
+            }
+            // ---- boundary edges:  w(p) += sigma * [ Y_k g(p) + A_k ],  A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k)   (see the header of this file)
+            unsigned long long edges = group & m_edge;
+#ifdef CRH_ABLATE
+            if (r.debug & 8u) edges = 0ull;
+#endif
+            while (edges) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(edges);
+                edges &= edges - 1ull;
+                const float4 ea4 = entries[j * 3u + 0u];
+                const float2 yr = *reinterpret_cast<const float2*>(&entries[j * 3u + 1u]);
+                const uint32_t flags = __builtin_amdgcn_readlane(eflags, j);
+                const float c0 = ea4.x, ebx = ea4.y, enay = ea4.z, ymin = yr.x, ymax = yr.y;
+                const int thr = 1 - (int)(flags & kEdgeTl);
+                // the 16 sample rows + q0, one row per lane: g at the left tile boundary and the half-open y range
+                const float eq = fmaf(ry_row, ebx, fmaf(0.0f, enay, c0));
+                const unsigned long long gq_all = __builtin_amdgcn_ballot_w64(__float_as_int(eq) >= thr);
+                const unsigned long long y_all = __builtin_amdgcn_ballot_w64(ymin <= sy_row) & __builtin_amdgcn_ballot_w64(sy_row < ymax);
+                const uint32_t gq = (uint32_t)gq_all & 0xFFFFu, ym = (uint32_t)y_all & 0xFFFFu;
+                const bool g0 = (((uint32_t)gq_all >> 16) & 1u) != 0u, xr = (flags & 0x1000u) != 0u;
+                // A = +1: xr & gq & ~g0 & ~ym;  A = -1: (xr & ~gq & g0) | (ym & gq & (~xr | g0))
+                const uint32_t a_plus = (xr && !g0) ? gq & ~ym : 0u;
+                const uint32_t a_minus = ((xr && g0) ? ~gq & 0xFFFFu : 0u) | ((!xr || g0) ? ym & gq : 0u);
+                const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma
+                const uint32_t not_ym = ~ym >> rq;                   // bit 4 b clear: the lane's sample row b is inside the edge's y range
+                const float h = fmaf(sx, enay, c0);
+                unsigned long long accept[ROWS]; // lanes whose sample row b takes the edge's unit: Y_k g(p)
+#pragma unroll
+                for (int b = 0; b < ROWS; b += 2) {
+                    const f32x2 y = {sy0 + (float)(4 * b), sy0 + (float)(4 * b + 4)};
+                    const f32x2 ev = fma2(y, splat2(ebx), f32x2{h, h});
+                    if (ym == 0xFFFFu) { // (the edge spans the tile's rows: nothing to leave out)
+                        accept[b] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[0]) >= thr);
+                        accept[b + 1] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[1]) >= thr);
+                    } else {
+                        accept[b] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev[0]), not_ym, 4 * b) >= thr);
+                        accept[b + 1] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev[1]), not_ym, 4 * b + 4) >= thr);
+                    }
+                }
+                const uint32_t up = positive ? a_plus : a_minus, down = positive ? a_minus : a_plus; // rows whose constant A_k sigma is +1 / -1
+                // Two bits per row — 01: +1, 11: -1 — in one scalar word; the lane shifts its rows down and takes signed two-bit fields
+                const int consts = (int)((((uint32_t)bit_double(up) & 0x55555555u) | (uint32_t)bit_double(down)) >> (2u * rq));
+                if (flags & kEdgeHull) { // the hull's half of the cell
+                    const int unit = positive ? 65536 : -65536;
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b) cell[b] += __builtin_amdgcn_inverse_ballot_w64(accept[b]) ? unit : 0;
+                    if (up | down) {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b) cell[b] += __builtin_amdgcn_sbfe(consts, 8u * b, 2u) * 65536;
+                    }
+                } else {
+                    if (positive) {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b) cell[b] = add_lane_bit(cell[b], accept[b]);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b) cell[b] = sub_lane_bit(cell[b], accept[b]);
+                    }
+                    if (up | down) {
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b) cell[b] += __builtin_amdgcn_sbfe(consts, 8u * b, 2u);
+                    }
+                }
+            }
+            // ---- curve triangles: the four implicit-curve tests (shaders.wgsl:236-266), one straight-line variant per kind
+            unsigned long long tris = group & m_tri;
+#ifdef CRH_ABLATE
+            if (r.debug & 32u) tris = 0ull;
+#endif
+            while (tris) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(tris);
+                tris &= tris - 1ull;
+                const uint32_t prim = __builtin_amdgcn_readlane(my_key, j);
+                const uint32_t flags = __builtin_amdgcn_readlane(eflags, j);
+                const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
+                const float4 ea4 = entries[j * 3u + 0u], eb4 = entries[j * 3u + 1u], ec4 = entries[j * 3u + 2u];
+                const uint32_t kind = (flags >> 4) & 15u;
+                const TriCoverage cov = tri_coverage(ea4, eb4, ec4, flags);
+                const int back = (flags & 8u) ? 0 : -1; // front (ccw on screen) increments, back decrements (renderer.rs:577-582)
+                const uint32_t box_rows = __builtin_amdgcn_readfirstlane(__float_as_uint(ea4.w)) >> 16;
+                const float dx0 = tx0 - frag.v0x, dy0 = ty0 - frag.v0y;
+                auto curve = [&](auto kind_tag) {
+                    constexpr uint32_t K = decltype(kind_tag)::value;
+                    constexpr int NA = K == KIND_IQ ? 2 : (K == KIND_RC ? 4 : 3); // attributes the kind interpolates
+                    float hx[NA]; // attribute planes, tile relative: the row-independent inner fma
+#pragma unroll
+                    for (int t = 0; t < NA; ++t) hx[t] = fmaf(sx, frag.gx[t], fmaf(dy0, frag.gy[t], fmaf(dx0, frag.gx[t], frag.a0[t])));
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b) {
+                        if (((box_rows >> (4 * b)) & 15u) == 0u) continue; // none of the four sample rows 4 b .. 4 b + 3 is in the triangle's box
+                        const unsigned long long inside = inside_row(cov, b);
+                        if (inside == 0ull) continue; // curve triangles are small: most rows of the tile are not touched
+                        const float y = sy0 + (float)(4 * b);
+                        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int t = 0; t < NA; ++t) a[t] = fmaf(y, frag.gy[t], hx[t]);
+                        const float lhs = (K == KIND_IQ || K == KIND_RQ) ? a[0] * a[0] : a[0] * a[0] * a[0];
+                        const float rhs = K == KIND_IQ ? a[1] : (K == KIND_RC ? a[1] * a[2] * a[3] : a[1] * a[2]);
+                        const unsigned long long filled = inside & __builtin_amdgcn_ballot_w64(lhs - rhs <= 0.0f);
+                        cell[b] = add_lane_bit(cell[b] ^ back, filled) ^ back; // ~(~c + bit) = c - bit
+                    }
+                };
+                if (kind == KIND_IQ)
+                    curve(std::integral_constant<uint32_t, KIND_IQ>{});
+                else if (kind == KIND_IC)
+                    curve(std::integral_constant<uint32_t, KIND_IC>{});
+                else if (kind == KIND_RQ)
+                    curve(std::integral_constant<uint32_t, KIND_RQ>{});
+                else
+                    curve(std::integral_constant<uint32_t, KIND_RC>{});
+            }
+            if (end >= 64u) break; // (the group runs on into the next chunk)
+            rest = end >= 63u ? 0ull : rest & (~0ull << (end + 1u));
+            // ---- entry `end` is a cover: color_cover (renderer.rs:340-354, 736-754) — blend where the winding is not zero, zero the winding of
+            //      the covered samples; premultiplied "over" (shaders.wgsl:304-309, blending of examples/showcase/main.rs:32-43)
+            const uint32_t flags = __builtin_amdgcn_readlane(eflags, end);
+            const uint32_t kind = (flags >> 4) & 15u;
+#ifdef CRH_ABLATE
+            if ((r.debug & 16u) && kind == EK_SYNTH) continue;
+#endif
+            bool blend[ROWS];
+            float cs0, cs1, cs2, cs3;
+            if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
+                const float4 ea4 = entries[end * 3u + 0u];
+                const uint32_t code = (((flags >> 8) & 31u) - 4u) % 9u;
+                const int add = ((int)(code % 3u) - 1) + ((int)(code / 3u) - 1) * 65536;
+                cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
+                bool every = true;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) {
+                    const int t = cell[b] + add;
+                    const int fill = __builtin_amdgcn_sbfe(t, 0u, 16u);
+                    const bool in_hull = t != fill; // (65536 x the hull winding is what is left, whatever the sign of the fill's)
+                    blend[b] = in_hull && ((uint32_t)fill & wmask) != 0u;
+                    cell[b] = in_hull ? 0 : fill;
+                    every = every && blend[b];
+                }
+                if (end == verify_at) { // X of the late start: does it overwrite every sample? (it does unless a sample inherited a winding)
+                    verify_at = 0xFFFFFFFFu;
+                    if (__builtin_amdgcn_ballot_w64(every) != ~0ull || (r.debug & 33554432u) != 0u) { // no (or debug bit 25, tests: never trusted): the colours behind it matter — the whole list, from cleared state
+#pragma unroll
+                        for (int b = 0; b < ROWS; ++b) {
+                            cell[b] = 0;
+                            col[b][0] = col[b][1] = col[b][2] = col[b][3] = 0.0f;
+                        }
+                        if (LONG && n > 64u) { // the first chunk has to be set up again
+                            verify_entry = 0xFFFFFFFFu;
+                            again_from_the_top = true;
+                            break;
+                        }
+                        rest = all;
+                        continue;
+                    }
+                }
+            } else { // a triangle of a folded hull strip, drawn as the reference draws it
+                const uint32_t prim = __builtin_amdgcn_readlane(my_key, end);
+                const PrimFragment frag = load_uniform(reinterpret_cast<const PrimFragment*>(slots + (size_t)prim * 32u + 64u));
+                const float4 ea4 = entries[end * 3u + 0u], eb4 = entries[end * 3u + 1u], ec4 = entries[end * 3u + 2u];
+                const TriCoverage cov = tri_coverage(ea4, eb4, ec4, flags);
+                cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) {
+                    const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_row(cov, b));
+                    const int fill = __builtin_amdgcn_sbfe(cell[b], 0u, 16u);
+                    blend[b] = inside && ((uint32_t)fill & wmask) != 0u;
+                    cell[b] = inside ? cell[b] - fill : cell[b]; // (the fill winding to zero, the hull's — zero in such items — as it is)
+                }
+            }
+            // an opaque source over finite colours: src + dst * (1 - 1) is the source (r.occlude: every colour of the pass is tame; a source
+            // component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic): a select per channel, no multiply-add
+            const bool replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
+            if (replace) {
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) {
+                    col[b][0] = blend[b] ? cs0 : col[b][0];
+                    col[b][1] = blend[b] ? cs1 : col[b][1];
+                    col[b][2] = blend[b] ? cs2 : col[b][2];
+                    col[b][3] = blend[b] ? cs3 : col[b][3];
+                }
+            } else {
+                const float one_minus_a = 1.0f - cs3;
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) { // unconditional, in place (a select with the old value where nothing blends)
+                    const float n0 = cs0 + col[b][0] * one_minus_a, n1 = cs1 + col[b][1] * one_minus_a;
+                    const float n2 = cs2 + col[b][2] * one_minus_a, n3 = cs3 + col[b][3] * one_minus_a;
+                    col[b][0] = blend[b] ? n0 : col[b][0];
+                    col[b][1] = blend[b] ? n1 : col[b][1];
+                    col[b][2] = blend[b] ? n2 : col[b][2];
+                    col[b][3] = blend[b] ? n3 : col[b][3];
+                }
+            }
+            if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) { // an Rgba8Unorm attachment keeps 8 bits of what the blender writes (idempotent on the others)
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) col[b][ch] = attachment_unorm8(col[b][ch]);
+            }
+        } // groups of the chunk
+        if (LONG && again_from_the_top) { // (X of the late start did not overwrite every sample: the whole list, chunk 0 first)
+            again_from_the_top = false;
+            q0 = 0u - 64u;
+        }
+    }
+    // ---- RGBA8 unorm / binary16 store
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b) {
+        const uint32_t gy = ty * kTile + 4u * b + rq;
+        if (gx < r.width && gy < r.height) store_pixel(r, gx, gy, col[b][0], col[b][1], col[b][2], col[b][3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- k_raster_rows (round 4)
 // The same pass with the winding numbers ACCUMULATED IN LDS and the lanes spread over (entry, sample row) instead of every lane evaluating
 // every entry on its own samples (renderer.rs:304-318, 340-354, 565-582; vertex.rs:28-35; shaders.wgsl:233-266, 304-309). msaa 1, no strokes.
@@ -3084,6 +3624,9 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
     constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
     const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
     const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u); // the places of the tile order (a multiple of 8: place b is drawn on XCD b mod 8)
+    // fill scenes at msaa 1: the class-batched walk with packed counters (k_raster_fill); CRH_FILL_KERNEL=0 keeps k_raster_edges<1, 4, false, *> (A/B runs, tests: the two are bit-equal)
+    const char* fill_env = getenv("CRH_FILL_KERNEL"); // (read per launch: tests switch it inside one process)
+    const bool fill_kernel = !(fill_env && fill_env[0] == '0') && r.winding_mask <= 0xFFFFu && r.fill_cells != 0u;
 #define CRH_LAUNCH_EDGES(S_, ROWS_, STROKES_, LONG_) \
     hipLaunchKernelGGL((k_raster_edges<S_, ROWS_, STROKES_, LONG_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 1 && !has_stroke && r.rows) { // the row-span kernel: winding numbers accumulated in LDS, lanes over (entry, sample row)
@@ -3095,6 +3638,10 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
         if (has_stroke) CRH_LAUNCH_EDGES(4, 1, true, false); else CRH_LAUNCH_EDGES(4, 1, false, false);
     } else if (has_stroke) {
         CRH_LAUNCH_EDGES(1, 4, true, false);
+    } else if (fill_kernel && r.long_lists) {
+        hipLaunchKernelGGL((k_raster_fill<true>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
+    } else if (fill_kernel) {
+        hipLaunchKernelGGL((k_raster_fill<false>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
     } else if (r.long_lists) {
         CRH_LAUNCH_EDGES(1, 4, false, true);
     } else {

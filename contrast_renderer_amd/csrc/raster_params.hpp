@@ -80,6 +80,7 @@ struct RasterParams {
     const uint32_t* bin_batches;      // [2 n_bin_batches] first item of every run and the one behind its last, the long runs first, or nullptr: equal numbers of items
     uint32_t n_bin_batches;           // (overflow[kExtraTurnsWord]: turns beyond the first that the runs' workgroups needed — stale costs)
     uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
+    uint32_t fill_cells;              // no tile list of this frame has shown 16 384 entries: k_raster_fill's packed counters (fill + 65536 * hull per sample) are exact; 0: k_raster_edges
 };
 
 } // namespace crh
