@@ -1133,7 +1133,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.item_cost = nullptr;
     static const bool bin_dump = getenv("CRH_BIN_DUMP") != nullptr; // tools/bin_phases.py (a library built with -DCRH_ABLATE): a record per workgroup behind the costs
     if (edges && (!f->pairs_known || bin_dump) && !no_batches) { // (a verified pass: it says what every item takes of a batch)
-        HIP_TRY(f->item_cost.ensure((size_t)p.n_items * (bin_dump ? 40 : 8) + 48));
+        HIP_TRY(f->item_cost.ensure((size_t)p.n_items * ((bin_dump || (p.debug & 65536u)) ? 40 : 8) + 48)); // (debug bit 16, -DCRH_ABLATE builds: every workgroup leaves a record behind the costs)
         p.item_cost = f->item_cost.as<uint32_t>();
     }
     if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);

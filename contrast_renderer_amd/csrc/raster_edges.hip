@@ -2308,6 +2308,96 @@ CRH_D int sub_lane_bit(int v, unsigned long long mask) { // v - (this lane's bit
     return v;
 #endif
 }
+// One compare-exchange step of a sorting network on the 64 lanes' u32 keys, partner inside the 16-lane row: the partner's key comes in as a DPP
+// operand of v_min_u32 / v_max_u32 themselves (no LDS permute, no address arithmetic); keep_min: the lanes that keep the smaller key.
+// (s_nop 1: a DPP operand written by the VALU instruction in front needs two wait states, and the assembler does not see into the asm.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CRH_CX_DPP(key_, keep_min_, ctrl_)                                                                                                  \
+    {                                                                                                                                       \
+        uint32_t lo_, hi_;                                                                                                                  \
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %2 " ctrl_ " row_mask:0xf bank_mask:0xf\n\tv_max_u32_dpp %1, %2, %2 " ctrl_ " row_mask:0xf bank_mask:0xf" \
+            : "=&v"(lo_), "=&v"(hi_)                                                                                                        \
+            : "v"(key_));                                                                                                                   \
+        key_ = __builtin_amdgcn_inverse_ballot_w64(keep_min_) ? lo_ : hi_;                                                                   \
+    }
+#else
+#define CRH_CX_DPP(key_, keep_min_, ctrl_) { (void)(keep_min_); }
+#endif
+// ... partner = lane ^ 4 = quad mirror of the half-row mirror: one DPP move, then as above
+CRH_D uint32_t cx_xor4(uint32_t key, unsigned long long keep_min) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x141, 0xF, 0xF, false); // row_half_mirror
+    uint32_t lo, hi;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %3 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n\tv_max_u32_dpp %1, %2, %3 quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(t), "v"(key));
+    return __builtin_amdgcn_inverse_ballot_w64(keep_min) ? lo : hi;
+#else
+    return key;
+#endif
+}
+// ... partner in another row (lane ^ 16, ^ 31, ^ 32, ^ 63): through the LDS crossbar
+CRH_D uint32_t cx_far(uint32_t key, uint32_t lane, uint32_t xor_mask, unsigned long long keep_min) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ xor_mask) << 2), (int)key);
+    return __builtin_amdgcn_inverse_ballot_w64(keep_min) ? min(key, other) : max(key, other);
+#else
+    return key;
+#endif
+}
+// The normalised bitonic network (every merge begins with a mirror step, so all exchanges keep the minimum in the lower lane) over the first
+// `depth` lanes — 8, 16, 32 or 64 (wave uniform) —, ascending; lanes without a key hold 0xFFFFFFFF.
+CRH_D uint32_t sort_keys_in_lanes(uint32_t key, uint32_t lane, uint32_t depth) {
+    constexpr unsigned long long kBit0 = 0x5555555555555555ull, kBit1 = 0x3333333333333333ull, kBit2 = 0x0F0F0F0F0F0F0F0Full, kBit3 = 0x00FF00FF00FF00FFull,
+                                 kBit4 = 0x0000FFFF0000FFFFull, kBit5 = 0x00000000FFFFFFFFull; // lanes whose bit b is clear
+    CRH_CX_DPP(key, kBit0, "quad_perm:[1,0,3,2]") // kk = 2
+    CRH_CX_DPP(key, kBit1, "quad_perm:[3,2,1,0]") // kk = 4: mirror, 1
+    CRH_CX_DPP(key, kBit0, "quad_perm:[1,0,3,2]")
+    CRH_CX_DPP(key, kBit2, "row_half_mirror")     // kk = 8: mirror, 2, 1
+    CRH_CX_DPP(key, kBit1, "quad_perm:[2,3,0,1]")
+    CRH_CX_DPP(key, kBit0, "quad_perm:[1,0,3,2]")
+    if (depth > 8u) {
+        CRH_CX_DPP(key, kBit3, "row_mirror")      // kk = 16: mirror, 4, 2, 1
+        key = cx_xor4(key, kBit2);
+        CRH_CX_DPP(key, kBit1, "quad_perm:[2,3,0,1]")
+        CRH_CX_DPP(key, kBit0, "quad_perm:[1,0,3,2]")
+    }
+    if (depth > 16u) {
+        key = cx_far(key, lane, 31u, kBit4);      // kk = 32: mirror, 8, 4, 2, 1
+        CRH_CX_DPP(key, kBit3, "row_ror:8")
+        key = cx_xor4(key, kBit2);
+        CRH_CX_DPP(key, kBit1, "quad_perm:[2,3,0,1]")
+        CRH_CX_DPP(key, kBit0, "quad_perm:[1,0,3,2]")
+    }
+    if (depth > 32u) {
+        key = cx_far(key, lane, 63u, kBit5);      // kk = 64: mirror, 16, 8, 4, 2, 1
+        key = cx_far(key, lane, 16u, kBit4);
+        CRH_CX_DPP(key, kBit3, "row_ror:8")
+        key = cx_xor4(key, kBit2);
+        CRH_CX_DPP(key, kBit1, "quad_perm:[2,3,0,1]")
+        CRH_CX_DPP(key, kBit0, "quad_perm:[1,0,3,2]")
+    }
+    return key;
+}
+// "over" on the lanes of `mask` only, the others keep their colour: the blend runs under the mask as the EXEC mask (no select per channel);
+// dst = src + dst * (1 - alpha) as a multiply and an add (Rust does not contract), or dst = src for an opaque source
+CRH_D void blend_lanes(float (&c)[4], unsigned long long mask, float s0, float s1, float s2, float s3, float one_minus_a, bool replace) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long saved;
+    if (replace)
+        asm volatile("s_and_saveexec_b64 %4, %5\n\tv_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %9\n\ts_mov_b64 exec, %4"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "=&s"(saved)
+                     : "s"(mask), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+    else
+        asm volatile("s_and_saveexec_b64 %4, %5\n\t"
+                     "v_mul_f32 %0, %0, %10\n\tv_mul_f32 %1, %1, %10\n\tv_mul_f32 %2, %2, %10\n\tv_mul_f32 %3, %3, %10\n\t"
+                     "v_add_f32 %0, %6, %0\n\tv_add_f32 %1, %7, %1\n\tv_add_f32 %2, %8, %2\n\tv_add_f32 %3, %9, %3\n\ts_mov_b64 exec, %4"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "=&s"(saved)
+                     : "s"(mask), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(one_minus_a));
+#else
+    (void)mask, (void)s0, (void)s1, (void)s2, (void)s3, (void)one_minus_a, (void)replace;
+#endif
+}
 // bit `bit` of `rows` clear -> the sign bit set in x (a sample row that is left out fails every  x >= 0 / x >= 1  test): v_lshlrev_b32 + v_and_or_b32
 CRH_D int reject_unless_row(int x, uint32_t not_rows, int bit) { return (int)(((not_rows << (31 - bit)) & 0x80000000u) | (uint32_t)x); }
 template <bool LONG>
@@ -2398,19 +2488,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
         }
     } else if (n <= 64u) {
         if (lane < n) my_key = r.tile_list[list_begin + lane];
-        if (n > 1u) {
-            const uint32_t depth = n <= 8u ? 8u : (n <= 16u ? 16u : (n <= 32u ? 32u : 64u)); // a network as deep as the list needs (the keys sit in the leading lanes)
-#pragma unroll
-            for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
-                if (kk > depth) break;
-#pragma unroll
-                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-                    const uint32_t other = __shfl_xor(my_key, j, 64);
-                    const bool keep_min = ((lane & j) == 0) == ((lane & kk) == 0);
-                    my_key = keep_min ? min(my_key, other) : max(my_key, other);
-                }
-            }
-        }
+        if (n > 1u) my_key = sort_keys_in_lanes(my_key, lane, n <= 8u ? 8u : (n <= 16u ? 16u : (n <= 32u ? 32u : 64u))); // a network as deep as the list needs (the keys sit in the leading lanes)
     } else {
         uint32_t padded = 128;
         while (padded < n) padded <<= 1;
@@ -2720,26 +2798,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
 #ifdef CRH_ABLATE
             if ((r.debug & 16u) && kind == EK_SYNTH) continue;
 #endif
-            bool blend[ROWS];
+            unsigned long long blend[ROWS]; // lanes whose sample row b takes the source
             float cs0, cs1, cs2, cs3;
             if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
                 const float4 ea4 = entries[end * 3u + 0u];
-                const uint32_t code = (((flags >> 8) & 31u) - 4u) % 9u;
+                const uint32_t code_all = (flags >> 8) & 31u, code = (code_all - 4u) % 9u;
                 const int add = ((int)(code % 3u) - 1) + ((int)(code / 3u) - 1) * 65536;
                 cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
-                bool every = true;
+                if (code_all >= 4u + kCoverHull) { // the whole tile lies inside the hull (no hull edge in the list, hull backdrop not zero): every sample is tested, every winding zeroed
 #pragma unroll
-                for (int b = 0; b < ROWS; ++b) {
-                    const int t = cell[b] + add;
-                    const int fill = __builtin_amdgcn_sbfe(t, 0u, 16u);
-                    const bool in_hull = t != fill; // (65536 x the hull winding is what is left, whatever the sign of the fill's)
-                    blend[b] = in_hull && ((uint32_t)fill & wmask) != 0u;
-                    cell[b] = in_hull ? 0 : fill;
-                    every = every && blend[b];
+                    for (int b = 0; b < ROWS; ++b) {
+                        blend[b] = __builtin_amdgcn_ballot_w64((((uint32_t)(cell[b] + add)) & wmask) != 0u);
+                        cell[b] = 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < ROWS; ++b) {
+                        const int t = cell[b] + add;
+                        const int fill = __builtin_amdgcn_sbfe(t, 0u, 16u);
+                        const unsigned long long in_hull = __builtin_amdgcn_ballot_w64(t != fill); // (65536 x the hull winding is what is left, whatever the sign of the fill's)
+                        blend[b] = in_hull & __builtin_amdgcn_ballot_w64(((uint32_t)fill & wmask) != 0u);
+                        cell[b] = __builtin_amdgcn_inverse_ballot_w64(in_hull) ? 0 : fill;
+                    }
                 }
                 if (end == verify_at) { // X of the late start: does it overwrite every sample? (it does unless a sample inherited a winding)
                     verify_at = 0xFFFFFFFFu;
-                    if (__builtin_amdgcn_ballot_w64(every) != ~0ull || (r.debug & 33554432u) != 0u) { // no (or debug bit 25, tests: never trusted): the colours behind it matter — the whole list, from cleared state
+                    if ((blend[0] & blend[1] & blend[2] & blend[3]) != ~0ull || (r.debug & 33554432u) != 0u) { // no (or debug bit 25, tests: never trusted): the colours behind it matter — the whole list, from cleared state
 #pragma unroll
                         for (int b = 0; b < ROWS; ++b) {
                             cell[b] = 0;
@@ -2762,35 +2846,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
                 cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b) {
-                    const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_row(cov, b));
+                    const unsigned long long inside = inside_row(cov, b);
                     const int fill = __builtin_amdgcn_sbfe(cell[b], 0u, 16u);
-                    blend[b] = inside && ((uint32_t)fill & wmask) != 0u;
-                    cell[b] = inside ? cell[b] - fill : cell[b]; // (the fill winding to zero, the hull's — zero in such items — as it is)
+                    blend[b] = inside & __builtin_amdgcn_ballot_w64(((uint32_t)fill & wmask) != 0u);
+                    cell[b] = __builtin_amdgcn_inverse_ballot_w64(inside) ? cell[b] - fill : cell[b]; // (the fill winding to zero, the hull's — zero in such items — as it is)
                 }
             }
             // an opaque source over finite colours: src + dst * (1 - 1) is the source (r.occlude: every colour of the pass is tame; a source
-            // component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic): a select per channel, no multiply-add
+            // component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic)
             const bool replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
-            if (replace) {
+            const float one_minus_a = 1.0f - cs3;
 #pragma unroll
-                for (int b = 0; b < ROWS; ++b) {
-                    col[b][0] = blend[b] ? cs0 : col[b][0];
-                    col[b][1] = blend[b] ? cs1 : col[b][1];
-                    col[b][2] = blend[b] ? cs2 : col[b][2];
-                    col[b][3] = blend[b] ? cs3 : col[b][3];
-                }
-            } else {
-                const float one_minus_a = 1.0f - cs3;
-#pragma unroll
-                for (int b = 0; b < ROWS; ++b) { // unconditional, in place (a select with the old value where nothing blends)
-                    const float n0 = cs0 + col[b][0] * one_minus_a, n1 = cs1 + col[b][1] * one_minus_a;
-                    const float n2 = cs2 + col[b][2] * one_minus_a, n3 = cs3 + col[b][3] * one_minus_a;
-                    col[b][0] = blend[b] ? n0 : col[b][0];
-                    col[b][1] = blend[b] ? n1 : col[b][1];
-                    col[b][2] = blend[b] ? n2 : col[b][2];
-                    col[b][3] = blend[b] ? n3 : col[b][3];
-                }
-            }
+            for (int b = 0; b < ROWS; ++b) blend_lanes(col[b], blend[b], cs0, cs1, cs2, cs3, one_minus_a, replace);
             if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) { // an Rgba8Unorm attachment keeps 8 bits of what the blender writes (idempotent on the others)
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
