@@ -2288,25 +2288,19 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 //     rates, tools/valu_rate.hip, a scalar instruction costs a SIMD as much as a compare); a triangle's three edge tests are one saturating
 //     subtract each, a three-way minimum and ONE compare.
 // LONG: as k_raster_edges (the late start found across the chunks of a long list).
-CRH_D int add_lane_bit(int v, unsigned long long mask) { // v + (this lane's bit of mask): the mask is the carry-in
+CRH_D int add_lane_bit(int v, unsigned long long mask) { // v + (this lane's bit of mask): the mask is the carry-in (in place: no copy at a loop's back edge)
 #if defined(__HIP_DEVICE_COMPILE__)
-    int out;
     unsigned long long carry;
-    asm("v_addc_co_u32 %0, %1, %2, 0, %3" : "=v"(out), "=s"(carry) : "v"(v), "s"(mask));
-    return out;
-#else
-    return v;
+    asm("v_addc_co_u32 %0, %1, %0, 0, %2" : "+v"(v), "=s"(carry) : "s"(mask));
 #endif
+    return v;
 }
 CRH_D int sub_lane_bit(int v, unsigned long long mask) { // v - (this lane's bit of mask)
 #if defined(__HIP_DEVICE_COMPILE__)
-    int out;
     unsigned long long carry;
-    asm("v_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(out), "=s"(carry) : "v"(v), "s"(mask));
-    return out;
-#else
-    return v;
+    asm("v_subb_co_u32 %0, %1, %0, 0, %2" : "+v"(v), "=s"(carry) : "s"(mask));
 #endif
+    return v;
 }
 // One compare-exchange step of a sorting network on the 64 lanes' u32 keys, partner inside the 16-lane row: the partner's key comes in as a DPP
 // operand of v_min_u32 / v_max_u32 themselves (no LDS permute, no address arithmetic); keep_min: the lanes that keep the smaller key.
@@ -2379,23 +2373,81 @@ CRH_D uint32_t sort_keys_in_lanes(uint32_t key, uint32_t lane, uint32_t depth) {
     }
     return key;
 }
-// "over" on the lanes of `mask` only, the others keep their colour: the blend runs under the mask as the EXEC mask (no select per channel);
-// dst = src + dst * (1 - alpha) as a multiply and an add (Rust does not contract), or dst = src for an opaque source
-CRH_D void blend_lanes(float (&c)[4], unsigned long long mask, float s0, float s1, float s2, float s3, float one_minus_a, bool replace) {
+// "over" on the lanes of mask[b] only (sample row b), the others keep their colour: the blends run under the masks as the EXEC mask — no
+// select per channel —, dst = src + dst * (1 - alpha) as a multiply and an add (Rust does not contract), or dst = src for an opaque source.
+// One asm statement for the four rows: the colour registers are updated in place (per row, the compiler moved them to temporaries and back).
+CRH_D void blend_rows(float (&c)[4][4], const unsigned long long (&mask)[4], float s0, float s1, float s2, float s3, float one_minus_a, bool replace) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long saved;
-    if (replace)
-        asm volatile("s_and_saveexec_b64 %4, %5\n\tv_mov_b32 %0, %6\n\tv_mov_b32 %1, %7\n\tv_mov_b32 %2, %8\n\tv_mov_b32 %3, %9\n\ts_mov_b64 exec, %4"
-                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "=&s"(saved)
-                     : "s"(mask), "v"(s0), "v"(s1), "v"(s2), "v"(s3));
-    else
-        asm volatile("s_and_saveexec_b64 %4, %5\n\t"
-                     "v_mul_f32 %0, %0, %10\n\tv_mul_f32 %1, %1, %10\n\tv_mul_f32 %2, %2, %10\n\tv_mul_f32 %3, %3, %10\n\t"
-                     "v_add_f32 %0, %6, %0\n\tv_add_f32 %1, %7, %1\n\tv_add_f32 %2, %8, %2\n\tv_add_f32 %3, %9, %3\n\ts_mov_b64 exec, %4"
-                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "=&s"(saved)
-                     : "s"(mask), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(one_minus_a));
+    if (replace) {
+        asm volatile("s_mov_b64 %[saved], exec\n\t"
+                 "s_mov_b64 exec, %[m0]\n\t"
+                 "v_mov_b32 %[c00], %[s0]\n\t"
+                 "v_mov_b32 %[c01], %[s1]\n\t"
+                 "v_mov_b32 %[c02], %[s2]\n\t"
+                 "v_mov_b32 %[c03], %[s3]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "v_mov_b32 %[c10], %[s0]\n\t"
+                 "v_mov_b32 %[c11], %[s1]\n\t"
+                 "v_mov_b32 %[c12], %[s2]\n\t"
+                 "v_mov_b32 %[c13], %[s3]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\t"
+                 "v_mov_b32 %[c20], %[s0]\n\t"
+                 "v_mov_b32 %[c21], %[s1]\n\t"
+                 "v_mov_b32 %[c22], %[s2]\n\t"
+                 "v_mov_b32 %[c23], %[s3]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\t"
+                 "v_mov_b32 %[c30], %[s0]\n\t"
+                 "v_mov_b32 %[c31], %[s1]\n\t"
+                 "v_mov_b32 %[c32], %[s2]\n\t"
+                 "v_mov_b32 %[c33], %[s3]\n\t"
+                 "s_mov_b64 exec, %[saved]"
+                 : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), [c02] "+v"(c[0][2]), [c03] "+v"(c[0][3]), [c10] "+v"(c[1][0]), [c11] "+v"(c[1][1]), [c12] "+v"(c[1][2]), [c13] "+v"(c[1][3]), [c20] "+v"(c[2][0]), [c21] "+v"(c[2][1]), [c22] "+v"(c[2][2]), [c23] "+v"(c[2][3]), [c30] "+v"(c[3][0]), [c31] "+v"(c[3][1]), [c32] "+v"(c[3][2]), [c33] "+v"(c[3][3]), [saved] "=&s"(saved)
+                 : [m0] "s"(mask[0]), [m1] "s"(mask[1]), [m2] "s"(mask[2]), [m3] "s"(mask[3]), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3));
+    } else {
+        asm volatile("s_mov_b64 %[saved], exec\n\t"
+                 "s_mov_b64 exec, %[m0]\n\t"
+                 "v_mul_f32 %[c00], %[c00], %[oma]\n\t"
+                 "v_mul_f32 %[c01], %[c01], %[oma]\n\t"
+                 "v_mul_f32 %[c02], %[c02], %[oma]\n\t"
+                 "v_mul_f32 %[c03], %[c03], %[oma]\n\t"
+                 "v_add_f32 %[c00], %[s0], %[c00]\n\t"
+                 "v_add_f32 %[c01], %[s1], %[c01]\n\t"
+                 "v_add_f32 %[c02], %[s2], %[c02]\n\t"
+                 "v_add_f32 %[c03], %[s3], %[c03]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\t"
+                 "v_mul_f32 %[c10], %[c10], %[oma]\n\t"
+                 "v_mul_f32 %[c11], %[c11], %[oma]\n\t"
+                 "v_mul_f32 %[c12], %[c12], %[oma]\n\t"
+                 "v_mul_f32 %[c13], %[c13], %[oma]\n\t"
+                 "v_add_f32 %[c10], %[s0], %[c10]\n\t"
+                 "v_add_f32 %[c11], %[s1], %[c11]\n\t"
+                 "v_add_f32 %[c12], %[s2], %[c12]\n\t"
+                 "v_add_f32 %[c13], %[s3], %[c13]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\t"
+                 "v_mul_f32 %[c20], %[c20], %[oma]\n\t"
+                 "v_mul_f32 %[c21], %[c21], %[oma]\n\t"
+                 "v_mul_f32 %[c22], %[c22], %[oma]\n\t"
+                 "v_mul_f32 %[c23], %[c23], %[oma]\n\t"
+                 "v_add_f32 %[c20], %[s0], %[c20]\n\t"
+                 "v_add_f32 %[c21], %[s1], %[c21]\n\t"
+                 "v_add_f32 %[c22], %[s2], %[c22]\n\t"
+                 "v_add_f32 %[c23], %[s3], %[c23]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\t"
+                 "v_mul_f32 %[c30], %[c30], %[oma]\n\t"
+                 "v_mul_f32 %[c31], %[c31], %[oma]\n\t"
+                 "v_mul_f32 %[c32], %[c32], %[oma]\n\t"
+                 "v_mul_f32 %[c33], %[c33], %[oma]\n\t"
+                 "v_add_f32 %[c30], %[s0], %[c30]\n\t"
+                 "v_add_f32 %[c31], %[s1], %[c31]\n\t"
+                 "v_add_f32 %[c32], %[s2], %[c32]\n\t"
+                 "v_add_f32 %[c33], %[s3], %[c33]\n\t"
+                 "s_mov_b64 exec, %[saved]"
+                 : [c00] "+v"(c[0][0]), [c01] "+v"(c[0][1]), [c02] "+v"(c[0][2]), [c03] "+v"(c[0][3]), [c10] "+v"(c[1][0]), [c11] "+v"(c[1][1]), [c12] "+v"(c[1][2]), [c13] "+v"(c[1][3]), [c20] "+v"(c[2][0]), [c21] "+v"(c[2][1]), [c22] "+v"(c[2][2]), [c23] "+v"(c[2][3]), [c30] "+v"(c[3][0]), [c31] "+v"(c[3][1]), [c32] "+v"(c[3][2]), [c33] "+v"(c[3][3]), [saved] "=&s"(saved)
+                 : [m0] "s"(mask[0]), [m1] "s"(mask[1]), [m2] "s"(mask[2]), [m3] "s"(mask[3]), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2), [s3] "v"(s3), [oma] "v"(one_minus_a));
+    }
 #else
-    (void)mask, (void)s0, (void)s1, (void)s2, (void)s3, (void)one_minus_a, (void)replace;
+    (void)c, (void)mask, (void)s0, (void)s1, (void)s2, (void)s3, (void)one_minus_a, (void)replace;
 #endif
 }
 // bit `bit` of `rows` clear -> the sign bit set in x (a sample row that is left out fails every  x >= 0 / x >= 1  test): v_lshlrev_b32 + v_and_or_b32
@@ -2444,11 +2496,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
     const uint32_t list_begin = r.direct ? r.tile_base[tile] : r.tile_offset[tile];
     uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : (r.direct ? r.tile_count[tile] : r.tile_offset[tile + 1] - list_begin);
     constexpr uint32_t kLdsSortMax = kSortBytesMax / 4u;
-    if (n > r.sort_capacity && n <= kLdsSortMax) { // the host grows the sort buffer (overflow[3] = the longest list) and runs the frame again
-        if (r.direct && threadIdx.x == 0u) atomicMax(&r.overflow[3], n); // (otherwise the scan of the counts has published it)
-        n = 0;
-    } else if (n > kLdsSortMax && r.direct && threadIdx.x == 0u) {
-        atomicMax(&r.overflow[3], n);
+    {   // a list the sort buffer cannot hold: the host grows the buffer (overflow[3] = the longest list; without lists in place the scan of the
+        // counts has published it) and runs the frame again. (n is decided by selects on scalars only, and pinned to a scalar register: joined
+        // behind the lane-0 branch of the report, the compiler took it — and with it every branch of the walk — for lane dependent.)
+        const bool too_long = n > r.sort_capacity && n <= kLdsSortMax;
+        if (r.direct != 0u && (too_long || n > kLdsSortMax) && threadIdx.x == 0u) atomicMax(&r.overflow[3], n);
+        n = __builtin_amdgcn_readfirstlane(too_long ? 0u : n);
     }
 #ifdef CRH_ABLATE
     if (r.debug & 64u) n = 0;
@@ -2560,44 +2613,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
     uint32_t first_j = walk_from & 63u;
     bool again_from_the_top = false;
     for (uint32_t q0 = LONG ? walk_from & ~63u : 0u; q0 < n; q0 += 64u) {
-        if (sorted_in_place)
-            my_key = q0 + lane < n ? __hip_atomic_load(segment + q0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
-        else if (n > 64u)
-            my_key = q0 + lane < n ? keys[q0 + lane] : 0xFFFFFFFFu;
-        const uint32_t count = min(64u, n - q0);
-        // ---- entry set-up, vectorised across the chunk: lane j prepares entry j (the records of k_raster_edges) and says what class it is
-        float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = e0, e2 = e0;
-        uint32_t eflags = 15u << 4; // (no entry: no class)
-        uint32_t item_first = 0, item_synth_a = 0;
-        if (lane < count) {
-            const uint8_t* slot = slots + (size_t)my_key * 32u;
-            const uint32_t flags = *reinterpret_cast<const uint32_t*>(slot);
-            const uint32_t kind = (flags >> 4) & 15u;
-            eflags = flags;
-            if (kind == EK_EDGE) {
-                const EdgeRec er = *reinterpret_cast<const EdgeRec*>(slot);
-                const float c = er.bx * (ty0 - er.lo_y) + er.nay * (tx0 - er.lo_x);
-                const bool xr = er.lo_x <= tx0 && tx0 < er.hi_x; // the edge crosses the line of the left tile boundary
-                eflags = flags | (xr ? 0x1000u : 0u);
-                e0 = make_float4(c, er.bx, er.nay, 0.0f);
-                e1 = make_float4(fminf(er.lo_y, er.hi_y), fmaxf(er.lo_y, er.hi_y), 0.0f, 0.0f);
-            } else if (kind == EK_SYNTH) {
-                const SynthRec sr = *reinterpret_cast<const SynthRec*>(slot);
-                e0 = make_float4(sr.r, sr.g, sr.b, sr.a);
-                item_first = sr.first_slot, item_synth_a = sr.synth_a;
-            } else {
-                const PrimCoverage mine = *reinterpret_cast<const PrimCoverage*>(slot);
-                const int bx0 = max((int)mine.box.x, tpx) - tpx, bx1 = min((int)mine.box.y, tpx + kTile - 1) - tpx;
-                const int by0 = max((int)mine.box.z, tpy) - tpy, by1 = min((int)mine.box.w, tpy + kTile - 1) - tpy;
-                const uint32_t col_bits = bx1 >= bx0 ? (2u << bx1) - (1u << bx0) : 0u, row_bits = by1 >= by0 ? (2u << by1) - (1u << by0) : 0u;
-                float cc[3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) cc[i] = mine.bx[i] * (ty0 - mine.lo_y[i]) + mine.nay[i] * (tx0 - mine.lo_x[i]);
-                e0 = make_float4(cc[0], cc[1], cc[2], __uint_as_float(col_bits | (row_bits << 16)));
-                e1 = make_float4(mine.bx[0], mine.bx[1], mine.bx[2], 0.0f);
-                e2 = make_float4(mine.nay[0], mine.nay[1], mine.nay[2], 0.0f);
-            }
+        // (loads at a clamped index and a select, not a load under a lane-dependent condition: the loop has no divergent branch, see the set-up)
+        if (sorted_in_place) {
+            const uint32_t k_at = __hip_atomic_load(segment + min(q0 + lane, n - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            my_key = q0 + lane < n ? k_at : 0xFFFFFFFFu;
+        } else if (n > 64u) {
+            const uint32_t k_at = keys[min(q0 + lane, n - 1u)];
+            my_key = q0 + lane < n ? k_at : 0xFFFFFFFFu;
         }
+        const uint32_t count = min(64u, n - q0);
+        // ---- entry set-up, vectorised across the chunk: lane j prepares entry j (the records of k_raster_edges) and says what class it is.
+        // WITHOUT a divergent branch: the three kinds of record are all decoded from the same 64 bytes and the results selected (the paths of
+        // a three-way branch run one after the other anyway when a chunk holds all kinds). With it, this loop is a region of uniform branches
+        // only, which the compiler leaves as written — behind ONE divergent branch it linearised the whole walk into guarded blocks with a
+        // dozen register copies per entry where they meet.
+        const uint32_t first_key = __builtin_amdgcn_readfirstlane(my_key);
+        const uint32_t safe_key = lane < count ? my_key : first_key; // (a slot that exists: entry 0's)
+        const uint4* slot16 = reinterpret_cast<const uint4*>(slots + (size_t)safe_key * 32u);
+        const uint4 w0 = slot16[0], w1 = slot16[1];
+        const uint32_t flags = w0.x, kind = (flags >> 4) & 15u;
+        const bool is_edge = kind == EK_EDGE, is_synth = kind == EK_SYNTH;
+        const uint4* tail16 = slot16 + ((is_edge || is_synth) ? 0 : 2); // the second half of a triangle's coverage record (the others read their own line again)
+        const uint4 w2 = tail16[0], w3 = tail16[1];
+        auto f = [](uint32_t v) { return __uint_as_float(v); };
+        // a boundary edge (EdgeRec: flags, -, lo_x, lo_y | hi_x, hi_y, bx, nay)
+        const float e_c = f(w1.z) * (ty0 - f(w0.w)) + f(w1.w) * (tx0 - f(w0.z));
+        const bool xr = f(w0.z) <= tx0 && tx0 < f(w1.x); // the edge crosses the line of the left tile boundary
+        const float e_ymin = fminf(f(w0.w), f(w1.y)), e_ymax = fmaxf(f(w0.w), f(w1.y));
+        // a backdrop unit or a COVER (SynthRec: flags, first_slot, r, g | b, a, synth_a, -); a COVER's two folded backdrop units decoded here, once:
+        // (code - 4) % 9 = bd + 1 + 3 (hbd + 1) -> eflags bits 16-17 and 18-19
+        // (... with multiplications: a division the compiler would put behind a lane-dependent branch; exact for these small operands)
+        const uint32_t code_p5 = ((flags >> 8) & 31u) + 5u, code9 = code_p5 - 9u * ((code_p5 * 57u) >> 9); // (code + 5) % 9, code + 5 <= 36
+        const uint32_t code9_div3 = (code9 * 11u) >> 5, code9_mod3 = code9 - 3u * code9_div3;               // code9 <= 8
+        // a curve triangle (PrimCoverage: flags, desc, box | lo_x[3], lo_y[3], bx[3], nay[3])
+        const int px0 = (int)(w0.z & 0xFFFFu), px1 = (int)(w0.z >> 16), py0 = (int)(w0.w & 0xFFFFu), py1 = (int)(w0.w >> 16);
+        const int bx0 = max(px0, tpx) - tpx, bx1 = min(px1, tpx + kTile - 1) - tpx;
+        const int by0 = max(py0, tpy) - tpy, by1 = min(py1, tpy + kTile - 1) - tpy;
+        const uint32_t col_bits = bx1 >= bx0 ? (2u << bx1) - (1u << bx0) : 0u, row_bits = by1 >= by0 ? (2u << by1) - (1u << by0) : 0u;
+        const float cc0 = f(w2.z) * (ty0 - f(w1.w)) + f(w3.y) * (tx0 - f(w1.x));
+        const float cc1 = f(w2.w) * (ty0 - f(w2.x)) + f(w3.z) * (tx0 - f(w1.y));
+        const float cc2 = f(w3.x) * (ty0 - f(w2.y)) + f(w3.w) * (tx0 - f(w1.z));
+        const float4 e0 = make_float4(is_edge ? e_c : (is_synth ? f(w0.z) : cc0), is_edge ? f(w1.z) : (is_synth ? f(w0.w) : cc1), is_edge ? f(w1.w) : (is_synth ? f(w1.x) : cc2),
+                                      is_synth ? f(w1.y) : f(col_bits | (row_bits << 16)));
+        const float4 e1 = make_float4(is_edge ? e_ymin : f(w2.z), is_edge ? e_ymax : f(w2.w), f(w3.x), 0.0f);
+        const float4 e2 = make_float4(f(w3.y), f(w3.z), f(w3.w), 0.0f);
+        // (bit 20: an opaque source none of whose components is -0 — `replace` below —, decided here so that the walk's branch on it is on a scalar)
+        const bool opaque_source = f(w1.y) == 1.0f && w0.z != 0x80000000u && w0.w != 0x80000000u && w1.x != 0x80000000u;
+        const uint32_t eflags = lane < count ? flags | (is_edge ? (xr ? 0x1000u : 0u) : (is_synth ? (code9_mod3 << 16) | (code9_div3 << 18) | (opaque_source ? 1u << 20 : 0u) : 0u)) : 15u << 4; // (no entry: no class)
+        const uint32_t item_first = w0.y, item_synth_a = w1.z; // (read at COVER entries only)
         float4* __restrict__ entries = entry_buffer;
         __builtin_amdgcn_wave_barrier();
         entries[lane * 3u + 0u] = e0;
@@ -2698,24 +2761,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
                 const unsigned long long y_all = __builtin_amdgcn_ballot_w64(ymin <= sy_row) & __builtin_amdgcn_ballot_w64(sy_row < ymax);
                 const uint32_t gq = (uint32_t)gq_all & 0xFFFFu, ym = (uint32_t)y_all & 0xFFFFu;
                 const bool g0 = (((uint32_t)gq_all >> 16) & 1u) != 0u, xr = (flags & 0x1000u) != 0u;
-                // A = +1: xr & gq & ~g0 & ~ym;  A = -1: (xr & ~gq & g0) | (ym & gq & (~xr | g0))
-                const uint32_t a_plus = (xr && !g0) ? gq & ~ym : 0u;
-                const uint32_t a_minus = ((xr && g0) ? ~gq & 0xFFFFu : 0u) | ((!xr || g0) ? ym & gq : 0u);
+                // A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k), three cases:  !xr: -(ym & gq);  xr & !g0: +(gq & ~ym);  xr & g0: -(~gq | ym)
+                uint32_t a_plus = 0u, a_minus = ym & gq;
+                if (xr) {
+                    a_plus = g0 ? 0u : gq & ~ym;
+                    a_minus = g0 ? (~gq & 0xFFFFu) | ym : 0u;
+                }
                 const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma
-                const uint32_t not_ym = ~ym >> rq;                   // bit 4 b clear: the lane's sample row b is inside the edge's y range
                 const float h = fmaf(sx, enay, c0);
+                const f32x2 y01 = {sy0, sy0 + 4.0f}, y23 = {sy0 + 8.0f, sy0 + 12.0f};
+                const f32x2 ev01 = fma2(y01, splat2(ebx), f32x2{h, h}), ev23 = fma2(y23, splat2(ebx), f32x2{h, h});
                 unsigned long long accept[ROWS]; // lanes whose sample row b takes the edge's unit: Y_k g(p)
-#pragma unroll
-                for (int b = 0; b < ROWS; b += 2) {
-                    const f32x2 y = {sy0 + (float)(4 * b), sy0 + (float)(4 * b + 4)};
-                    const f32x2 ev = fma2(y, splat2(ebx), f32x2{h, h});
-                    if (ym == 0xFFFFu) { // (the edge spans the tile's rows: nothing to leave out)
-                        accept[b] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[0]) >= thr);
-                        accept[b + 1] = __builtin_amdgcn_ballot_w64(__float_as_int(ev[1]) >= thr);
-                    } else {
-                        accept[b] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev[0]), not_ym, 4 * b) >= thr);
-                        accept[b + 1] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev[1]), not_ym, 4 * b + 4) >= thr);
-                    }
+                if (ym == 0xFFFFu) { // (the edge spans the tile's rows: nothing to leave out)
+                    accept[0] = __builtin_amdgcn_ballot_w64(__float_as_int(ev01[0]) >= thr);
+                    accept[1] = __builtin_amdgcn_ballot_w64(__float_as_int(ev01[1]) >= thr);
+                    accept[2] = __builtin_amdgcn_ballot_w64(__float_as_int(ev23[0]) >= thr);
+                    accept[3] = __builtin_amdgcn_ballot_w64(__float_as_int(ev23[1]) >= thr);
+                } else {
+                    const uint32_t not_ym = ~ym >> rq; // bit 4 b clear: the lane's sample row b is inside the edge's y range
+                    accept[0] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev01[0]), not_ym, 0) >= thr);
+                    accept[1] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev01[1]), not_ym, 4) >= thr);
+                    accept[2] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev23[0]), not_ym, 8) >= thr);
+                    accept[3] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev23[1]), not_ym, 12) >= thr);
                 }
                 const uint32_t up = positive ? a_plus : a_minus, down = positive ? a_minus : a_plus; // rows whose constant A_k sigma is +1 / -1
                 // Two bits per row — 01: +1, 11: -1 — in one scalar word; the lane shifts its rows down and takes signed two-bit fields
@@ -2800,10 +2867,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
 #endif
             unsigned long long blend[ROWS]; // lanes whose sample row b takes the source
             float cs0, cs1, cs2, cs3;
+            // replace: an opaque source over finite colours — src + dst * (1 - 1) is the source (r.occlude: every colour of the pass is tame; a source
+            // component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic)
+            bool replace;
             if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
+                replace = r.occlude != 0u && (flags & (1u << 20)) != 0u;
                 const float4 ea4 = entries[end * 3u + 0u];
-                const uint32_t code_all = (flags >> 8) & 31u, code = (code_all - 4u) % 9u;
-                const int add = ((int)(code % 3u) - 1) + ((int)(code / 3u) - 1) * 65536;
+                const uint32_t code_all = (flags >> 8) & 31u;
+                const int add = ((int)((flags >> 16) & 3u) - 1) + ((int)((flags >> 18) & 3u) - 1) * 65536;
                 cs0 = ea4.x, cs1 = ea4.y, cs2 = ea4.z, cs3 = ea4.w;
                 if (code_all >= 4u + kCoverHull) { // the whole tile lies inside the hull (no hull edge in the list, hull backdrop not zero): every sample is tested, every winding zeroed
 #pragma unroll
@@ -2844,6 +2915,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
                 const float4 ea4 = entries[end * 3u + 0u], eb4 = entries[end * 3u + 1u], ec4 = entries[end * 3u + 2u];
                 const TriCoverage cov = tri_coverage(ea4, eb4, ec4, flags);
                 cs0 = frag.a0[0], cs1 = frag.a0[1], cs2 = frag.a0[2], cs3 = frag.a0[3];
+                replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b) {
                     const unsigned long long inside = inside_row(cov, b);
@@ -2852,12 +2924,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
                     cell[b] = __builtin_amdgcn_inverse_ballot_w64(inside) ? cell[b] - fill : cell[b]; // (the fill winding to zero, the hull's — zero in such items — as it is)
                 }
             }
-            // an opaque source over finite colours: src + dst * (1 - 1) is the source (r.occlude: every colour of the pass is tame; a source
-            // component that is -0 would come out as +0 through the arithmetic, so it takes the arithmetic)
-            const bool replace = r.occlude != 0u && cs3 == 1.0f && __float_as_uint(cs0) != 0x80000000u && __float_as_uint(cs1) != 0x80000000u && __float_as_uint(cs2) != 0x80000000u;
             const float one_minus_a = 1.0f - cs3;
-#pragma unroll
-            for (int b = 0; b < ROWS; ++b) blend_lanes(col[b], blend[b], cs0, cs1, cs2, cs3, one_minus_a, replace);
+            blend_rows(col, blend, cs0, cs1, cs2, cs3, one_minus_a, replace);
             if (r.format == CRH_FORMAT_RGBA8_ATTACHMENT) { // an Rgba8Unorm attachment keeps 8 bits of what the blender writes (idempotent on the others)
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
