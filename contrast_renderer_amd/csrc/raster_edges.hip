@@ -2762,51 +2762,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
                 const uint32_t gq = (uint32_t)gq_all & 0xFFFFu, ym = (uint32_t)y_all & 0xFFFFu;
                 const bool g0 = (((uint32_t)gq_all >> 16) & 1u) != 0u, xr = (flags & 0x1000u) != 0u;
                 // A_k = xr (g(q_k) - g(q_0)) - Y_k g(q_k), three cases:  !xr: -(ym & gq);  xr & !g0: +(gq & ~ym);  xr & g0: -(~gq | ym)
-                uint32_t a_plus = 0u, a_minus = ym & gq;
-                if (xr) {
-                    a_plus = g0 ? 0u : gq & ~ym;
-                    a_minus = g0 ? (~gq & 0xFFFFu) | ym : 0u;
-                }
+                const uint32_t ygq = ym & gq;
+                const uint32_t a_plus = (xr && !g0) ? gq ^ ygq : 0u;
+                const uint32_t a_minus = xr ? (g0 ? (gq ^ 0xFFFFu) | ym : 0u) : ygq;
                 const bool positive = (flags & kEdgeSigmaPos) != 0u; // sigma
+                const int weight = (flags & kEdgeHull) ? 65536 : 1;  // the half of the cell the edge's chain belongs to
+                const int unit = positive ? weight : -weight;
                 const float h = fmaf(sx, enay, c0);
                 const f32x2 y01 = {sy0, sy0 + 4.0f}, y23 = {sy0 + 8.0f, sy0 + 12.0f};
                 const f32x2 ev01 = fma2(y01, splat2(ebx), f32x2{h, h}), ev23 = fma2(y23, splat2(ebx), f32x2{h, h});
-                unsigned long long accept[ROWS]; // lanes whose sample row b takes the edge's unit: Y_k g(p)
-                if (ym == 0xFFFFu) { // (the edge spans the tile's rows: nothing to leave out)
-                    accept[0] = __builtin_amdgcn_ballot_w64(__float_as_int(ev01[0]) >= thr);
-                    accept[1] = __builtin_amdgcn_ballot_w64(__float_as_int(ev01[1]) >= thr);
-                    accept[2] = __builtin_amdgcn_ballot_w64(__float_as_int(ev23[0]) >= thr);
-                    accept[3] = __builtin_amdgcn_ballot_w64(__float_as_int(ev23[1]) >= thr);
-                } else {
-                    const uint32_t not_ym = ~ym >> rq; // bit 4 b clear: the lane's sample row b is inside the edge's y range
-                    accept[0] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev01[0]), not_ym, 0) >= thr);
-                    accept[1] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev01[1]), not_ym, 4) >= thr);
-                    accept[2] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev23[0]), not_ym, 8) >= thr);
-                    accept[3] = __builtin_amdgcn_ballot_w64(reject_unless_row(__float_as_int(ev23[1]), not_ym, 12) >= thr);
-                }
-                const uint32_t up = positive ? a_plus : a_minus, down = positive ? a_minus : a_plus; // rows whose constant A_k sigma is +1 / -1
-                // Two bits per row — 01: +1, 11: -1 — in one scalar word; the lane shifts its rows down and takes signed two-bit fields
-                const int consts = (int)((((uint32_t)bit_double(up) & 0x55555555u) | (uint32_t)bit_double(down)) >> (2u * rq));
-                if (flags & kEdgeHull) { // the hull's half of the cell
-                    const int unit = positive ? 65536 : -65536;
+                // Straight-line code from here (an if / else per property of the edge — hull or fill, sigma, "spans all rows" — came back from the
+                // compiler as guarded blocks with the four counters copied at every join): the lanes whose sample row b takes the edge's unit,
+                // Y_k g(p), with the rows outside the y range failing the compare through their sign bit
+                const uint32_t not_ym = ~ym >> rq; // bit 4 b clear: the lane's sample row b is inside the edge's y range
+                cell[0] += (reject_unless_row(__float_as_int(ev01[0]), not_ym, 0) >= thr) ? unit : 0;
+                cell[1] += (reject_unless_row(__float_as_int(ev01[1]), not_ym, 4) >= thr) ? unit : 0;
+                cell[2] += (reject_unless_row(__float_as_int(ev23[0]), not_ym, 8) >= thr) ? unit : 0;
+                cell[3] += (reject_unless_row(__float_as_int(ev23[1]), not_ym, 12) >= thr) ? unit : 0;
+                if (a_plus | a_minus) { // the edge crosses the left tile boundary (or runs left of it): row constants A_k sigma. Two bits per row —
+                                        // 01: +1, 11: -1 — in one scalar word; the lane shifts its rows down and takes signed two-bit fields
+                    const uint32_t up = positive ? a_plus : a_minus, down = positive ? a_minus : a_plus;
+                    const int consts = (int)((((uint32_t)bit_double(up) & 0x55555555u) | (uint32_t)bit_double(down)) >> (2u * rq));
 #pragma unroll
-                    for (int b = 0; b < ROWS; ++b) cell[b] += __builtin_amdgcn_inverse_ballot_w64(accept[b]) ? unit : 0;
-                    if (up | down) {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b) cell[b] += __builtin_amdgcn_sbfe(consts, 8u * b, 2u) * 65536;
-                    }
-                } else {
-                    if (positive) {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b) cell[b] = add_lane_bit(cell[b], accept[b]);
-                    } else {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b) cell[b] = sub_lane_bit(cell[b], accept[b]);
-                    }
-                    if (up | down) {
-#pragma unroll
-                        for (int b = 0; b < ROWS; ++b) cell[b] += __builtin_amdgcn_sbfe(consts, 8u * b, 2u);
-                    }
+                    for (int b = 0; b < ROWS; ++b) cell[b] = __mul24(__builtin_amdgcn_sbfe(consts, 8u * b, 2u), weight) + cell[b];
                 }
             }
             // ---- curve triangles: the four implicit-curve tests (shaders.wgsl:236-266), one straight-line variant per kind
