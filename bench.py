@@ -41,7 +41,7 @@ def mark_to_kernel(workload, triangle_pass=False):
     return {
         # (the last argument: the variant that looks for its late start across the chunks of long tile lists — the host picks it for frames with
         # many entries per tile and opaque whole-tile covers: the 100 000 path scene)
-        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_fill<true>" if workload == "s100k" else "crh::k_raster_fill<false>"),
+        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else "crh::k_raster_fill<true>",
         # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
         "raster_rows": "crh::k_raster_rows<true>" if workload == "s100k" else "crh::k_raster_rows<false>",  # the row-span kernel, where the library's trial picked it
         "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else "crh::k_bin_flat<1>",
@@ -328,6 +328,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--scaling", default=None, choices=("weak", "strong"), help="default: strong at N > 1 (the metric's scene split N ways) with the weak figure in a side block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-animated", action="store_true", help="N = 1: skip the `animated` side block (new instance transforms every step)")
     ap.add_argument("--repeats", type=int, default=5, help="blocks of --steps steps timed again behind the timed region (never `value`): their min / median / max ms per step go to `spread`")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend for the barrier / id broadcast (nccl = RCCL)")
     ap.add_argument("--exchange", default="cabi", choices=("cabi", "torch"), help="cabi: crh_frame_exchange over RCCL (the product path); torch: the "
@@ -644,6 +645,58 @@ def main():
                      "paths_per_gpu": int(args.paths), "paths_total": int(args.paths * world),
                      "note": f"every rank draws its OWN {args.paths} paths (generator streams rank x {args.paths} ...): {world} x the metric's scene per step, same loop and exchange"}
         scene = strong_scene
+    # A scene that MOVES (never `value`): every step new instance transforms — a zoom about the frame's centre by 1 % per frame, in and out over
+    # twenty frames, what the reference's own loop does with its view (examples/showcase/main.rs:154-161, 236-250) — uploaded with
+    # crh_scene_set_instances in front of the step; the dashed workload also moves one Shape's dash phase per frame (main.rs:243-250 through
+    # crh_scene_set_dynamic_stroke_options). The tile lists change from frame to frame: what the frame-coherent state of the steady figure
+    # (lists in place, batches cut by cost, heavy tiles first) is worth when the frames are not identical shows here.
+    animated = None
+    if world == 1 and not args.reupload and not args.no_animated:
+        n_sets = 20
+        zoom = [1.01 ** (k if k <= n_sets // 2 else n_sets - k) for k in range(n_sets)]
+        moved = []
+        for z in zoom:
+            t = np.array(transforms, dtype=np.float32, copy=True).reshape(-1, 16)
+            t[:, [0, 1, 4, 5, 12, 13]] *= np.float32(z)
+            moved.append(t)
+        phase_of = None
+        if args.workload == "dashed":
+            from contrast_renderer_amd.path import DashInterval, DynamicStrokeOptions, Join, Cap
+            pattern = [DashInterval(2.0, 3.0, Cap(0), Cap(3)), DashInterval(5.0, 6.0, Cap(3), Cap(0))]  # Shape 0's own pattern (scenes.scene_dashed_strokes), its phase moving
+            phase_of = lambda i: DynamicStrokeOptions.Dashed(Join.Miter, pattern, 0.25 * (i % n_sets))
+
+        shown = [frame, Frame(renderer, *size)]  # two targets, as a swap chain has: frame i is CONSUMED (crh_frame_synchronize: the pixels are final,
+                                                 # a pass whose optimistic list places were outgrown has been drawn again) before its target is drawn into again
+
+        def run_animated(n):
+            for i in range(n):
+                target = shown[i % 2]
+                target.synchronize()
+                scene.tessellate()  # (first: it does not depend on the instances, and started now it runs in the gap behind the raster kernel of the frame before)
+                scene.set_instances(moved[i % n_sets], colors)
+                if phase_of is not None:
+                    scene.set_dynamic_stroke_options(0, 0, phase_of(i))
+                target.clear()
+                scene.render(target)
+        try:
+            run_animated(2 * n_sets)  # (untimed: the first pass over the twenty views)
+            sync()
+            ta = time.perf_counter()
+            run_animated(max(args.steps, n_sets))
+            sync()
+            animated_s = (time.perf_counter() - ta) / max(args.steps, n_sets)
+            scene.check()
+            animated = {"ms_per_step": animated_s * 1e3, "value": args.paths / animated_s, "unit": "paths/s", "steps": max(args.steps, n_sets),
+                        "views": n_sets, "zoom_per_frame": 0.01, "dash_phase_moves": phase_of is not None,
+                        "note": "every step: crh_frame_synchronize of the target (two targets in turn: the frame drawn two steps ago is consumed — final pixels — before "
+                                "its target is reused), crh_scene_tessellate, crh_scene_set_instances with the next of twenty views (zoom about the centre, 1 % per frame, in and out)"
+                                + (" + crh_scene_set_dynamic_stroke_options of Shape 0 with a new dash phase" if phase_of is not None else "")
+                                + ", then clear + render: the step of the metric with the instances renewed; host calls and the instance upload inside the clock"}
+        except Exception as e:  # (reported, never fatal: a side block)
+            animated = {"error": f"{type(e).__name__}: {e}"}
+        scene.set_instances(transforms, colors)
+        renderer.synchronize()
+        del shown
     check = None
     if world == 1 and not args.no_check:  # the pixels this run timed, against the oracle's frame of the same scene (its CRC-32 is committed: the oracle takes minutes at this size)
         import zlib
@@ -777,6 +830,7 @@ def main():
                           "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
                           "note": "all kernels of a step: control data read + emitted bytes written (tessellation), emitted bytes + 80 B / shape read and W*H*4 written (raster)"},
         "kernels": kernels,
+        "animated": animated,
         "check": check,
         # the boundary hands over host buffers once per scene (crh_scene_upload); never part of `value`
         "host_inclusive": {"upload_ms": upload_s * 1e3, "paths_per_s_first_frame": batch.n_shapes / (upload_s + step_s),

@@ -17,7 +17,7 @@
 namespace crh {
 typedef void (*MarkFn)(void*, const char*, uint64_t);
 void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke);
-void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes);
+void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_setup);
 void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_fill);
@@ -32,7 +32,7 @@ void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* sha
 bool bin_itemwise(const RasterParams& r);
 void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs);
 void flat_batch_limits(uint32_t limits[4]);
-void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, hipStream_t stream);
+void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, uint32_t tiles_x, uint32_t radius, hipStream_t stream);
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
 } // namespace crh
@@ -288,6 +288,11 @@ struct crh_frame {
         DevBuf bin_queue;                           // the edge pass: items handed from k_bin_flat to k_bin_edges
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
         hipEvent_t raster_done = nullptr; // recorded on the raster stream after the raster kernel that read this set
+        // The pass' flag words (overflow[0 .. kExtraTurnsWord]) copied to pinned host memory on the side stream as soon as its raster kernel is
+        // through: a caller that consumes every frame (crh_frame_synchronize before the target is drawn into again — any animation) finds them
+        // there instead of paying two device-to-host copies and two stream synchronisations per frame
+        uint32_t* flags_host = nullptr;
+        hipEvent_t flags_ready = nullptr; // (fires after raster_done)
         bool used = false;
     } sets[kPipelineDepth];
     int next_set = 0, last_set = 0;
@@ -317,6 +322,19 @@ struct crh_frame {
     // straight into them (no pair stream, scan or scatter). A tile that outgrows its place is noticed like any overflow (settle_frame):
     // the pass is drawn again the exact way and the places are taken anew; after three such misses the frame stays on the exact way.
     DevBuf tile_base, tile_caps;
+    // Round 5: the places FOLLOW the scene. Every pass with its lists in place leaves, behind its binning kernels and beside its raster kernel, the
+    // places of the NEXT pass — the prefix of (the longest count within three tiles + half + 64) — in the other of two buffers: no host involvement, and a list is only
+    // outgrown when it grows by half from one pass into this frame to the next (a zoom of 1 % per frame outgrew the places of one verified
+    // pass within a dozen frames; after three redraws the frame fell back to the pair stream, 0.05 ms per frame slower).
+    DevBuf tile_base_b;
+    int base_cur = 0;            // which of tile_base / tile_base_b the next pass reads
+    // A frame whose passes see the instances change is `moving`: its places are then sized by the longest list within kMovingListRadius tiles
+    // (a camera shifts the content by whole tiles between two passes into one target); a frame of resident instances keeps tight places —
+    // lists side by side, measured 1 % faster on the steady figure (0.3125 against 0.3155 ms per step).
+    bool moving = false;
+    uint64_t last_pass_instances = ~0ull;
+    uint64_t places_instances = 0; // crh_scene::instances_version of the pass whose counts the current places come from (unchanged instances: unchanged counts, no new places)
+    uint32_t direct_clean = 0;   // passes with lists in place since the last one that outgrew them (thirty-two forgive the misses)
     bool direct_ready = false;
     crh_scene* direct_scene = nullptr;
     uint64_t direct_generation = 0;
@@ -362,8 +380,15 @@ struct crh_scene {
     uint32_t n_segments = 0;
     bool has_stroke = false, big_shapes = false;
     bool capacity_known = false;
+    uint64_t instances_version = 0; // counts crh_scene_set_instances calls
     uint64_t input_bytes = 0, emitted_bytes = 0;
     uint32_t totals_host[NCH] = {};
+    // How many Shapes the hull kernels beyond k_hull_small find queued (a property of the geometry): fetched once behind the first
+    // tessellation of these paths, asynchronously; later runs do not launch a kernel whose queue is empty (50 000 glyphs: two launches per
+    // frame that executed no vector instruction and waited 51 us each for wave slots on the tessellation lane)
+    uint32_t* hull_queued_host = nullptr; // pinned, [4]
+    hipEvent_t hull_queued_ready = nullptr;
+    int hull_queued_state = 0; // 0 unknown, 1 the copy is on its way, 2 known
     std::vector<uint32_t> shape_dyn_begin_host;
     // inputs
     DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
@@ -458,6 +483,9 @@ struct crh_scene {
         upload_c.release();
         geometry_stage.release();
         for (InstanceSlot& k : slot) k.release();
+        if (hull_queued_host) (void)hipHostFree(hull_queued_host), hull_queued_host = nullptr;
+        if (hull_queued_ready) (void)hipEventDestroy(hull_queued_ready), hull_queued_ready = nullptr;
+        hull_queued_state = 0;
     }
 };
 
@@ -611,6 +639,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
         if (st != CRH_OK) return st;
     }
     sc->tessellated_once = true;
+    if (again) sc->hull_queued_state = 0; // (the run that overflowed queued nothing: its hull kernels returned at once; the caller has synchronised)
     SceneDev& d = sc->d;
     const hipStream_t ts = r->tessellation_stream();
     // the previous frame's k_prim_setup must have consumed the vertex streams this run overwrites; its binning and raster may still run
@@ -638,7 +667,15 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     }
     if (sc->has_stroke) HIP_TRY(hipMemsetAsync(d.line_pair_cut, 0, sc->line_pair_cut.cap, ts));
     const uint64_t bytes2[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, (uint64_t)sc->totals_host[CH_HULL] * 8};
-    launch_emit(d, ts, r->mark_fn_tess(), r, bytes2, sc->has_stroke, sc->big_shapes);
+    if (sc->hull_queued_state == 1 && hipEventQuery(sc->hull_queued_ready) == hipSuccess) sc->hull_queued_state = 2;
+    launch_emit(d, ts, r->mark_fn_tess(), r, bytes2, sc->has_stroke, sc->big_shapes, sc->hull_queued_state == 2 ? sc->hull_queued_host : nullptr);
+    if (sc->hull_queued_state == 0 && (sc->has_stroke || sc->big_shapes)) {
+        if (!sc->hull_queued_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc->hull_queued_host), 16, hipHostMallocDefault));
+        if (!sc->hull_queued_ready) HIP_TRY(hipEventCreateWithFlags(&sc->hull_queued_ready, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(sc->hull_queued_host, d.hull_large_count, 16, hipMemcpyDeviceToHost, ts));
+        HIP_TRY(hipEventRecord(sc->hull_queued_ready, ts));
+        sc->hull_queued_state = 1;
+    }
     // contiguous primitive ids per Shape, in draw order (transform independent, so it belongs to the tessellation); the previous
     // frame's tile walks read the old ranges until its fill pass is through
     if (sc->rendered_once && !sc->last_render_one_event) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0)); // (one event stood for both: waited for above)
@@ -776,6 +813,7 @@ size_t grown_pair_bytes(const crh_frame* f, const uint32_t ov[8]) {
 }
 // The pass of this plain frame — 1: boundary edges, per-sample raster kernel; 2: strip triangles; 3: boundary edges, row-span raster kernel
 // (k_raster_rows: msaa 1, no strokes) — and, through `timed`, which trial (candidate 0 edges, 1 triangles, 2 rows) its events belong to, or -1.
+constexpr uint32_t kMovingListRadius = 3u;
 int choose_pass(crh_scene* sc, const crh_frame* f, int* timed) {
     *timed = -1;
     const bool rows_eligible = sc->renderer->config.msaa_sample_count == 1 && !sc->has_stroke && getenv("CRH_NO_ROWS") == nullptr;
@@ -994,6 +1032,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // (each wait on another stream's event is a packet the binning lane — the critical one — spends 5 - 10 us on, satisfied or not: the
     // frame's set and the Scene's record buffer were as a rule last used by the same raster kernel, and then one wait says it all)
     if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.raster_done, 0));
+    if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.flags_ready, 0)); // (the copy of the flag words this pass is about to clear)
     if (sc->rec_used[rec] && !(set.used && set.raster_serial == sc->rec_raster_serial[rec])) HIP_TRY(hipStreamWaitEvent(bin, sc->rec_raster_done[rec], 0));
     RasterParams p;
     p.width = f->width;
@@ -1116,6 +1155,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // Geometry that has stayed for two passes without its lists in place (a Scene drawn into this frame after another one, paths uploaded
     // again into the Scene): one verified pass more, which puts them in place. (Not at once: a caller that uploads new paths for every
     // frame would pay a read-back per frame for places it never uses.)
+    if (!recorded) {
+        if (f->seen_scene == sc && f->last_pass_instances != ~0ull && f->last_pass_instances != sc->instances_version) f->moving = true;
+        f->last_pass_instances = sc->instances_version;
+    }
     if (f->seen_scene == sc && f->seen_generation == sc->generation) f->seen_passes += 1u;
     else f->seen_scene = sc, f->seen_generation = sc->generation, f->seen_passes = 0u;
     if (edges && !recorded && f->pairs_known && f->seen_passes == 2u && !no_direct && f->direct_misses < 3u &&
@@ -1125,7 +1168,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.direct = direct ? 1u : 0u;
     const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->generation;
     p.skip_queue = skip_queue ? 1u : 0u;
-    p.tile_base = f->tile_base.as<uint32_t>();
+    p.tile_base = (f->base_cur ? f->tile_base_b : f->tile_base).as<uint32_t>();
     p.tile_order = f->tile_order_ready ? f->tile_order.as<uint32_t>() : nullptr;
     const bool no_batches = getenv("CRH_NO_BIN_BATCHES") != nullptr; // A/B runs and tests (read per pass: they switch it inside one process)
     const bool batches = edges && !no_batches && f->n_bin_batches != 0u && f->batches_scene == sc && f->batches_generation == sc->generation && f->batches_items == p.n_items;
@@ -1136,7 +1179,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         HIP_TRY(f->item_cost.ensure((size_t)p.n_items * ((bin_dump || (p.debug & 65536u)) ? 40 : 8) + 48)); // (debug bit 16, -DCRH_ABLATE builds: every workgroup leaves a record behind the costs)
         p.item_cost = f->item_cost.as<uint32_t>();
     }
-    if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 4);
+    if (direct) f->pair_capacity_bytes = std::max<size_t>(f->pair_capacity_bytes, (size_t)f->direct_entries * 6); // (half as much again: the places move with the scene; a pass whose places do not fit says so, overflow[0])
     HIP_TRY(set.tile_list.ensure(f->pair_capacity_bytes));
     for (int attempt = 0; attempt < 6; ++attempt) { // (a region of the edge pass' pair stream may fill before the total does: each retry adds headroom)
         p.tile_list = set.tile_list.as<uint32_t>();
@@ -1174,10 +1217,13 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                 uint32_t total = 0;
                 HIP_TRY(f->tile_caps.ensure((size_t)p.n_tiles * 4 + 4));
                 HIP_TRY(f->tile_base.ensure((size_t)p.n_tiles * 4 + 4));
-                launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), f->tile_base.as<uint32_t>(), p.scan_scratch, p.n_tiles, bin);
-                HIP_TRY(hipMemcpyAsync(&total, f->tile_base.as<uint32_t>() + p.n_tiles, 4, hipMemcpyDeviceToHost, bin));
+                HIP_TRY(f->tile_base_b.ensure((size_t)p.n_tiles * 4 + 4));
+                uint32_t* const places = (f->base_cur ? f->tile_base_b : f->tile_base).as<uint32_t>(); // (the buffer the next pass reads)
+                launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), places, p.scan_scratch, p.n_tiles, p.tiles_x, f->moving ? kMovingListRadius : 0u, bin);
+                HIP_TRY(hipMemcpyAsync(&total, places + p.n_tiles, 4, hipMemcpyDeviceToHost, bin));
                 HIP_TRY(hipStreamSynchronize(bin));
                 f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
+                f->places_instances = recorded ? ~0ull : sc->instances_version;
                 f->queue_seen = ov[6] != 0;
                 f->n_bin_batches = 0;
                 if (p.item_cost && !bin_itemwise(p) && p.n_items != 0u) { // k_bin_flat wrote every item's cost: the later passes' batches
@@ -1222,6 +1268,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     if (edges) {
         if (!one_event) HIP_TRY(hipEventRecord(sc->ranges_free, bin)); // k_bin_edges, the only reader of the slot ranges, is behind us
         launch_scatter(p, bin, r->mark_fn_bin(), r);
+        if (direct && f->places_instances != sc->instances_version) { // the places of the next pass into this frame, from this pass' counts: behind the event the raster kernel waits for, beside that kernel (resident instances: the same counts, the same places)
+            f->places_instances = sc->instances_version;
+            uint32_t* const next_places = (f->base_cur ? f->tile_base : f->tile_base_b).as<uint32_t>();
+            launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), next_places, p.scan_scratch, p.n_tiles, p.tiles_x, f->moving ? kMovingListRadius : 0u, bin);
+            f->base_cur ^= 1;
+        }
     } else {
         launch_fill(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->ranges_free);
     }
@@ -1239,6 +1291,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         launch_raster(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
+    HIP_TRY(hipStreamWaitEvent(r->aux_stream, set.raster_done, 0));
+    HIP_TRY(hipMemcpyAsync(set.flags_host, set.overflow_p, sizeof(uint32_t) * (kExtraTurnsWord + 1u), hipMemcpyDeviceToHost, r->aux_stream));
+    HIP_TRY(hipEventRecord(set.flags_ready, r->aux_stream));
     set.raster_serial = sc->rec_raster_serial[rec] = ++r->render_serial;
     r->raster_events[1] = r->raster_events[0], r->raster_events[0] = sc->rec_raster_done[rec];
     if (trial && timed % 2 == 1 && trial->started) {
@@ -1269,6 +1324,13 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
 // The runs of k_bin_flat are cut by what the items cost in the frame's verified pass; when the instances move (a zoom), a run no longer fits
 // one batch and its workgroup takes several turns — correct, but the balance is gone. A quarter of the workgroups in that state: the
 // runs are dropped and the next pass is a verified one, which measures again. (Called where the frame's flags are read anyway.)
+void stale_batches_known(crh_frame* f, uint32_t extra) {
+    if (!f->last_used_batches || f->n_bin_batches == 0u) return;
+    if ((uint64_t)extra * 4u > f->n_bin_batches && f->batches_age >= 16u) { // (not more often than every sixteen passes: a verified pass drains the pipeline)
+        if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u of %u runs of k_bin_flat needed more than one turn: the costs are measured again\n", extra, f->n_bin_batches);
+        f->n_bin_batches = 0, f->pairs_known = false;
+    }
+}
 crh_status stale_batches(crh_frame* f, hipStream_t stream) {
     if (!f->last_used_batches || f->n_bin_batches == 0u) return CRH_OK;
     uint32_t extra = 0;
@@ -1301,7 +1363,7 @@ crh_status settle_frame(crh_frame* f) {
     }
     if (ov[0] != 0 && f->last_direct) { // a tile outgrew the place the earlier frame left it: the exact way again, with the read-back, and new places
         if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] direct tile lists: a list outgrew its place, the pass is drawn again\n");
-        f->direct_ready = false, f->pairs_known = false, f->direct_misses += 1u;
+        f->direct_ready = false, f->pairs_known = false, f->direct_misses += 1u, f->direct_clean = 0u;
     }
     const bool queue_missed = ov[6] != 0 && f->last_skipped_queue; // items were queued for a kernel that was not launched: again, with it
     if (queue_missed) f->queue_seen = true, f->pairs_known = false;
@@ -1327,16 +1389,15 @@ crh_status settle_frame(crh_frame* f) {
 crh_status settle_frame_cheaply(crh_frame* f) {
     crh_renderer* r = f->renderer;
     const crh_frame::BinSet& set = f->sets[f->last_set];
-    if (set.used) HIP_TRY(hipEventSynchronize(set.raster_done));
+    if (set.used) HIP_TRY(hipEventSynchronize(set.flags_ready)); // (behind raster_done: the pixels are written, the pass' flag words are on the host)
     if (!f->check_pending) return CRH_OK;
-    uint32_t ov[8];
-    HIP_TRY(hipMemcpyAsync(ov, set.overflow_p, 32, hipMemcpyDeviceToHost, r->aux_stream));
-    HIP_TRY(hipStreamSynchronize(r->aux_stream));
+    const uint32_t* ov = set.flags_host;
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
     if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small || (ov[6] != 0 && f->last_skipped_queue)) return settle_frame(f);
-    const crh_status stale = stale_batches(f, r->aux_stream);
-    if (stale != CRH_OK) return stale;
+    f->longest_list = std::max(f->longest_list, ov[3]);
+    if (f->last_direct && ++f->direct_clean >= 32u) f->direct_misses = 0u, f->direct_clean = 0u;
+    stale_batches_known(f, ov[kExtraTurnsWord]);
     f->check_pending = false;
     return CRH_OK;
 }
@@ -1604,6 +1665,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
     sc->capacity_known = false;
+    if (sc->hull_queued_state == 1) (void)hipEventSynchronize(sc->hull_queued_ready); // (a copy of the old paths' counts still on its way)
+    sc->hull_queued_state = 0;
     sc->instances_set = false;
     sc->layout_valid = false;
     // control bytes + 1 type byte per segment, 8 B start per path, 32 B options per stroked path
@@ -1838,7 +1901,9 @@ crh_status crh_frame_create_format(crh_renderer* r, uint32_t width, uint32_t hei
         ok = ok && hip_ok(set.tile_count_cursor.ensure((size_t)f->n_tiles * 8 + 512), "hipMalloc") && hip_ok(set.tile_offset.ensure((size_t)(f->n_tiles + 1) * 4), "hipMalloc") &&
              hip_ok(set.tile_list.ensure(f->pair_capacity_bytes), "hipMalloc") &&
              hip_ok(hipEventCreateWithFlags(&set.bin_done, hipEventDisableTiming), "hipEventCreate") &&
-             hip_ok(hipEventCreateWithFlags(&set.raster_done, hipEventDisableTiming), "hipEventCreate");
+             hip_ok(hipEventCreateWithFlags(&set.raster_done, hipEventDisableTiming), "hipEventCreate") &&
+             hip_ok(hipEventCreateWithFlags(&set.flags_ready, hipEventDisableTiming), "hipEventCreate") &&
+             hip_ok(hipHostMalloc(reinterpret_cast<void**>(&set.flags_host), sizeof(uint32_t) * 128, hipHostMallocDefault), "hipHostMalloc");
     if (!ok) {
         crh_frame_destroy(f);
         return CRH_ERR_HIP;
@@ -1871,7 +1936,7 @@ void crh_frame_destroy(crh_frame* f) {
                 break;
             }
     }
-    DevBuf* all[] = {&f->tile_order, &f->item_cost, &f->bin_batches, &f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
+    DevBuf* all[] = {&f->tile_order, &f->item_cost, &f->bin_batches, &f->tile_base, &f->tile_base_b, &f->tile_caps, &f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
                      &f->item_nslots, &f->item_slot_begin};
     for (DevBuf* b : all) b->release();
     f->item_upload_t.release();
@@ -1882,6 +1947,8 @@ void crh_frame_destroy(crh_frame* f) {
         for (DevBuf* b : bins) b->release();
         if (set.bin_done) (void)hipEventDestroy(set.bin_done);
         if (set.raster_done) (void)hipEventDestroy(set.raster_done);
+        if (set.flags_ready) (void)hipEventDestroy(set.flags_ready);
+        if (set.flags_host) (void)hipHostFree(set.flags_host), set.flags_host = nullptr;
     }
     if (f->ext_read) { // an exchange may still be reading or writing the pixels on its own stream
         if (f->ext_read_set) (void)hipEventSynchronize(f->ext_read);
@@ -1953,11 +2020,13 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
     if (sc->d.n_shapes) {
         HIP_TRY(tb.ensure((size_t)sc->d.n_shapes * 64));
         HIP_TRY(cb.ensure((size_t)sc->d.n_shapes * 16));
-        // on the upload stream: behind the k_prim_setup that last read this set, ahead of the next one (events), overlapping the binning of
-        // the frame in between; no host synchronisation (the host arrays are copied to pinned staging memory before the calls return)
+        // On the BINNING stream, in order behind the binning of the frame before — the copies run while that frame's raster kernel does — and in
+        // front of the binning that reads them; no host synchronisation (the host arrays are copied to pinned staging memory before the calls
+        // return). Round 5: on a stream of their own (rounds 2 - 4) the copies were as early, but the binning stream's wait for the copy
+        // engine's event cost a consumed animation 0.05 ms per frame (tools/r05_host_calls.py: 0.357 against 0.308 ms per step of 10 000 paths).
         InstanceSlot& slot = sc->slot[next];
         HIP_TRY(slot.init());
-        const hipStream_t up = r->pipeline ? r->upload_stream : r->stream;
+        const hipStream_t up = r->pipeline ? r->bin_stream : r->stream;
         if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_event, 0)); // the setup that read this set two updates ago
         HIP_TRY(sc->upload_t.copy(tb.p, transforms, (size_t)sc->d.n_shapes * 64, up));
         HIP_TRY(sc->upload_c.copy(cb.p, colors, (size_t)sc->d.n_shapes * 16, up));
@@ -1965,6 +2034,7 @@ crh_status crh_scene_set_instances(crh_scene* sc, const float* transforms, const
         slot.was_written = true;
     }
     sc->instances_cur = next;
+    sc->instances_version += 1u;
     sc->instances_projective_of[next] = !all_instances_plain(transforms, sc->d.n_shapes);
     sc->instances_tame_of[next] = all_colors_tame(colors, sc->d.n_shapes);
     sc->instances_projective = sc->instances_projective_of[next];
@@ -2037,7 +2107,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
         HIP_TRY(cb.ensure((size_t)n_instances * 16 + 16));
         InstanceSlot& slot = f->item_slot[next];
         HIP_TRY(slot.init());
-        const hipStream_t up = r->pipeline ? r->upload_stream : r->stream;
+        const hipStream_t up = r->pipeline ? r->bin_stream : r->stream;
         if (slot.was_read) HIP_TRY(hipStreamWaitEvent(up, slot.read_event, 0));
         HIP_TRY(f->item_upload_t.copy(tb.p, transforms, (size_t)n_instances * 64, up));
         HIP_TRY(f->item_upload_c.copy(cb.p, colors, (size_t)n_instances * 16, up));

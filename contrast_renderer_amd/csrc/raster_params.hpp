@@ -64,7 +64,7 @@ struct RasterParams {
     uint32_t* pair_cursor;            // pairs written so far (one atomic per flushed block of a wave)
     uint32_t hint_tris, hint_edges;   // about how many stroke / curve triangles and boundary edges the pass' items have in total (0: unknown) — sizes the batches of k_bin_flat
     // Direct tile lists (edge pass, frames after the first verified one): the lists keep the places of the previous frame — tile_base[t] =
-    // exclusive prefix of (count + count / 2 + 16) of that frame — and the binning kernels store every key where it belongs, straight from
+    // exclusive prefix of (c + c / 2 + 64), c = the longest count within three tiles, of the pass before (k_tile_caps) — and the binning kernels store every key where it belongs, straight from
     // their stages: no pair stream, no scan of the counts, no scatter kernel. A tile that outgrows its place sets overflow[0]; the host
     // draws the frame again the exact way and re-bases the lists.
     uint32_t direct;

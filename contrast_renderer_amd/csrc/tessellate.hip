@@ -687,7 +687,8 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(64), 0, stream, s);
     if (mark) mark(ctx, "tess_scan", bytes[1]);
 }
-void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes) {
+// hull_queued: what the three queues behind k_hull_small held when these paths were tessellated before ([0] <= 256 candidates, [1] <= 2048, [2] beyond), or nullptr: not known yet
+void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued) {
     if (s.n_elems == 0) return;
     hipLaunchKernelGGL(k_emit, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
     if (mark) mark(ctx, "tess_emit", bytes[2]);
@@ -699,9 +700,10 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
     hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(64 * kHullWaves), 0, stream, s);
     if (mark) mark(ctx, "tess_hull", bytes[3]);
     if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
-        hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(s.n_shapes, 16384u)), dim3(64), 0, stream, s); // (6 KB of LDS each: the GPU holds 6 600 at once; 4096 made a wave take two Shapes one after the other)
-        hipLaunchKernelGGL((k_hull_large<kHullMax, 1>), dim3(min(s.n_shapes, 1024u)), dim3(64), 0, stream, s);
-        hipLaunchKernelGGL(k_hull_huge, dim3(min(s.n_shapes, 256u)), dim3(256), 0, stream, s);
+        // (a kernel whose queue is known to be empty is not launched: it would execute nothing, but wait for wave slots beside the raster grid)
+        if (!hull_queued || hull_queued[0]) hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(hull_queued ? hull_queued[0] : s.n_shapes, 16384u)), dim3(64), 0, stream, s); // (6 KB of LDS each: the GPU holds 6 600 at once; 4096 made a wave take two Shapes one after the other)
+        if (!hull_queued || hull_queued[1]) hipLaunchKernelGGL((k_hull_large<kHullMax, 1>), dim3(min(hull_queued ? hull_queued[1] : s.n_shapes, 1024u)), dim3(64), 0, stream, s);
+        if (!hull_queued || hull_queued[2]) hipLaunchKernelGGL(k_hull_huge, dim3(min(hull_queued ? hull_queued[2] : s.n_shapes, 256u)), dim3(256), 0, stream, s);
         if (mark) mark(ctx, "tess_hull_large", 0);
     }
 }
