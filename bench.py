@@ -196,7 +196,11 @@ def run_loopback(args, size, scaling, np):
     fmt = FORMAT_RGBA16F if args.layers == "rgba16f" else FORMAT_RGBA8
     renderer = Renderer(Configuration(msaa_sample_count=1, clip_nesting_counter_bits=4, winding_counter_bits=4), device=0)
     shards = []
-    if scaling == "strong":
+    tile_split = args.split == "tile"
+    if tile_split:  # every rank holds the whole scene and draws its slab of tile rows
+        sc = scenes.scene_cubic_fill(args.paths, size, config_index=2)
+        scaling = "strong"
+    elif scaling == "strong":
         sc = scenes.scene_cubic_fill(args.paths, size, config_index=2)
         for k in range(n):
             lo, hi = shard_range(args.paths, k, n)
@@ -206,6 +210,15 @@ def run_loopback(args, size, scaling, np):
             one = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=k * args.paths)
             shards.append((one["batch"], one["transforms"], one["colors"]))
     scene_objs, layers = [], []
+    if tile_split:
+        from contrast_renderer_amd.renderer import slab_rows
+        scene = Scene(renderer, sc["batch"], tessellate=True)
+        scene.check()
+        scene.set_instances(sc["transforms"], sc["colors"])
+        for k in range(n):  # (ONE Scene object stands for the n identical copies the ranks of a node would hold: each `draw` of it is one rank's)
+            scene_objs.append(scene)
+            layers.append(Frame(renderer, *size, fmt))
+            layers[-1].set_tile_rows(*slab_rows(size[1], k, n))
     for batch, t, c in shards:
         scene = Scene(renderer, batch, tessellate=True)
         scene.check()
@@ -222,9 +235,11 @@ def run_loopback(args, size, scaling, np):
             layer.clear()
             scene.render(layer)
 
+    exchange = (lambda: comms[0].local_gather_slabs(layers, result)) if tile_split else (lambda: comms[0].local_exchange(layers, result))
+
     def step():
         draw()
-        comms[0].local_exchange(layers, result)
+        exchange()
 
     for _ in range(20 + args.warmup):  # (the library's pass trial, as in the default run)
         step()
@@ -241,7 +256,7 @@ def run_loopback(args, size, scaling, np):
     for _ in range(5):
         renderer.synchronize()
         t1 = time.perf_counter()
-        comms[0].local_exchange(layers, result)
+        exchange()
         per_rank = [c.last_timing() for c in comms]
         wall.append(time.perf_counter() - t1)
         phases.append(per_rank)
@@ -264,6 +279,12 @@ def run_loopback(args, size, scaling, np):
     total_paths = args.paths if scaling == "strong" else args.paths * n
     step_s = elapsed / max(1, args.steps)
     image = result.download()
+    equals_single = None
+    if tile_split:  # the gathered frame against ONE render of the whole scene into a whole frame: equal, bit for bit
+        single = Frame(renderer, *size)
+        single.clear()
+        scene_objs[0].render(single)
+        equals_single = bool(np.array_equal(image, single.download()))
     out = {
         "metric": "paths/sec, 10k mixed-Bezier paths @ 4096^2 (tessellate + tile raster)",
         "value": total_paths / step_s,
@@ -280,7 +301,9 @@ def run_loopback(args, size, scaling, np):
         "data": "synthetic",
         "config": {
             "workload": (f"LOOPBACK x{n} on ONE GPU — {'BASELINE configs[3]' if args.workload == 's100k' else 'BASELINE configs[1]'}: {total_paths} filled closed cubic paths, "
-                         f"{size[0]}x{size[1]}, msaa 1; the {n} contiguous shards ({scaling}) are rendered one after the other into {n} {args.layers} layers, then "
+                         f"{size[0]}x{size[1]}, msaa 1; " + (f"TILE SPLIT: the whole scene is tessellated, binned and drawn {n} times, each time into the slab of tile rows of one of {n} {args.layers} layers, then "
+                                                            "crh_comm_local_gather_slabs (the slabs straight into the result frame); for comparison: "
+                                                            if tile_split else f"the {n} contiguous shards ({scaling}) are rendered one after the other into {n} {args.layers} layers, then ") +
                          "crh_comm_local_exchange (occupancy bitmaps, sparse slab all-to-all, ordered over-composite, gather: csrc/comm.hip with D2D copies in place of RCCL)"),
             "paths_total": int(total_paths),
             "parallelism": f"one GPU plays {n} ranks; `value` = {total_paths} paths / (all {n} shards drawn + one exchange) — NOT an {n}-GPU number",
@@ -288,6 +311,8 @@ def run_loopback(args, size, scaling, np):
         },
         "loopback": {
             "ranks": n,
+            "split": args.split,
+            "gathered_equals_single_gpu_frame": equals_single,
             "draw_all_shards_ms": draw_s * 1e3,
             "draw_per_rank_ms": draw_s * 1e3 / n,
             "exchange_wall_ms": {"median": sorted(wall)[len(wall) // 2] * 1e3, "min": min(wall) * 1e3,
@@ -344,6 +369,11 @@ def main():
                     "the other into N layers and exchanged through crh_comm_local_exchange (csrc/comm.hip with device-to-device copies in place of RCCL): "
                     "the whole of BASELINE configs[3] on one box, with the exchange's per-phase GPU time and bytes on the wire")
     ap.add_argument("--layers", default="rgba8", choices=("rgba8", "rgba16f"), help="--loopback: storage format of the per-rank layers")
+    ap.add_argument("--split", default="path", choices=("path", "tile"),
+                    help="N > 1 / --loopback: path = contiguous path-index shards, every rank draws a full-size layer, ordered composite (north_star; RGBA8 layers: <= 2/255 "
+                         "against one GPU); tile = SURVEY.md §8(e)'s other split: every rank holds ALL paths and draws its slab of tile rows "
+                         "(crh_frame_set_tile_rows), nothing is composited, the gathered frame is bit-equal to one GPU's. The default N > 1 run times path as "
+                         "`value` and tile in the `tile_split` side block")
     ap.add_argument("--workload", default="cubic", choices=("cubic", "glyphs", "dashed", "s100k"),
                     help="cubic = BASELINE configs[1] (the metric's configuration); glyphs = configs[2]; dashed = configs[4]; s100k = configs[3] (100k paths @ 8192^2, split over the ranks)")
     args = ap.parse_args()
@@ -397,7 +427,11 @@ def main():
         return run_loopback(args, size, scaling, np)
     if args.workload in ("cubic", "s100k"):
         label = "BASELINE configs[1]" if args.workload == "cubic" else "BASELINE configs[3]"
-        if scaling == "weak" or world == 1:
+        if args.split == "tile" and world > 1:  # THE scene on every rank, split by tile rows (the frames' slabs, below)
+            sc = scenes.scene_cubic_fill(args.paths, size, config_index=2)
+            shard = (0, args.paths)
+            scaling = "strong"
+        elif scaling == "weak" or world == 1:
             sc = scenes.scene_cubic_fill(args.paths, size, config_index=2, first_path=rank * args.paths)
             shard = (0, args.paths)
         else:  # THE scene, split by index
@@ -432,6 +466,15 @@ def main():
 
     # N > 1: two layers, so that the exchange of step i runs while step i + 1 is being tessellated and rasterized into the other one
     frames = [frame] + ([Frame(renderer, *size)] if world > 1 else [])
+    tile_split = args.split == "tile" and world > 1
+    gather_mode = tile_split  # (finish() reads it: the `tile_split` side block of a path-sharded run switches it on for its own steps)
+    if tile_split:
+        exchange_note_tile = "crh_frame_gather_slabs (C ABI): every rank's slab of rows straight into rank 0's frame, one grouped ncclSend / ncclRecv per rank"
+        if args.workload not in ("cubic", "s100k"):
+            raise SystemExit("--split tile: workloads cubic / s100k")
+        from contrast_renderer_amd.renderer import slab_rows
+        for f in frames:
+            f.set_tile_rows(*slab_rows(size[1], rank, world))
     comm, result, exchange_note = None, None, None
     layer_views, slab = [], None
     if world > 1 and args.exchange == "cabi":
@@ -451,6 +494,8 @@ def main():
         if int(created.item()) == 0 and comm is not None:
             comm, result = None, None
             exchange_note = "FALLBACK to torch.distributed (crh_comm_create failed on another rank)"
+        if comm is not None and tile_split:
+            exchange_note = exchange_note_tile
     if world > 1 and os.environ.get("CRH_BENCH_FAIL_FIRST_EXCHANGE") is not None:  # (tests: every rank holds a communicator whose exchange fails)
         class _Failing:
             def exchange(self, *a):
@@ -482,7 +527,10 @@ def main():
         """The exchange step of the path for step i's layer; the renderer may already be working on step i + 1."""
         f = frames[i % len(frames)]
         if comm is not None:
-            comm.exchange(f, result)  # waits for step i's raster kernel only, then runs on the communicator's own stream
+            if gather_mode:
+                comm.gather_slabs(f, result)  # the tile split: the slabs travel straight from the layers' rows into the result frame
+            else:
+                comm.exchange(f, result)  # waits for step i's raster kernel only, then runs on the communicator's own stream
             return result
         f.synchronize()
         received, _ = D.exchange_layers(layer_views[i % len(frames)], rank, world)
@@ -645,6 +693,40 @@ def main():
                      "paths_per_gpu": int(args.paths), "paths_total": int(args.paths * world),
                      "note": f"every rank draws its OWN {args.paths} paths (generator streams rank x {args.paths} ...): {world} x the metric's scene per step, same loop and exchange"}
         scene = strong_scene
+    # The other split beside the path-sharded default (N > 1): every rank holds the WHOLE scene and draws its slab of tile rows — same loop, same
+    # exchange (which then moves nothing in its all-to-all and composites nothing): the first run on real links decides between the two.
+    tile_side = None
+    if world > 1 and default_scaling and scaling == "strong" and args.split == "path" and args.workload == "cubic" and not args.reupload:
+        from contrast_renderer_amd.renderer import slab_rows
+        strong_scene = scene
+        whole = scenes.scene_cubic_fill(args.paths, size, config_index=2)
+        scene = Scene(renderer, whole["batch"], tessellate=True)
+        scene.check()
+        scene.set_instances(whole["transforms"], whole["colors"])
+        renderer.synchronize()
+        for f in frames:
+            f.set_tile_rows(*slab_rows(size[1], rank, world))
+        gather_mode = True
+        run(20 + args.warmup)
+        sync()
+        tt = time.perf_counter()
+        run(args.steps)
+        sync()
+        tile_elapsed = time.perf_counter() - tt
+        tmax = torch.tensor([tile_elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tile_elapsed = float(tmax.item())
+        scene.check()
+        sent = comm.last_traffic() if comm is not None else None
+        tile_side = {"split": "tile", "scaling": "strong", "value": args.paths / (tile_elapsed / args.steps), "unit": "paths/s", "ms_per_step": tile_elapsed / args.steps * 1e3,
+                     "paths_per_gpu": int(args.paths), "bytes_sent_by_rank0_last_step": sent[0] if sent else None,
+                     "note": f"every rank tessellates and bins all {args.paths} paths and draws 1/{world} of the tile rows (crh_frame_set_tile_rows); the exchange gathers the slabs — "
+                             "no compositing, the frame is bit-equal to one GPU's (tests/test_comm.py::test_tile_split_gathers_the_single_gpu_frame_bit_for_bit)"}
+        renderer.synchronize()
+        gather_mode = False
+        for f in frames:
+            f.set_tile_rows(0, size[1])
+        scene = strong_scene
     # A scene that MOVES (never `value`): every step new instance transforms — a zoom about the frame's centre by 1 % per frame, in and out over
     # twenty frames, what the reference's own loop does with its view (examples/showcase/main.rs:154-161, 236-250) — uploaded with
     # crh_scene_set_instances in front of the step; the dashed workload also moves one Shape's dash phase per frame (main.rs:243-250 through
@@ -716,7 +798,15 @@ def main():
     if args.check and world > 1:  # (scene is the strong / chosen one again)
         gathered = run(1)  # one more pass outside the timed region: the gathered image on rank 0
         sync()
-        if rank == 0:
+        if rank == 0 and tile_split:  # the gathered frame against this rank's own render of the whole scene into a whole frame: equal
+            got = gathered.download() if comm is not None else gathered.cpu().numpy()
+            whole_frame = Frame(renderer, *size)
+            whole_frame.clear()
+            scene.render(whole_frame)
+            expect = whole_frame.download()
+            check = {"gathered_equals_single_gpu_frame": bool(np.array_equal(got, expect)),
+                     "max_abs_difference": int(np.abs(got.astype(np.int32) - expect.astype(np.int32)).max())}
+        elif rank == 0:
             got = gathered.download() if comm is not None else gathered.cpu().numpy()
             layers = []
             for other in range(world):  # the same shards, rendered one after the other by this rank alone
@@ -791,7 +881,8 @@ def main():
             "paths_per_gpu": int(batch.n_shapes),
             "paths_total": int(total_paths),
             "segments_per_gpu": int(batch.n_segments),
-            "parallelism": "single GPU" if world == 1 else f"path-index sharding x{world} ({scaling}); {exchange_note}; the exchange of step i overlaps the rendering of step i + 1",
+            "parallelism": "single GPU" if world == 1 else ((f"TILE split x{world}: every rank holds all paths and draws its slab of tile rows" if tile_split else f"path-index sharding x{world} ({scaling})")
+                                                               + f"; {exchange_note}; the exchange of step i overlaps the rendering of step i + 1"),
             "covered_fraction": covered,
         },
         "setup": "20 untimed steps before the warm-up: the library times its raster formulations (boundary edges per sample / strip triangles / boundary edges as row spans: same pixels) on this scene and keeps the fastest",
@@ -841,6 +932,8 @@ def main():
         out["exchange"].update(exchange_stats or {})
     if weak_side is not None:
         out["weak_scaling"] = weak_side
+    if tile_side is not None:
+        out["tile_split"] = tile_side
     # The CPU baseline (the oracle as the checker's clock, on rank 0 at N = 1 only) — after the GPU part: run before it, its sixteen busy
     # threads left the process with a ~20 ms host stall inside the timed region in one run out of three (the GPU idle, ms_per_step doubled)
     cpu_baseline = None

@@ -251,6 +251,7 @@ def load_library():
         "crh_frame_destroy": (None, [V]),
         "crh_frame_clear": (C.c_int, [V]),
         "crh_frame_synchronize": (C.c_int, [V]),
+        "crh_frame_set_tile_rows": (C.c_int, [V, C.c_uint32, C.c_uint32]),
         "crh_frame_clear_depth": (C.c_int, [V, C.c_float]),
         "crh_frame_upload_depth": (C.c_int, [V, C.POINTER(C.c_float)]),
         "crh_frame_download_depth": (C.c_int, [V, C.POINTER(C.c_float)]),
@@ -269,7 +270,9 @@ def load_library():
         "crh_comm_create_local": (C.c_int, [V, C.c_uint32, C.c_uint32, V, C.POINTER(V)]),
         "crh_comm_destroy": (None, [V]),
         "crh_frame_exchange": (C.c_int, [V, V, V]),
+        "crh_frame_gather_slabs": (C.c_int, [V, V, V]),
         "crh_comm_local_exchange": (C.c_int, [V, C.POINTER(V), V]),
+        "crh_comm_local_gather_slabs": (C.c_int, [V, C.POINTER(V), V]),
         "crh_comm_last_traffic": (C.c_int, [V, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "crh_comm_last_timing": (C.c_int, [V, C.POINTER(C.c_float)]),
         "crh_comm_last_peer_bytes": (C.c_int, [V, C.POINTER(C.c_uint64)]),

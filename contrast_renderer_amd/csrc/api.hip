@@ -331,6 +331,7 @@ struct crh_frame {
     // A frame whose passes see the instances change is `moving`: its places are then sized by the longest list within kMovingListRadius tiles
     // (a camera shifts the content by whole tiles between two passes into one target); a frame of resident instances keeps tight places —
     // lists side by side, measured 1 % faster on the steady figure (0.3125 against 0.3155 ms per step).
+    uint32_t slab_ty0 = 0, slab_ty1 = 0xFFFFFFFFu; // crh_frame_set_tile_rows: the tile rows the raster kernels draw (all of them by default)
     bool moving = false;
     uint64_t last_pass_instances = ~0ull;
     uint64_t places_instances = 0; // crh_scene::instances_version of the pass whose counts the current places come from (unchanged instances: unchanged counts, no new places)
@@ -362,6 +363,7 @@ struct crh_frame {
     // strip triangles with a non-finite determinant — as the reference's rasterizer does.
     DevBuf tile_order;             // [workgroups of the edge pass' raster grid] the tile each one draws (order_tiles_heavy_first), or not ready: the kernels' own order
     bool tile_order_ready = false;
+    uint32_t tile_order_places = 0; // the leading places of the order that hold tiles (a frame with a slab: 1 / world of them)
     // k_bin_flat's batches by cost (RasterParams::item_cost / bin_batches): built at a verified edge pass, used by the later passes of the same
     // geometry with the same number of items (any partition of the items bins the same lists: stale costs only cost time)
     DevBuf item_cost, bin_batches;
@@ -894,6 +896,7 @@ crh_status order_tiles_heavy_first(crh_frame* f, const uint32_t* tile_count_dev,
     const uint32_t blocks_x = (tiles_x + kBlock - 1u) >> kB, blocks = blocks_x * ((tiles_y + kBlock - 1u) >> kB);
     const uint32_t grid = ((blocks + 7u) / 8u) * kBlock * kBlock * 8u, turns = grid / 8u;
     std::vector<uint32_t> order(grid), rest;
+    uint32_t used_turns = 0;
     rest.reserve(turns);
     for (uint32_t x = 0; x < 8u; ++x) { // XCD x: its workgroups in launch order
         uint32_t at = 0;
@@ -901,7 +904,7 @@ crh_status order_tiles_heavy_first(crh_frame* f, const uint32_t* tile_count_dev,
         for (uint32_t turn = 0; turn < turns; ++turn) {
             const uint32_t block = (turn >> (2u * kB)) * 8u + x;
             const uint32_t tx = (block % blocks_x) * kBlock + (turn & (kBlock - 1u)), ty = (block / blocks_x) * kBlock + ((turn >> kB) & (kBlock - 1u));
-            if (tx >= tiles_x || ty >= tiles_y) continue;
+            if (tx >= tiles_x || ty >= tiles_y || ty < f->slab_ty0 || ty >= f->slab_ty1) continue; // (beyond the frame or outside the frame's slab: no workgroup's business)
             const uint32_t tile = ty * tiles_x + tx;
             if ((double)count[tile] > threshold) order[(at++) * 8u + x] = tile;
             else rest.push_back(tile);
@@ -916,12 +919,14 @@ crh_status order_tiles_heavy_first(crh_frame* f, const uint32_t* tile_count_dev,
             for (uint32_t tile : all) order[(at++) * 8u + x] = tile;
         }
         for (uint32_t tile : rest) order[(at++) * 8u + x] = tile;
+        used_turns = std::max(used_turns, at);
         for (; at < turns; ++at) order[at * 8u + x] = 0xFFFFFFFFu; // (workgroups beyond the frame: nothing to draw)
     }
     HIP_TRY(f->tile_order.ensure((size_t)grid * 4));
     HIP_TRY(hipMemcpyAsync(f->tile_order.p, order.data(), (size_t)grid * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     f->tile_order_ready = true;
+    f->tile_order_places = std::max(1u, used_turns) * 8u; // (the raster kernels' grid: the places behind hold no tile)
     return CRH_OK;
 }
 
@@ -1040,6 +1045,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.tiles_x = f->tiles_x;
     p.tiles_y = f->tiles_y;
     p.n_tiles = f->n_tiles;
+    p.slab_ty0 = f->slab_ty0, p.slab_ty1 = std::min(f->slab_ty1, f->tiles_y);
     p.winding_mask = (1u << r->config.winding_counter_bits) - 1u;
     p.clip_mask_count = (1u << r->config.clip_nesting_counter_bits) - 1u;
     p.items = recorded ? f->items.as<DrawItem>() : nullptr;
@@ -1170,6 +1176,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = (f->base_cur ? f->tile_base_b : f->tile_base).as<uint32_t>();
     p.tile_order = f->tile_order_ready ? f->tile_order.as<uint32_t>() : nullptr;
+    p.order_places = f->tile_order_ready ? f->tile_order_places : 0u;
     const bool no_batches = getenv("CRH_NO_BIN_BATCHES") != nullptr; // A/B runs and tests (read per pass: they switch it inside one process)
     const bool batches = edges && !no_batches && f->n_bin_batches != 0u && f->batches_scene == sc && f->batches_generation == sc->generation && f->batches_items == p.n_items;
     p.bin_batches = batches ? f->bin_batches.as<uint32_t>() : nullptr, p.n_bin_batches = batches ? f->n_bin_batches : 0u;
@@ -2251,11 +2258,34 @@ crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written) {
 }
 // The entries per tile of the frame's last pass, on the device, when a tile without entries is a transparent tile (NULL otherwise: the
 // exchange then looks at the pixels). Valid after crh_internal_frame_info (which settles the pass).
-crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles) {
-    if (!f || !counts || !n_tiles) return CRH_ERR_INVALID_ARGUMENT;
+crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles, uint32_t* first_tile, uint32_t* end_tile) {
+    if (!f || !counts || !n_tiles || !first_tile || !end_tile) return CRH_ERR_INVALID_ARGUMENT;
     const bool usable = f->counts_describe_pixels && !f->cleared && !f->check_pending && f->sets[f->last_set].used;
     *counts = usable ? f->sets[f->last_set].tile_count_cursor.as<uint32_t>() + f->n_tiles : nullptr;
     *n_tiles = f->n_tiles;
+    // (a frame with a slab: the tiles outside it have entries — every rank bins everything — but were not drawn: transparent)
+    *first_tile = std::min(f->slab_ty0, f->tiles_y) * f->tiles_x, *end_tile = std::min(f->slab_ty1, f->tiles_y) * f->tiles_x;
+    return CRH_OK;
+}
+// The tile split of the multi-GPU path ("shard by tile"): the passes into this frame draw the tile rows that cover the pixel rows
+// [row_begin, row_end) only — crh_comm_slab_rows gives a rank's —, everything else stays transparent (the buffer is cleared here, once; the
+// raster kernels leave the other tiles alone from then on). Binning and tessellation are not split: every rank has every list. Exchanged
+// with crh_frame_exchange like any layer: the all-to-all then carries nothing (a rank's layer is empty outside its own slab), the
+// composite of a slab is its owner's pixels, and the gathered image is bit-equal to a single GPU's — no compositing of rounded layers.
+crh_status crh_frame_set_tile_rows(crh_frame* f, uint32_t row_begin, uint32_t row_end) {
+    if (!f || !f->renderer || row_begin > row_end || row_end > f->height || ((row_begin % 16u) != 0u && row_begin != f->height) || ((row_end % 16u) != 0u && row_end != f->height)) return CRH_ERR_INVALID_ARGUMENT; // (an empty slab, e.g. (height, height), is a rank without tile rows)
+    crh_renderer* r = f->renderer;
+    HIP_TRY(hipSetDevice(r->device));
+    const crh_status st = settle_frame(f); // (what the frame shows is final, nothing of it will be drawn again)
+    if (st != CRH_OK) return st;
+    {
+        const crh_status ext = wait_for_external(f);
+        if (ext != CRH_OK) return ext;
+    }
+    HIP_TRY(hipMemsetAsync(f->rgba8.p, 0, f->image_bytes(), r->stream));
+    f->slab_ty0 = (row_begin + 15u) / 16u, f->slab_ty1 = (row_begin == 0u && row_end == f->height) ? 0xFFFFFFFFu : (row_end + 15u) / 16u;
+    f->cleared = true, f->counts_describe_pixels = false, f->check_pending = false, f->last_scene = nullptr;
+    f->pairs_known = false, f->tile_order_ready = false; // (the next pass is a verified one: it orders the slab's tiles)
     return CRH_OK;
 }
 int crh_internal_renderer_device(crh_renderer* r) { return r ? r->device : -1; }

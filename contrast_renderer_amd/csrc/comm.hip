@@ -39,7 +39,7 @@ void set_last_error(const std::string& text);
 extern "C" crh_status crh_internal_frame_geometry(crh_frame* f, uint32_t* width, uint32_t* height, uint32_t* format, int* device);
 extern "C" crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device);
 extern "C" crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written);
-extern "C" crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles);
+extern "C" crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles, uint32_t* first_tile, uint32_t* end_tile);
 extern "C" int crh_internal_renderer_device(crh_renderer* r);
 
 namespace {
@@ -263,9 +263,10 @@ __global__ __launch_bounds__(256) void k_tile_occupancy(const P* pixels, uint32_
 // ... or, where the layer's last pass says how many entries every tile had (and nothing else has touched the pixels): a tile without
 // entries was written transparent by the raster kernel — the bitmap without reading the layer (a quarter of the packing at 8192^2).
 // A tile with entries that came out transparent all the same is sent as what it is.
-__global__ __launch_bounds__(256) void k_bitmap_from_counts(const uint32_t* counts, uint32_t n_tiles, uint32_t n_words, uint32_t* bitmap) {
+// [first_tile, end_tile): the tiles the layer's passes draw (a frame with a slab of tile rows, crh_frame_set_tile_rows: the others have entries but no pixels)
+__global__ __launch_bounds__(256) void k_bitmap_from_counts(const uint32_t* counts, uint32_t n_tiles, uint32_t n_words, uint32_t* bitmap, uint32_t first_tile, uint32_t end_tile) {
     const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
-    const unsigned long long any = __ballot(tile < n_tiles && counts[tile] != 0u);
+    const unsigned long long any = __ballot(tile < n_tiles && tile >= first_tile && tile < end_tile && counts[tile] != 0u);
     const uint32_t lane = threadIdx.x & 63u, word = tile >> 5;
     if ((lane & 31u) == 0u && word < n_words) bitmap[word] = (uint32_t)(any >> (lane & 32u));
 }
@@ -400,6 +401,8 @@ struct crh_comm {
     uint32_t width = 0, height = 0, format = 0, tiles_x = 0, tiles_y = 0, n_tiles = 0, n_words = 0;
     uint32_t agreed_width = 0, agreed_height = 0, agreed_format = 0, agreed_words = 0;
     bool agreed = false;
+    uint32_t gather_width = 0, gather_height = 0; // crh_frame_gather_slabs: the geometry all ranks were found to share (checked once per change)
+    bool gather_agreed = false;
     size_t tile_bytes() const { return format == CRH_FORMAT_RGBA16F ? 2048u : 1024u; }
     uint32_t stride() const { return kHeaderWords + n_words; } // words per rank in bitmaps_all
     Buf bitmap, prefix, pack;        // this rank's layer: [header | bitmap], prefix sums of the bitmap, the packed non-empty tiles
@@ -488,10 +491,10 @@ crh_status phase_pack(crh_comm* c, crh_frame* layer) {
     HIP_TRY(hipMemcpyAsync(c->bitmap.p, header, kHeaderWords * 4, hipMemcpyHostToDevice, c->stream));
     uint32_t* bitmap = c->bitmap.as<uint32_t>() + kHeaderWords;
     const uint32_t* counts = nullptr;
-    uint32_t counted_tiles = 0;
-    if (layer_status == CRH_OK && getenv("CRH_EXCHANGE_SCAN_PIXELS") == nullptr) (void)crh_internal_frame_tile_counts(layer, &counts, &counted_tiles);
+    uint32_t counted_tiles = 0, first_tile = 0, end_tile = 0;
+    if (layer_status == CRH_OK && getenv("CRH_EXCHANGE_SCAN_PIXELS") == nullptr) (void)crh_internal_frame_tile_counts(layer, &counts, &counted_tiles, &first_tile, &end_tile);
     if (layer_status == CRH_OK && counts && counted_tiles == c->n_tiles) {
-        hipLaunchKernelGGL(k_bitmap_from_counts, dim3((c->n_words * 32u + 255u) / 256u), dim3(256), 0, c->stream, counts, c->n_tiles, c->n_words, bitmap);
+        hipLaunchKernelGGL(k_bitmap_from_counts, dim3((c->n_words * 32u + 255u) / 256u), dim3(256), 0, c->stream, counts, c->n_tiles, c->n_words, bitmap, first_tile, end_tile);
     } else if (layer_status == CRH_OK) {
         if (format == CRH_FORMAT_RGBA16F)
             hipLaunchKernelGGL(k_tile_occupancy<uint2>, dim3(c->n_words), dim3(256), 0, c->stream, static_cast<const uint2*>(pixels), w, h, c->tiles_x, c->n_tiles, bitmap);
@@ -850,6 +853,133 @@ crh_status crh_frame_exchange(crh_comm* c, crh_frame* layer, crh_frame* result) 
     c->timed = true;
     if (c->rank == 0) return phase_unpack(c, result);
     return CRH_OK; // no wait: the layer's next pass is ordered behind its packing, the buffers' next use is on this stream
+}
+
+// The tile split's own exchange (round 5): rank g's layer holds its slab of tile rows and nothing else (crh_frame_set_tile_rows), every slab has
+// the same place in every rank's frame, so the slabs go STRAIGHT from the layers' pixel rows into the result frame's — one grouped
+// ncclSend / ncclRecv per rank, no occupancy bitmaps, no packing, no plan on the host, no composite, no unpacking (crh_frame_exchange of
+// such layers works too, and spends 0.2 ms of its 0.25 on phases that have nothing to do). RGBA8 storage on both sides.
+namespace {
+crh_status slab_bytes(const crh_comm* c, uint32_t width, uint32_t height, uint32_t rank, size_t* offset, size_t* bytes) {
+    uint32_t r0 = 0, r1 = 0;
+    const crh_status st = crh_comm_slab_rows(height, rank, c->world, &r0, &r1);
+    *offset = (size_t)r0 * width * 4u, *bytes = (size_t)(r1 - r0) * width * 4u;
+    return st;
+}
+void mark_all_phases(crh_comm* c) { // (crh_comm_last_timing reads every phase: the ones this exchange does not have are empty)
+    for (int k = 0; k < CRH_COMM_PHASES; ++k)
+        if (k != kGather) begin_phase(c, (Phase)k), end_phase(c, (Phase)k);
+}
+} // namespace
+crh_status crh_frame_gather_slabs(crh_comm* c, crh_frame* layer, crh_frame* result) {
+    if (!c || !layer || !c->nccl || (c->rank == 0) != (result != nullptr)) return CRH_ERR_INVALID_ARGUMENT;
+    Rccl* api = rccl();
+    c->timed = false;
+    uint32_t w = 0, h = 0, format = 0, rw = 0, rh = 0, rformat = 0;
+    int device = 0;
+    crh_status st = crh_internal_frame_geometry(layer, &w, &h, &format, &device);
+    if (st != CRH_OK) return st;
+    if (device != c->device || format == CRH_FORMAT_RGBA16F) return CRH_ERR_INVALID_ARGUMENT;
+    if (result && ((st = crh_internal_frame_geometry(result, &rw, &rh, &rformat, &device)) != CRH_OK || rw != w || rh != h || rformat == CRH_FORMAT_RGBA16F || device != c->device))
+        return st != CRH_OK ? st : CRH_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    void* pixels = nullptr;
+    const crh_status layer_status = crh_internal_frame_info(layer, &pixels, &w, &h, &device); // settles the layer: its pixels are final
+    // the ranks' transfers only match when their frames have one size, and a failed layer must fail every rank: 16 bytes all-gathered, read on
+    // the host when this rank's geometry (or the first exchange) asks for it, and always for the status word
+    HIP_TRY(c->host_header.ensure(kHeaderWords * 4));
+    HIP_TRY(c->bitmap.ensure(kHeaderWords * 4));
+    HIP_TRY(c->headers_all.ensure((size_t)c->world * kHeaderWords * 4));
+    HIP_TRY(c->host_headers.ensure((size_t)c->world * kHeaderWords * 4));
+    uint32_t* header = c->host_header.as<uint32_t>();
+    header[0] = kMagic, header[1] = w, header[2] = h, header[3] = (uint32_t)layer_status;
+    HIP_TRY(hipMemcpyAsync(c->bitmap.p, header, kHeaderWords * 4, hipMemcpyHostToDevice, c->stream));
+    mark_all_phases(c);
+    NCCL_TRY(api->AllGather(c->bitmap.p, c->headers_all.p, kHeaderWords * 4, ncclUint8, c->nccl, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->host_headers.p, c->headers_all.p, (size_t)c->world * kHeaderWords * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(c->bitmaps_on_host, c->stream));
+    HIP_TRY(hipEventSynchronize(c->bitmaps_on_host));
+    for (uint32_t k = 0; k < c->world; ++k) {
+        const uint32_t* hd = c->host_headers.as<uint32_t>() + (size_t)k * kHeaderWords;
+        if (hd[0] != kMagic || hd[1] != w || hd[2] != h) {
+            set_last_error("crh_frame_gather_slabs: rank " + std::to_string(k) + " gathers a layer of another size");
+            return CRH_ERR_INVALID_ARGUMENT; // on every rank
+        }
+        if (hd[3] != (uint32_t)CRH_OK) {
+            set_last_error("crh_frame_gather_slabs: the layer of rank " + std::to_string(k) + " could not be read");
+            return (crh_status)hd[3]; // on every rank
+        }
+    }
+    c->gather_agreed = true, c->gather_width = w, c->gather_height = h;
+    void* out = nullptr;
+    if (result && (st = crh_internal_frame_info(result, &out, &rw, &rh, &device)) != CRH_OK) return st;
+    begin_phase(c, kGather);
+    bool ok = nccl_ok(api->GroupStart(), "ncclGroupStart");
+    if (!ok) return CRH_ERR_HIP;
+    c->bytes_sent = 0, c->bytes_dense = 0;
+    c->peer_bytes.assign(c->world, 0);
+    for (uint32_t p = 0; p < c->world && ok; ++p) {
+        size_t off = 0, bytes = 0;
+        (void)slab_bytes(c, w, h, p, &off, &bytes);
+        if (!bytes) continue;
+        if (c->rank == 0 && p == 0)
+            ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(out) + off, static_cast<const uint8_t*>(pixels) + off, bytes, hipMemcpyDeviceToDevice, c->stream), "hipMemcpyAsync");
+        else if (c->rank == 0)
+            ok = nccl_ok(api->Recv(static_cast<uint8_t*>(out) + off, bytes, ncclUint8, (int)p, c->nccl, c->stream), "ncclRecv");
+        else if (p == c->rank) {
+            ok = nccl_ok(api->Send(static_cast<const uint8_t*>(pixels) + off, bytes, ncclUint8, 0, c->nccl, c->stream), "ncclSend");
+            c->bytes_sent = c->bytes_dense = bytes;
+        }
+    }
+    ok = nccl_ok(api->GroupEnd(), "ncclGroupEnd") && ok;
+    if (!ok) return CRH_ERR_HIP;
+    end_phase(c, kGather);
+    c->timed = true;
+    if ((st = crh_internal_frame_touched(layer, c->stream, 0)) != CRH_OK) return st; // the layer's next pass is ordered behind the transfer
+    if (result) return crh_internal_frame_touched(result, c->stream, 1);
+    return CRH_OK;
+}
+// ... over a loopback group (one device, one thread): device-to-device copies in place of the transfers
+crh_status crh_comm_local_gather_slabs(crh_comm* rank0, crh_frame* const* layers, crh_frame* result) {
+    if (!rank0 || !rank0->local_group || rank0->rank != 0 || !layers || !result) return CRH_ERR_INVALID_ARGUMENT;
+    std::vector<crh_comm*>& g = *rank0->local_group;
+    const uint32_t world = rank0->world;
+    uint32_t rw = 0, rh = 0, rformat = 0;
+    int device = 0;
+    crh_status st = crh_internal_frame_geometry(result, &rw, &rh, &rformat, &device);
+    if (st != CRH_OK) return st;
+    if (rformat == CRH_FORMAT_RGBA16F || device != rank0->device) return CRH_ERR_INVALID_ARGUMENT;
+    std::vector<void*> pixels(world, nullptr);
+    for (uint32_t k = 0; k < world; ++k) {
+        if (!g[k] || !layers[k]) return CRH_ERR_INVALID_ARGUMENT;
+        uint32_t w = 0, h = 0, format = 0;
+        if ((st = crh_internal_frame_geometry(layers[k], &w, &h, &format, &device)) != CRH_OK) return st;
+        if (w != rw || h != rh || format == CRH_FORMAT_RGBA16F) {
+            set_last_error("crh_comm_local_gather_slabs: rank " + std::to_string(k) + " gathers a layer of another size or format");
+            return CRH_ERR_INVALID_ARGUMENT;
+        }
+        if ((st = crh_internal_frame_info(layers[k], &pixels[k], &w, &h, &device)) != CRH_OK) return st;
+    }
+    void* out = nullptr;
+    if ((st = crh_internal_frame_info(result, &out, &rw, &rh, &device)) != CRH_OK) return st;
+    HIP_TRY(hipSetDevice(rank0->device));
+    for (uint32_t k = 0; k < world; ++k) { // every rank "sends" on its own stream; rank 0's stream is where the result is complete
+        crh_comm* c = g[k];
+        c->timed = false;
+        mark_all_phases(c);
+        begin_phase(c, kGather);
+        size_t off = 0, bytes = 0;
+        (void)slab_bytes(c, rw, rh, k, &off, &bytes);
+        if (bytes) HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(out) + off, static_cast<const uint8_t*>(pixels[k]) + off, bytes, hipMemcpyDeviceToDevice, c->stream));
+        end_phase(c, kGather);
+        c->bytes_sent = c->bytes_dense = k ? bytes : 0;
+        c->peer_bytes.assign(world, 0);
+        c->timed = true;
+        HIP_TRY(hipEventRecord(c->composited, c->stream));
+        if ((st = crh_internal_frame_touched(layers[k], c->stream, 0)) != CRH_OK) return st;
+    }
+    for (uint32_t k = 1; k < world; ++k) HIP_TRY(hipStreamWaitEvent(rank0->stream, g[k]->composited, 0));
+    return crh_internal_frame_touched(result, rank0->stream, 1);
 }
 
 // The same exchange over a loopback group (all communicators on one device, one thread): layers[k] = rank k's layer. Streams wait for

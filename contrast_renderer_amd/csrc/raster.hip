@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         if (mine == 0xFFFFFFFFu) return;
         ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
     }
-    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    if (tx >= r.tiles_x || ty >= r.tiles_y || ty < r.slab_ty0 || ty >= r.slab_ty1) return; // (beyond the frame, or not in this pass' slab of tile rows)
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* __restrict__ keys = sort_buffer + wave * r.sort_capacity;
@@ -1135,7 +1135,7 @@ void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, h
     // 8x8-tile blocks, an equal number per XCD (k_raster_tile's tile order)
     constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
     const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
-    const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
+    const dim3 grid((r.tile_order && r.order_places) ? r.order_places : ((blocks + 7u) / 8u) * kBlock * kBlock * 8u);
 #define CRH_LAUNCH_TILE(S_, ROWS_, OPS_, STROKES_) \
     hipLaunchKernelGGL((k_raster_tile<S_, ROWS_, OPS_, STROKES_>), grid, dim3(64 * (4 / ROWS_)), (4 / ROWS_) * r.sort_capacity * 4u, stream, s, r)
     if (samples == 4) {

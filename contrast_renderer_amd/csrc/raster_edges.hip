@@ -471,8 +471,9 @@ constexpr uint32_t kRectLds = 256; // tiles of an item's rectangle whose backdro
 CRH_D void bin_triangles(Stage& st, const RasterParams& r, uint32_t lane, bool drawn, const PrimCoverage& cov, uint32_t key, float s_lo, float s_hi) {
     TileTest test;
     test.set(cov, s_lo, s_hi);
-    const uint32_t bx0 = cov.box.x / kTile, bx1 = cov.box.y / kTile, by0 = cov.box.z / kTile, by1 = cov.box.w / kTile;
-    const uint32_t nx = bx1 - bx0 + 1u, nt = drawn ? nx * (by1 - by0 + 1u) : 0u;
+    // (the tile rows of the pass' slab only, crh_frame_set_tile_rows: the raster kernels draw no others)
+    const uint32_t bx0 = cov.box.x / kTile, bx1 = cov.box.y / kTile, by0 = max((uint32_t)cov.box.z / kTile, r.slab_ty0), by1 = min((uint32_t)cov.box.w / kTile + 1u, r.slab_ty1); // [by0, by1)
+    const uint32_t nx = bx1 - bx0 + 1u, nt = (drawn && by0 < by1) ? nx * (by1 - by0) : 0u;
     const bool big = nt > kBigRect || (nt != 0u && (r.debug & 2u) != 0u); // debug bit 1 (tests): every triangle takes the wide path
     const uint32_t mine = big ? 0u : nt, longest = wave_max_u32(mine);
     uint32_t tx = bx0, ty = by0;
@@ -691,9 +692,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
 #ifdef CRH_ABLATE
         if (r.debug & 8192u) n_edges = 0u;
 #endif
-        const uint32_t tx_a = (uint32_t)max(px0, 0) / kTile, tx_b = (uint32_t)max(px1, 0) / kTile, ty_a = (uint32_t)max(py0, 0) / kTile, ty_b = (uint32_t)max(py1, 0) / kTile;
-        const uint32_t nx = tx_b - tx_a + 1u, n_rect = nx * (ty_b - ty_a + 1u);
-        const bool in_frame = n_edges != 0u && minx <= maxx && px0 <= px1 && py0 <= py1;
+        // (... of the pass' slab of tile rows, crh_frame_set_tile_rows: every tile row's backdrops and entries are its own, so the others are simply left out)
+        const uint32_t tx_a = (uint32_t)max(px0, 0) / kTile, tx_b = (uint32_t)max(px1, 0) / kTile, ty_a = max((uint32_t)max(py0, 0) / kTile, r.slab_ty0);
+        const uint32_t ty_b_end = min((uint32_t)max(py1, 0) / kTile + 1u, r.slab_ty1), ty_b = ty_b_end - 1u; // (only used when ty_a < ty_b_end)
+        const uint32_t nx = tx_b - tx_a + 1u, n_rect = ty_a < ty_b_end ? nx * (ty_b_end - ty_a) : 0u;
+        const bool in_frame = n_edges != 0u && minx <= maxx && px0 <= px1 && py0 <= py1 && ty_a < ty_b_end;
         if (in_frame && n_rect <= kRectLds && (r.debug & 1u) == 0u) {
             // ---------------- lane = EDGE (the common case: the rectangle's backdrops fit the LDS table). The transposed loop below costs
             // edges x tiles of the rectangle; here every edge visits the tiles of its OWN box and the tile rows whose backdrop line it
@@ -1202,8 +1205,11 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
                 if (fi.box[0] <= fi.box[2]) { // something is drawn
                     const int px0 = (int)floorf(fminf(fmaxf(minx, 0.0f), W)), px1 = (int)floorf(fmaxf(fminf(maxx, W - 1.0f), -1.0f));
                     const int py0 = (int)floorf(fminf(fmaxf(miny, 0.0f), H)), py1 = (int)floorf(fmaxf(fminf(maxy, H - 1.0f), -1.0f));
-                    if (px0 <= px1 && py0 <= py1) {
-                        fi.tx_a = (uint32_t)px0 / kTile, fi.tx_b = (uint32_t)px1 / kTile, fi.ty_a = (uint32_t)py0 / kTile, fi.ty_b = (uint32_t)py1 / kTile;
+                    // (the tile rows of the pass' slab only, crh_frame_set_tile_rows: a tile row's backdrops, counts and entries are its own; an item
+                    // without a row in the slab has no rectangle and is not binned)
+                    const uint32_t row_a = max((uint32_t)max(py0, 0) / kTile, r.slab_ty0), row_end = min((uint32_t)max(py1, 0) / kTile + 1u, r.slab_ty1);
+                    if (px0 <= px1 && py0 <= py1 && row_a < row_end) {
+                        fi.tx_a = (uint32_t)px0 / kTile, fi.tx_b = (uint32_t)px1 / kTile, fi.ty_a = row_a, fi.ty_b = row_end - 1u;
                         fi.nx = fi.tx_b - fi.tx_a + 1u;
                         n_rect = fi.nx * (fi.ty_b - fi.ty_a + 1u);
                     }
@@ -1330,9 +1336,11 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
             const bool gmax = accepts(fmaf(r_last, e.bx, fmaf(up ? r_last : 0.0f, e.nay, c)), e.tl), gmin = accepts(fmaf(ry_first, e.bx, fmaf(up ? 0.0f : r_last, e.nay, c)), e.tl);
             return gmax != gmin && e.ymin <= ty0 + r_last && e.ymax >= q0y && e.lo_x <= tx0 + r_last && e.hi_x >= tx0;
         };
-        auto walk_tri = [&](const FlatTri& t, bool live, auto&& visit) {
-            const uint32_t nt = live ? t.nt : 0u, longest = wave_max_u32(nt);
-            uint32_t tx = t.bx0, ty = t.by0;
+        auto walk_tri = [&](const FlatTri& t, bool live, auto&& visit) { // (the triangle's tile box, cut to the rows of its item's rectangle: the slab of a tile split)
+            const FlatItem& of = items[t.item];
+            const uint32_t nxt = t.bx1 - t.bx0 + 1u, row_a = max(t.by0, of.ty_a), row_end = min(t.by0 + t.nt / nxt, of.ty_b + 1u);
+            const uint32_t nt = (live && row_a < row_end) ? nxt * (row_end - row_a) : 0u, longest = wave_max_u32(nt);
+            uint32_t tx = t.bx0, ty = row_a;
             for (uint32_t w = 0; w < longest; ++w) {
                 visit(w < nt && t.test.hit(tx, ty), tx, ty);
                 if (++tx > t.bx1) tx = t.bx0, ++ty;
@@ -1634,7 +1642,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         if (mine == 0xFFFFFFFFu) return;
         ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
     }
-    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    if (tx >= r.tiles_x || ty >= r.tiles_y || ty < r.slab_ty0 || ty >= r.slab_ty1) return; // (beyond the frame, or not in this pass' slab of tile rows)
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* __restrict__ keys = sort_buffer + wave * r.sort_capacity;
@@ -2467,7 +2475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TIL
         if (mine == 0xFFFFFFFFu) return;
         ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
     }
-    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    if (tx >= r.tiles_x || ty >= r.tiles_y || ty < r.slab_ty0 || ty >= r.slab_ty1) return; // (beyond the frame, or not in this pass' slab of tile rows)
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* __restrict__ keys = sort_buffer;
@@ -3010,7 +3018,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_ROW_TILE
         if (mine == 0xFFFFFFFFu) return;
         ty = mine / r.tiles_x, tx = mine - ty * r.tiles_x;
     }
-    if (tx >= r.tiles_x || ty >= r.tiles_y) return;
+    if (tx >= r.tiles_x || ty >= r.tiles_y || ty < r.slab_ty0 || ty >= r.slab_ty1) return; // (beyond the frame, or not in this pass' slab of tile rows)
     const uint32_t tile = ty * r.tiles_x + tx;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* __restrict__ keys = sort_buffer;
@@ -3750,7 +3758,7 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
                          uint64_t raster_bytes, bool has_stroke) {
     constexpr uint32_t kBlock = 1u << CRH_XCD_BLOCK_LOG2;
     const uint32_t blocks = ((r.tiles_x + kBlock - 1u) / kBlock) * ((r.tiles_y + kBlock - 1u) / kBlock);
-    const dim3 grid(((blocks + 7u) / 8u) * kBlock * kBlock * 8u); // the places of the tile order (a multiple of 8: place b is drawn on XCD b mod 8)
+    const dim3 grid((r.tile_order && r.order_places) ? r.order_places : ((blocks + 7u) / 8u) * kBlock * kBlock * 8u); // the places of the tile order (a multiple of 8: place b is drawn on XCD b mod 8)
     // fill scenes at msaa 1: the class-batched walk with packed counters (k_raster_fill); CRH_FILL_KERNEL=0 keeps k_raster_edges<1, 4, false, *> (A/B runs, tests: the two are bit-equal)
     const char* fill_env = getenv("CRH_FILL_KERNEL"); // (read per launch: tests switch it inside one process)
     const bool fill_kernel = !(fill_env && fill_env[0] == '0') && r.winding_mask <= 0xFFFFu && r.fill_cells != 0u;

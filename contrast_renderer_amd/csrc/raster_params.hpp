@@ -80,6 +80,8 @@ struct RasterParams {
     const uint32_t* bin_batches;      // [2 n_bin_batches] first item of every run and the one behind its last, the long runs first, or nullptr: equal numbers of items
     uint32_t n_bin_batches;           // (overflow[kExtraTurnsWord]: turns beyond the first that the runs' workgroups needed — stale costs)
     uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
+    uint32_t order_places;            // with tile_order: the places of the order that hold a tile (a multiple of 8; the grid of the raster kernels), 0: all of them
+    uint32_t slab_ty0, slab_ty1;      // the tile rows [slab_ty0, slab_ty1) this pass draws (crh_frame_set_tile_rows: the tile split of the multi-GPU path — every rank bins everything and draws its slab); the other tiles are left alone
     uint32_t fill_cells;              // no tile list of this frame has shown 16 384 entries: k_raster_fill's packed counters (fill + 65536 * hull per sample) are exact; 0: k_raster_edges
 };
 

@@ -119,6 +119,11 @@ class Frame:
         """Waits for the last render into this frame only (the next frame of a double-buffered loop keeps running)."""
         check(self.lib.crh_frame_synchronize(self.handle))
 
+    def set_tile_rows(self, row_begin, row_end):
+        """The tile split of the multi-GPU path: passes into this frame draw the pixel rows [row_begin, row_end) only (whole 16-pixel tile rows;
+        slab_rows() gives a rank's), the rest stays transparent; (0, height) gives the whole frame back."""
+        check(self.lib.crh_frame_set_tile_rows(self.handle, int(row_begin), int(row_end)))
+
     def clear_depth(self, value=1.0):
         """LoadOp::Clear(value) of the depth attachment (main.rs:223-226); it exists when the configuration tests or writes depth."""
         check(self.lib.crh_frame_clear_depth(self.handle, value))
@@ -203,6 +208,15 @@ class Comm:
         """Loopback group, called on rank 0's communicator: layers[k] = rank k's frame."""
         arr = (C.c_void_p * len(layers))(*[f.handle for f in layers])
         check(self.lib.crh_comm_local_exchange(self.handle, arr, result.handle))
+
+    def gather_slabs(self, layer: Frame, result: Frame = None):
+        """Collective (RCCL), the tile split's exchange: every rank's slab of rows (Frame.set_tile_rows) straight into rank 0's `result`."""
+        check(self.lib.crh_frame_gather_slabs(self.handle, layer.handle, result.handle if result is not None else None))
+
+    def local_gather_slabs(self, layers, result: Frame):
+        """... over the loopback group, called on rank 0's communicator."""
+        arr = (C.c_void_p * len(layers))(*[f.handle for f in layers])
+        check(self.lib.crh_comm_local_gather_slabs(self.handle, arr, result.handle))
 
     def last_traffic(self):
         sent, dense = C.c_uint64(), C.c_uint64()

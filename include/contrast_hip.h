@@ -382,6 +382,18 @@ void crh_comm_destroy(crh_comm* comm);
 /* collective: `layer` = this rank's frame; `result` = the frame that receives the image on rank 0, NULL on every other rank.
  * Waits for the last pass into `layer` only; runs on a stream of its own, so the renderer may already be drawing the next step. */
 crh_status crh_frame_exchange(crh_comm* comm, crh_frame* layer, crh_frame* result);
+/* The other split of SURVEY.md §8(e) — shard by TILE instead of by path index (no such component upstream either; it mirrors what a wgpu
+ * scissor rectangle on renderer.rs:267-355's passes would do): the passes into `frame` draw the tile rows that cover the pixel rows
+ * [row_begin, row_end) only (multiples of 16, or the frame's height; crh_comm_slab_rows gives rank g's), the rest of the frame is and stays
+ * transparent. Every rank uploads, tessellates and bins ALL paths and draws 1 / world of the tiles; crh_frame_exchange of such layers
+ * moves nothing in its all-to-all, composites nothing, and gathers an image that is bit-equal to a single GPU's (path sharding with RGBA8
+ * layers: <= 2/255). (0, height) gives the whole frame back. Waits for the frame's last pass. */
+crh_status crh_frame_set_tile_rows(crh_frame* frame, uint32_t row_begin, uint32_t row_end);
+/* collective, the tile split's own exchange: every rank's `layer` holds its slab of rows (crh_frame_set_tile_rows with crh_comm_slab_rows' rows)
+ * and the slabs travel straight from the layers' pixel rows into rank 0's `result` frame (NULL elsewhere): one grouped ncclSend / ncclRecv
+ * per rank, no bitmaps, packing, plan, composite or unpacking. RGBA8 storage on both sides, frames of one size on every rank (checked).
+ * crh_comm_last_timing then reports the transfer under [4], crh_comm_last_traffic the slab's bytes. */
+crh_status crh_frame_gather_slabs(crh_comm* comm, crh_frame* layer, crh_frame* result);
 /* bytes this rank sent in the last exchange, and what dense slabs (no empty-tile suppression) would have been */
 crh_status crh_comm_last_traffic(const crh_comm* comm, uint64_t* bytes_sent, uint64_t* bytes_dense);
 /* GPU time of the phases of this rank's last exchange, in milliseconds (HIP events on the communicator's stream; waits for the exchange):
@@ -400,6 +412,7 @@ crh_status crh_comm_info(const crh_comm* comm, uint32_t* nranks, int32_t* rccl_v
  * result) then runs every rank's part with device-to-device copies in place of the transfers. */
 crh_status crh_comm_create_local(crh_renderer* renderer, uint32_t rank, uint32_t world, crh_comm* rank0, crh_comm** out);
 crh_status crh_comm_local_exchange(crh_comm* rank0, crh_frame* const* layers, crh_frame* result);
+crh_status crh_comm_local_gather_slabs(crh_comm* rank0, crh_frame* const* layers, crh_frame* result); /* crh_frame_gather_slabs over the loopback group */
 
 const char* crh_last_error(void);
 const char* crh_version(void);

@@ -447,6 +447,7 @@ class Frame {
     Frame(const Frame&) = delete;
     Frame& operator=(const Frame&) = delete;
     void clear() { check(crh_frame_clear(handle_)); } // LoadOp::Clear(TRANSPARENT) + depth clear 1.0 + stencil clear
+    void set_tile_rows(uint32_t row_begin, uint32_t row_end) { check(crh_frame_set_tile_rows(handle_, row_begin, row_end)); } // the tile split of the multi-GPU path: draw these pixel rows only
     // the depth attachment (present when the Configuration tests or writes depth): LoadOp::Clear(value), the depth of the 3-D scene
     // the Shapes are decals in ([height][width], replicated to the samples), and read back of every sample
     void clear_depth(float value) { check(crh_frame_clear_depth(handle_, value)); }

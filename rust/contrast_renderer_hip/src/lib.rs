@@ -442,6 +442,10 @@ impl Frame {
     pub fn synchronize(&self) {
         status(unsafe { ffi::crh_frame_synchronize(self.raw) }).unwrap()
     }
+    /// The tile split of the multi-GPU path: passes into this frame draw the pixel rows `rows` only (whole 16-pixel tile rows)
+    pub fn set_tile_rows(&self, rows: std::ops::Range<u32>) {
+        status(unsafe { ffi::crh_frame_set_tile_rows(self.raw, rows.start, rows.end) }).unwrap()
+    }
 }
 impl Drop for Frame {
     fn drop(&mut self) {
@@ -677,6 +681,11 @@ impl Comm {
     pub fn exchange(&self, layer: &mut Frame, result: Option<&mut Frame>) -> Result<(), Error> {
         assert_eq!(self.rank == 0, result.is_some());
         status(unsafe { ffi::crh_frame_exchange(self.raw, layer.raw, result.map_or(ptr::null_mut(), |frame| frame.raw)) })
+    }
+    /// Collective, the tile split: every rank's slab of rows (`Frame::set_tile_rows`) straight into rank 0's `result`.
+    pub fn gather_slabs(&self, layer: &mut Frame, result: Option<&mut Frame>) -> Result<(), Error> {
+        assert_eq!(self.rank == 0, result.is_some());
+        status(unsafe { ffi::crh_frame_gather_slabs(self.raw, layer.raw, result.map_or(ptr::null_mut(), |frame| frame.raw)) })
     }
 }
 impl Drop for Comm {

@@ -78,6 +78,67 @@ def test_loopback_exchange_equals_the_ordered_composite_of_the_layers(world, siz
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,size,msaa,kind", [(2, (256, 256), 1, "mixed"), (3, (200, 136), 4, "mixed"), (8, (512, 384), 1, "cubic"), (5, (96, 40), 1, "mixed")])
+def test_tile_split_gathers_the_single_gpu_frame_bit_for_bit(world, size, msaa, kind, oracle_lib):
+    """SURVEY.md §8(e)'s other split: every rank holds ALL paths (uploads, tessellates, bins everything) and draws only the tile rows of its
+    slab (crh_frame_set_tile_rows); the same crh_frame_exchange then has nothing to send in its all-to-all and nothing to composite, and the
+    gathered image is the single-GPU frame — EQUAL, not within 2/255 — which is the oracle's. Several passes in a row (lists in place,
+    slab-restricted tile order), a slab moved between passes, and the whole frame given back."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from contrast_renderer_amd import scenes
+    from oracle.binding import Oracle
+    sc = scenes.scene_mixed(40, size, seed=world) if kind == "mixed" else scenes.scene_cubic_fill(300, size, r_lo=4.0, r_hi=40.0)
+    r = R.Renderer(R.Configuration(msaa, 4, 4), device=0)
+    scene = R.Scene(r, sc["batch"])
+    scene.set_instances(sc["transforms"], sc["colors"])
+    whole = Oracle(sc["batch"]).render(size[0], size[1], msaa, 4, sc["transforms"], sc["colors"])
+    layers = [R.Frame(r, *size) for _ in range(world)]
+    for rank, f in enumerate(layers):
+        f.set_tile_rows(*R.slab_rows(size[1], rank, world))
+    comms = [R.Comm(r, 0, world)]
+    comms += [R.Comm(r, k, world, rank0=comms[0]) for k in range(1, world)]
+    result = R.Frame(r, *size)
+    for step in range(5):  # (the third pass on has its lists in place and the slab's tiles in the verified pass' order)
+        for f in layers:
+            f.clear()
+            scene.render(f)
+        comms[0].local_exchange(layers, result)
+        assert np.array_equal(result.download(), whole), f"pass {step}"
+    for rank, f in enumerate(layers):  # a rank's layer holds its slab and nothing else
+        r0, r1 = R.slab_rows(size[1], rank, world)
+        image = f.download()
+        assert np.array_equal(image[r0:r1], whole[r0:r1]) and not image[:r0].any() and not image[r1:].any()
+    # nothing but the gather travelled: every rank's tiles outside its own slab are empty
+    for rank, c in enumerate(comms):
+        assert sum(c.last_peer_bytes()) == 0, rank
+    # the slabs dealt the other way round, then the first layer whole again
+    for rank, f in enumerate(layers):
+        f.set_tile_rows(*R.slab_rows(size[1], world - 1 - rank, world))
+        f.clear()
+        scene.render(f)
+    comms[0].local_exchange(layers, result)
+    assert np.array_equal(result.download(), whole)
+    # the split's own exchange: the slabs straight from the layers' rows into the result frame (no bitmaps, packing, composite, unpacking)
+    # (rank k's layer holds slab k again: that is what the gather takes from it)
+    for _ in range(2):
+        for rank, f in enumerate(layers):
+            f.set_tile_rows(*R.slab_rows(size[1], rank, world))
+            f.clear()
+            scene.render(f)
+        result.clear()
+        comms[0].local_gather_slabs(layers, result)
+        assert np.array_equal(result.download(), whole)
+    layers[0].set_tile_rows(0, size[1])
+    layers[0].clear()
+    scene.render(layers[0])
+    assert np.array_equal(layers[0].download(), whole)
+    with pytest.raises(R.ContrastError):
+        layers[0].set_tile_rows(8, size[1])  # not a whole tile row
+
+
+@pytest.mark.gpu
 def test_rccl_exchange_with_itself(oracle_lib):
     """World size 1 over RCCL: ncclCommInitRank, ncclAllGather and an (empty) ncclGroupStart / End pair run for real; the slab "transfer"
     to itself is a device-to-device copy, so ncclSend / ncclRecv are NOT reached here (they need a peer: a multi-GPU node)."""
@@ -95,6 +156,11 @@ def test_rccl_exchange_with_itself(oracle_lib):
     # and again into the same frames while the renderer already draws the next step into the layer's sibling
     comm.exchange(layers[0], result)
     assert np.array_equal(result.download(), layers[0].download())
+    # the tile split's exchange over RCCL (world 1: the header all-gather and an empty group run for real, the slab is a device-to-device copy)
+    other = R.Frame(r, 320, 200)
+    comm.gather_slabs(layers[0], other)
+    assert np.array_equal(other.download(), layers[0].download())
+    assert comm.last_timing()["gather"] >= 0.0
 
 
 @pytest.mark.gpu

@@ -106,6 +106,50 @@ def test_sharded_render_exchange_composite_gather(world, height, oracle_lib):
     assert (image[..., 3] > 0).mean() > 0.05  # something was drawn
 
 
+def _tile_split_worker(rank, world, init_file, out_dir, width, height, n_shapes):
+    import torch
+    import torch.distributed as dist
+    from contrast_renderer_amd import scenes
+    from oracle.binding import Oracle
+
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    try:
+        sc = scenes.scene_mixed(n_shapes, (width, height))
+        # every rank holds ALL the paths and draws its slab of tile rows only (crh_frame_set_tile_rows on the GPU; here the oracle's frame
+        # with everything outside the slab left transparent)
+        whole = Oracle(sc["batch"]).render(width, height, 1, 4, sc["transforms"], sc["colors"])
+        r0, r1 = D.slab_rows(height, world)[rank]
+        layer_np = np.zeros_like(whole)
+        layer_np[r0:r1] = whole[r0:r1]
+        received, (s0, s1) = D.exchange_layers(torch.from_numpy(layer_np), rank, world)
+        assert (s0, s1) == (r0, r1)
+        for peer in range(world):  # the all-to-all carried nothing but this rank's own slab
+            assert (peer == rank) or not received[peer].numpy().any()
+        slab = torch.from_numpy(D.composite_over_reference(received.numpy()))
+        image = D.gather_slabs(slab, rank, world, height)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "image.npy"), image.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height", [(2, 136), (3, 200)])
+def test_tile_split_exchange_gathers_the_single_process_frame_exactly(world, height, oracle_lib):
+    """The other split of SURVEY.md §8(e) through the same exchange: slabs of tile rows instead of ranges of paths. No layer is composited
+    over another one, so the gathered frame EQUALS the single-process render (path sharding: within 2/255)."""
+    import torch.multiprocessing as mp
+    from contrast_renderer_amd import scenes
+    from oracle.binding import Oracle
+
+    width, n_shapes = 160, 11
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_tile_split_worker, args=(world, os.path.join(tmp, "rendezvous"), tmp, width, height, n_shapes), nprocs=world, join=True)
+        image = np.load(os.path.join(tmp, "image.npy"))
+    sc = scenes.scene_mixed(n_shapes, (width, height))
+    assert np.array_equal(image, Oracle(sc["batch"]).render(width, height, 1, 4, sc["transforms"], sc["colors"]))
+
+
 def test_shard_bytes_equal_the_same_shapes_of_the_full_batch(oracle_lib):
     """Sharding must not change a single emitted byte: shape i of the full batch == shape i - begin of its shard."""
     from contrast_renderer_amd import scenes
