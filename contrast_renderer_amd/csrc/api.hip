@@ -350,7 +350,7 @@ struct crh_frame {
     bool queue_seen = true;       // the verified pass handed items from k_bin_flat on to k_bin_edges (until known otherwise: the queue kernel is launched)
     bool last_skipped_queue = false;
     bool last_used_batches = false; // the pass pending verification took k_bin_flat's runs by cost (stale_batches)
-    uint32_t sort_capacity = 1024; // primitives per tile the raster kernel sorts in LDS; grown from the longest tile list
+    uint32_t sort_capacity = 128;  // primitives per tile the raster kernel sorts in LDS (a power of two, >= 128: the LDS path pads to 128); grown from the longest tile list a verified pass reports, before its raster kernel runs. (1 024 until round 4: at msaa 4 — four wavefronts, 16 KB — that alone kept the workgroups with their colours in LDS at three per CU.)
     uint32_t longest_list = 0;     // the longest tile list any pass into this frame has reported (overflow[3]); gates k_raster_rows
     uint32_t opaque_covers = 0;    // ... and how many (item, tile) covers of it were opaque over the whole tile (without them there is nothing to start late behind)
     uint32_t mean_list = 0;        // entries per tile of the last verified EDGE pass (the pairs the pass needed / tiles): long lists get k_raster_edges' LONG variant

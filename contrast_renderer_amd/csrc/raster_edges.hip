@@ -1620,6 +1620,9 @@ CRH_D SlotMasks slot_masks(uint32_t rows16) {
 #endif
 // (A second argument — the maximum — was tried to leave register room for the binning kernels beside this one: at a cap of four the
 // compiler takes 106 registers and nothing else fits either; and a maximum above the hardware's eight makes LLVM drop the whole attribute.)
+#ifndef CRH_COL_LDS_SAMPLES
+#define CRH_COL_LDS_SAMPLES 2 // msaa 4: samples of a lane whose colours live in LDS between the covers (k_raster_edges); dashed scene, raster alone: 0 (round 4) 1.60, 2: 1.545, 3: 1.572, 4 (four workgroups per CU): 1.80 - 1.87 ms
+#endif
 #ifndef CRH_STROKE_TILE_WAVES
 #define CRH_STROKE_TILE_WAVES 5 // dashed strokes, msaa 4 (ms): 1 (145 registers): 2.96, 4: 2.34, 5: 2.24, 6: 2.83, 8: 5.05 — the kernel waits, it does not issue
 #endif
@@ -1633,6 +1636,15 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     extern __shared__ uint32_t sort_buffer[];
     __shared__ float4 entry_buffer[4 / ROWS][64 * 3];
     __shared__ uint8_t compact_table[STROKES ? 4 / ROWS : 1][STROKES ? 256 : 4]; // (lane, slot) codes of the samples a stroke triangle has to decide
+    // msaa 4 (round 5): a lane's sixteen colour floats — read and written at COVER entries only — live in LDS between the covers (a private
+    // 64-byte place per lane: no barrier, no bank conflict), so that the stroke fragment stages get the register file (the dashed scene's
+    // kernel kept 124 bytes per lane in scratch memory, 30 frames' worth of scratch stores per launch)
+    // (... of kColLdsSamples of its four samples: with all four a workgroup takes 33.7 KB of LDS at the usual sort capacity, four instead of
+    // five fit a CU, and the kernel is slower than with its spills — 1.87 against 1.60 ms on the dashed scene; with two, 1.545: the kernel is
+    // bound by the vector instructions of the dash evaluation, not by its scratch traffic)
+    constexpr bool kColLds = S == 4;
+    constexpr int kColLdsSamples = CRH_COL_LDS_SAMPLES;
+    __shared__ float4 col_lds[kColLds ? 4 / ROWS : 1][kColLds ? ROWS * kColLdsSamples * 64 : 1];
     constexpr uint32_t kB = CRH_XCD_BLOCK_LOG2, kBlock = 1u << kB;
     const uint32_t turn = bid >> 3;
     const uint32_t blocks_x = (r.tiles_x + kBlock - 1u) >> kB, block = (turn >> (2u * kB)) * 8u + (bid & 7u);
@@ -1687,6 +1699,26 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    auto col_fetch = [&]() { // the lane's colours: LDS -> registers (in front of what blends or stores them)
+        if constexpr (kColLds) {
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < kColLdsSamples; ++q) {
+                    const float4 v = col_lds[threadIdx.x >> 6][(uint32_t)(b * kColLdsSamples + q) * 64u + (threadIdx.x & 63u)];
+                    col[b][q][0] = v.x, col[b][q][1] = v.y, col[b][q][2] = v.z, col[b][q][3] = v.w;
+                }
+        }
+    };
+    auto col_keep = [&]() { // registers -> LDS (the registers are free again until the next cover)
+        if constexpr (kColLds) {
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                for (int q = 0; q < kColLdsSamples; ++q) col_lds[threadIdx.x >> 6][(uint32_t)(b * kColLdsSamples + q) * 64u + (threadIdx.x & 63u)] = make_float4(col[b][q][0], col[b][q][1], col[b][q][2], col[b][q][3]);
+        }
+    };
+    col_keep();
     const uint32_t list_begin = r.direct ? r.tile_base[tile] : r.tile_offset[tile];
     uint32_t n = (r.overflow[0] | r.overflow[5]) ? 0u : (r.direct ? r.tile_count[tile] : r.tile_offset[tile + 1] - list_begin);
     constexpr uint32_t kLdsSortMax = kSortBytesMax / (4u * (4u / ROWS));
@@ -2163,6 +2195,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #endif
             bool blend[ROWS][S];
             float cs0, cs1, cs2, cs3;
+            col_fetch();
             if (kind == EK_SYNTH) { // COVER over the samples inside the hull, one unit of both backdrops folded in
                 const uint32_t code = 4u + (((flags >> 8) & 31u) - 4u) % 9u;
                 const int bd = (int)((code - 4u) % 3u) - 1, hbd = (int)((code - 4u) / 3u) - 1;
@@ -2192,6 +2225,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
                                 winding[b][q] = 0, hullw[b][q] = 0;
                                 col[b][q][0] = col[b][q][1] = col[b][q][2] = col[b][q][3] = 0.0f;
                             }
+                        col_keep();
                         j = 0;
                         if (kLongLateStart && n > 64u) { // the first chunk has to be set up again
                             verify_entry = 0xFFFFFFFFu;
@@ -2249,6 +2283,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                         for (int ch = 0; ch < 4; ++ch) col[b][q][ch] = attachment_unorm8(col[b][q][ch]);
             }
+            col_keep();
         }
         } // entries of the chunk
         if (kLongLateStart && again_from_the_top) { // (X of the late start did not overwrite every sample: the whole list, chunk 0 first)
@@ -2257,6 +2292,7 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
         }
     }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
+    col_fetch();
 #pragma unroll
     for (int b = 0; b < ROWS; ++b) {
         const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
