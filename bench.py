@@ -512,12 +512,20 @@ def main():
         exchange_note = exchange_note or "torch.distributed statement of the exchange (dense slabs, validation only)"
         torch_path()
 
+    reupload_other = [None]
+
     def launch(i):
         """Enqueues step i's tessellation + render (asynchronous on the renderer's streams)."""
         nonlocal scene
         f = frames[i % len(frames)]
         if args.reupload:
-            scene = Scene(renderer, batch, tessellate=False, existing=scene)  # crh_scene_upload into the existing Scene: validation, element stream, H2D
+            # crh_scene_upload into an existing Scene: validation, element stream, H2D. TWO Scenes in turn — geometry double-buffered as an application
+            # double-buffers its vertex buffers: an upload into the Scene of the frame still in flight has to wait for that frame (it may have
+            # to be drawn again from the old paths), an upload into the other one does not
+            if reupload_other[0] is None:
+                reupload_other[0] = Scene(renderer, batch, tessellate=True)
+            scene, reupload_other[0] = reupload_other[0], scene
+            scene = Scene(renderer, batch, tessellate=False, existing=scene)
             scene.set_instances(transforms, colors)
         scene.tessellate()
         f.clear()

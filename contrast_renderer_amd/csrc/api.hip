@@ -662,7 +662,10 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke);
     if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
         HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, ts));
-        HIP_TRY(r->sync());
+        // (the tessellation stream alone: it has waited for the consumers of this set's streams — vertices_free, above — before the count kernel, and
+        // the frames before this one go on binning and rasterizing on their streams while the host waits here. Until round 4 this was a wait for
+        // every stream: new paths every frame, bench.py --reupload, ran one frame at a time)
+        HIP_TRY(hipStreamSynchronize(ts));
         crh_status st = ensure_outputs(sc);
         if (st != CRH_OK) return st;
         sc->capacity_known = true;
