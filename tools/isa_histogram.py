@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 from bench import kernel_source_hash  # noqa: E402
 from contrast_renderer_amd.build import FLAGS  # noqa: E402
 
-KERNELS = {"raster_edges.hip": ["k_raster_edges", "k_raster_rows", "k_bin_flat", "k_bin_edges", "k_scatter"], "raster.hip": ["k_raster_tile", "k_prim_setup"], "tessellate.hip": ["k_count", "k_emit", "k_hull_small"]}
+KERNELS = {"raster_edges.hip": ["k_raster_fill", "k_raster_edges", "k_raster_rows", "k_bin_flat", "k_bin_edges", "k_scatter"], "raster.hip": ["k_raster_tile", "k_prim_setup"], "tessellate.hip": ["k_count", "k_emit", "k_hull_small"]}
 
 
 def classify(m):
