@@ -677,6 +677,12 @@ impl Comm {
         status(unsafe { ffi::crh_comm_shard(n_items, rank, world, &mut begin, &mut end) }).unwrap();
         begin..end
     }
+    /// The pixel rows of rank `rank`'s slab of a frame `height` pixels high (whole 16-pixel tile rows)
+    pub fn slab_rows(height: u32, rank: u32, world: u32) -> Range<u32> {
+        let (mut begin, mut end) = (0u32, 0u32);
+        status(unsafe { ffi::crh_comm_slab_rows(height, rank, world, &mut begin, &mut end) }).unwrap();
+        begin..end
+    }
     /// Collective. `result` must be `Some` on rank 0 and `None` elsewhere.
     pub fn exchange(&self, layer: &mut Frame, result: Option<&mut Frame>) -> Result<(), Error> {
         assert_eq!(self.rank == 0, result.is_some());
