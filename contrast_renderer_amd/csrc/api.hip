@@ -16,7 +16,7 @@
 
 namespace crh {
 typedef void (*MarkFn)(void*, const char*, uint64_t);
-void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke);
+void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool need_totals);
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_setup);
@@ -374,7 +374,7 @@ struct crh_frame {
     uint64_t triangle_pass_generation = 0; // ... of that Scene's geometry: a re-upload (or a new Scene at the same address) starts on the edge pass again
 };
 
-constexpr int kTessBufs = 32; // buffers a tessellation run writes (crh_scene::tess_bufs)
+constexpr int kTessBufs = 33; // buffers a tessellation run writes (crh_scene::tess_bufs)
 struct crh_scene {
     crh_renderer* renderer; // nullptr once the renderer has been destroyed (only crh_scene_destroy is valid then)
     int device = 0;
@@ -394,8 +394,9 @@ struct crh_scene {
     std::vector<uint32_t> shape_dyn_begin_host;
     // inputs
     DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
+    DevBuf tess_run; // the one-pass tessellation's runs of Shapes (scene.hpp)
     // scan state
-    DevBuf elem_scan, wg_total, wg_base, group_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status;
+    DevBuf elem_scan, wg_total, wg_base, group_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status, path_scan;
     // outputs
     DevBuf line_v, joint_v, solid_v, iq_v, ic_v, rq_v, rc_v, hull_cand, hull_v, line_i, joint_i, solid_i, solid_flag, line_pair_cut, line_pair_mode, line_inc;
     // instances + binning
@@ -464,7 +465,7 @@ struct crh_scene {
     void tess_bufs(DevBuf* (&out)[kTessBufs]) {
         DevBuf* all[kTessBufs] = {&elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                                   &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut, &line_pair_mode,
-                                  &line_inc, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
+                                  &line_inc, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin, &path_scan};
         for (int i = 0; i < kTessBufs; ++i) out[i] = all[i];
     }
     // host copies for the parity taps
@@ -472,7 +473,7 @@ struct crh_scene {
     bool layout_valid = false;
 
     void release_all() {
-        DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin,
+        DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin, &tess_run, &path_scan,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
@@ -545,6 +546,7 @@ void bind_tess_pointers(crh_scene* sc) {
     d.group_base = sc->group_base.as<uint32_t>();
     d.totals = sc->totals.as<uint32_t>();
     d.shape_base = sc->shape_base.as<uint32_t>();
+    d.path_scan = sc->path_scan.as<uint32_t>();
     d.hull_count = sc->hull_count.as<uint32_t>();
     d.hull_large_count = sc->hull_large.as<uint32_t>();
     d.hull_large_list = sc->hull_large.as<uint32_t>() + 4;
@@ -655,11 +657,11 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     HIP_TRY(hipMemsetAsync(d.status, 0xFF, 4, ts));
     if (d.n_elems == 0) { // nothing to tessellate: every offset is zero
         HIP_TRY(hipMemsetAsync(d.totals, 0, NCH * 4, ts));
-        HIP_TRY(hipMemsetAsync(d.shape_base, 0, (size_t)(d.n_shapes + 1) * NCH * 4, ts));
+        if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.shape_base, 0, (size_t)d.n_shapes * kShapeRow * 4, ts));
         if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.hull_count, 0, (size_t)d.n_shapes * 4, ts));
     }
     const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
-    launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke);
+    launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke, !sc->capacity_known);
     if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
         HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, ts));
         // (the tessellation stream alone: it has waited for the consumers of this set's streams — vertices_free, above — before the count kernel, and
@@ -719,9 +721,10 @@ crh_status fetch_layout(crh_scene* sc) {
     uint32_t word;
     crh_status st = settle_tessellation(sc, &word);
     if (st != CRH_OK) return st;
-    sc->shape_base_host.resize((size_t)(sc->d.n_shapes + 1) * NCH);
+    sc->shape_base_host.resize((size_t)sc->d.n_shapes * kShapeRow);
     sc->hull_count_host.resize(sc->d.n_shapes);
-    HIP_TRY(hipMemcpyAsync(sc->shape_base_host.data(), sc->d.shape_base, sc->shape_base_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
+    if (sc->d.n_shapes) HIP_TRY(hipMemcpyAsync(sc->shape_base_host.data(), sc->d.shape_base, sc->shape_base_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
+    if (sc->d.n_shapes == 0) sc->shape_base_host.clear();
     if (sc->d.n_shapes) HIP_TRY(hipMemcpyAsync(sc->hull_count_host.data(), sc->d.hull_count, sc->hull_count_host.size() * 4, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipMemcpyAsync(sc->totals_host, sc->d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
@@ -730,7 +733,7 @@ crh_status fetch_layout(crh_scene* sc) {
 }
 
 void shape_layout(const crh_scene* sc, uint32_t s, uint64_t vo[8], uint64_t io[3]) {
-    const uint32_t* a = &sc->shape_base_host[(size_t)s * NCH];
+    const uint32_t* a = &sc->shape_base_host[(size_t)s * kShapeRow]; // begin[NCH], end[NCH]
     const uint32_t* b = a + NCH;
     auto n = [&](int c) { return (uint64_t)(b[c] - a[c]); };
     uint64_t v = 0;
@@ -788,7 +791,7 @@ crh_status fetch_outputs(crh_scene* sc, HostCopy& h) {
 
 // the byte image of renderer.rs:198-209 for shape s, assembled from the scene-wide streams
 void assemble_shape(const crh_scene* sc, const HostCopy& h, uint32_t s, uint8_t* vb, uint8_t* ib) {
-    const uint32_t* a = &sc->shape_base_host[(size_t)s * NCH];
+    const uint32_t* a = &sc->shape_base_host[(size_t)s * kShapeRow]; // begin[NCH], end[NCH]
     const uint32_t* b = a + NCH;
     auto put = [](uint8_t*& dst, const std::vector<uint8_t>& src, size_t begin, size_t bytes) {
         if (dst && bytes) {
@@ -1555,18 +1558,36 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     //      for them through an event). Nothing of the Scene is touched before the geometry is known to be finite.
     const size_t n_pool = (size_t)b->n_control_floats + 2u * (size_t)b->n_paths;
     struct Part { size_t at, bytes; };
-    Part part[12];
+    // The one-pass tessellation's runs: consecutive Shapes with at most kTessBlock elements between them, one workgroup each; a Shape with more
+    // elements than that sends the Scene down the two-pass path (n_runs = 0).
+    std::vector<uint32_t> runs;
+    {
+        const bool two_pass_only = std::getenv("CRH_TESS_TWO_PASS") != nullptr; // (A/B runs and the tests of that path; read per upload)
+        bool fits = !two_pass_only && b->n_shapes != 0u;
+        uint32_t in_run = 0;
+        if (fits) runs.push_back(0u);
+        for (uint32_t s = 0; s < b->n_shapes && fits; ++s) {
+            const uint32_t p0 = b->shape_path_begin[s], p1 = b->shape_path_begin[s + 1];
+            const uint64_t elems = (uint64_t)(b->path_segment_begin[p1] - b->path_segment_begin[p0]) + 2ull * (p1 - p0);
+            if (elems > (uint64_t)kTessBlock) fits = false;
+            else if (in_run + elems > (uint64_t)kTessBlock) runs.push_back(s), in_run = (uint32_t)elems;
+            else in_run += (uint32_t)elems;
+        }
+        if (fits) runs.push_back(b->n_shapes);
+        else runs.clear();
+    }
+    Part part[13];
     size_t arena_bytes = 0;
     {
-        const size_t sizes[12] = {(size_t)n_elems, (size_t)n_elems * 4, (size_t)n_elems * 4, (size_t)n_elems * 4, n_pool * 4, ((size_t)b->n_paths + 1) * 4, (size_t)b->n_paths * 4,
+        const size_t sizes[13] = {(size_t)n_elems, (size_t)n_elems * 4, (size_t)n_elems * 4, (size_t)n_elems * 4, n_pool * 4, ((size_t)b->n_paths + 1) * 4, (size_t)b->n_paths * 4,
                                   (size_t)b->n_paths * 4, ((size_t)b->n_shapes + 1) * 4, ((size_t)b->n_shapes + 1) * 4, (size_t)b->n_stroke_options * sizeof(crh_stroke_options),
-                                  (size_t)b->n_dynamic_stroke_options * sizeof(crh_dynamic_stroke_descriptor)};
-        for (int k = 0; k < 12; ++k) {
+                                  (size_t)b->n_dynamic_stroke_options * sizeof(crh_dynamic_stroke_descriptor), runs.size() * 4};
+        for (int k = 0; k < 13; ++k) {
             part[k] = Part{arena_bytes, sizes[k]};
             arena_bytes += (sizes[k] + 255u) & ~(size_t)255u;
         }
     }
-    enum { P_TYPE, P_OFF, P_PREV, P_PATH, P_POOL, P_PATH_BEGIN, P_PATH_SHAPE, P_PATH_STROKE, P_SHAPE_BEGIN, P_DYN_BEGIN, P_OPTIONS, P_DESCRIPTORS };
+    enum { P_TYPE, P_OFF, P_PREV, P_PATH, P_POOL, P_PATH_BEGIN, P_PATH_SHAPE, P_PATH_STROKE, P_SHAPE_BEGIN, P_DYN_BEGIN, P_OPTIONS, P_DESCRIPTORS, P_RUNS };
     uint8_t* arena = nullptr;
     if (!hip_ok(sc->geometry_stage.begin(arena_bytes + 256u, &arena), "hipHostMalloc")) {
         if (!existing) delete sc;
@@ -1629,6 +1650,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         sc->shape_dyn_begin_host.assign(dyn_begin, dyn_begin + b->n_shapes + 1);
         if (b->n_stroke_options) std::memcpy(arena + part[P_OPTIONS].at, b->stroke_options, part[P_OPTIONS].bytes);
         if (!descriptors.empty()) std::memcpy(arena + part[P_DESCRIPTORS].at, descriptors.data(), part[P_DESCRIPTORS].bytes);
+        if (!runs.empty()) std::memcpy(arena + part[P_RUNS].at, runs.data(), part[P_RUNS].bytes);
     }
     sc->renderer = r;
     sc->device = r->device;
@@ -1696,6 +1718,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.n_paths = b->n_paths;
     d.n_shapes = b->n_shapes;
     d.n_wg = (n_elems + kTessBlock - 1) / kTessBlock;
+    d.n_runs = (runs.empty() || n_elems == 0u) ? 0u : (uint32_t)runs.size() - 1u;
     hipStream_t st = r->stream;
     crh_status rc;
     {   // thirteen asynchronous copies out of the arena, behind whatever still reads the old geometry; no host wait
@@ -1712,7 +1735,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         };
         up(sc->elem_type, P_TYPE), up(sc->elem_off0, P_OFF), up(sc->elem_off, P_OFF), up(sc->elem_prev_off, P_PREV), up(sc->elem_path, P_PATH), up(sc->pool, P_POOL);
         up(sc->path_elem_begin, P_PATH_BEGIN), up(sc->path_shape, P_PATH_SHAPE), up(sc->path_stroke, P_PATH_STROKE), up(sc->shape_elem_begin, P_SHAPE_BEGIN);
-        up(sc->shape_dyn_begin, P_DYN_BEGIN), up(sc->stroke_options, P_OPTIONS), up(sc->descriptors, P_DESCRIPTORS);
+        up(sc->shape_dyn_begin, P_DYN_BEGIN), up(sc->stroke_options, P_OPTIONS), up(sc->descriptors, P_DESCRIPTORS), up(sc->tess_run, P_RUNS);
         // the status word: cleared IN FRONT of geometry_ready — the tessellation stream waits for that event only, then clears the word itself and
         // lets its kernels write error codes; a memset enqueued behind the event would be unordered against those writes
         if (ok) ok = hip_ok(sc->status.ensure(4), "hipMalloc") && hip_ok(hipMemsetAsync(sc->status.p, 0xFF, 4, st), "hipMemset");
@@ -1723,9 +1746,11 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         }
         sc->geometry_pending = true;
     }
-    if (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
-        !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->group_base.ensure(((size_t)d.n_wg / 64 + 2) * NCH * 4), "hipMalloc") ||
-        !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)(b->n_shapes + 1) * NCH * 4), "hipMalloc") ||
+    // (the scan state of the two-pass path — 40 B per element and the rows' totals — exists only for Scenes that take it)
+    if ((d.n_runs == 0u && (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
+        !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->group_base.ensure(((size_t)d.n_wg / 64 + 2) * NCH * 4), "hipMalloc"))) ||
+        (d.n_runs != 0u && has_stroke && !hip_ok(sc->path_scan.ensure((size_t)b->n_paths * 12), "hipMalloc")) ||
+        !hip_ok(sc->totals.ensure(kTotalsWords * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)b->n_shapes * kShapeRow * 4), "hipMalloc") ||
         !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((3 * (size_t)b->n_shapes + 4) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
@@ -1747,6 +1772,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.shape_dyn_begin = sc->shape_dyn_begin.as<uint32_t>();
     d.stroke_options = sc->stroke_options.as<crh_stroke_options>();
     d.descriptors = sc->descriptors.as<crh_dynamic_stroke_descriptor>();
+    d.tess_run = sc->tess_run.as<uint32_t>();
     bind_tess_pointers(sc);
     if (!existing) r->scenes.push_back(sc);
     *out = sc;

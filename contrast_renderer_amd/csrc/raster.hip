@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(SceneDev s, RasterParams r) {
     const uint32_t prim0 = r.shape_prim_begin[item];
     const uint32_t cover_op = (it.ops >> 4) ? (it.ops >> 4) - 1u : (uint32_t)CRH_OP_COLOR;
     if (prim0 + n_candidates > r.prim_capacity) return; // cannot happen: the capacity is an upper bound derived from the totals
-    const uint32_t* b0 = s.shape_base + shape * NCH;
+    const uint32_t* b0 = s.shape_base + shape * kShapeRow;
     const uint32_t lv0 = b0[CH_LINE_V], j0 = b0[CH_JOINT], sv0 = b0[CH_SOLID_V], iq0 = b0[CH_IQ], ic0 = b0[CH_IC_V], rq0 = b0[CH_RQ], rc0 = b0[CH_RC_V],
                    hull0 = b0[CH_HULL];
     const uint32_t dyn0 = s.shape_dyn_begin[shape];

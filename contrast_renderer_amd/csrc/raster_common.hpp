@@ -135,7 +135,7 @@ CRH_D T load_uniform(const T* p) { // p must be wave uniform
 }
 
 CRH_D uint32_t shape_candidates(const SceneDev& s, uint32_t shape, uint32_t c[8]) {
-    const uint32_t* b0 = s.shape_base + shape * NCH;
+    const uint32_t* b0 = s.shape_base + shape * kShapeRow; // begin[NCH], end[NCH]
     const uint32_t* b1 = b0 + NCH;
     const uint32_t lvn = b1[CH_LINE_V] - b0[CH_LINE_V], svn = b1[CH_SOLID_V] - b0[CH_SOLID_V], hn = s.hull_count[shape];
     c[0] = lvn >= 3u ? lvn - 2u : 0u;                  // stroke line strip triangles

@@ -68,7 +68,7 @@ struct ItemSlots {
 CRH_D ItemSlots item_slots(const SceneDev& s, const DrawItem& it) {
     ItemSlots k;
     shape_candidates(s, it.shape, k.cb);
-    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    const uint32_t* b0 = s.shape_base + it.shape * kShapeRow;
     const bool stencil = (it.ops & 1u) != 0u, cover = (it.ops >> 4) != 0u;
     const uint32_t hn = s.hull_count[it.shape];
     k.n_tri = stencil ? k.cb[1] + (k.cb[6] - k.cb[2]) : 0u; // stroke line + joint triangles, then the four curve lists
@@ -92,7 +92,7 @@ struct ItemCtx {
 };
 CRH_D ItemCtx item_ctx(const SceneDev& s, const RasterParams& r, const DrawItem& it, const uint32_t cb[8]) {
     ItemCtx c;
-    const uint32_t* b0 = s.shape_base + it.shape * NCH;
+    const uint32_t* b0 = s.shape_base + it.shape * kShapeRow;
     c.shape = it.shape, c.instance = it.instance, c.dyn0 = s.shape_dyn_begin[it.shape];
     c.lv0 = b0[CH_LINE_V], c.jn0 = b0[CH_JOINT], c.iq0 = b0[CH_IQ], c.ic0 = b0[CH_IC_V], c.rq0 = b0[CH_RQ], c.rc0 = b0[CH_RC_V], c.hull0 = b0[CH_HULL], c.sv0 = b0[CH_SOLID_V];
 #pragma unroll

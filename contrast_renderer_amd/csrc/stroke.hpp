@@ -580,7 +580,9 @@ CRH_D void emit_tail(const SceneDev& s, uint32_t e, uint32_t path, const crh_str
     }
 }
 
-CRH_D void emit_stroke_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, const crh_stroke_options& so, const uint32_t g[NCH]) {
+// `scan(e, ch)`: the exclusive prefix of channel ch at element e — gscan() behind the two-pass scan, the workgroup's LDS rows in k_tess_fused
+template <class Scan>
+CRH_D void emit_stroke_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, const crh_stroke_options& so, const uint32_t g[NCH], const Scan& scan) {
     if (type == ELEM_MOVE) return;
     const uint32_t shape_first = s.shape_elem_begin[s.path_shape[path]];
     StrokeCursor cur;
@@ -589,9 +591,9 @@ CRH_D void emit_stroke_element(const SceneDev& s, uint32_t e, uint32_t type, uin
     cur.path = path;
     cur.vertex_at = g[CH_LINE_V];
     cur.cuts_at = g[CH_LINE_CUT];
-    cur.shape_vertex = gscan(s, shape_first, CH_LINE_V);
+    cur.shape_vertex = scan(shape_first, CH_LINE_V);
     cur.joint_at = g[CH_JOINT];
-    cur.shape_joint = gscan(s, shape_first, CH_JOINT);
+    cur.shape_joint = scan(shape_first, CH_JOINT);
     cur.hull_at = g[CH_HULL];
     if (type == ELEM_END) {
         emit_tail(s, e, path, so, cur);
@@ -659,9 +661,14 @@ __global__ __launch_bounds__(64) void k_stroke_lengths(SceneDev s) {
     const float width = s.stroke_options[stroke].width;
     const uint32_t move = s.path_elem_begin[path], end = s.path_elem_begin[path + 1] - 1u;
     // the END element's own records come after its exclusive prefix: the path's last pair is found via the next element
-    const uint32_t pair_begin = gscan(s, move, CH_LINE_V) >> 1;
-    const uint32_t pair_end = (end + 1u < s.n_elems ? gscan(s, end + 1u, CH_LINE_V) : s.totals[CH_LINE_V]) >> 1;
-    uint32_t joint = gscan(s, move, CH_JOINT);
+    uint32_t pair_begin, pair_end, joint;
+    if (s.n_runs) { // (k_tess_fused left them behind: there is no scan to ask)
+        pair_begin = s.path_scan[3u * path], pair_end = s.path_scan[3u * path + 1u], joint = s.path_scan[3u * path + 2u];
+    } else {
+        pair_begin = gscan(s, move, CH_LINE_V) >> 1;
+        pair_end = (end + 1u < s.n_elems ? gscan(s, end + 1u, CH_LINE_V) : s.totals[CH_LINE_V]) >> 1;
+        joint = gscan(s, move, CH_JOINT);
+    }
     float length = 0.0f;
     for (uint32_t p = pair_begin; p < pair_end; ++p) {
         const uint8_t mode = s.line_pair_mode[p];

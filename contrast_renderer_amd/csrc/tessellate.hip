@@ -8,6 +8,12 @@
 //
 // Two-phase emission reproduces the sequential `start_index` bookkeeping of the reference (fill.rs:361-365,
 // stroke.rs:95,108,126-129) exactly: offsets are exclusive prefix sums in element order.
+//
+//   k_tess_fused  (round 5) the three of them in ONE launch when no Shape has more elements than a workgroup has lanes: Shape-aligned
+//                 workgroups (a run of consecutive Shapes each), the ten-channel scan in LDS, ONE atomic per channel and workgroup for the
+//                 workgroup's range of every stream — no scan across workgroups, no elem_scan[] in memory. The parity surface is a Shape's
+//                 byte image (renderer.rs:198-209), assembled from shape_base: in which order the runs lie inside the scene-wide streams is
+//                 not part of it (and differs from launch to launch).
 #include "fill.hpp"
 #include "scene.hpp"
 #include "stroke.hpp"
@@ -133,6 +139,16 @@ CRH_D void count_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint
     }
 }
 
+CRH_D void count_element(const SceneDev& s, uint32_t e, uint32_t cnt[NCH]) {
+    const uint32_t type = s.elem_type[e];
+    const uint32_t path = s.elem_path[e];
+    const int32_t stroke = s.path_stroke[path];
+    if (stroke < 0)
+        count_fill_element(s, e, type, path, cnt);
+    else
+        count_stroke_element(s, e, type, path, s.stroke_options[stroke], cnt);
+}
+
 #ifdef CRH_TESS_WAVES
 #define CRH_TESS_OCCUPANCY __attribute__((amdgpu_waves_per_eu(CRH_TESS_WAVES)))
 #else
@@ -145,15 +161,7 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_count(SceneDe
     uint32_t cnt[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) cnt[c] = 0;
-    if (e < s.n_elems) {
-        const uint32_t type = s.elem_type[e];
-        const uint32_t path = s.elem_path[e];
-        const int32_t stroke = s.path_stroke[path];
-        if (stroke < 0)
-            count_fill_element(s, e, type, path, cnt);
-        else
-            count_stroke_element(s, e, type, path, s.stroke_options[stroke], cnt);
-    }
+    if (e < s.n_elems) count_element(s, e, cnt);
     uint32_t excl[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -232,11 +240,17 @@ __global__ __launch_bounds__(64) void k_scan_groups(SceneDev s) {
 #pragma unroll
         for (int k = 0; k < NCH; ++k) t = c == (uint32_t)k ? running[k] : t;
         s.totals[c] = t;
-        // the sentinel row, and the rows of trailing empty Shapes (they have no element to publish them)
-        for (uint32_t shape = s.n_shapes;; --shape) {
-            s.shape_base[shape * NCH + c] = t;
-            if (shape == 0 || s.shape_elem_begin[shape - 1u] != s.n_elems) break;
-        }
+    }
+}
+// where every Shape's records begin and end in the ten streams (one lane per Shape; an empty Shape begins where it ends)
+__global__ __launch_bounds__(256) void k_shape_rows(SceneDev s) {
+    const uint32_t shape = blockIdx.x * 256u + threadIdx.x;
+    if (shape >= s.n_shapes) return;
+    const uint32_t e0 = s.shape_elem_begin[shape], e1 = s.shape_elem_begin[shape + 1u];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        s.shape_base[shape * kShapeRow + c] = e0 < s.n_elems ? gscan(s, e0, c) : s.totals[c];
+        s.shape_base[shape * kShapeRow + NCH + c] = e1 < s.n_elems ? gscan(s, e1, c) : s.totals[c];
     }
 }
 
@@ -248,19 +262,31 @@ CRH_D bool fits(const SceneDev& s) {
     return ok;
 }
 
-CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, const uint32_t g[NCH]) {
+struct GlobalScan { // the two-pass path: group base + row base + the element's prefix inside its row
+    const SceneDev* s;
+    CRH_D uint32_t operator()(uint32_t e, int ch) const { return gscan(*s, e, ch); }
+};
+constexpr uint32_t kScanPitch = NCH + 1; // (odd: lanes of consecutive elements reading one channel spread over the LDS banks)
+struct LocalScan { // k_tess_fused: rows [0, n] of the workgroup's run in LDS, the run's reserved bases already added
+    const uint32_t* rows;
+    uint32_t first;
+    CRH_D uint32_t operator()(uint32_t e, int ch) const { return rows[(e - first) * kScanPitch + (uint32_t)ch]; }
+};
+
+template <class Scan>
+CRH_D void emit_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, const uint32_t g[NCH], const Scan& scan) {
     const uint32_t shape = s.path_shape[path];
     const uint32_t shape_first = s.shape_elem_begin[shape];
     const uint32_t move = s.path_elem_begin[path];
     const uint32_t end = s.path_elem_begin[path + 1] - 1u;
-    const uint32_t shape_solid = gscan(s, shape_first, CH_SOLID_V), shape_ends = gscan(s, shape_first, CH_SOLID_END);
-    const uint32_t move_solid = gscan(s, move, CH_SOLID_V), move_ends = gscan(s, move, CH_SOLID_END);
+    const uint32_t shape_solid = scan(shape_first, CH_SOLID_V), shape_ends = scan(shape_first, CH_SOLID_END);
+    const uint32_t move_solid = scan(move, CH_SOLID_V), move_ends = scan(move, CH_SOLID_END);
     SolidCursor solid;
     solid.s = &s;
     solid.vertex_base = move_solid;
     solid.index_base = move_solid + move_ends;
     solid.first_value = move_solid - shape_solid;
-    solid.n = gscan(s, end, CH_SOLID_V) - move_solid;
+    solid.n = scan(end, CH_SOLID_V) - move_solid;
     solid.j = g[CH_SOLID_V] - move_solid;
     (void)shape_ends;
     HullCursor hull = {&s, g[CH_HULL], path};
@@ -331,21 +357,134 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_emit(SceneDev
     for (int c = 0; c < NCH; ++c) g[c] = gscan(s, e, c);
     const uint32_t type = s.elem_type[e];
     const uint32_t path = s.elem_path[e];
-    if (type == ELEM_MOVE && s.shape_elem_begin[s.path_shape[path]] == e) {
-        // the first lane of a Shape publishes the Shape's base offsets — also for the empty Shapes (no paths) right before it
-        uint32_t shape = s.path_shape[path];
-        for (;;) {
+    const int32_t stroke = s.path_stroke[path];
+    const GlobalScan scan = {&s};
+    if (stroke < 0)
+        emit_fill_element(s, e, type, path, g, scan);
+    else
+        emit_stroke_element(s, e, type, path, s.stroke_options[stroke], g, scan);
+}
+
+// ------------------------------------------------------------------------------------------------ k_tess_fused
+// One launch instead of k_count + two scan launches + k_emit (fill.rs:263-367, stroke.rs:205-465 and the loop renderer.rs:187-196 for a
+// whole scene). Workgroup b takes the Shapes [tess_run[b], tess_run[b + 1]) — at most kTessBlock elements, lane = element —:
+//   1  the lane counts what its element emits (the counting sinks), ten-channel exclusive scan over the workgroup (wave shuffles + LDS);
+//   2  eight lanes reserve the workgroup's range of every stream: one atomic per channel, the two pairs of channels whose SUMS address
+//      an index stream share a 64-bit one (scene.hpp, kAllocWord); the last workgroup through publishes totals[];
+//   3  the prefix rows go to LDS with the bases added — every offset the emission asks for (its own, its path's MOVE and END, its
+//      Shape's first element) is a row of this workgroup —, lanes over the run's Shapes write their shape_base rows;
+//   4  the lane emits with the writing sinks.
+// count_only: the first tessellation of new paths (capacities unknown) reserves and publishes only; the host sizes the streams from totals[]
+// and launches again. A workgroup whose range does not fit (stale capacities) raises the overflow code and emits nothing; totals[] are
+// exact either way.
+__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_fused(SceneDev s, uint32_t count_only) {
+    __shared__ uint32_t rows[(kTessBlock + 1) * kScanPitch];
+    __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
+    __shared__ uint32_t run_base[NCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t shape0 = s.tess_run[blockIdx.x], shape1 = s.tess_run[blockIdx.x + 1u];
+    const uint32_t first = s.shape_elem_begin[shape0], n = s.shape_elem_begin[shape1] - first; // (<= kTessBlock: the host cut the runs)
+    const uint32_t e = first + tid;
+    uint32_t cnt[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) s.shape_base[shape * NCH + c] = g[c];
-            if (shape == 0 || s.shape_elem_begin[shape - 1u] != e) break;
-            shape -= 1u;
+    for (int c = 0; c < NCH; ++c) cnt[c] = 0;
+    if (tid < n) count_element(s, e, cnt);
+    uint32_t excl[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t v = cnt[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += up;
+        }
+        excl[c] = v - cnt[c];
+        if (lane == 63) wave_total[wave][c] = v;
+    }
+    __syncthreads();
+    uint32_t total[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t base = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)kTessBlock / 64u; ++w) {
+            const uint32_t v = wave_total[w][c];
+            base += w < wave ? v : 0u;
+            all += v;
+        }
+        excl[c] += base;
+        total[c] = all;
+    }
+    // ---- 2: the workgroup's ranges
+    uint32_t* const cursors = s.totals + kAllocWord;
+    if (tid < 8u) {
+        auto pick = [&](uint32_t ch) { // total[ch] for a lane-dependent ch without indexing the register array
+            uint32_t v = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) v = ch == (uint32_t)c ? total[c] : v;
+            return v;
+        };
+        if (tid < 2u) {
+            const uint32_t lo_ch = tid == 0u ? CH_LINE_V : CH_SOLID_V, hi_ch = tid == 0u ? CH_LINE_CUT : CH_SOLID_END;
+            const unsigned long long add = (unsigned long long)pick(lo_ch) | ((unsigned long long)pick(hi_ch) << 32);
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cursors) + tid, add);
+            run_base[lo_ch] = (uint32_t)old, run_base[hi_ch] = (uint32_t)(old >> 32);
+        } else {
+            const uint32_t k = tid - 2u;
+            const uint32_t ch = k == 0u ? CH_HULL : (k == 1u ? CH_JOINT : (k == 2u ? CH_IQ : (k == 3u ? CH_IC_V : (k == 4u ? CH_RQ : CH_RC_V))));
+            run_base[ch] = atomicAdd(cursors + 4u + k, pick(ch));
         }
     }
+    __syncthreads();
+    if (tid == 0u) { // the last workgroup through turns the cursors into totals[] (what the kernels behind this one and the host read)
+        __threadfence();
+        if (atomicAdd(cursors + 10u, 1u) == gridDim.x - 1u) {
+            __threadfence();
+            const unsigned long long line = atomicAdd(reinterpret_cast<unsigned long long*>(cursors), 0ull), solid = atomicAdd(reinterpret_cast<unsigned long long*>(cursors) + 1, 0ull);
+            s.totals[CH_LINE_V] = (uint32_t)line, s.totals[CH_LINE_CUT] = (uint32_t)(line >> 32);
+            s.totals[CH_SOLID_V] = (uint32_t)solid, s.totals[CH_SOLID_END] = (uint32_t)(solid >> 32);
+            s.totals[CH_HULL] = atomicAdd(cursors + 4u, 0u), s.totals[CH_JOINT] = atomicAdd(cursors + 5u, 0u), s.totals[CH_IQ] = atomicAdd(cursors + 6u, 0u);
+            s.totals[CH_IC_V] = atomicAdd(cursors + 7u, 0u), s.totals[CH_RQ] = atomicAdd(cursors + 8u, 0u), s.totals[CH_RC_V] = atomicAdd(cursors + 9u, 0u);
+        }
+    }
+    if (count_only) return;
+    // ---- 3: the rows
+    bool ok = true;
+    uint32_t g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint32_t base = run_base[c];
+        ok = ok && base + total[c] <= s.capacity[c] && base + total[c] >= base;
+        g[c] = base + excl[c];
+        if (tid < n) rows[tid * kScanPitch + c] = g[c];
+        if (tid == 0u) rows[n * kScanPitch + c] = base + total[c];
+    }
+    if (!ok) { // (uniform) stale capacities: the host reallocates from totals[] and runs again
+        if (tid == 0u) raise_error(s, 0, CRH_ERR_UNSUPPORTED + 0x80u);
+        return;
+    }
+    __syncthreads();
+    for (uint32_t shape = shape0 + tid; shape < shape1; shape += kTessBlock) {
+        const uint32_t* b0 = rows + (s.shape_elem_begin[shape] - first) * kScanPitch;
+        const uint32_t* b1 = rows + (s.shape_elem_begin[shape + 1u] - first) * kScanPitch;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s.shape_base[shape * kShapeRow + c] = b0[c], s.shape_base[shape * kShapeRow + NCH + c] = b1[c];
+    }
+    if (tid >= n) return;
+    // ---- 4: emission
+    const uint32_t type = s.elem_type[e];
+    const uint32_t path = s.elem_path[e];
     const int32_t stroke = s.path_stroke[path];
-    if (stroke < 0)
-        emit_fill_element(s, e, type, path, g);
-    else
-        emit_stroke_element(s, e, type, path, s.stroke_options[stroke], g);
+    const LocalScan scan = {rows, first};
+    if (stroke < 0) {
+        emit_fill_element(s, e, type, path, g, scan);
+    } else {
+        if (type == ELEM_MOVE) { // what k_stroke_lengths walks: the path's vertex pairs and its first join
+            const uint32_t end = s.path_elem_begin[path + 1u] - 1u;
+            s.path_scan[3u * path] = g[CH_LINE_V] >> 1, s.path_scan[3u * path + 1u] = scan(end + 1u, CH_LINE_V) >> 1, s.path_scan[3u * path + 2u] = g[CH_JOINT];
+        }
+        emit_stroke_element(s, e, type, path, s.stroke_options[stroke], g, scan);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_hull
@@ -435,8 +574,8 @@ __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
         n_of[u] = 0;
         base_of[u] = 0;
         if (shape < s.n_shapes) {
-            base_of[u] = s.shape_base[shape * NCH + CH_HULL];
-            n_of[u] = s.shape_base[(shape + 1) * NCH + CH_HULL] - base_of[u];
+            base_of[u] = s.shape_base[shape * kShapeRow + CH_HULL];
+            n_of[u] = s.shape_base[shape * kShapeRow + NCH + CH_HULL] - base_of[u];
         }
     }
     const float inf = __uint_as_float(0x7f800000u);
@@ -512,7 +651,7 @@ __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
     const uint32_t h = ml + mu;
     const uint8_t* lower_chain = stack[slot];
     const uint8_t* upper_chain = stack[slot] + kHullSmall;
-    const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
+    const uint32_t base = s.shape_base[shape * kShapeRow + CH_HULL];
     for (uint32_t i = upper; i < h; i += 2u) { // triangle_fan_to_strip order (vertex.rs:28-35); the pair shares the writes
         const uint32_t c = fan_to_strip_source(i, h);
         const float2 q = pts[c < ml ? lower_chain[c] : upper_chain[c - ml]];
@@ -531,8 +670,8 @@ __global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
     const uint32_t queued = s.hull_large_count[QUEUE];
     for (uint32_t q = blockIdx.x; q < queued; q += gridDim.x) {
         const uint32_t shape = s.hull_large_list[QUEUE * s.n_shapes + q];
-        const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
-        const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
+        const uint32_t base = s.shape_base[shape * kShapeRow + CH_HULL];
+        const uint32_t n = s.shape_base[shape * kShapeRow + NCH + CH_HULL] - base;
         uint32_t padded = 1;
         while (padded < n) padded <<= 1;
         const float inf = __uint_as_float(0x7f800000u);
@@ -596,8 +735,8 @@ __global__ __launch_bounds__(256) void k_hull_huge(SceneDev s) {
     const uint32_t queued = s.hull_large_count[2];
     for (uint32_t q = blockIdx.x; q < queued; q += gridDim.x) {
         const uint32_t shape = s.hull_large_list[2u * s.n_shapes + q];
-        const uint32_t base = s.shape_base[shape * NCH + CH_HULL];
-        const uint32_t n = s.shape_base[(shape + 1) * NCH + CH_HULL] - base;
+        const uint32_t base = s.shape_base[shape * kShapeRow + CH_HULL];
+        const uint32_t n = s.shape_base[shape * kShapeRow + NCH + CH_HULL] - base;
         float2* pts = s.hull_sort + 2u * (size_t)base;   // next_pow2(n) <= 2n slots
         float2* chain = s.hull_chain + 2u * (size_t)base; // the chain never holds more than 2n points
         uint32_t padded = 1;
@@ -675,23 +814,41 @@ void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke) {
+void launch_stroke_records(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx) {
     if (s.n_elems == 0) return;
-    if (has_stroke) {
-        hipLaunchKernelGGL(k_stroke_records, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
-        if (mark) mark(ctx, "stroke_records", 0);
+    hipLaunchKernelGGL(k_stroke_records, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
+    if (mark) mark(ctx, "stroke_records", 0);
+}
+// need_totals: the capacities of the streams are not known yet (new paths). The two-pass path counts and scans in any case; the one-pass kernel
+// comes through here only then, as a counting pass (launch_emit runs it whole).
+void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool need_totals) {
+    if (s.n_elems == 0) return;
+    if (has_stroke) launch_stroke_records(s, stream, mark, ctx);
+    if (s.n_runs) {
+        if (!need_totals) return;
+        (void)hipMemsetAsync(s.totals, 0, kTotalsWords * 4u, stream);
+        hipLaunchKernelGGL(k_tess_fused, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s, 1u);
+        if (mark) mark(ctx, "tess_count", bytes[0]);
+        return;
     }
     hipLaunchKernelGGL(k_count, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
     if (mark) mark(ctx, "tess_count", bytes[0]);
     hipLaunchKernelGGL(k_scan_rows, dim3((s.n_wg + 63u) / 64u), dim3(64), 0, stream, s);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(64), 0, stream, s);
+    hipLaunchKernelGGL(k_shape_rows, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s);
     if (mark) mark(ctx, "tess_scan", bytes[1]);
 }
 // hull_queued: what the three queues behind k_hull_small held when these paths were tessellated before ([0] <= 256 candidates, [1] <= 2048, [2] beyond), or nullptr: not known yet
 void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued) {
     if (s.n_elems == 0) return;
-    hipLaunchKernelGGL(k_emit, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
-    if (mark) mark(ctx, "tess_emit", bytes[2]);
+    if (s.n_runs) {
+        (void)hipMemsetAsync(s.totals, 0, kTotalsWords * 4u, stream);
+        hipLaunchKernelGGL(k_tess_fused, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s, 0u);
+        if (mark) mark(ctx, "tess_fused", bytes[2]);
+    } else {
+        hipLaunchKernelGGL(k_emit, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
+        if (mark) mark(ctx, "tess_emit", bytes[2]);
+    }
     if (has_stroke) {
         hipLaunchKernelGGL(k_stroke_lengths, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
         if (mark) mark(ctx, "stroke_lengths", 0);
