@@ -394,7 +394,7 @@ struct crh_scene {
     std::vector<uint32_t> shape_dyn_begin_host;
     // inputs
     DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
-    DevBuf tess_run; // the one-pass tessellation's runs of Shapes (scene.hpp)
+    DevBuf tess_run, elem_cnt, run_base; // the one-pass tessellation: runs of Shapes, every element's packed counts, the runs' bases (scene.hpp) — per upload
     // scan state
     DevBuf elem_scan, wg_total, wg_base, group_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status, path_scan;
     // outputs
@@ -473,7 +473,7 @@ struct crh_scene {
     bool layout_valid = false;
 
     void release_all() {
-        DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin, &tess_run, &path_scan,
+        DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin, &tess_run, &elem_cnt, &run_base, &path_scan,
                          &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
@@ -1455,19 +1455,31 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     }
     const int n_cus = prop.multiProcessorCount;
     r->n_cus = n_cus;
-    auto make_stream = [&](hipStream_t* st, int lane) -> bool { // lane 0: unrestricted, 1: front lanes, 2: raster lane
+    // Stream priorities of the tessellation, binning and raster lanes (-1 high, 0 normal, 1 low; CRH_LANE_PRIORITY="t b r" for A/B runs). The
+    // tessellation of frame i + 1 runs in the gap between two raster kernels beside the binning of frame i, which the next raster kernel waits
+    // for: at LOW priority its workgroups take the slots the binning workgroups leave (round 5, with the one-pass kernel — all of a frame's
+    // tessellation in one grid —: S10k 0.334 -> 0.314 ms per step, glyphs 0.721 -> 0.711; with the four small kernels of the two-pass path
+    // priorities had measured within noise). Starting it behind that binning instead — beside the raster kernel — leaves it without wave
+    // slots until that grid drains, at any priority: 0.398.
+    int lane_priority[3] = {1, 0, 0};
+    if (const char* e = getenv("CRH_LANE_PRIORITY")) (void)sscanf(e, "%d %d %d", &lane_priority[0], &lane_priority[1], &lane_priority[2]);
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    auto make_stream = [&](hipStream_t* st, int lane, int priority = 0) -> bool { // lane 0: unrestricted, 1: front lanes, 2: raster lane
+        if (priority != 0) return hip_ok(hipStreamCreateWithPriority(st, hipStreamNonBlocking, priority < 0 ? prio_high : prio_low), "hipStreamCreateWithPriority");
         if (!r->pipeline || front_cus <= 0 || front_cus >= n_cus || lane == 0) return hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
         std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
         for (int c = 0; c < n_cus; ++c)
             if ((c < front_cus) == (lane == 1)) mask[(size_t)c / 32] |= 1u << (c % 32);
         return hip_ok(hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()), "hipExtStreamCreateWithCUMask");
     };
-    if (!make_stream(&r->stream, 2) || !make_stream(&r->tess_stream, 1) || !make_stream(&r->bin_stream, 1) || !make_stream(&r->aux_stream, 0) ||
+    if (!make_stream(&r->stream, 2, lane_priority[2]) || !make_stream(&r->tess_stream, 1, lane_priority[0]) || !make_stream(&r->bin_stream, 1, lane_priority[1]) || !make_stream(&r->aux_stream, 0) ||
         !make_stream(&r->upload_stream, 0)) {
         delete r;
         return CRH_ERR_HIP;
     }
     r->raster_exclusive = getenv("CRH_RASTER_EXCLUSIVE") != nullptr;
+
     *out = r;
     return CRH_OK;
 }
@@ -1749,8 +1761,9 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     // (the scan state of the two-pass path — 40 B per element and the rows' totals — exists only for Scenes that take it)
     if ((d.n_runs == 0u && (!hip_ok(sc->elem_scan.ensure((size_t)n_elems * sizeof(ElemScan)), "hipMalloc elem_scan") ||
         !hip_ok(sc->wg_total.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->wg_base.ensure((size_t)d.n_wg * NCH * 4), "hipMalloc") || !hip_ok(sc->group_base.ensure(((size_t)d.n_wg / 64 + 2) * NCH * 4), "hipMalloc"))) ||
+        (d.n_runs != 0u && (!hip_ok(sc->elem_cnt.ensure((size_t)n_elems * 4), "hipMalloc") || !hip_ok(sc->run_base.ensure(((size_t)d.n_runs + 1) * NCH * 4), "hipMalloc"))) ||
         (d.n_runs != 0u && has_stroke && !hip_ok(sc->path_scan.ensure((size_t)b->n_paths * 12), "hipMalloc")) ||
-        !hip_ok(sc->totals.ensure(kTotalsWords * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)b->n_shapes * kShapeRow * 4), "hipMalloc") ||
+        !hip_ok(sc->totals.ensure(NCH * 4), "hipMalloc") || !hip_ok(sc->shape_base.ensure((size_t)b->n_shapes * kShapeRow * 4), "hipMalloc") ||
         !hip_ok(sc->hull_count.ensure((size_t)b->n_shapes * 4), "hipMalloc") || !hip_ok(sc->hull_large.ensure((3 * (size_t)b->n_shapes + 4) * 4), "hipMalloc") || !hip_ok(sc->status.ensure(4), "hipMalloc") ||
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
@@ -1772,7 +1785,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.shape_dyn_begin = sc->shape_dyn_begin.as<uint32_t>();
     d.stroke_options = sc->stroke_options.as<crh_stroke_options>();
     d.descriptors = sc->descriptors.as<crh_dynamic_stroke_descriptor>();
-    d.tess_run = sc->tess_run.as<uint32_t>();
+    d.tess_run = sc->tess_run.as<uint32_t>(), d.elem_cnt = sc->elem_cnt.as<uint32_t>(), d.run_base = sc->run_base.as<uint32_t>();
     bind_tess_pointers(sc);
     if (!existing) r->scenes.push_back(sc);
     *out = sc;

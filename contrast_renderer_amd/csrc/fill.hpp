@@ -92,8 +92,16 @@ CRH_D void triangulate_quadrilateral(const Pt cp[4], float w[4][4], Sink& sink, 
         if (fabsf(equilibrium - fabsf(area[i])) <= kErrorMargin) enclosing = enclosing < 0 ? i : -1;
     float2 v[4];
     for (int j = 0; j < 4; ++j) v[j] = point_to_vec(cp[j]);
+    // (which corner is left out is known at run time only: the corners are picked with selects — indexing the register arrays with a
+    // variable sent v[], w[][] and area[] to scratch memory, 176 B per lane of the emitting kernel)
+    auto pick = [](int i, float a0, float a1, float a2, float a3) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); };
+    auto emit_corner = [&](int i) {
+        const float wi[4] = {pick(i, w[0][0], w[1][0], w[2][0], w[3][0]), pick(i, w[0][1], w[1][1], w[2][1], w[3][1]), pick(i, w[0][2], w[1][2], w[2][2], w[3][2]),
+                             pick(i, w[0][3], w[1][3], w[2][3], w[3][3])};
+        sink.curve(make_float2(pick(i, v[0].x, v[1].x, v[2].x, v[3].x), pick(i, v[0].y, v[1].y, v[2].y, v[3].y)), wi);
+    };
     auto emit_triangle = [&](int skip) {
-        const float a = area[skip];
+        const float a = pick(skip, area[0], area[1], area[2], area[3]);
         if (fabsf(a) > kErrorMargin) {
             int i0 = skip == 0 ? 1 : 0;
             int i1 = skip <= 1 ? 2 : 1;
@@ -103,9 +111,9 @@ CRH_D void triangulate_quadrilateral(const Pt cp[4], float w[4][4], Sink& sink, 
                 i0 = i2;
                 i2 = t;
             }
-            sink.curve(v[i0], w[i0]);
-            sink.curve(v[i1], w[i1]);
-            sink.curve(v[i2], w[i2]);
+            emit_corner(i0);
+            emit_corner(i1);
+            emit_corner(i2);
         }
     };
     if (enclosing >= 0) {

@@ -135,15 +135,20 @@ CRH_D float solve_quadratic(float c0, float c1, float c2, Root* r, int& n) {
     }
     return D;
 }
-inline __host__ __device__ __noinline__ float solve_cubic(float f0, float f1, float f2, float f3, Root* r, int& n) {
-    if (fabsf(f3) <= kErrorMargin) return solve_quadratic(f0, f1, f2, r, n);
+// (The binary64 body is one out-of-line function per kernel. It hands its roots back BY VALUE: through a pointer the caller's array had to
+// live in scratch memory — 48 B per lane of every kernel that classifies a rational cubic.)
+struct CubicRoots {
+    Root r0, r1, r2;
+    float discriminant;
+};
+inline __host__ __device__ __noinline__ CubicRoots solve_cubic_roots(float f0, float f1, float f2, float f3) {
+    Root r[3];
     const double a = f3, b = f2, c = f1, d = f0;
     const double d0 = b * b - 3.0 * a * c;
     const double d1 = 2.0 * b * b * b - 9.0 * a * b * c + 27.0 * a * a * d;
     const double inner = d1 * d1 - 4.0 * d0 * d0 * d0;
     const double disc = 18.0 * a * b * c * d - 4.0 * b * b * b * d + b * b * c * c - 4.0 * a * c * c * c - 27.0 * a * a * d * d;
     const float den = (float)(3.0 * a);
-    n = 3;
     if (inner >= 0.0) {
         const double s = sqrt(inner);
         const double C = crh_d_cbrt((d1 + (d1 < 0.0 ? -s : s)) * 0.5);
@@ -166,7 +171,14 @@ inline __host__ __device__ __noinline__ float solve_cubic(float f0, float f1, fl
             r[k] = {(float)(-(b + m * cs)), 0.0f, den};
         }
     }
-    return (float)disc;
+    return CubicRoots{r[0], r[1], r[2], (float)disc};
+}
+CRH_D float solve_cubic(float f0, float f1, float f2, float f3, Root* r, int& n) {
+    if (fabsf(f3) <= kErrorMargin) return solve_quadratic(f0, f1, f2, r, n);
+    const CubicRoots s = solve_cubic_roots(f0, f1, f2, f3);
+    n = 3;
+    r[0] = s.r0, r[1] = s.r1, r[2] = s.r2;
+    return s.discriminant;
 }
 CRH_D void push_monic_quadratic(Root* r, double s1, double s0, double shift) {
     const double D = s1 * s1 - 4.0 * s0;
@@ -180,15 +192,18 @@ CRH_D void push_monic_quadratic(Root* r, double s1, double s0, double shift) {
         r[1] = {(float)(0.5 * (-s1 - sq) + shift), 0.0f, 1.0f};
     }
 }
-inline __host__ __device__ __noinline__ float solve_quartic(const float cf[5], Root* r, int& n) {
-    if (fabsf(cf[4]) <= kErrorMargin) return solve_cubic(cf[0], cf[1], cf[2], cf[3], r, n);
-    const double a4 = cf[4];
-    const double b = cf[3] / a4, c = cf[2] / a4, d = cf[1] / a4, e = cf[0] / a4;
+struct QuarticRoots {
+    Root r0, r1, r2, r3;
+    float discriminant;
+};
+inline __host__ __device__ __noinline__ QuarticRoots solve_quartic_roots(float cf0, float cf1, float cf2, float cf3, float cf4) {
+    Root r[4];
+    const double a4 = cf4;
+    const double b = cf3 / a4, c = cf2 / a4, d = cf1 / a4, e = cf0 / a4;
     const double p = c - 0.375 * b * b;
     const double q = 0.125 * b * b * b - 0.5 * b * c + d;
     const double rr = -0.01171875 * b * b * b * b + 0.0625 * b * b * c - 0.25 * b * d + e;
     const double shift = -0.25 * b;
-    n = 4;
     if (fabs(q) <= 1e-12 * (1.0 + fabs(p) + fabs(rr))) {
         const double D = p * p - 4.0 * rr;
         if (D < 0.0) {
@@ -215,7 +230,7 @@ inline __host__ __device__ __noinline__ float solve_quartic(const float cf[5], R
                 }
             }
         }
-        return (float)D;
+        return QuarticRoots{r[0], r[1], r[2], r[3], (float)D};
     }
     const double rb = p, rc = 0.25 * p * p - rr, rd = -0.125 * q * q;
     const double d0 = rb * rb - 3.0 * rc;
@@ -246,7 +261,14 @@ inline __host__ __device__ __noinline__ float solve_quartic(const float cf[5], R
         push_monic_quadratic(r, s, 0.5 * p + m - q / (2.0 * s), shift);
         push_monic_quadratic(r + 2, -s, 0.5 * p + m + q / (2.0 * s), shift);
     }
-    return (float)inner;
+    return QuarticRoots{r[0], r[1], r[2], r[3], (float)inner};
+}
+CRH_D float solve_quartic(const float cf[5], Root* r, int& n) {
+    if (fabsf(cf[4]) <= kErrorMargin) return solve_cubic(cf[0], cf[1], cf[2], cf[3], r, n);
+    const QuarticRoots s = solve_quartic_roots(cf[0], cf[1], cf[2], cf[3], cf[4]);
+    n = 4;
+    r[0] = s.r0, r[1] = s.r1, r[2] = s.r2, r[3] = s.r3;
+    return s.discriminant;
 }
 
 // curve.rs:151-190

@@ -82,11 +82,13 @@ struct SceneDev {
     uint32_t* wg_total;    // [n_wg][NCH]
     uint32_t* wg_base;     // [n_wg][NCH]: exclusive prefix of the row inside its group of 64 rows (k_scan_rows)
     uint32_t* group_base;  // [n_wg / 64 + 2][NCH]: exclusive prefix of the group (k_scan_groups); its first NCH words double as the group totals before that
-    uint32_t* totals;      // [NCH] (+ the cursors of the one-pass kernel behind them, kAllocWord)
+    uint32_t* totals;      // [NCH]
     uint32_t* shape_base;  // [n_shapes][2][NCH] where each Shape's records begin and end in every stream (kShapeRow words per Shape)
-    // ---- the one-pass tessellation (k_tess_fused): Shape-aligned workgroups, no scan across workgroups ----
+    // ---- the one-pass tessellation (k_tess_runs): Shape-aligned workgroups, no scan across workgroups ----
     uint32_t n_runs;            // 0: the two-pass path (some Shape has more elements than a workgroup has lanes)
     const uint32_t* tess_run;   // [n_runs + 1] first Shape of every run of consecutive Shapes with <= kTessBlock elements in total
+    uint32_t* elem_cnt;         // [n_elems] what every element emits, packed (pack_counts): a property of the paths, counted once per upload
+    uint32_t* run_base;         // [n_runs + 1][NCH] where every run's records begin in the ten streams (row n_runs: the totals); per upload as well
     uint32_t* path_scan;        // [n_paths][3] a stroked path's first vertex pair, the pair behind its last one, its first join (k_stroke_lengths)
     // ---- outputs ----
     uint32_t capacity[NCH];
@@ -117,12 +119,6 @@ struct SceneDev {
 __device__ __forceinline__ void raise_error(const SceneDev& s, uint32_t path, uint32_t code) { atomicMin(s.status, (path << 8) | code); }
 
 constexpr uint32_t kShapeRow = 2u * NCH; // words of a Shape's row of shape_base: begin[NCH], end[NCH]
-// The cursors of k_tess_fused live behind the totals (same buffer: cleared and double-buffered with them). A workgroup reserves its range of
-// every stream with one atomic per channel; the two index streams are addressed by SUMS of two channels (line_i: LINE_V + LINE_CUT, solid_i:
-// SOLID_V + SOLID_END), so those pairs share one 64-bit cursor — both halves then see the workgroups in the same order and the sums of
-// different workgroups never overlap. Words from kAllocWord: pair (LINE_V | LINE_CUT << 32), pair (SOLID_V | SOLID_END << 32), six single
-// cursors (HULL, JOINT, IQ, IC_V, RQ, RC_V), the count of workgroups that are through (the last one publishes totals[]).
-constexpr uint32_t kAllocWord = 16u, kTotalsWords = 32u;
 
 // global exclusive prefix of channel ch at element e
 __device__ __forceinline__ uint32_t gscan(const SceneDev& s, uint32_t e, int ch) {

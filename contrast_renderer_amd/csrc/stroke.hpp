@@ -580,7 +580,7 @@ CRH_D void emit_tail(const SceneDev& s, uint32_t e, uint32_t path, const crh_str
     }
 }
 
-// `scan(e, ch)`: the exclusive prefix of channel ch at element e — gscan() behind the two-pass scan, the workgroup's LDS rows in k_tess_fused
+// `scan(e, ch)`: the exclusive prefix of channel ch at element e — gscan() behind the two-pass scan, the workgroup's LDS rows in k_tess_runs
 template <class Scan>
 CRH_D void emit_stroke_element(const SceneDev& s, uint32_t e, uint32_t type, uint32_t path, const crh_stroke_options& so, const uint32_t g[NCH], const Scan& scan) {
     if (type == ELEM_MOVE) return;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(64) void k_stroke_lengths(SceneDev s) {
     const uint32_t move = s.path_elem_begin[path], end = s.path_elem_begin[path + 1] - 1u;
     // the END element's own records come after its exclusive prefix: the path's last pair is found via the next element
     uint32_t pair_begin, pair_end, joint;
-    if (s.n_runs) { // (k_tess_fused left them behind: there is no scan to ask)
+    if (s.n_runs) { // (k_tess_runs left them behind: there is no scan to ask)
         pair_begin = s.path_scan[3u * path], pair_end = s.path_scan[3u * path + 1u], joint = s.path_scan[3u * path + 2u];
     } else {
         pair_begin = gscan(s, move, CH_LINE_V) >> 1;

@@ -9,11 +9,9 @@
 // Two-phase emission reproduces the sequential `start_index` bookkeeping of the reference (fill.rs:361-365,
 // stroke.rs:95,108,126-129) exactly: offsets are exclusive prefix sums in element order.
 //
-//   k_tess_fused  (round 5) the three of them in ONE launch when no Shape has more elements than a workgroup has lanes: Shape-aligned
-//                 workgroups (a run of consecutive Shapes each), the ten-channel scan in LDS, ONE atomic per channel and workgroup for the
-//                 workgroup's range of every stream — no scan across workgroups, no elem_scan[] in memory. The parity surface is a Shape's
-//                 byte image (renderer.rs:198-209), assembled from shape_base: in which order the runs lie inside the scene-wide streams is
-//                 not part of it (and differs from launch to launch).
+//   k_tess_runs   (round 5) the three of them in ONE launch per frame when no Shape has more elements than a workgroup has lanes:
+//                 Shape-aligned workgroups (a run of consecutive Shapes each), the ten-channel scan in LDS, the runs' bases and every
+//                 element's counts kept from the first tessellation of the paths — see "k_tess_runs" below.
 #include "fill.hpp"
 #include "scene.hpp"
 #include "stroke.hpp"
@@ -139,11 +137,14 @@ CRH_D void count_fill_element(const SceneDev& s, uint32_t e, uint32_t type, uint
     }
 }
 
+// STROKES = false: the Scene has no stroked path (the host knows) — the kernel is built without the stroke code: its root arrays are what
+// sends 80 / 176 B per lane of the general kernels to scratch memory, and the fill code alone needs 60 registers less
+template <bool STROKES = true>
 CRH_D void count_element(const SceneDev& s, uint32_t e, uint32_t cnt[NCH]) {
     const uint32_t type = s.elem_type[e];
     const uint32_t path = s.elem_path[e];
-    const int32_t stroke = s.path_stroke[path];
-    if (stroke < 0)
+    const int32_t stroke = STROKES ? s.path_stroke[path] : -1;
+    if (!STROKES || stroke < 0)
         count_fill_element(s, e, type, path, cnt);
     else
         count_stroke_element(s, e, type, path, s.stroke_options[stroke], cnt);
@@ -267,7 +268,7 @@ struct GlobalScan { // the two-pass path: group base + row base + the element's 
     CRH_D uint32_t operator()(uint32_t e, int ch) const { return gscan(*s, e, ch); }
 };
 constexpr uint32_t kScanPitch = NCH + 1; // (odd: lanes of consecutive elements reading one channel spread over the LDS banks)
-struct LocalScan { // k_tess_fused: rows [0, n] of the workgroup's run in LDS, the run's reserved bases already added
+struct LocalScan { // k_tess_runs: rows [0, n] of the workgroup's run in LDS, the run's reserved bases already added
     const uint32_t* rows;
     uint32_t first;
     CRH_D uint32_t operator()(uint32_t e, int ch) const { return rows[(e - first) * kScanPitch + (uint32_t)ch]; }
@@ -365,22 +366,47 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_emit(SceneDev
         emit_stroke_element(s, e, type, path, s.stroke_options[stroke], g, scan);
 }
 
-// ------------------------------------------------------------------------------------------------ k_tess_fused
-// One launch instead of k_count + two scan launches + k_emit (fill.rs:263-367, stroke.rs:205-465 and the loop renderer.rs:187-196 for a
-// whole scene). Workgroup b takes the Shapes [tess_run[b], tess_run[b + 1]) — at most kTessBlock elements, lane = element —:
-//   1  the lane counts what its element emits (the counting sinks), ten-channel exclusive scan over the workgroup (wave shuffles + LDS);
-//   2  eight lanes reserve the workgroup's range of every stream: one atomic per channel, the two pairs of channels whose SUMS address
-//      an index stream share a 64-bit one (scene.hpp, kAllocWord); the last workgroup through publishes totals[];
-//   3  the prefix rows go to LDS with the bases added — every offset the emission asks for (its own, its path's MOVE and END, its
-//      Shape's first element) is a row of this workgroup —, lanes over the run's Shapes write their shape_base rows;
-//   4  the lane emits with the writing sinks.
-// count_only: the first tessellation of new paths (capacities unknown) reserves and publishes only; the host sizes the streams from totals[]
-// and launches again. A workgroup whose range does not fit (stale capacities) raises the overflow code and emits nothing; totals[] are
-// exact either way.
-__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_fused(SceneDev s, uint32_t count_only) {
-    __shared__ uint32_t rows[(kTessBlock + 1) * kScanPitch];
+// ------------------------------------------------------------------------------------------------ k_tess_runs
+// One launch per frame instead of k_count + two scan launches + k_emit (fill.rs:263-367, stroke.rs:205-465 and the loop renderer.rs:187-196
+// for a whole scene), for Scenes whose Shapes fit a workgroup. Workgroup b takes the Shapes [tess_run[b], tess_run[b + 1]) — at most
+// kTessBlock elements, lane = element. HOW MANY records an element emits is a property of the uploaded paths, not of the frame: the first
+// tessellation of new paths (the one whose totals the host needs anyway, to size the streams) counts once —
+//   k_tess_count_runs  the counting sinks; every element's ten counts packed into one word (elem_cnt), the run's totals;
+//   k_scan_runs        exclusive prefix over the runs (one small workgroup): run_base, the scene's totals —
+// and every tessellation, that one included, is ONE kernel that analyses each element ONCE:
+//   k_tess_runs        the lane unpacks its counts, ten-channel exclusive scan over the workgroup (wave shuffles + LDS), the rows go to LDS
+//                      with the run's base added — every offset the emission asks for (its own, its path's MOVE and END, its Shape's first
+//                      element) is a row of this workgroup: no scan across workgroups, no look-back, no elem_scan[] in memory —, lanes over
+//                      the run's Shapes write their shape_base rows, the lane emits with the writing sinks.
+// (A first cut reserved the workgroups' ranges with one atomic per channel and workgroup instead of run_base — Shapes in arbitrary order
+// inside the streams. Bit-equal Shape by Shape, and slower than the two passes: 6 300 workgroups of the glyph scene queue up on the ten
+// cursors, 0.27 ms against 0.14)
+// Stroked elements: HULL = LINE_V + the joins' extra candidates; LINE_V in 24 bits (the host rejects step counts beyond 2^20).
+CRH_D uint32_t pack_counts(const uint32_t cnt[NCH], bool stroked, bool& fits_word) {
+    if (stroked) {
+        fits_word = cnt[CH_LINE_V] < (1u << 24);
+        return cnt[CH_LINE_V] | (cnt[CH_LINE_CUT] << 24) | (cnt[CH_JOINT] << 26) | ((cnt[CH_HULL] - cnt[CH_LINE_V]) << 28);
+    }
+    fits_word = true; // (one segment: at most 6 polygon vertices, 3 hull candidates, 12 curve vertices)
+    return cnt[CH_SOLID_V] | (cnt[CH_HULL] << 3) | (cnt[CH_SOLID_END] << 5) | (cnt[CH_IQ] << 6) | (cnt[CH_RQ] << 7) | (cnt[CH_IC_V] << 8) | (cnt[CH_RC_V] << 12);
+}
+CRH_D void unpack_counts(uint32_t w, bool stroked, uint32_t cnt[NCH]) {
+    const uint32_t line_v = w & 0xFFFFFFu;
+    cnt[CH_LINE_V] = stroked ? line_v : 0u;
+    cnt[CH_LINE_CUT] = stroked ? (w >> 24) & 3u : 0u;
+    cnt[CH_JOINT] = stroked ? (w >> 26) & 3u : 0u;
+    cnt[CH_HULL] = stroked ? line_v + (w >> 28) : (w >> 3) & 3u;
+    cnt[CH_SOLID_V] = stroked ? 0u : w & 7u;
+    cnt[CH_SOLID_END] = stroked ? 0u : (w >> 5) & 1u;
+    cnt[CH_IQ] = stroked ? 0u : (w >> 6) & 1u;
+    cnt[CH_RQ] = stroked ? 0u : (w >> 7) & 1u;
+    cnt[CH_IC_V] = stroked ? 0u : (w >> 8) & 15u;
+    cnt[CH_RC_V] = stroked ? 0u : (w >> 12) & 15u;
+}
+
+template <bool STROKES>
+__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_count_runs(SceneDev s) {
     __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
-    __shared__ uint32_t run_base[NCH];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shape0 = s.tess_run[blockIdx.x], shape1 = s.tess_run[blockIdx.x + 1u];
     const uint32_t first = s.shape_elem_begin[shape0], n = s.shape_elem_begin[shape1] - first; // (<= kTessBlock: the host cut the runs)
@@ -388,8 +414,92 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_fused(Sc
     uint32_t cnt[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) cnt[c] = 0;
-    if (tid < n) count_element(s, e, cnt);
-    uint32_t excl[NCH];
+    if (tid < n) {
+        count_element<STROKES>(s, e, cnt);
+        const uint32_t path = s.elem_path[e];
+        bool fits_word;
+        s.elem_cnt[e] = pack_counts(cnt, STROKES && s.path_stroke[path] >= 0, fits_word);
+        if (!fits_word) raise_error(s, path, CRH_ERR_UNSUPPORTED);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t v = cnt[c];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        if (lane == 0u) wave_total[wave][c] = v;
+    }
+    __syncthreads();
+    if (tid < NCH) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < (uint32_t)kTessBlock / 64u; ++w) total += wave_total[w][tid];
+        s.run_base[blockIdx.x * NCH + tid] = total;
+    }
+}
+
+// the runs' totals -> where every run begins (in place), the totals behind the last run and in totals[]: one workgroup, 256 runs a turn
+__global__ __launch_bounds__(256) void k_scan_runs(SceneDev s) {
+    __shared__ uint32_t wave_total[4][NCH];
+    __shared__ uint32_t carry[NCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid < NCH) carry[tid] = 0u;
+    __syncthreads();
+    for (uint32_t first = 0; first < s.n_runs; first += 256u) {
+        const uint32_t run = first + tid;
+        uint32_t mine[NCH], incl[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            mine[c] = run < s.n_runs ? s.run_base[run * NCH + c] : 0u;
+            uint32_t v = mine[c];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(v, d, 64);
+                if (lane >= (uint32_t)d) v += up;
+            }
+            incl[c] = v;
+            if (lane == 63u) wave_total[wave][c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            uint32_t base = carry[c];
+            for (uint32_t w = 0; w < wave; ++w) base += wave_total[w][c];
+            if (run < s.n_runs) s.run_base[run * NCH + c] = base + incl[c] - mine[c];
+        }
+        __syncthreads();
+        if (tid < NCH) carry[tid] += wave_total[0][tid] + wave_total[1][tid] + wave_total[2][tid] + wave_total[3][tid];
+        __syncthreads();
+    }
+    if (tid < NCH) s.run_base[s.n_runs * NCH + tid] = carry[tid], s.totals[tid] = carry[tid];
+}
+
+template <bool STROKES>
+__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_runs(SceneDev s) {
+    __shared__ uint32_t rows[(kTessBlock + 1) * kScanPitch];
+    __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t shape0 = s.tess_run[blockIdx.x], shape1 = s.tess_run[blockIdx.x + 1u];
+    const uint32_t first = s.shape_elem_begin[shape0], n = s.shape_elem_begin[shape1] - first;
+    const uint32_t e = first + tid;
+    const uint32_t* const scene_totals = s.run_base + s.n_runs * NCH;
+    if (blockIdx.x == 0u && tid < NCH) s.totals[tid] = scene_totals[tid]; // (this set's copy: what the kernels behind this one and the host read)
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) ok = ok && scene_totals[c] <= s.capacity[c];
+    if (!ok) { // (uniform) stale capacities: the host sizes the streams from totals[] and runs again
+        if (blockIdx.x == 0u && tid == 0u) raise_error(s, 0, CRH_ERR_UNSUPPORTED + 0x80u);
+        return;
+    }
+    uint32_t type = ELEM_MOVE, path = 0;
+    int32_t stroke = -1;
+    uint32_t cnt[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) cnt[c] = 0;
+    if (tid < n) {
+        type = s.elem_type[e], path = s.elem_path[e];
+        if (STROKES) stroke = s.path_stroke[path];
+        unpack_counts(s.elem_cnt[e], stroke >= 0, cnt);
+    }
+    uint32_t g[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         uint32_t v = cnt[c];
@@ -398,70 +508,18 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_fused(Sc
             const uint32_t up = __shfl_up(v, d, 64);
             if (lane >= (uint32_t)d) v += up;
         }
-        excl[c] = v - cnt[c];
+        g[c] = v - cnt[c];
         if (lane == 63) wave_total[wave][c] = v;
     }
     __syncthreads();
-    uint32_t total[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        uint32_t base = 0, all = 0;
+        uint32_t base = s.run_base[blockIdx.x * NCH + c];
 #pragma unroll
-        for (uint32_t w = 0; w < (uint32_t)kTessBlock / 64u; ++w) {
-            const uint32_t v = wave_total[w][c];
-            base += w < wave ? v : 0u;
-            all += v;
-        }
-        excl[c] += base;
-        total[c] = all;
-    }
-    // ---- 2: the workgroup's ranges
-    uint32_t* const cursors = s.totals + kAllocWord;
-    if (tid < 8u) {
-        auto pick = [&](uint32_t ch) { // total[ch] for a lane-dependent ch without indexing the register array
-            uint32_t v = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) v = ch == (uint32_t)c ? total[c] : v;
-            return v;
-        };
-        if (tid < 2u) {
-            const uint32_t lo_ch = tid == 0u ? CH_LINE_V : CH_SOLID_V, hi_ch = tid == 0u ? CH_LINE_CUT : CH_SOLID_END;
-            const unsigned long long add = (unsigned long long)pick(lo_ch) | ((unsigned long long)pick(hi_ch) << 32);
-            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(cursors) + tid, add);
-            run_base[lo_ch] = (uint32_t)old, run_base[hi_ch] = (uint32_t)(old >> 32);
-        } else {
-            const uint32_t k = tid - 2u;
-            const uint32_t ch = k == 0u ? CH_HULL : (k == 1u ? CH_JOINT : (k == 2u ? CH_IQ : (k == 3u ? CH_IC_V : (k == 4u ? CH_RQ : CH_RC_V))));
-            run_base[ch] = atomicAdd(cursors + 4u + k, pick(ch));
-        }
-    }
-    __syncthreads();
-    if (tid == 0u) { // the last workgroup through turns the cursors into totals[] (what the kernels behind this one and the host read)
-        __threadfence();
-        if (atomicAdd(cursors + 10u, 1u) == gridDim.x - 1u) {
-            __threadfence();
-            const unsigned long long line = atomicAdd(reinterpret_cast<unsigned long long*>(cursors), 0ull), solid = atomicAdd(reinterpret_cast<unsigned long long*>(cursors) + 1, 0ull);
-            s.totals[CH_LINE_V] = (uint32_t)line, s.totals[CH_LINE_CUT] = (uint32_t)(line >> 32);
-            s.totals[CH_SOLID_V] = (uint32_t)solid, s.totals[CH_SOLID_END] = (uint32_t)(solid >> 32);
-            s.totals[CH_HULL] = atomicAdd(cursors + 4u, 0u), s.totals[CH_JOINT] = atomicAdd(cursors + 5u, 0u), s.totals[CH_IQ] = atomicAdd(cursors + 6u, 0u);
-            s.totals[CH_IC_V] = atomicAdd(cursors + 7u, 0u), s.totals[CH_RQ] = atomicAdd(cursors + 8u, 0u), s.totals[CH_RC_V] = atomicAdd(cursors + 9u, 0u);
-        }
-    }
-    if (count_only) return;
-    // ---- 3: the rows
-    bool ok = true;
-    uint32_t g[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const uint32_t base = run_base[c];
-        ok = ok && base + total[c] <= s.capacity[c] && base + total[c] >= base;
-        g[c] = base + excl[c];
+        for (uint32_t w = 0; w + 1u < (uint32_t)kTessBlock / 64u; ++w) base += w < wave ? wave_total[w][c] : 0u;
+        g[c] += base;
         if (tid < n) rows[tid * kScanPitch + c] = g[c];
-        if (tid == 0u) rows[n * kScanPitch + c] = base + total[c];
-    }
-    if (!ok) { // (uniform) stale capacities: the host reallocates from totals[] and runs again
-        if (tid == 0u) raise_error(s, 0, CRH_ERR_UNSUPPORTED + 0x80u);
-        return;
+        if (tid == 0u) rows[n * kScanPitch + c] = s.run_base[(blockIdx.x + 1u) * NCH + c];
     }
     __syncthreads();
     for (uint32_t shape = shape0 + tid; shape < shape1; shape += kTessBlock) {
@@ -471,12 +529,8 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_fused(Sc
         for (int c = 0; c < NCH; ++c) s.shape_base[shape * kShapeRow + c] = b0[c], s.shape_base[shape * kShapeRow + NCH + c] = b1[c];
     }
     if (tid >= n) return;
-    // ---- 4: emission
-    const uint32_t type = s.elem_type[e];
-    const uint32_t path = s.elem_path[e];
-    const int32_t stroke = s.path_stroke[path];
     const LocalScan scan = {rows, first};
-    if (stroke < 0) {
+    if (!STROKES || stroke < 0) {
         emit_fill_element(s, e, type, path, g, scan);
     } else {
         if (type == ELEM_MOVE) { // what k_stroke_lengths walks: the path's vertex pairs and its first join
@@ -820,15 +874,17 @@ void launch_stroke_records(const SceneDev& s, hipStream_t stream, void (*mark)(v
     if (mark) mark(ctx, "stroke_records", 0);
 }
 // need_totals: the capacities of the streams are not known yet (new paths). The two-pass path counts and scans in any case; the one-pass kernel
-// comes through here only then, as a counting pass (launch_emit runs it whole).
+// counts (k_tess_count_runs, k_scan_runs) only then: per upload, not per frame.
 void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool need_totals) {
     if (s.n_elems == 0) return;
     if (has_stroke) launch_stroke_records(s, stream, mark, ctx);
     if (s.n_runs) {
         if (!need_totals) return;
-        (void)hipMemsetAsync(s.totals, 0, kTotalsWords * 4u, stream);
-        hipLaunchKernelGGL(k_tess_fused, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s, 1u);
+        if (has_stroke) hipLaunchKernelGGL(k_tess_count_runs<true>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+        else hipLaunchKernelGGL(k_tess_count_runs<false>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
         if (mark) mark(ctx, "tess_count", bytes[0]);
+        hipLaunchKernelGGL(k_scan_runs, dim3(1), dim3(256), 0, stream, s);
+        if (mark) mark(ctx, "tess_scan", bytes[1]);
         return;
     }
     hipLaunchKernelGGL(k_count, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
@@ -842,8 +898,8 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*
 void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued) {
     if (s.n_elems == 0) return;
     if (s.n_runs) {
-        (void)hipMemsetAsync(s.totals, 0, kTotalsWords * 4u, stream);
-        hipLaunchKernelGGL(k_tess_fused, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s, 0u);
+        if (has_stroke) hipLaunchKernelGGL(k_tess_runs<true>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+        else hipLaunchKernelGGL(k_tess_runs<false>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
         if (mark) mark(ctx, "tess_fused", bytes[2]);
     } else {
         hipLaunchKernelGGL(k_emit, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);
