@@ -465,7 +465,9 @@ def main():
     import ctypes as C
 
     # N > 1: two layers, so that the exchange of step i runs while step i + 1 is being tessellated and rasterized into the other one
-    frames = [frame] + ([Frame(renderer, *size)] if world > 1 else [])
+    # (--reupload: two targets as well — an application that re-uploads its paths every frame double-buffers Scene AND target: Scene k draws into target k,
+    # so the list places and batch runs a target keeps for "its" Scene survive the upload of same-structure paths, csrc/api.hip crh_scene::lineage)
+    frames = [frame] + ([Frame(renderer, *size)] if (world > 1 or args.reupload) else [])
     tile_split = args.split == "tile" and world > 1
     gather_mode = tile_split  # (finish() reads it: the `tile_split` side block of a path-sharded run switches it on for its own steps)
     if tile_split:
@@ -598,7 +600,7 @@ def main():
             comm, result = None, None
             exchange_note = "FALLBACK to torch.distributed (the first crh_frame_exchange failed" + (f": {failure}" if failure else " on another rank") + ")"
             torch_path()
-    run(20)
+    run(40 if args.reupload else 20)  # (--reupload: two Scenes and two targets in turn — twenty set-up steps for each pair)
     sync()
     if watchdog is not None:
         watchdog.cancel()

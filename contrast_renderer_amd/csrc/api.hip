@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -334,6 +335,7 @@ struct crh_frame {
     uint32_t slab_ty0 = 0, slab_ty1 = 0xFFFFFFFFu; // crh_frame_set_tile_rows: the tile rows the raster kernels draw (all of them by default)
     bool moving = false;
     uint64_t last_pass_instances = ~0ull;
+    uint64_t last_pass_geometry = 0; // crh_scene::generation of the latest plain pass
     uint64_t places_instances = 0; // crh_scene::instances_version of the pass whose counts the current places come from (unchanged instances: unchanged counts, no new places)
     uint32_t direct_clean = 0;   // passes with lists in place since the last one that outgrew them (thirty-two forgive the misses)
     bool direct_ready = false;
@@ -358,6 +360,7 @@ struct crh_frame {
     // last render, for the transparent re-run after a bin-capacity overflow
     crh_scene* last_scene = nullptr;
     bool check_pending = false;
+    bool last_tess_optimistic = false; // the pass pending verification drew an optimistic tessellation: its flag words hold that run's status (kTessStatusWord)
     // The edge pass met a boundary edge with a non-finite endpoint on this frame (finite vertices times a finite matrix can overflow): an
     // unclosed chain has no backdrops, so passes of that Scene into this frame are drawn by the triangle pass, which skips exactly the
     // strip triangles with a non-finite determinant — as the reference's rasterizer does.
@@ -385,6 +388,15 @@ struct crh_scene {
     uint64_t instances_version = 0; // counts crh_scene_set_instances calls
     uint64_t input_bytes = 0, emitted_bytes = 0;
     uint32_t totals_host[NCH] = {};
+    uint32_t cap_host[NCH] = {};   // records every stream of the current set holds (ensure_outputs: the totals + a sixteenth + 64) — what d.capacity says
+    // New paths of the SAME STRUCTURE (as many Shapes, paths, elements: an animation of control points) uploaded into a Scene whose streams
+    // are sized: the capacities are kept and the tessellation runs without the host waiting for its totals (`optimistic`; until something
+    // synchronises, totals_host holds the capacities — upper bounds). A run that does not fit raises the overflow code and emits nothing;
+    // the frame drawn from it finds the code among its flag words (kTessStatusWord) when it is settled, the host sizes the streams from
+    // the totals and the frame is drawn again — the way an outgrown tile list is handled.
+    bool optimistic = false;
+    bool counts_valid = false;     // elem_cnt / run_base belong to the uploaded paths (the one-pass path counts once per upload)
+    uint64_t lineage = 0;          // the generation of the first upload of this structure: what a frame's list places and batch runs are kept against
     // How many Shapes the hull kernels beyond k_hull_small find queued (a property of the geometry): fetched once behind the first
     // tessellation of these paths, asynchronously; later runs do not launch a kernel whose queue is empty (50 000 glyphs: two launches per
     // frame that executed no vector instruction and waited 51 us each for wave slots on the tessellation lane)
@@ -393,8 +405,8 @@ struct crh_scene {
     int hull_queued_state = 0; // 0 unknown, 1 the copy is on its way, 2 known
     std::vector<uint32_t> shape_dyn_begin_host;
     // inputs
-    DevBuf elem_type, elem_off0, elem_off, elem_prev_off, elem_path, pool, path_elem_begin, path_shape, path_stroke, shape_elem_begin, shape_dyn_begin, stroke_options, descriptors;
-    DevBuf tess_run, elem_cnt, run_base; // the one-pass tessellation: runs of Shapes, every element's packed counts, the runs' bases (scene.hpp) — per upload
+    DevBuf geometry; // the uploaded element stream: ONE arena (the layout of crh_scene_upload's pinned staging arena), one copy
+    DevBuf elem_cnt, run_base; // the one-pass tessellation: runs of Shapes, every element's packed counts, the runs' bases (scene.hpp) — per upload
     // scan state
     DevBuf elem_scan, wg_total, wg_base, group_base, totals, shape_base, hull_count, hull_large, hull_sort, hull_chain, status, path_scan;
     // outputs
@@ -422,6 +434,7 @@ struct crh_scene {
                                         // the next tessellation into this set need not wait for ranges_free as well. Per set: flip_tess_set swaps it with the shadow's
     uint64_t rec_raster_serial[kPipelineDepth] = {}; // the render call that recorded it (crh_renderer::render_serial)
     bool rec_used[kPipelineDepth] = {};
+    bool rec_used_ever[kPipelineDepth] = {}; // rec_raster_done[k] has been recorded (crh_scene_upload orders its copy behind them: rec_used is reset by every upload)
     int next_rec = 0;
     bool instances_set = false;
     // frame pipelining: tessellation runs on its own stream; these events order it against the raster stream
@@ -437,7 +450,7 @@ struct crh_scene {
         DevBuf buf[kTessBufs];
         hipEvent_t tess_done = nullptr, vertices_free = nullptr, ranges_free = nullptr;
         bool allocated = false, capacity_known = false, rendered_once = false, last_render_one_event = false;
-        uint32_t totals_host[NCH] = {};
+        uint32_t totals_host[NCH] = {}, cap_host[NCH] = {};
         uint64_t emitted_bytes = 0;
     } shadow;
     bool tessellated_once = false;
@@ -473,8 +486,8 @@ struct crh_scene {
     bool layout_valid = false;
 
     void release_all() {
-        DevBuf* all[] = {&elem_type, &elem_off0, &elem_off, &elem_prev_off, &elem_path, &pool, &path_elem_begin, &path_shape, &path_stroke, &shape_elem_begin, &shape_dyn_begin, &tess_run, &elem_cnt, &run_base, &path_scan,
-                         &stroke_options, &descriptors, &elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
+        DevBuf* all[] = {&geometry, &elem_cnt, &run_base, &path_scan,
+                         &elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
         for (DevBuf* b : all) b->release();
@@ -584,6 +597,10 @@ crh_status flip_tess_set(crh_scene* sc) {
         // the same input gives the same totals: the sizes of the current set are right for this one (an overflow is caught as ever)
         o.capacity_known = sc->capacity_known;
         std::memcpy(o.totals_host, sc->totals_host, sizeof(o.totals_host));
+        std::memcpy(o.cap_host, sc->cap_host, sizeof(o.cap_host));
+        // (rows nobody has written yet must not send a pass anywhere: an optimistic run that does not fit leaves them as they are)
+        if (o.buf[5].p) HIP_TRY(hipMemsetAsync(o.buf[5].p, 0, o.buf[5].cap, sc->renderer->tessellation_stream()));
+        if (o.buf[6].p) HIP_TRY(hipMemsetAsync(o.buf[6].p, 0, o.buf[6].cap, sc->renderer->tessellation_stream()));
         o.emitted_bytes = sc->emitted_bytes;
         o.rendered_once = false;
         o.allocated = true;
@@ -596,14 +613,18 @@ crh_status flip_tess_set(crh_scene* sc) {
     std::swap(sc->rendered_once, o.rendered_once);
     std::swap(sc->last_render_one_event, o.last_render_one_event);
     std::swap(sc->emitted_bytes, o.emitted_bytes);
-    for (int c = 0; c < NCH; ++c) std::swap(sc->totals_host[c], o.totals_host[c]);
-    for (int c = 0; c < NCH; ++c) sc->d.capacity[c] = sc->capacity_known ? sc->totals_host[c] : 0u;
+    for (int c = 0; c < NCH; ++c) std::swap(sc->totals_host[c], o.totals_host[c]), std::swap(sc->cap_host[c], o.cap_host[c]);
+    for (int c = 0; c < NCH; ++c) sc->d.capacity[c] = sc->capacity_known ? sc->cap_host[c] : 0u;
     bind_tess_pointers(sc);
     return CRH_OK;
 }
 
 crh_status ensure_outputs(crh_scene* sc) {
-    const uint32_t* t = sc->totals_host;
+    // (a sixteenth + 64 records beyond the totals: new paths of the same structure — crh_scene_upload into this Scene — then fit without a wait)
+    uint32_t want[NCH];
+    for (int c = 0; c < NCH; ++c) want[c] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, (uint64_t)sc->totals_host[c] + sc->totals_host[c] / 16u + 64u);
+    want[CH_LINE_V] &= ~1u; // (pairs)
+    const uint32_t* t = want;
     SceneDev& d = sc->d;
     const size_t pairs = t[CH_LINE_V] / 2 + 1;
     HIP_TRY(sc->line_v.ensure((size_t)t[CH_LINE_V] * 20));
@@ -627,8 +648,9 @@ crh_status ensure_outputs(crh_scene* sc) {
         HIP_TRY(sc->hull_sort.ensure((size_t)t[CH_HULL] * 16 + 16));
         HIP_TRY(sc->hull_chain.ensure((size_t)t[CH_HULL] * 16 + 16));
     }
-    for (int c = 0; c < NCH; ++c) d.capacity[c] = t[c];
+    for (int c = 0; c < NCH; ++c) d.capacity[c] = sc->cap_host[c] = t[c]; // (what THIS sizing guarantees; the buffers themselves only grow)
     bind_tess_pointers(sc);
+    t = sc->totals_host;
     sc->emitted_bytes = (uint64_t)t[CH_LINE_V] * 20 + ((uint64_t)t[CH_LINE_V] + t[CH_LINE_CUT]) * 2 + (uint64_t)t[CH_JOINT] * (5 * 24 + 6 * 2) +
                         (uint64_t)t[CH_SOLID_V] * 8 + ((uint64_t)t[CH_SOLID_V] + t[CH_SOLID_END]) * 2 + (uint64_t)t[CH_IQ] * 48 + (uint64_t)t[CH_IC_V] * 20 +
                         (uint64_t)t[CH_RQ] * 60 + (uint64_t)t[CH_RC_V] * 24;
@@ -661,8 +683,10 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
         if (d.n_shapes) HIP_TRY(hipMemsetAsync(d.hull_count, 0, (size_t)d.n_shapes * 4, ts));
     }
     const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
-    launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke, !sc->capacity_known);
-    if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate exactly
+    // (the one-pass path counts once per upload — elem_cnt, run_base —, the two-pass path every time)
+    launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke, !sc->capacity_known || !sc->counts_valid);
+    sc->counts_valid = true;
+    if (!sc->capacity_known) { // first run: the output sizes are data dependent, fetch the totals once and allocate
         HIP_TRY(hipMemcpyAsync(sc->totals_host, d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost, ts));
         // (the tessellation stream alone: it has waited for the consumers of this set's streams — vertices_free, above — before the count kernel, and
         // the frames before this one go on binning and rasterizing on their streams while the host waits here. Until round 4 this was a wait for
@@ -671,6 +695,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
         crh_status st = ensure_outputs(sc);
         if (st != CRH_OK) return st;
         sc->capacity_known = true;
+        sc->optimistic = false;
     }
     if (sc->has_stroke) HIP_TRY(hipMemsetAsync(d.line_pair_cut, 0, sc->line_pair_cut.cap, ts));
     const uint64_t bytes2[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, (uint64_t)sc->totals_host[CH_HULL] * 8};
@@ -704,10 +729,14 @@ crh_status settle_tessellation(crh_scene* sc, uint32_t* status_word) {
         HIP_TRY(hipMemcpyAsync(&word, sc->d.status, 4, hipMemcpyDeviceToHost, r->tessellation_stream()));
         HIP_TRY(r->sync());
         if (word != 0xFFFFFFFFu && (word & 0xFFu) >= 0x80u && attempt == 0) {
-            sc->capacity_known = false;
+            sc->capacity_known = false, sc->optimistic = false;
             crh_status st = run_tessellation(sc, true);
             if (st != CRH_OK) return st;
             continue;
+        }
+        if (sc->optimistic && sc->capacity_known) { // the run fitted: the host may know its totals now (until here totals_host held the capacities)
+            HIP_TRY(hipMemcpy(sc->totals_host, sc->d.totals, sizeof(uint32_t) * NCH, hipMemcpyDeviceToHost));
+            sc->optimistic = false;
         }
         *status_word = word;
         return CRH_OK;
@@ -1013,7 +1042,9 @@ crh_status settle_frames_of(crh_scene* sc, bool forget) {
     for (crh_frame* f : sc->renderer->frames) {
         if (f->last_scene != sc) continue;
         if (f->check_pending) {
-            const crh_status st = settle_frame(f);
+            // (the frame's own flags, behind its own raster kernel — not a wait for every stream: with two Scenes in turn the frame in flight
+            // belongs to the OTHER one, and waiting for it made every upload a full stop; only a frame that ran out of capacity pays for that)
+            const crh_status st = settle_frame_cheaply(f);
             if (st != CRH_OK && result == CRH_OK) result = st;
         }
         if (forget) f->last_scene = nullptr;
@@ -1045,6 +1076,10 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.raster_done, 0));
     if (set.used) HIP_TRY(hipStreamWaitEvent(bin, set.flags_ready, 0)); // (the copy of the flag words this pass is about to clear)
     if (sc->rec_used[rec] && !(set.used && set.raster_serial == sc->rec_raster_serial[rec])) HIP_TRY(hipStreamWaitEvent(bin, sc->rec_raster_done[rec], 0));
+    // A pass drawn from an optimistic tessellation (crh_scene::optimistic) takes the tessellation's status word along among its flag words — here, behind
+    // tess_done and in front of the binning kernels (whose end releases this set of streams to the tessellation after next, which clears the word)
+    f->last_tess_optimistic = sc->optimistic;
+    if (sc->optimistic && !std::getenv("CRH_NO_STATUS_COPY")) HIP_TRY(hipMemcpyAsync(static_cast<uint32_t*>(set.overflow_p) + kTessStatusWord, sc->d.status, 4, hipMemcpyDeviceToDevice, bin));
     RasterParams p;
     p.width = f->width;
     p.height = f->height;
@@ -1170,21 +1205,23 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     if (!recorded) {
         if (f->seen_scene == sc && f->last_pass_instances != ~0ull && f->last_pass_instances != sc->instances_version) f->moving = true;
         f->last_pass_instances = sc->instances_version;
+        if (f->seen_scene == sc && f->last_pass_geometry != 0 && f->last_pass_geometry != sc->generation) f->moving = true; // (new paths of the same structure: the lists change like those of moving instances)
+        f->last_pass_geometry = sc->generation;
     }
-    if (f->seen_scene == sc && f->seen_generation == sc->generation) f->seen_passes += 1u;
-    else f->seen_scene = sc, f->seen_generation = sc->generation, f->seen_passes = 0u;
+    if (f->seen_scene == sc && f->seen_generation == sc->lineage) f->seen_passes += 1u;
+    else f->seen_scene = sc, f->seen_generation = sc->lineage, f->seen_passes = 0u;
     if (edges && !recorded && f->pairs_known && f->seen_passes == 2u && !no_direct && f->direct_misses < 3u &&
-        !(f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation))
+        !(f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->lineage))
         f->pairs_known = false;
-    const bool direct = edges && !recorded && f->pairs_known && f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->generation && f->direct_misses < 3u && !no_direct;
+    const bool direct = edges && !recorded && f->pairs_known && f->direct_ready && f->direct_scene == sc && f->direct_generation == sc->lineage && f->direct_misses < 3u && !no_direct;
     p.direct = direct ? 1u : 0u;
-    const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->generation;
+    const bool skip_queue = edges && !recorded && f->pairs_known && !f->queue_seen && f->direct_scene == sc && f->direct_generation == sc->lineage;
     p.skip_queue = skip_queue ? 1u : 0u;
     p.tile_base = (f->base_cur ? f->tile_base_b : f->tile_base).as<uint32_t>();
     p.tile_order = f->tile_order_ready ? f->tile_order.as<uint32_t>() : nullptr;
     p.order_places = f->tile_order_ready ? f->tile_order_places : 0u;
     const bool no_batches = getenv("CRH_NO_BIN_BATCHES") != nullptr; // A/B runs and tests (read per pass: they switch it inside one process)
-    const bool batches = edges && !no_batches && f->n_bin_batches != 0u && f->batches_scene == sc && f->batches_generation == sc->generation && f->batches_items == p.n_items;
+    const bool batches = edges && !no_batches && f->n_bin_batches != 0u && f->batches_scene == sc && f->batches_generation == sc->lineage && f->batches_items == p.n_items;
     p.bin_batches = batches ? f->bin_batches.as<uint32_t>() : nullptr, p.n_bin_batches = batches ? f->n_bin_batches : 0u;
     p.item_cost = nullptr;
     static const bool bin_dump = getenv("CRH_BIN_DUMP") != nullptr; // tools/bin_phases.py (a library built with -DCRH_ABLATE): a record per workgroup behind the costs
@@ -1235,7 +1272,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                 launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), places, p.scan_scratch, p.n_tiles, p.tiles_x, f->moving ? kMovingListRadius : 0u, bin);
                 HIP_TRY(hipMemcpyAsync(&total, places + p.n_tiles, 4, hipMemcpyDeviceToHost, bin));
                 HIP_TRY(hipStreamSynchronize(bin));
-                f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->generation;
+                f->direct_entries = total, f->direct_ready = true, f->direct_scene = sc, f->direct_generation = sc->lineage;
                 f->places_instances = recorded ? ~0ull : sc->instances_version;
                 f->queue_seen = ov[6] != 0;
                 f->n_bin_batches = 0;
@@ -1247,7 +1284,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
                     HIP_TRY(f->bin_batches.ensure(starts.size() * 4));
                     HIP_TRY(hipMemcpyAsync(f->bin_batches.p, starts.data(), starts.size() * 4, hipMemcpyHostToDevice, bin));
                     HIP_TRY(hipStreamSynchronize(bin));
-                    f->n_bin_batches = (uint32_t)(starts.size() / 2), f->batches_items = p.n_items, f->batches_scene = sc, f->batches_generation = sc->generation, f->batches_age = 0;
+                    f->n_bin_batches = (uint32_t)(starts.size() / 2), f->batches_items = p.n_items, f->batches_scene = sc, f->batches_generation = sc->lineage, f->batches_age = 0;
                     if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] %u items in %u batches of k_bin_flat\n", p.n_items, f->n_bin_batches);
                 }
             }
@@ -1305,7 +1342,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     HIP_TRY(hipEventRecord(set.raster_done, r->stream));
     HIP_TRY(hipEventRecord(sc->rec_raster_done[rec], r->stream));
     HIP_TRY(hipStreamWaitEvent(r->aux_stream, set.raster_done, 0));
-    HIP_TRY(hipMemcpyAsync(set.flags_host, set.overflow_p, sizeof(uint32_t) * (kExtraTurnsWord + 1u), hipMemcpyDeviceToHost, r->aux_stream));
+    HIP_TRY(hipMemcpyAsync(set.flags_host, set.overflow_p, sizeof(uint32_t) * (kTessStatusWord + 1u), hipMemcpyDeviceToHost, r->aux_stream));
     HIP_TRY(hipEventRecord(set.flags_ready, r->aux_stream));
     set.raster_serial = sc->rec_raster_serial[rec] = ++r->render_serial;
     r->raster_events[1] = r->raster_events[0], r->raster_events[0] = sc->rec_raster_done[rec];
@@ -1314,7 +1351,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         trial->recorded = true;
     }
     set.used = true;
-    sc->rec_used[rec] = true;
+    sc->rec_used[rec] = true, sc->rec_used_ever[rec] = true;
     sc->rendered_once = true;
     HIP_TRY(hipGetLastError());
     f->last_set = f->next_set;
@@ -1355,13 +1392,24 @@ crh_status stale_batches(crh_frame* f, hipStream_t stream) {
     }
     return CRH_OK;
 }
+bool tess_status_overflowed(uint32_t word) { return word != 0xFFFFFFFFu && (word & 0xFFu) >= 0x80u; }
 crh_status settle_frame(crh_frame* f) {
     if (!f->check_pending) return CRH_OK;
     crh_renderer* r = f->renderer;
     uint32_t ov[8];
     HIP_TRY(r->sync());
     HIP_TRY(hipMemcpyAsync(ov, f->sets[f->last_set].overflow_p, 32, hipMemcpyDeviceToHost, r->stream));
+    uint32_t tess_word = 0xFFFFFFFFu;
+    if (f->last_tess_optimistic) HIP_TRY(hipMemcpyAsync(&tess_word, static_cast<const uint32_t*>(f->sets[f->last_set].overflow_p) + kTessStatusWord, 4, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(r->sync());
+    const bool tess_overflow = tess_status_overflowed(tess_word) && f->last_scene != nullptr;
+    if (tess_overflow) { // the optimistic tessellation this pass drew did not fit its streams: size them from the totals, tessellate, and draw again
+        if (getenv("CRH_PASS_VERBOSE")) std::fprintf(stderr, "[contrast-hip] the tessellation of re-uploaded paths outgrew the streams of the paths before them: sized again, the pass is drawn again\n");
+        crh_scene* const sc = f->last_scene;
+        sc->capacity_known = false, sc->optimistic = false;
+        const crh_status st = run_tessellation(sc, true);
+        if (st != CRH_OK) return st;
+    }
     {
         const crh_status stale = stale_batches(f, r->stream);
         if (stale != CRH_OK) return stale;
@@ -1380,7 +1428,8 @@ crh_status settle_frame(crh_frame* f) {
     }
     const bool queue_missed = ov[6] != 0 && f->last_skipped_queue; // items were queued for a kernel that was not launched: again, with it
     if (queue_missed) f->queue_seen = true, f->pairs_known = false;
-    if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed || queue_missed) {
+    if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed || queue_missed || tess_overflow) {
+        if (tess_overflow) f->pairs_known = false; // (what the pass learned, it learned from stale rows)
         if (ov[0] != 0 || ov[5] != 0) f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
@@ -1407,7 +1456,8 @@ crh_status settle_frame_cheaply(crh_frame* f) {
     const uint32_t* ov = set.flags_host;
     const uint32_t limit = 32768u / (4u * (r->config.msaa_sample_count == 4 ? 4u : 1u));
     const bool sort_too_small = ov[3] > f->sort_capacity && f->sort_capacity < limit;
-    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small || (ov[6] != 0 && f->last_skipped_queue)) return settle_frame(f);
+    if (ov[0] != 0 || ov[5] != 0 || ov[2] != 0 || ov[7] != 0 || sort_too_small || (ov[6] != 0 && f->last_skipped_queue) || (f->last_tess_optimistic && tess_status_overflowed(ov[kTessStatusWord])))
+        return settle_frame(f);
     f->longest_list = std::max(f->longest_list, ov[3]);
     if (f->last_direct && ++f->direct_clean >= 32u) f->direct_misses = 0u, f->direct_clean = 0u;
     stale_batches_known(f, ov[kExtraTurnsWord]);
@@ -1513,6 +1563,11 @@ crh_status crh_convert_dynamic_stroke_options(const crh_dynamic_stroke_options* 
 }
 
 crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene* existing, crh_scene** out) {
+    static const bool phase_timing = std::getenv("CRH_UPLOAD_TIMING") != nullptr; // development: host microseconds of the call's phases on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (phase_timing) std::fprintf(stderr, "[upload] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), name);
+    };
     if (!r || !b || !out) return CRH_ERR_INVALID_ARGUMENT;
     // ---- structure of the batch: a C ABI cannot trust its index arrays (the Rust types make these states unrepresentable)
     {
@@ -1561,10 +1616,13 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     const uint32_t n_elems = b->n_segments + 2u * b->n_paths;
     HIP_TRY(hipSetDevice(r->device));
     if (existing) {
+        phase("validated");
         const crh_status st = settle_frames_of(existing, false);
         if (st != CRH_OK) return st;
+        phase("frames settled");
     }
     crh_scene* sc = existing ? existing : new crh_scene;
+    // ---- the one-pass tessellation's runs ... (below) and: are these paths of the structure the Scene already holds?
     // ---- element stream: MOVE, segments..., END per path; pool = start point + records, -0 canonicalised (safe_float.rs:44-52) — built straight
     //      into pinned staging memory (one arena for all thirteen arrays; the copies to the device are asynchronous, the tessellation waits
     //      for them through an event). Nothing of the Scene is touched before the geometry is known to be finite.
@@ -1601,6 +1659,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     }
     enum { P_TYPE, P_OFF, P_PREV, P_PATH, P_POOL, P_PATH_BEGIN, P_PATH_SHAPE, P_PATH_STROKE, P_SHAPE_BEGIN, P_DYN_BEGIN, P_OPTIONS, P_DESCRIPTORS, P_RUNS };
     uint8_t* arena = nullptr;
+    phase("runs");
     if (!hip_ok(sc->geometry_stage.begin(arena_bytes + 256u, &arena), "hipHostMalloc")) {
         if (!existing) delete sc;
         return CRH_ERR_HIP;
@@ -1664,6 +1723,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         if (!descriptors.empty()) std::memcpy(arena + part[P_DESCRIPTORS].at, descriptors.data(), part[P_DESCRIPTORS].bytes);
         if (!runs.empty()) std::memcpy(arena + part[P_RUNS].at, runs.data(), part[P_RUNS].bytes);
     }
+    phase("element stream built");
     sc->renderer = r;
     sc->device = r->device;
     static std::atomic<uint64_t> next_generation{1}; // unique across scenes (and threads): a new Scene at a recycled address is not mistaken for the old one
@@ -1681,9 +1741,14 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
                 return CRH_ERR_HIP;
             }
     }
+    // New paths of the structure the Scene holds (as many Shapes, paths, elements, the same tessellation path) and sized streams: the capacities
+    // stay, no wait for the totals (crh_scene::optimistic). CRH_NO_OPTIMISTIC_UPLOAD: A/B runs and the tests of the other way.
+    const uint32_t new_runs = (runs.empty() || n_elems == 0u) ? 0u : (uint32_t)runs.size() - 1u;
+    const bool same_structure = existing && sc->capacity_known && sc->d.n_elems == n_elems && sc->d.n_paths == b->n_paths && sc->d.n_shapes == b->n_shapes && sc->has_stroke == has_stroke &&
+                                sc->d.n_runs == new_runs && n_elems != 0u && std::getenv("CRH_NO_OPTIMISTIC_UPLOAD") == nullptr;
     sc->rendered_once = false;
     sc->last_render_one_event = false;
-    if (sc->shadow.allocated) { // sized for the previous contents
+    if (sc->shadow.allocated && !same_structure) { // sized for the previous contents
         if (!hip_ok(r->sync(), "sync")) return CRH_ERR_HIP;
         for (DevBuf& buf : sc->shadow.buf) buf.release();
         sc->shadow.allocated = false;
@@ -1708,7 +1773,14 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     for (bool& used : sc->rec_used) used = false;
     sc->n_segments = b->n_segments;
     sc->has_stroke = has_stroke;
-    sc->capacity_known = false;
+    sc->capacity_known = same_structure, sc->optimistic = same_structure, sc->counts_valid = false;
+    if (same_structure) {
+        std::memcpy(sc->totals_host, sc->cap_host, sizeof(sc->totals_host)); // (upper bounds, for what the host sizes from the totals)
+        if (sc->shadow.allocated) std::memcpy(sc->shadow.totals_host, sc->shadow.cap_host, sizeof(sc->shadow.totals_host));
+    } else {
+        sc->lineage = sc->generation;
+    }
+    if (std::getenv("CRH_NO_LINEAGE")) sc->lineage = sc->generation; // (A/B runs: a frame's list places and batch runs do not outlive an upload)
     if (sc->hull_queued_state == 1) (void)hipEventSynchronize(sc->hull_queued_ready); // (a copy of the old paths' counts still on its way)
     sc->hull_queued_state = 0;
     sc->instances_set = false;
@@ -1730,24 +1802,29 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.n_paths = b->n_paths;
     d.n_shapes = b->n_shapes;
     d.n_wg = (n_elems + kTessBlock - 1) / kTessBlock;
-    d.n_runs = (runs.empty() || n_elems == 0u) ? 0u : (uint32_t)runs.size() - 1u;
-    hipStream_t st = r->stream;
+    d.n_runs = new_runs;
+    for (int c = 0; c < NCH; ++c) d.capacity[c] = same_structure ? sc->cap_host[c] : 0u;
+    // ONE asynchronous copy of the whole arena into a device arena of the same layout (round 5; until then fourteen copies into fourteen buffers on the
+    // raster stream, in line behind the raster kernel of the frame in front). It runs on the upload stream, behind the last readers of the Scene's old
+    // paths only: its tessellation and the raster kernels of the passes that drew it (their binning comes first on the way) — the frames in flight
+    // from OTHER Scenes are not waited for, so new paths travel while the frame in front is drawn. No host wait.
+    const hipStream_t st = r->upload_stream;
     crh_status rc;
-    {   // thirteen asynchronous copies out of the arena, behind whatever still reads the old geometry; no host wait
+    {
         if (!sc->geometry_ready && !hip_ok(hipEventCreateWithFlags(&sc->geometry_ready, hipEventDisableTiming), "hipEventCreate")) {
             rc = CRH_ERR_HIP;
             goto fail;
         }
         bool ok = true;
         if (existing && sc->tess_done && sc->tessellated_once_before_upload) ok = hip_ok(hipStreamWaitEvent(st, sc->tess_done, 0), "hipStreamWaitEvent"); // a tessellation of the old paths may still run
-        auto up = [&](DevBuf& buf, int k) {
-            if (!ok) return;
-            ok = hip_ok(buf.ensure(part[k].bytes), "hipMalloc");
-            if (ok && part[k].bytes) ok = hip_ok(hipMemcpyAsync(buf.p, arena + part[k].at, part[k].bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
-        };
-        up(sc->elem_type, P_TYPE), up(sc->elem_off0, P_OFF), up(sc->elem_off, P_OFF), up(sc->elem_prev_off, P_PREV), up(sc->elem_path, P_PATH), up(sc->pool, P_POOL);
-        up(sc->path_elem_begin, P_PATH_BEGIN), up(sc->path_shape, P_PATH_SHAPE), up(sc->path_stroke, P_PATH_STROKE), up(sc->shape_elem_begin, P_SHAPE_BEGIN);
-        up(sc->shape_dyn_begin, P_DYN_BEGIN), up(sc->stroke_options, P_OPTIONS), up(sc->descriptors, P_DESCRIPTORS), up(sc->tess_run, P_RUNS);
+        if (existing && sc->shadow.tess_done && sc->tessellated_once_before_upload) ok = ok && hip_ok(hipStreamWaitEvent(st, sc->shadow.tess_done, 0), "hipStreamWaitEvent");
+        for (int k = 0; k < kPipelineDepth && ok; ++k)
+            if (existing && sc->rec_used_ever[k]) ok = hip_ok(hipStreamWaitEvent(st, sc->rec_raster_done[k], 0), "hipStreamWaitEvent");
+        // (the element offsets exist twice on the device when a path is stroked: k_stroke_records rewrites elem_off, elem_off0 stays)
+        const size_t second_off = has_stroke ? ((part[P_OFF].bytes + 255u) & ~(size_t)255u) : 0u;
+        ok = ok && hip_ok(sc->geometry.ensure(arena_bytes + second_off + 256u), "hipMalloc");
+        if (ok && arena_bytes) ok = hip_ok(hipMemcpyAsync(sc->geometry.p, arena, arena_bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        if (ok && second_off) ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(sc->geometry.p) + arena_bytes, arena + part[P_OFF].at, part[P_OFF].bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
         // the status word: cleared IN FRONT of geometry_ready — the tessellation stream waits for that event only, then clears the word itself and
         // lets its kernels write error codes; a memset enqueued behind the event would be unordered against those writes
         if (ok) ok = hip_ok(sc->status.ensure(4), "hipMalloc") && hip_ok(hipMemsetAsync(sc->status.p, 0xFF, 4, st), "hipMemset");
@@ -1772,22 +1849,28 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         rc = CRH_ERR_HIP;
         goto fail;
     }
-    d.elem_type = sc->elem_type.as<uint8_t>();
-    d.elem_off0 = sc->elem_off0.as<uint32_t>();
-    d.elem_off = sc->elem_off.as<uint32_t>();
-    d.elem_prev_off = sc->elem_prev_off.as<uint32_t>();
-    d.elem_path = sc->elem_path.as<uint32_t>();
-    d.pool = sc->pool.as<float>();
-    d.path_elem_begin = sc->path_elem_begin.as<uint32_t>();
-    d.path_shape = sc->path_shape.as<uint32_t>();
-    d.path_stroke = sc->path_stroke.as<int32_t>();
-    d.shape_elem_begin = sc->shape_elem_begin.as<uint32_t>();
-    d.shape_dyn_begin = sc->shape_dyn_begin.as<uint32_t>();
-    d.stroke_options = sc->stroke_options.as<crh_stroke_options>();
-    d.descriptors = sc->descriptors.as<crh_dynamic_stroke_descriptor>();
-    d.tess_run = sc->tess_run.as<uint32_t>(), d.elem_cnt = sc->elem_cnt.as<uint32_t>(), d.run_base = sc->run_base.as<uint32_t>();
+    {
+        uint8_t* const g = static_cast<uint8_t*>(sc->geometry.p);
+        auto at = [&](int k) { return g + part[k].at; };
+        d.elem_type = at(P_TYPE);
+        d.elem_off0 = reinterpret_cast<const uint32_t*>(at(P_OFF));
+        d.elem_off = has_stroke ? reinterpret_cast<uint32_t*>(g + arena_bytes) : reinterpret_cast<uint32_t*>(at(P_OFF)); // (only k_stroke_records writes it)
+        d.elem_prev_off = reinterpret_cast<uint32_t*>(at(P_PREV));
+        d.elem_path = reinterpret_cast<const uint32_t*>(at(P_PATH));
+        d.pool = reinterpret_cast<const float*>(at(P_POOL));
+        d.path_elem_begin = reinterpret_cast<const uint32_t*>(at(P_PATH_BEGIN));
+        d.path_shape = reinterpret_cast<const uint32_t*>(at(P_PATH_SHAPE));
+        d.path_stroke = reinterpret_cast<const int32_t*>(at(P_PATH_STROKE));
+        d.shape_elem_begin = reinterpret_cast<const uint32_t*>(at(P_SHAPE_BEGIN));
+        d.shape_dyn_begin = reinterpret_cast<const uint32_t*>(at(P_DYN_BEGIN));
+        d.stroke_options = reinterpret_cast<const crh_stroke_options*>(at(P_OPTIONS));
+        d.descriptors = reinterpret_cast<crh_dynamic_stroke_descriptor*>(at(P_DESCRIPTORS));
+        d.tess_run = reinterpret_cast<const uint32_t*>(at(P_RUNS));
+    }
+    d.elem_cnt = sc->elem_cnt.as<uint32_t>(), d.run_base = sc->run_base.as<uint32_t>();
     bind_tess_pointers(sc);
     if (!existing) r->scenes.push_back(sc);
+    phase("enqueued");
     *out = sc;
     return CRH_OK;
 fail:
@@ -1920,6 +2003,7 @@ crh_status crh_scene_set_dynamic_stroke_options(crh_scene* sc, uint32_t shape, u
         const crh_status pending = settle_frames_of(sc, false);
         if (pending != CRH_OK) return pending;
     }
+    if (sc->geometry_ready) HIP_TRY(hipEventSynchronize(sc->geometry_ready)); // (the arena of the last upload — the descriptors are part of it — may still be on its way)
     HIP_TRY(hipMemcpyAsync(sc->d.descriptors + begin + group, &d, sizeof(d), hipMemcpyHostToDevice, sc->renderer->stream));
     HIP_TRY(sc->renderer->sync());
     return CRH_OK;

@@ -931,7 +931,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
 // The same binning with the lanes packed ACROSS draw items. k_bin_edges gives every item a wavefront per role and each of them walks
 // item -> ranges -> vertices -> records -> LDS passes -> returning atomics alone: 20 000 wavefronts of 33 us for the benchmark scene, a
 // third to two thirds of their lanes idle (18 triangles, 40 edges per item), and that sum of wavefront lifetimes, not arithmetic, was the
-// kernel's time. Here a 256-thread workgroup takes a batch of up to 32 consecutive items at once:
+// kernel's time. Here a workgroup (kFlatThreads lanes) takes a batch of up to kFlatThreads / 8 consecutive items at once:
 //   0  lane = item: the item's record (ItemCtx, slot ranges, counts) into LDS — ONE round of dependent loads for the whole batch;
 //   A  lane = triangle / lane = edge over the batch (prefix sums of the items' counts in LDS, five-step search): set-up records written
 //      to the heap, the primitive kept in registers, the item's pixel box and the facing of its hull strip gathered with LDS atomics;
@@ -955,7 +955,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
 #define CRH_FLAT_STAGE 128
 #endif
 #ifndef CRH_FLAT_THREADS
-#define CRH_FLAT_THREADS 256 // threads of a workgroup of k_bin_flat: 256 (four wavefronts, a batch of up to 32 items) or 64 (ONE wavefront, a quarter of every table)
+#define CRH_FLAT_THREADS 128 // threads of a workgroup of k_bin_flat: 256 (four wavefronts, a batch of up to 32 items), 128 or 64 (ONE wavefront, a quarter of every table).
+                             // Round 5 (tools/r05b_flat_shape.sh): alone the kernel is fastest with 256 (S10k 0.112 ms; 128: 0.124; 64: 0.200) — but it runs in the gap between
+                             // two raster kernels, where a workgroup starts as soon as ALL its wavefronts find registers and LDS on one CU, and a two-wave workgroup finds
+                             // them earlier behind the draining raster grid: pipelined step S10k 0.3175 -> 0.3013 ms (64: 0.349), glyphs 0.716 -> 0.696 (0.708), S100k 2.07 -> 2.05 (1.94)
 #endif
 constexpr uint32_t kFlatThreads = CRH_FLAT_THREADS, kFlatWaveCount = kFlatThreads / 64u;
 static_assert(kFlatThreads == 64u || kFlatThreads == 128u || kFlatThreads == kFlatThreads, "CRH_FLAT_THREADS");

@@ -20,6 +20,7 @@ struct DrawItem {
     uint32_t refs; // bits 0-7 clip depth of the stencil phase, 8-15 clip depth of the cover phase, 16-23 alpha layer
 };
 
+constexpr uint32_t kTessStatusWord = 126; // ... the status word of the optimistic tessellation a pass drew (api.hip: crh_scene::optimistic), copied in by the host side
 constexpr uint32_t kExtraTurnsWord = 76; // of RasterParams::overflow: behind the 8 flag words and the 64 cursors of the pair sub-streams
 struct RasterParams {
     uint32_t width, height, tiles_x, tiles_y, n_tiles; // 16x16-pixel tiles

@@ -142,3 +142,95 @@ def test_stale_capacities_are_caught_and_sized_again(gpu, oracle_lib):
         frame.clear()
         scene.render(frame, sc["transforms"], sc["colors"])
         assert np.array_equal(frame.download(), oracle.render(320, 320, sc["msaa"], sc["winding_bits"], sc["transforms"], sc["colors"]))
+
+
+def _wobbly_scene(n_shapes, seed, kind, size=(512, 512)):
+    """n_shapes Shapes of one closed path of eight segments each — one structure (as many Shapes, paths and elements) whatever `kind` is:
+    kind 0 octagons (few records per segment), kind 1 the benchmark's mixed integral / rational cubic blobs drawn from the PCG streams
+    behind path `seed * n_shapes` (several times the records). Returns (batch, transforms, colors)."""
+    from contrast_renderer_amd import scenes
+    from contrast_renderer_amd.path import Path, batch_from_shapes
+    if kind == 1:
+        sc = scenes.scene_cubic_fill(n_shapes, size, r_lo=8.0, r_hi=40.0, first_path=seed * n_shapes)
+        return sc["batch"], sc["transforms"], sc["colors"]
+    rng = np.random.RandomState(seed)
+    shapes = []
+    for _ in range(n_shapes):
+        cx, cy = rng.uniform(40, size[0] - 40), rng.uniform(40, size[1] - 40)
+        rad = rng.uniform(10, 36)
+        pts = [(cx + rad * np.cos(-2 * np.pi * i / 8 + 0.1 * rng.uniform(-1, 1)), cy + rad * np.sin(-2 * np.pi * i / 8 + 0.1 * rng.uniform(-1, 1))) for i in range(8)]
+        p = Path(start=pts[0])
+        for i in range(1, 9):
+            p.push_line(pts[i % 8])
+        shapes.append(([], [p]))
+    batch = batch_from_shapes(shapes)
+    transforms = np.tile(scenes.ortho_pixels(*size), (n_shapes, 1, 1))
+    colors = np.concatenate([rng.uniform(0, 1, (n_shapes, 3)), rng.uniform(0.4, 1.0, (n_shapes, 1))], axis=1).astype(np.float32)
+    return batch, transforms, colors
+
+
+@pytest.mark.parametrize("optimistic", [True, False])
+def test_new_paths_of_the_same_structure_keep_the_capacities(gpu, oracle_lib, optimistic, monkeypatch, capfd):
+    """crh_scene_upload into an existing Scene with paths of the structure it holds: no wait for the totals (api.hip: crh_scene::optimistic).
+    Control points that move (the counts change a little: the headroom), then polygons replaced by cubics of the same structure (several
+    times the records: the run does not fit, the frame finds the overflow code among its flags, everything is sized and drawn again), then
+    back. Every frame and every Shape's bytes against the oracle; CRH_NO_OPTIMISTIC_UPLOAD is the old way."""
+    if not optimistic:
+        monkeypatch.setenv("CRH_NO_OPTIMISTIC_UPLOAD", "1")
+    monkeypatch.setenv("CRH_PASS_VERBOSE", "1")  # (the library says on stderr when a frame finds its tessellation's overflow code)
+    r = gpu.Renderer(gpu.Configuration(msaa_sample_count=1, winding_counter_bits=4), device=0)
+    frames = [gpu.Frame(r, 512, 512), gpu.Frame(r, 512, 512)]
+    scene = None
+    n = 300
+    sequence = [(0, 4), (0, 5), (1, 1), (1, 2), (1, 3), (0, 8), (1, 6), (1, 7), (0, 9), (1, 10)]  # (the streams never shrink: the octagons come first)
+    for step, (kind, seed) in enumerate(sequence):
+        batch, transforms, colors = _wobbly_scene(n, seed, kind)
+        oracle = oracle_lib.Oracle(batch, 4)
+        assert oracle.status() == 0
+        scene = gpu.Scene(r, batch, tessellate=False, existing=scene)
+        scene.set_instances(transforms, colors)
+        scene.tessellate()
+        f = frames[step % 2]
+        f.clear()
+        scene.render(f)
+        if step % 3 == 2:  # some steps: the Shape bytes as well (a synchronising call between upload and download)
+            _assert_equal(scene, oracle, f"step {step} (kind {kind})")
+        image = f.download()
+        expect = oracle.render(512, 512, 1, 4, transforms, colors)
+        assert np.array_equal(image, expect), f"step {step} (kind {kind}): {(image != expect).any(axis=2).sum()} pixels differ"
+        assert scene.status() == 0
+        _assert_equal(scene, oracle, f"step {step} (kind {kind}), after the frame")
+    redrawn = capfd.readouterr().err.count("outgrew the streams")
+    assert (redrawn >= 1) if optimistic else (redrawn == 0), redrawn  # octagons -> cubics of the same structure does not fit: found by the frame
+
+
+def test_two_scenes_in_turn_with_frames_in_flight(gpu, oracle_lib):
+    """The loop of bench.py --reupload: two Scenes and two frames in turn, new paths of the same structure every step, nothing waited for
+    until the end; then every frame's pixels."""
+    r = gpu.Renderer(gpu.Configuration(msaa_sample_count=1, winding_counter_bits=4), device=0)
+    n = 400
+    frames = [gpu.Frame(r, 512, 512), gpu.Frame(r, 512, 512)]
+    first = _wobbly_scene(n, 100, 0)
+    scenes_ = [gpu.Scene(r, first[0]), gpu.Scene(r, first[0])]
+    for s in scenes_:
+        assert s.status() == 0
+    last = [None, None]
+    for step in range(12):
+        batch, transforms, colors = _wobbly_scene(n, 101 + step, 0 if step % 5 == 3 else 1)
+        k = step % 2
+        if last[k] is not None:  # the frame about to be reused is consumed first
+            image = frames[k].download()
+            o, tr, co = last[k]
+            assert np.array_equal(image, o.render(512, 512, 1, 4, tr, co)), f"frame of step {step - 2}"
+        scenes_[k] = gpu.Scene(r, batch, tessellate=False, existing=scenes_[k])
+        scenes_[k].set_instances(transforms, colors)
+        scenes_[k].tessellate()
+        frames[k].clear()
+        scenes_[k].render(frames[k])
+        oracle = oracle_lib.Oracle(batch, 4)
+        assert oracle.status() == 0
+        last[k] = (oracle, transforms, colors)
+    for k in range(2):
+        o, tr, co = last[k]
+        assert np.array_equal(frames[k].download(), o.render(512, 512, 1, 4, tr, co))
+        assert scenes_[k].status() == 0
