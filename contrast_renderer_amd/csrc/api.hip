@@ -29,6 +29,8 @@ void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint6
 void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_items, uint32_t* item_nslots, uint32_t* slot_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_bin);
 void launch_scatter(const RasterParams& r, hipStream_t stream, MarkFn mark, void* ctx);
+void launch_shape_bounds(const SceneDev& s, float* bounds, hipStream_t stream);
+void launch_slab_items(const RasterParams& r, uint8_t* elsewhere, hipStream_t stream);
 void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream);
 bool bin_itemwise(const RasterParams& r);
 void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs);
@@ -287,6 +289,7 @@ struct crh_frame {
         uint64_t raster_serial = 0; // the render call that recorded raster_done
         DevBuf pair_tile, pair_pos, pair_key;       // the edge pass: (tile, key) pairs as the binning waves produced them (same capacity as tile_list)
         DevBuf bin_queue;                           // the edge pass: items handed from k_bin_flat to k_bin_edges
+        DevBuf item_elsewhere;                      // a pass with a slab: one byte per item, 1 = the item misses the slab (k_slab_items)
         hipEvent_t bin_done = nullptr;    // recorded on the binning stream after the fill pass
         hipEvent_t raster_done = nullptr; // recorded on the raster stream after the raster kernel that read this set
         // The pass' flag words (overflow[0 .. kExtraTurnsWord]) copied to pinned host memory on the side stream as soon as its raster kernel is
@@ -405,6 +408,8 @@ struct crh_scene {
     int hull_queued_state = 0; // 0 unknown, 1 the copy is on its way, 2 known
     std::vector<uint32_t> shape_dyn_begin_host;
     // inputs
+    DevBuf shape_bounds;             // [n_shapes][4] every Shape's box in its own coordinates (k_shape_bounds): passes with a slab (the tile split) leave out the items that miss it
+    uint64_t bounds_generation = 0;  // ... of which upload (the same paths tessellate to the same hulls: once per upload, by the first pass with a slab)
     DevBuf geometry; // the uploaded element stream: ONE arena (the layout of crh_scene_upload's pinned staging arena), one copy
     DevBuf elem_cnt, run_base; // the one-pass tessellation: runs of Shapes, every element's packed counts, the runs' bases (scene.hpp) — per upload
     // scan state
@@ -486,7 +491,7 @@ struct crh_scene {
     bool layout_valid = false;
 
     void release_all() {
-        DevBuf* all[] = {&geometry, &elem_cnt, &run_base, &path_scan,
+        DevBuf* all[] = {&geometry, &shape_bounds, &elem_cnt, &run_base, &path_scan,
                          &elem_scan, &wg_total, &wg_base, &group_base, &totals, &shape_base, &hull_count, &hull_large, &hull_sort, &hull_chain, &status, &line_v, &joint_v,
                          &solid_v, &iq_v, &ic_v, &rq_v, &rc_v, &hull_cand, &hull_v, &line_i, &joint_i, &solid_i, &solid_flag, &line_pair_cut,
                          &line_pair_mode, &line_inc, &transforms, &colors, &transforms_b, &colors_b, &shape_ncand, &shape_prim_begin, &prim_scan_scratch, &shape_nslots, &shape_slot_begin};
@@ -1087,6 +1092,17 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.tiles_y = f->tiles_y;
     p.n_tiles = f->n_tiles;
     p.slab_ty0 = f->slab_ty0, p.slab_ty1 = std::min(f->slab_ty1, f->tiles_y);
+    p.shape_bounds = nullptr, p.item_elsewhere = nullptr;
+    // a pass with a slab (the tile split): the Shapes' boxes let the binning kernels leave out the items without a row in it before they set them up
+    static const bool no_slab_cull = getenv("CRH_NO_SLAB_CULL") != nullptr; // A/B runs
+    if ((p.slab_ty0 > 0u || p.slab_ty1 < f->tiles_y) && !no_slab_cull && sc->d.n_shapes != 0u) {
+        HIP_TRY(sc->shape_bounds.ensure((size_t)sc->d.n_shapes * 16));
+        if (sc->bounds_generation != sc->generation) {
+            launch_shape_bounds(sc->d, sc->shape_bounds.as<float>(), bin);
+            sc->bounds_generation = sc->generation;
+        }
+        p.shape_bounds = sc->shape_bounds.as<float>();
+    }
     p.winding_mask = (1u << r->config.winding_counter_bits) - 1u;
     p.clip_mask_count = (1u << r->config.clip_nesting_counter_bits) - 1u;
     p.items = recorded ? f->items.as<DrawItem>() : nullptr;
@@ -1243,6 +1259,11 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
             p.pair_key = set.pair_key.as<uint32_t>();
             HIP_TRY(set.bin_queue.ensure((size_t)p.n_items * 4 + 4));
             p.bin_queue = set.bin_queue.as<uint32_t>();
+            if (p.shape_bounds) { // a pass with a slab: which items miss it (transforms, items and slab are all set by now)
+                HIP_TRY(set.item_elsewhere.ensure((size_t)p.n_items + 4));
+                launch_slab_items(p, set.item_elsewhere.as<uint8_t>(), bin);
+                p.item_elsewhere = set.item_elsewhere.as<uint8_t>();
+            }
             launch_bin_edges(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
         } else
         launch_bin(sc->d, p, r->config.msaa_sample_count, bin, r->mark_fn_bin(), r, sc->vertices_free);
@@ -2076,7 +2097,7 @@ void crh_frame_destroy(crh_frame* f) {
     f->item_upload_c.release();
     for (InstanceSlot& k : f->item_slot) k.release();
     for (crh_frame::BinSet& set : f->sets) {
-        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key, &set.bin_queue};
+        DevBuf* bins[] = {&set.tile_count_cursor, &set.tile_offset, &set.tile_list, &set.scan_scratch, &set.pair_tile, &set.pair_pos, &set.pair_key, &set.bin_queue, &set.item_elsewhere};
         for (DevBuf* b : bins) b->release();
         if (set.bin_done) (void)hipEventDestroy(set.bin_done);
         if (set.raster_done) (void)hipEventDestroy(set.raster_done);

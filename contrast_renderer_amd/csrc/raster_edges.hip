@@ -108,6 +108,54 @@ CRH_D float2 to_framebuffer(const ItemCtx& c, float w, float h, float x, float y
     const float cy = (c.m1 * x + c.m5 * y) + c.m13;
     return make_float2((cx * 0.5f + 0.5f) * w, (0.5f - cy * 0.5f) * h);
 }
+// The tile split of the multi-GPU path: does the item's Shape, as this instance places it, miss the rows of the pass' slab altogether? Then the
+// binning kernels need not set its primitives up (one rank of eight used to set all 100 000 items of config 4 up to find that 7 in 8 have no row
+// in its slab). The box is the Shape's own (k_shape_bounds), its four corners go through the instance's affine map — the extremes of y are at
+// corners —, a tile row of margin absorbs the rounding of that map against the vertices' own. Unbounded boxes (stroked Shapes, degenerate hulls)
+// and anything not finite never pass the test.
+CRH_D bool item_misses_slab(const RasterParams& r, const DrawItem& it) {
+    if (!r.shape_bounds) return false;
+    const float* bb = r.shape_bounds + 4u * it.shape;
+    const float* m = r.transforms + 16u * it.instance;
+    const float m1 = m[1], m5 = m[5], m13 = m[13]; // (the row of the instance matrix to_framebuffer() takes y from)
+    const float y00 = (m1 * bb[0] + m5 * bb[1]) + m13, y10 = (m1 * bb[2] + m5 * bb[1]) + m13, y01 = (m1 * bb[0] + m5 * bb[3]) + m13, y11 = (m1 * bb[2] + m5 * bb[3]) + m13;
+    const float h = (float)r.height;
+    const float cy_hi = fmaxf(fmaxf(y00, y10), fmaxf(y01, y11)), cy_lo = fminf(fminf(y00, y10), fminf(y01, y11));
+    const float top = (0.5f - cy_hi * 0.5f) * h, bottom = (0.5f - cy_lo * 0.5f) * h; // (to_framebuffer: y grows downwards)
+    const float slab_top = (float)(r.slab_ty0 * kTile), slab_bottom = (float)(min(r.slab_ty1, r.tiles_y) * kTile);
+    const bool finite = is_finite(y00) && is_finite(y10) && is_finite(y01) && is_finite(y11);
+    return finite && (bottom + (float)kTile < slab_top || top - (float)kTile >= slab_bottom);
+}
+__global__ __launch_bounds__(256) void k_shape_bounds(SceneDev s, float* bounds) {
+    const uint32_t shape = blockIdx.x * 256u + threadIdx.x;
+    if (shape >= s.n_shapes) return;
+    const uint32_t* b0 = s.shape_base + shape * kShapeRow;
+    const uint32_t* b1 = b0 + NCH;
+    const uint32_t hn = s.hull_count[shape];
+    const float inf = __uint_as_float(0x7f800000u);
+    float4 box = make_float4(-inf, -inf, inf, inf); // unbounded: never left out
+    // a filled Shape draws polygon vertices and curve control points — all of them hull candidates (fill.rs:263-367), so the hull's box holds
+    // them; a stroked one also draws join triangles around the path's own control points (stroke.rs:53-121), which an offset stroke leaves outside
+    const bool stroked = (b1[CH_LINE_V] - b0[CH_LINE_V]) + (b1[CH_JOINT] - b0[CH_JOINT]) != 0u;
+    if (!stroked && hn >= 3u) {
+        box = make_float4(inf, inf, -inf, -inf);
+        const Vertex0* v = s.hull_v + b0[CH_HULL];
+        for (uint32_t i = 0; i < hn; ++i) box.x = fminf(box.x, v[i].x), box.y = fminf(box.y, v[i].y), box.z = fmaxf(box.z, v[i].x), box.w = fmaxf(box.w, v[i].y);
+    }
+    reinterpret_cast<float4*>(bounds)[shape] = box;
+}
+void launch_shape_bounds(const SceneDev& s, float* bounds, hipStream_t stream) {
+    if (s.n_shapes) hipLaunchKernelGGL(k_shape_bounds, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s, bounds);
+}
+// one lane per item of a pass with a slab: r.item_elsewhere[item] = the item misses the slab. (A kernel of its own in front of the binning kernels:
+// the test inside k_bin_flat's first phase cost that kernel its last free registers — 12 B of scratch, whose accesses wait with the record stores.)
+__global__ __launch_bounds__(256) void k_slab_items(RasterParams r, uint8_t* elsewhere) {
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    if (item < r.n_items) elsewhere[item] = item_misses_slab(r, item_of(r, item)) ? 1u : 0u;
+}
+void launch_slab_items(const RasterParams& r, uint8_t* elsewhere, hipStream_t stream) {
+    if (r.n_items) hipLaunchKernelGGL(k_slab_items, dim3((r.n_items + 255u) / 256u), dim3(256), 0, stream, r, elsewhere);
+}
 __global__ __launch_bounds__(256) void k_item_nslots(SceneDev s, RasterParams r, uint32_t n_items, uint32_t* out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_items) return;
@@ -603,6 +651,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CRH_BIN_WAV
     const ItemCtx ctx = item_ctx(s, r, it, k.cb);
     const uint32_t slot0 = r.slot_begin[item];
     if (slot0 + k.total > r.slot_capacity) continue; // cannot happen: the capacity is the scan's total
+    if (r.item_elsewhere && r.item_elsewhere[item] != 0u) continue; // (a pass with a slab: no tile row of the item's box is in it)
 #ifdef CRH_ABLATE
     unsigned long long phase_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1081,6 +1130,7 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
         if (tid < n_cand) {
             const uint32_t item = next + tid;
             const DrawItem it = item_of(r, item);
+            const bool elsewhere = r.item_elsewhere && r.item_elsewhere[item] != 0u; // (a pass with a slab: the item has no tile row in it — neither binned here nor queued)
             const ItemSlots k = item_slots(s, it);
             FlatItem& fi = items[tid];
             fi.ctx = item_ctx(s, r, it, k.cb);
@@ -1090,7 +1140,7 @@ __global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CR
             const float* c = fi.ctx.col;
             const bool opaque = c[3] == 1.0f && is_finite(c[0]) && is_finite(c[1]) && is_finite(c[2]) && r.occlude != 0u && (r.debug & 32768u) == 0u;
             const bool oversize = k.n_tri > kFlatTris || k.n_fe + k.n_hull > kFlatEdges || all_queued || slot0 + k.total > r.slot_capacity;
-            fi.flags = (opaque ? kFiOpaque : 0u) | (oversize ? kFiSkip : 0u) | ((oversize && slot0 + k.total <= r.slot_capacity) ? kFiQueue : 0u);
+            fi.flags = (opaque ? kFiOpaque : 0u) | ((oversize || elsewhere) ? kFiSkip : 0u) | ((oversize && !elsewhere && slot0 + k.total <= r.slot_capacity) ? kFiQueue : 0u);
             fi.box[0] = fi.box[1] = 0x7FFFFFFF, fi.box[2] = fi.box[3] = (int)0x80000000;
             fi.faces = 0u;
             fi.n_rect = 0u;

@@ -83,6 +83,9 @@ struct RasterParams {
     uint32_t rows;                    // the edge pass' lists are drawn by k_raster_rows (winding numbers accumulated in LDS, lanes over (entry, sample row)): the host measured it to be the faster kernel for this Scene (msaa 1, no strokes)
     uint32_t order_places;            // with tile_order: the places of the order that hold a tile (a multiple of 8; the grid of the raster kernels), 0: all of them
     uint32_t slab_ty0, slab_ty1;      // the tile rows [slab_ty0, slab_ty1) this pass draws (crh_frame_set_tile_rows: the tile split of the multi-GPU path — every rank bins everything and draws its slab); the other tiles are left alone
+    const uint8_t* item_elsewhere;    // [n_items] 1: the item misses this pass' slab (k_slab_items), or nullptr
+    const float* shape_bounds;        // [n_shapes][4] min x, min y, max x, max y of everything a Shape draws, in its own coordinates (k_shape_bounds), or nullptr — a pass with a slab:
+                                      // the binning kernels leave out an item whose box on the frame misses the slab's rows BEFORE they set its primitives up
     uint32_t fill_cells;              // no tile list of this frame has shown 16 384 entries: k_raster_fill's packed counters (fill + 65536 * hull per sample) are exact; 0: k_raster_edges
 };
 

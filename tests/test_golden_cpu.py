@@ -126,10 +126,13 @@ def test_binning_runs_partition_the_items_within_a_batch_and_start_with_the_long
     for var in ("CRH_BIN_BATCH_TICKS", "CRH_BIN_BATCH_ITEMS", "CRH_BIN_BATCH_ORDER"):
         monkeypatch.delenv(var, raising=False)
     rng = np.random.default_rng(11)
+    limits = (C.c_uint32 * 4)()
+    lib.crh_debug_flat_batches(None, 0, np.zeros((1, 2), dtype=np.uint32).ctypes.data_as(C.POINTER(C.c_uint32)), 1, limits)
+    pool = limits[3]  # (the tables scale with the kernel's workgroup shape: an item's rectangle beyond the pool is reported as "too wide", never as a count)
     for n in (0, 1, 31, 33, 1000, 20000):
         tris = rng.integers(0, 60, n).astype(np.uint32)
         edges = rng.integers(0, 200, n).astype(np.uint32)
-        cells = np.minimum(rng.lognormal(3.0, 1.5, n), 1400).astype(np.uint32)
+        cells = np.minimum(rng.lognormal(3.0, 1.5, n), pool - pool // 10).astype(np.uint32)
         folded = (rng.uniform(size=n) < 0.1).astype(np.uint32)
         kind = rng.uniform(size=n)  # 3 %: wider than the pool, 3 %: not binned by this kernel
         cost = np.zeros((n, 2), dtype=np.uint32)
