@@ -1,9 +1,10 @@
-"""The one-pass tessellation (k_tess_fused, csrc/tessellate.hip) against the oracle and against the two-pass path it replaces.
+"""The one-pass tessellation (k_tess_runs, csrc/tessellate.hip) against the oracle and against the two-pass path it replaces, and what goes
+with it: new paths of the structure a Scene holds uploaded without a wait for their totals (crh_scene::optimistic).
 
-Shape-aligned workgroups reserve their ranges of the scene-wide streams with one atomic per channel, so the ORDER of the Shapes inside the
-streams differs from launch to launch; the parity surface — every Shape's byte image, renderer.rs:198-209 — and the pixels must not.
-CRH_TESS_TWO_PASS=1 (read per upload) keeps a Scene on k_count / k_scan_* / k_emit; a Shape with more elements than a workgroup has lanes
-takes that path by itself. Which path ran is read off the kernel marks."""
+What an element emits is counted once per upload (k_tess_count_runs, k_scan_runs); every tessellation is then ONE kernel of Shape-aligned
+workgroups that scans in LDS and analyses each element once. The parity surface — every Shape's byte image, renderer.rs:198-209 — and the
+pixels must be the oracle's on either path. CRH_TESS_TWO_PASS=1 (read per upload) keeps a Scene on k_count / k_scan_* / k_emit; a Shape with
+more elements than a workgroup has lanes takes that path by itself. Which path ran is read off the kernel marks."""
 import numpy as np
 import pytest
 
@@ -63,7 +64,7 @@ def test_both_tessellation_paths_match_the_oracle(gpu, oracle_lib, case, two_pas
     _assert_equal(scene, oracle, case)
     frame = gpu.Frame(r, sc["width"], sc["height"])
     expect = oracle.render(sc["width"], sc["height"], sc["msaa"], sc["winding_bits"], sc["transforms"], sc["colors"])
-    for step in range(3):  # again on the other set of buffers, and on the first one once more: another order of the runs each time
+    for step in range(3):  # again on the other set of buffers, and on the first one once more
         if step:
             scene.tessellate()
         frame.clear()
