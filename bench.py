@@ -515,12 +515,17 @@ def main():
         torch_path()
 
     reupload_other = [None]
+    reupload_steps = [0]
 
     def launch(i):
         """Enqueues step i's tessellation + render (asynchronous on the renderer's streams)."""
         nonlocal scene
         f = frames[i % len(frames)]
         if args.reupload:
+            # (target k goes with Scene k across run() calls — an odd number of warm-up steps must not swap the pairs: a target keeps its list
+            # places and batch runs for "its" Scene)
+            f = frames[reupload_steps[0] % len(frames)]
+            reupload_steps[0] += 1
             # crh_scene_upload into an existing Scene: validation, element stream, H2D. TWO Scenes in turn — geometry double-buffered as an application
             # double-buffers its vertex buffers: an upload into the Scene of the frame still in flight has to wait for that frame (it may have
             # to be drawn again from the old paths), an upload into the other one does not
@@ -612,10 +617,14 @@ def main():
     # kernels' times in the run come from a second loop of the same length right after, outside the clock.)
     renderer.enable_timing(0 if os.environ.get("CRH_BENCH_NO_MARKS") is not None else 2)
     sync()
+    if os.environ.get("CRH_PASS_VERBOSE"):
+        sys.stderr.write("[bench] the timed block begins\n")
     t0 = time.perf_counter()
     run(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("CRH_PASS_VERBOSE"):
+        sys.stderr.write("[bench] the timed block ends\n")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.backend == "gloo" else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
