@@ -751,6 +751,28 @@ def main():
     # crh_scene_set_instances in front of the step; the dashed workload also moves one Shape's dash phase per frame (main.rs:243-250 through
     # crh_scene_set_dynamic_stroke_options). The tile lists change from frame to frame: what the frame-coherent state of the steady figure
     # (lists in place, batches cut by cost, heavy tiles first) is worth when the frames are not identical shows here.
+    # `recount` (a side block, never `value`): the one-pass tessellation keeps what every element emits and where every run of Shapes begins from the
+    # FIRST tessellation of the uploaded paths (properties of the paths: csrc/tessellate.hip k_tess_count_runs / k_scan_runs) — the timed steps re-analyse
+    # and re-emit every vertex, but do not count again. Here they do: the counting pass and the scan over the runs in front of every step's kernel,
+    # as for paths that have just been uploaded.
+    recount = None
+    if world == 1 and not args.reupload and not args.no_animated:
+        try:
+            os.environ["CRH_TESS_COUNT_EVERY_RUN"] = "1"
+            run(args.warmup + 2)
+            sync()
+            tr = time.perf_counter()
+            run(args.steps)
+            sync()
+            recount_s = (time.perf_counter() - tr) / args.steps
+            recount = {"ms_per_step": recount_s * 1e3, "value": args.paths / recount_s, "unit": "paths/s", "steps": args.steps,
+                       "note": "the timed loop with k_tess_count_runs + k_scan_runs in front of every step's k_tess_runs (CRH_TESS_COUNT_EVERY_RUN=1): nothing about "
+                               "the paths is kept from an earlier tessellation but the streams' capacities"}
+        except Exception as e:  # (reported, never fatal: a side block)
+            recount = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            os.environ.pop("CRH_TESS_COUNT_EVERY_RUN", None)
+            sync()
     animated = None
     if world == 1 and not args.reupload and not args.no_animated:
         n_sets = 20
@@ -941,6 +963,7 @@ def main():
                           "note": "all kernels of a step: control data read + emitted bytes written (tessellation), emitted bytes + 80 B / shape read and W*H*4 written (raster)"},
         "kernels": kernels,
         "animated": animated,
+        "recount": recount,
         "check": check,
         # the boundary hands over host buffers once per scene (crh_scene_upload); never part of `value`
         "host_inclusive": {"upload_ms": upload_s * 1e3, "paths_per_s_first_frame": batch.n_shapes / (upload_s + step_s),

@@ -161,9 +161,11 @@ CRH_D uint32_t angle_steps(Pl st, Pl et, float angle_step, Cx& polar_start, Cx& 
     return f >= 4294967040.0f ? 0xFFFFFFFFu : (uint32_t)f;
 }
 
-struct CubicIntervals {
+struct CubicIntervals { // at most four intervals [a_k, b_k]; no arrays: an index known at run time only would send them to scratch memory
     int n;
-    float a[4], b[4];
+    float a0, b0, a1, b1, a2, b2, a3, b3;
+    CRH_D float a(int k) const { return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3)); }
+    CRH_D float b(int k) const { return k == 0 ? b0 : (k == 1 ? b1 : (k == 2 ? b2 : b3)); }
 };
 // the split at the inflection points of cubic_uniform_tangent_angle! (curve.rs:257-286)
 CRH_D CubicIntervals cubic_intervals(const Pt pb[4], bool integral) {
@@ -171,48 +173,57 @@ CRH_D CubicIntervals cubic_intervals(const Pt pb[4], bool integral) {
     inflection_coefficients(pb, integral, d);
     Root roots[3];
     const float discriminant = integral ? integral_inflection_points(d, false, roots) : rational_inflection_points(d, false, roots);
-    float split[3];
-    int ns = 0;
+    // the roots inside [0, 1], in the order found ...
+    float v[3];
+    bool f[3];
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
-        if (roots[k].den == 0.0f) continue;
         const float t = roots[k].re / roots[k].den;
-        if (t >= 0.0f && t <= 1.0f) split[ns++] = t;
+        f[k] = roots[k].den != 0.0f && t >= 0.0f && t <= 1.0f;
+        v[k] = t;
     }
-    for (int i = 1; i < ns; ++i) // stable insertion sort
-        for (int j = i; j > 0 && split[j] < split[j - 1]; --j) {
-            const float t = split[j];
-            split[j] = split[j - 1];
-            split[j - 1] = t;
-        }
+    int ns = (f[0] ? 1 : 0) + (f[1] ? 1 : 0) + (f[2] ? 1 : 0);
+    float c0 = f[0] ? v[0] : (f[1] ? v[1] : v[2]);
+    float c1 = f[0] ? (f[1] ? v[1] : v[2]) : v[2];
+    float c2 = v[2];
+    // ... sorted (a stable insertion sort of at most three: the same compares in the same order) ...
+    if (ns >= 2 && c1 < c0) {
+        const float s = c0;
+        c0 = c1, c1 = s;
+    }
+    if (ns == 3 && c2 < c1) {
+        const float s = c2;
+        c2 = c1;
+        if (s < c0) c1 = c0, c0 = s;
+        else c1 = s;
+    }
+    // ... without near-duplicates: `i = 1; while i < ns { if split[i] - split[i - 1] < margin { remove split[i] } else { i += 1 } }` takes two turns at most
     {
         int i = 1;
-        while (i < ns) {
-            if (split[i] - split[i - 1] < kErrorMargin) {
-                for (int j = i; j + 1 < ns; ++j) split[j] = split[j + 1];
-                ns -= 1;
-            } else {
-                i += 1;
+#pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+            if (i < ns) {
+                const float hi = i == 1 ? c1 : c2, lo = i == 1 ? c0 : c1;
+                if (hi - lo < kErrorMargin) {
+                    if (i == 1) c1 = c2;
+                    ns -= 1;
+                } else {
+                    i += 1;
+                }
             }
         }
     }
     CubicIntervals iv;
-    iv.n = 0;
-    float previous_split = 0.0f;
-    for (int k = 0; k < ns; ++k) {
-        if (fabsf(discriminant) < kErrorMargin) {
-            iv.a[iv.n] = previous_split;
-            iv.b[iv.n] = split[k] - kEpsilon;
-            previous_split = split[k] + kEpsilon;
-        } else {
-            iv.a[iv.n] = previous_split;
-            iv.b[iv.n] = split[k];
-            previous_split = split[k];
-        }
-        iv.n += 1;
-    }
-    iv.a[iv.n] = previous_split;
-    iv.b[iv.n] = 1.0f;
-    iv.n += 1;
+    const bool shrink = fabsf(discriminant) < kErrorMargin; // (intervals stop short of an inflection point of a curve with a cusp)
+    const float lo_of = shrink ? kEpsilon : 0.0f;
+    auto end_of = [&](float s) { return shrink ? s - kEpsilon : s; };
+    auto begin_behind = [&](float s) { return shrink ? s + kEpsilon : s; };
+    (void)lo_of;
+    iv.n = ns + 1;
+    iv.a0 = 0.0f, iv.b0 = ns >= 1 ? end_of(c0) : 1.0f;
+    iv.a1 = begin_behind(c0), iv.b1 = ns >= 2 ? end_of(c1) : 1.0f;
+    iv.a2 = begin_behind(c1), iv.b2 = ns >= 3 ? end_of(c2) : 1.0f;
+    iv.a3 = begin_behind(c2), iv.b3 = 1.0f;
     return iv;
 }
 
@@ -227,12 +238,14 @@ CRH_D void stroke_power_basis(const SceneDev& s, uint32_t e, uint32_t type, Pt p
             cp[1] = vec_to_point(p[0], p[1]);
             cp[2] = vec_to_point(p[2], p[3]);
             quadratic_power_basis(cp, pb);
+            pb[3] = pb[2] * 0.0f; // (never read for a quadratic; left unset, the four points stayed in scratch memory)
             break;
         case ELEM_RQ:
             cp[0] = prev;
             cp[1] = weighted_vec_to_point(p[0], p[1], p[2]);
             cp[2] = vec_to_point(p[3], p[4]);
             quadratic_power_basis(cp, pb);
+            pb[3] = pb[2] * 0.0f;
             break;
         case ELEM_IC:
             cp[0] = prev;
@@ -266,8 +279,8 @@ CRH_D uint32_t curve_parameter_count(const SceneDev& s, uint32_t e, uint32_t typ
     const CubicIntervals iv = cubic_intervals(pb, type == ELEM_IC);
     uint32_t n = 0;
     for (int k = 0; k < iv.n; ++k) {
-        const Pl st = signum(cubic_tangent(pb, iv.a[k]));
-        const Pl et = signum(cubic_tangent(pb, iv.b[k]));
+        const Pl st = signum(cubic_tangent(pb, iv.a(k)));
+        const Pl et = signum(cubic_tangent(pb, iv.b(k)));
         const uint32_t steps = angle_steps(st, et, so.angle_step, ps, pr);
         n += (steps >= 2u ? steps - 1u : 0u) + 1u;
     }
@@ -283,22 +296,26 @@ __global__ __launch_bounds__(64) void k_stroke_records(SceneDev s) {
     uint32_t prev_off = s.elem_off0[move];                                // previous_control_point = path.start (stroke.rs:207)
     for (uint32_t e = move + 1u; e < end; ++e) {
         const uint32_t type = s.elem_type[e];
-        uint32_t* head = type == ELEM_IQ ? &head_iq : (type == ELEM_IC ? &head_ic : (type == ELEM_RQ ? &head_rq : &head_rc));
+        uint32_t head = type == ELEM_IQ ? head_iq : (type == ELEM_IC ? head_ic : (type == ELEM_RQ ? head_rq : head_rc)); // (a copy: a pointer to one of the four would keep them in scratch memory)
         uint32_t src = e; // lines are taken with next() (stroke.rs:223): always their own record
         if (type != ELEM_LINE) {
-            if (*head == ~0u) *head = e;
-            src = *head;
+            if (head == ~0u) head = e;
+            src = head;
         }
         const uint32_t rec = s.elem_off0[src];
         s.elem_off[e] = rec;
         s.elem_prev_off[e] = prev_off;
         const SegGeom g = segment_geometry(s, e, type);
-        if (g.skip) continue; // stroke.rs:267-269: neither the iterator nor previous_control_point move
-        if (type != ELEM_LINE) {
-            uint32_t j = *head + 1u;
+        if (!g.skip && type != ELEM_LINE) {
+            uint32_t j = head + 1u;
             while (j < end && s.elem_type[j] != type) ++j;
-            *head = j;
+            head = j;
         }
+        if (type == ELEM_IQ) head_iq = head;
+        else if (type == ELEM_IC) head_ic = head;
+        else if (type == ELEM_RQ) head_rq = head;
+        else if (type != ELEM_LINE) head_rc = head;
+        if (g.skip) continue; // stroke.rs:267-269: neither the iterator nor previous_control_point move
         const uint32_t end_point = type == ELEM_LINE ? 0u : (type == ELEM_IQ ? 2u : (type == ELEM_IC ? 4u : (type == ELEM_RQ ? 3u : 8u)));
         prev_off = rec + end_point;
     }
@@ -466,12 +483,12 @@ CRH_D uint32_t interpolate_normal(Pl st, Pl et, float angle_step, float* out, So
         int n = 0;
         solve(normal, r, n);
         float parameter = 0.0f;
-        for (int k = 0; k < n; ++k) {
-            if (r[k].den == 0.0f) continue;
-            const float t = r[k].re / r[k].den;
-            if (t >= 0.0f && t <= 1.0f) {
-                parameter = t;
-                break;
+        bool found = false; // (the first root inside [0, 1]; four fixed turns: r[] stays in registers — a loop to a run-time n sent it to scratch memory)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < n && !found && r[k].den != 0.0f) {
+                const float t = r[k].re / r[k].den;
+                if (t >= 0.0f && t <= 1.0f) parameter = t, found = true;
             }
         }
         out[i - 1u] = parameter;
@@ -516,7 +533,7 @@ CRH_D uint32_t sample_parameters(uint32_t type, const Pt pb[4], const SegGeom& g
     const CubicIntervals iv = cubic_intervals(pb, integral);
     uint32_t total = 0;
     for (int k = 0; k < iv.n; ++k) {
-        const float a = iv.a[k], b = iv.b[k];
+        const float a = iv.a(k), b = iv.b(k);
         Pt trimmed[4];
         reparametrize_cubic(pb, a, b, trimmed);
         const Pl st = signum(cubic_tangent(pb, a));
