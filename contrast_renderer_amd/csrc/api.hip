@@ -1654,20 +1654,34 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     // The one-pass tessellation's runs: consecutive Shapes with at most kTessBlock elements between them, one workgroup each; a Shape with more
     // elements than that sends the Scene down the two-pass path (n_runs = 0).
     std::vector<uint32_t> runs;
+    uint32_t run_block = (uint32_t)kTessBlock;
     {
         const bool two_pass_only = std::getenv("CRH_TESS_TWO_PASS") != nullptr; // (A/B runs and the tests of that path; read per upload)
-        bool fits = !two_pass_only && b->n_shapes != 0u;
-        uint32_t in_run = 0;
-        if (fits) runs.push_back(0u);
-        for (uint32_t s = 0; s < b->n_shapes && fits; ++s) {
-            const uint32_t p0 = b->shape_path_begin[s], p1 = b->shape_path_begin[s + 1];
-            const uint64_t elems = (uint64_t)(b->path_segment_begin[p1] - b->path_segment_begin[p0]) + 2ull * (p1 - p0);
-            if (elems > (uint64_t)kTessBlock) fits = false;
-            else if (in_run + elems > (uint64_t)kTessBlock) runs.push_back(s), in_run = (uint32_t)elems;
-            else in_run += (uint32_t)elems;
+        auto cut = [&](uint32_t block) {
+            runs.clear();
+            bool fits = !two_pass_only && b->n_shapes != 0u;
+            uint32_t in_run = 0;
+            if (fits) runs.push_back(0u);
+            for (uint32_t s = 0; s < b->n_shapes && fits; ++s) {
+                const uint32_t p0 = b->shape_path_begin[s], p1 = b->shape_path_begin[s + 1];
+                const uint64_t elems = (uint64_t)(b->path_segment_begin[p1] - b->path_segment_begin[p0]) + 2ull * (p1 - p0);
+                if (elems > (uint64_t)block) fits = false;
+                else if (in_run + elems > (uint64_t)block) runs.push_back(s), in_run = (uint32_t)elems;
+                else in_run += (uint32_t)elems;
+            }
+            if (fits) runs.push_back(b->n_shapes);
+            else runs.clear();
+            return fits;
+        };
+        // Workgroups of 128 lanes for scenes of MANY small Shapes: beyond four rounds of resident workgroups (4 096 runs) the two-wave
+        // workgroups find their slots in the gap between two raster kernels sooner (50 000 glyphs: 6 300 runs, pipelined step 0.70 -> 0.64 ms;
+        // the metric's 266 runs and config 4's 2 660 are no faster that way: tools/r05b_variants.sh). CRH_TESS_RUN_BLOCK pins it.
+        const char* pinned = std::getenv("CRH_TESS_RUN_BLOCK");
+        if (cut(run_block) && kTessBlock == 256 && (pinned ? std::atoi(pinned) == 128 : runs.size() > 4096u)) {
+            const std::vector<uint32_t> wide = runs;
+            if (cut(128u)) run_block = 128u;
+            else runs = wide;
         }
-        if (fits) runs.push_back(b->n_shapes);
-        else runs.clear();
     }
     Part part[13];
     size_t arena_bytes = 0;
@@ -1768,7 +1782,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     // stay, no wait for the totals (crh_scene::optimistic). CRH_NO_OPTIMISTIC_UPLOAD: A/B runs and the tests of the other way.
     const uint32_t new_runs = (runs.empty() || n_elems == 0u) ? 0u : (uint32_t)runs.size() - 1u;
     const bool same_structure = existing && sc->capacity_known && sc->d.n_elems == n_elems && sc->d.n_paths == b->n_paths && sc->d.n_shapes == b->n_shapes && sc->has_stroke == has_stroke &&
-                                sc->d.n_runs == new_runs && n_elems != 0u && std::getenv("CRH_NO_OPTIMISTIC_UPLOAD") == nullptr;
+                                sc->d.n_runs == new_runs && sc->d.run_block == run_block && n_elems != 0u && std::getenv("CRH_NO_OPTIMISTIC_UPLOAD") == nullptr;
     sc->rendered_once = false;
     sc->last_render_one_event = false;
     if (sc->shadow.allocated && !same_structure) { // sized for the previous contents
@@ -1826,6 +1840,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     d.n_shapes = b->n_shapes;
     d.n_wg = (n_elems + kTessBlock - 1) / kTessBlock;
     d.n_runs = new_runs;
+    d.run_block = run_block;
     for (int c = 0; c < NCH; ++c) d.capacity[c] = same_structure ? sc->cap_host[c] : 0u;
     // ONE asynchronous copy of the whole arena into a device arena of the same layout (round 5; until then fourteen copies into fourteen buffers on the
     // raster stream, in line behind the raster kernel of the frame in front). It runs on the upload stream, behind the last readers of the Scene's old

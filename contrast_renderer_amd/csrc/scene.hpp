@@ -86,7 +86,8 @@ struct SceneDev {
     uint32_t* shape_base;  // [n_shapes][2][NCH] where each Shape's records begin and end in every stream (kShapeRow words per Shape)
     // ---- the one-pass tessellation (k_tess_runs): Shape-aligned workgroups, no scan across workgroups ----
     uint32_t n_runs;            // 0: the two-pass path (some Shape has more elements than a workgroup has lanes)
-    const uint32_t* tess_run;   // [n_runs + 1] first Shape of every run of consecutive Shapes with <= kTessBlock elements in total
+    uint32_t run_block;         // elements a run holds at most = lanes of a workgroup of k_tess_runs: kTessBlock, or 128 when that makes more than 4 096 runs of Shapes that fit 128
+    const uint32_t* tess_run;   // [n_runs + 1] first Shape of every run of consecutive Shapes with <= run_block elements in total
     uint32_t* elem_cnt;         // [n_elems] what every element emits, packed (pack_counts): a property of the paths, counted once per upload
     uint32_t* run_base;         // [n_runs + 1][NCH] where every run's records begin in the ten streams (row n_runs: the totals); per upload as well
     uint32_t* path_scan;        // [n_paths][3] a stroked path's first vertex pair, the pair behind its last one, its first join (k_stroke_lengths)

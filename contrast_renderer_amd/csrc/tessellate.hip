@@ -404,12 +404,13 @@ CRH_D void unpack_counts(uint32_t w, bool stroked, uint32_t cnt[NCH]) {
     cnt[CH_RC_V] = stroked ? 0u : (w >> 12) & 15u;
 }
 
-template <bool STROKES>
-__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_count_runs(SceneDev s) {
-    __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
+// BLOCK: lanes of a workgroup = the elements a run holds at most (SceneDev::run_block: 256, or 128 for scenes of many small Shapes)
+template <bool STROKES, int BLOCK>
+__global__ __launch_bounds__(BLOCK) CRH_TESS_OCCUPANCY void k_tess_count_runs(SceneDev s) {
+    __shared__ uint32_t wave_total[BLOCK / 64][NCH];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shape0 = s.tess_run[blockIdx.x], shape1 = s.tess_run[blockIdx.x + 1u];
-    const uint32_t first = s.shape_elem_begin[shape0], n = s.shape_elem_begin[shape1] - first; // (<= kTessBlock: the host cut the runs)
+    const uint32_t first = s.shape_elem_begin[shape0], n = s.shape_elem_begin[shape1] - first; // (<= BLOCK: the host cut the runs)
     const uint32_t e = first + tid;
     uint32_t cnt[NCH];
 #pragma unroll
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_count_ru
     __syncthreads();
     if (tid < NCH) {
         uint32_t total = 0;
-        for (uint32_t w = 0; w < (uint32_t)kTessBlock / 64u; ++w) total += wave_total[w][tid];
+        for (uint32_t w = 0; w < (uint32_t)BLOCK / 64u; ++w) total += wave_total[w][tid];
         s.run_base[blockIdx.x * NCH + tid] = total;
     }
 }
@@ -472,10 +473,10 @@ __global__ __launch_bounds__(256) void k_scan_runs(SceneDev s) {
     if (tid < NCH) s.run_base[s.n_runs * NCH + tid] = carry[tid], s.totals[tid] = carry[tid];
 }
 
-template <bool STROKES>
-__global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_runs(SceneDev s) {
-    __shared__ uint32_t rows[(kTessBlock + 1) * kScanPitch];
-    __shared__ uint32_t wave_total[kTessBlock / 64][NCH];
+template <bool STROKES, int BLOCK>
+__global__ __launch_bounds__(BLOCK) CRH_TESS_OCCUPANCY void k_tess_runs(SceneDev s) {
+    __shared__ uint32_t rows[(BLOCK + 1) * kScanPitch];
+    __shared__ uint32_t wave_total[BLOCK / 64][NCH];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t shape0 = s.tess_run[blockIdx.x], shape1 = s.tess_run[blockIdx.x + 1u];
     const uint32_t first = s.shape_elem_begin[shape0], n = s.shape_elem_begin[shape1] - first;
@@ -516,13 +517,13 @@ __global__ __launch_bounds__(kTessBlock) CRH_TESS_OCCUPANCY void k_tess_runs(Sce
     for (int c = 0; c < NCH; ++c) {
         uint32_t base = s.run_base[blockIdx.x * NCH + c];
 #pragma unroll
-        for (uint32_t w = 0; w + 1u < (uint32_t)kTessBlock / 64u; ++w) base += w < wave ? wave_total[w][c] : 0u;
+        for (uint32_t w = 0; w + 1u < (uint32_t)BLOCK / 64u; ++w) base += w < wave ? wave_total[w][c] : 0u;
         g[c] += base;
         if (tid < n) rows[tid * kScanPitch + c] = g[c];
         if (tid == 0u) rows[n * kScanPitch + c] = s.run_base[(blockIdx.x + 1u) * NCH + c];
     }
     __syncthreads();
-    for (uint32_t shape = shape0 + tid; shape < shape1; shape += kTessBlock) {
+    for (uint32_t shape = shape0 + tid; shape < shape1; shape += BLOCK) {
         const uint32_t* b0 = rows + (s.shape_elem_begin[shape] - first) * kScanPitch;
         const uint32_t* b1 = rows + (s.shape_elem_begin[shape + 1u] - first) * kScanPitch;
 #pragma unroll
@@ -880,8 +881,13 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*
     if (has_stroke) launch_stroke_records(s, stream, mark, ctx);
     if (s.n_runs) {
         if (!need_totals) return;
-        if (has_stroke) hipLaunchKernelGGL(k_tess_count_runs<true>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
-        else hipLaunchKernelGGL(k_tess_count_runs<false>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+        if (s.run_block == 128u) {
+            if (has_stroke) hipLaunchKernelGGL((k_tess_count_runs<true, 128>), dim3(s.n_runs), dim3(128), 0, stream, s);
+            else hipLaunchKernelGGL((k_tess_count_runs<false, 128>), dim3(s.n_runs), dim3(128), 0, stream, s);
+        } else {
+            if (has_stroke) hipLaunchKernelGGL((k_tess_count_runs<true, kTessBlock>), dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+            else hipLaunchKernelGGL((k_tess_count_runs<false, kTessBlock>), dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+        }
         if (mark) mark(ctx, "tess_count", bytes[0]);
         hipLaunchKernelGGL(k_scan_runs, dim3(1), dim3(256), 0, stream, s);
         if (mark) mark(ctx, "tess_scan", bytes[1]);
@@ -898,8 +904,13 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*
 void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued) {
     if (s.n_elems == 0) return;
     if (s.n_runs) {
-        if (has_stroke) hipLaunchKernelGGL(k_tess_runs<true>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
-        else hipLaunchKernelGGL(k_tess_runs<false>, dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+        if (s.run_block == 128u) {
+            if (has_stroke) hipLaunchKernelGGL((k_tess_runs<true, 128>), dim3(s.n_runs), dim3(128), 0, stream, s);
+            else hipLaunchKernelGGL((k_tess_runs<false, 128>), dim3(s.n_runs), dim3(128), 0, stream, s);
+        } else {
+            if (has_stroke) hipLaunchKernelGGL((k_tess_runs<true, kTessBlock>), dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+            else hipLaunchKernelGGL((k_tess_runs<false, kTessBlock>), dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
+        }
         if (mark) mark(ctx, "tess_fused", bytes[2]);
     } else {
         hipLaunchKernelGGL(k_emit, dim3(s.n_wg), dim3(kTessBlock), 0, stream, s);

@@ -51,10 +51,13 @@ def _cases():
     }
 
 
-@pytest.mark.parametrize("two_pass", [False, True])
+@pytest.mark.parametrize("two_pass", [False, True, "runs of 128"])
 @pytest.mark.parametrize("case", list(_cases()))
 def test_both_tessellation_paths_match_the_oracle(gpu, oracle_lib, case, two_pass, monkeypatch):
     sc = _cases()[case]()
+    if two_pass == "runs of 128":  # the one-pass kernel's 128-lane build (taken by itself beyond 4 096 runs; a Shape beyond 128 elements keeps 256)
+        monkeypatch.setenv("CRH_TESS_RUN_BLOCK", "128")
+        two_pass = False
     if two_pass:
         monkeypatch.setenv("CRH_TESS_TWO_PASS", "1")
     r = _renderer(gpu, sc)
