@@ -34,7 +34,7 @@ void launch_slab_items(const RasterParams& r, uint8_t* elsewhere, hipStream_t st
 void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream);
 bool bin_itemwise(const RasterParams& r);
 void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs);
-void flat_batch_limits(uint32_t limits[4]);
+void flat_batch_limits(uint32_t n_items, uint32_t limits[4]);
 void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, uint32_t tiles_x, uint32_t radius, hipStream_t stream);
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_fmath(int fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t stream);
@@ -2368,7 +2368,7 @@ extern "C" crh_status crh_debug_frame_bin_dump(crh_frame* f, uint32_t* out, uint
 extern "C" int crh_debug_flat_batches(const uint32_t* cost, uint32_t n_items, uint32_t* runs, uint32_t cap_runs, uint32_t limits[4]) {
     std::vector<uint32_t> out;
     flat_batches(cost, n_items, out);
-    flat_batch_limits(limits);
+    flat_batch_limits(n_items, limits);
     if (out.size() / 2 > cap_runs) return -1;
     std::copy(out.begin(), out.end(), runs);
     return (int)(out.size() / 2);

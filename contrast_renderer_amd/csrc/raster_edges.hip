@@ -1093,13 +1093,21 @@ struct FlatTri { // a set-up triangle between the passes: its tile test and tile
 #else
 #define CRH_FLAT_PHASE(k)
 #endif
-template <int S>
+// what a batch holds follows from the workgroup's lanes (the tables of k_bin_flat<S, THREADS>; the host cuts its runs by the same numbers)
+struct FlatShape {
+    uint32_t threads, batch, tris, edges, pool;
+};
+constexpr FlatShape flat_shape(uint32_t threads) { return FlatShape{threads, threads / 8u, threads, threads * CRH_FLAT_ROUNDS, CRH_FLAT_POOL * threads}; }
+template <int S, uint32_t THREADS>
 #ifdef CRH_FLAT_VGPRS
 #define CRH_FLAT_BUDGET __attribute__((amdgpu_num_vgpr(CRH_FLAT_VGPRS)))
 #else
 #define CRH_FLAT_BUDGET
 #endif
-__global__ __launch_bounds__(kFlatThreads) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WAVES))) CRH_FLAT_BUDGET void k_bin_flat(SceneDev s, RasterParams r, uint32_t items_per_group) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CRH_FLAT_WAVES))) CRH_FLAT_BUDGET void k_bin_flat(SceneDev s, RasterParams r, uint32_t items_per_group) {
+    // (the namespace's constants of these names describe the default shape; inside the kernel they are this instantiation's)
+    constexpr uint32_t kFlatThreads = THREADS, kFlatWaveCount = THREADS / 64u, kFlatBatch = THREADS / 8u, kFlatTris = THREADS, kFlatEdges = THREADS * kFlatEdgeRounds, kFlatPool = CRH_FLAT_POOL * THREADS;
+    static_assert(kFlatBatch >= 1u && kFlatBatch <= kFlatItems, "a batch's index tables hold 32 items");
     __shared__ uint32_t stage_tile[kFlatWaveCount][kFlatStage], stage_pos[kFlatWaveCount][kFlatStage], stage_key[kFlatWaveCount][kFlatStage];
     __shared__ FlatItem items[kFlatBatch];
     __shared__ uint32_t tri_begin[kFlatItems + 1], edge_begin[kFlatItems + 1], pool_begin[kFlatItems + 1];
@@ -3737,11 +3745,21 @@ void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* sha
 // NUMBERS of items per workgroup the ones with large Shapes took two to four batches (10 000 Shapes of 16-256 px: the longest workgroup
 // lived 1.84 x the mean, and the kernel lasts as long as that one); with one full batch per workgroup every workgroup lives one chain and
 // the hardware's dispatch balances the rest. runs[2 k], runs[2 k + 1] = the first item of run k and the one behind its last.
+// The lanes of k_bin_flat's workgroups for a pass of n_items items: 128 (alone the kernel is fastest with 256, in the gap between two raster kernels
+// with 128: §4.3 of DESIGN.md), 64 from 65 536 items on (100 000 paths @ 8192^2: pipelined step 2.05 -> 1.94 ms; 50 000 glyphs and the metric's
+// 10 000 paths are slower that way). CRH_BIN_FLAT_THREADS pins it (64 / 128; read per pass).
+uint32_t flat_threads_for(uint32_t n_items) {
+    if (const char* e = getenv("CRH_BIN_FLAT_THREADS")) return atoi(e) == 64 ? 64u : kFlatThreads;
+    return (n_items >= 65536u && kFlatThreads == 128u) ? 64u : kFlatThreads;
+}
 bool bin_itemwise(const RasterParams& r) { // (read per launch: tests and A/B runs switch it inside one process)
+    const FlatShape shape = flat_shape(flat_threads_for(r.n_items));
     return getenv("CRH_BIN_ITEMWISE") != nullptr ||
-           (getenv("CRH_BIN_FLAT") == nullptr && r.n_items != 0u && (r.hint_tris / r.n_items > kFlatTris / 2u || r.hint_edges / r.n_items > kFlatEdges / 2u));
+           (getenv("CRH_BIN_FLAT") == nullptr && r.n_items != 0u && (r.hint_tris / r.n_items > shape.tris / 2u || r.hint_edges / r.n_items > shape.edges / 2u));
 }
 void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>& runs) {
+    const FlatShape shape = flat_shape(flat_threads_for(n_items));
+    const uint32_t kFlatBatch = shape.batch, kFlatTris = shape.tris, kFlatEdges = shape.edges, kFlatPool = shape.pool; // (of the kernel that will take these runs)
     struct Run {
         uint32_t first, last;
         float ticks;
@@ -3773,7 +3791,10 @@ void flat_batches(const uint32_t* cost, uint32_t n_items, std::vector<uint32_t>&
     runs.clear();
     for (const Run& run : all) runs.push_back(run.first), runs.push_back(run.last);
 }
-void flat_batch_limits(uint32_t limits[4]) { limits[0] = kFlatBatch, limits[1] = kFlatTris, limits[2] = kFlatEdges, limits[3] = kFlatPool; }
+void flat_batch_limits(uint32_t n_items, uint32_t limits[4]) {
+    const FlatShape shape = flat_shape(flat_threads_for(n_items));
+    limits[0] = shape.batch, limits[1] = shape.tris, limits[2] = shape.edges, limits[3] = shape.pool;
+}
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, hipEvent_t after_bin) {
     // tile_count and, right behind it, the overflow words (overflow[8 ...] are the cursors of the pair sub-streams): one memset (tile_cursor, in front, is the triangle pass')
     (void)hipMemsetAsync(r.tile_count, 0, sizeof(uint32_t) * r.n_tiles + 32 + 4 * kSubStreams + 32, stream); // (... and kExtraTurnsWord behind them)
@@ -3795,19 +3816,22 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         // k_bin_flat: a batch of items per 256-thread workgroup. A workgroup lives about as long whether it holds two items or twenty (the
         // same chain of phases), so the grid is sized to ONE round of resident workgroups — three per CU — as long as that leaves a batch
         // within the kernel's 32 items; what a batch cannot hold is queued and binned item by item behind it.
-        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * CRH_FLAT_WAVES * (4u / kFlatWaveCount); // workgroups the CUs of the binning lane hold at once
-        // ... and within what the lanes of a batch hold (256 triangles, 768 edges): an item that does not fit is left to the workgroup's next
-        // turn, which doubles the workgroup's life — the averages of the scene keep a batch nine tenths full
-        const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)kFlatTris * 9u / 10u * r.n_items / r.hint_tris) : kFlatBatch;
-        const uint32_t by_edges = r.hint_edges ? (uint32_t)((uint64_t)kFlatEdges * 9u / 10u * r.n_items / r.hint_edges) : kFlatBatch;
-        const uint32_t fitting = max(1u, min(kFlatBatch, min(by_tris, by_edges)));
-        const uint32_t items_per_group = pinned ? min(pinned, kFlatBatch) : min(fitting, max(1u, (r.n_items + resident - 1u) / resident));
+        const FlatShape shape = flat_shape(flat_threads_for(r.n_items));
+        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * CRH_FLAT_WAVES * (4u / (shape.threads / 64u)); // workgroups the CUs of the binning lane hold at once
+        // ... and within what the lanes of a batch hold (threads triangles, three times as many edges): an item that does not fit is left to the
+        // workgroup's next turn, which doubles the workgroup's life — the averages of the scene keep a batch nine tenths full
+        const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)shape.tris * 9u / 10u * r.n_items / r.hint_tris) : shape.batch;
+        const uint32_t by_edges = r.hint_edges ? (uint32_t)((uint64_t)shape.edges * 9u / 10u * r.n_items / r.hint_edges) : shape.batch;
+        const uint32_t fitting = max(1u, min(shape.batch, min(by_tris, by_edges)));
+        const uint32_t items_per_group = pinned ? min(pinned, shape.batch) : min(fitting, max(1u, (r.n_items + resident - 1u) / resident));
         const uint32_t flat_grid = r.bin_batches ? r.n_bin_batches : (r.n_items + items_per_group - 1u) / items_per_group, queue_grid = min(r.n_items, 4096u);
         if (samples == 4) {
-            hipLaunchKernelGGL((k_bin_flat<4>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
+            if (shape.threads == 64u) hipLaunchKernelGGL((k_bin_flat<4, 64u>), dim3(flat_grid), dim3(64), 0, stream, s, r, items_per_group);
+            else hipLaunchKernelGGL((k_bin_flat<4, kFlatThreads>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
             if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<4, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
         } else {
-            hipLaunchKernelGGL((k_bin_flat<1>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
+            if (shape.threads == 64u) hipLaunchKernelGGL((k_bin_flat<1, 64u>), dim3(flat_grid), dim3(64), 0, stream, s, r, items_per_group);
+            else hipLaunchKernelGGL((k_bin_flat<1, kFlatThreads>), dim3(flat_grid), dim3(kFlatThreads), 0, stream, s, r, items_per_group);
             if (!r.skip_queue) hipLaunchKernelGGL((k_bin_edges<1, true>), dim3(queue_grid), dim3(128), 0, stream, s, r);
         }
     }
