@@ -670,6 +670,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
         if (st != CRH_OK) return st;
     }
     sc->tessellated_once = true;
+    if (again) sc->bounds_generation = 0; // (boxes taken from the hulls of a run that did not fit are nobody's)
     if (again) sc->hull_queued_state = 0; // (the run that overflowed queued nothing: its hull kernels returned at once; the caller has synchronised)
     SceneDev& d = sc->d;
     const hipStream_t ts = r->tessellation_stream();

@@ -238,3 +238,33 @@ def test_two_scenes_in_turn_with_frames_in_flight(gpu, oracle_lib):
         o, tr, co = last[k]
         assert np.array_equal(frames[k].download(), o.render(512, 512, 1, 4, tr, co))
         assert scenes_[k].status() == 0
+
+
+def test_slabs_of_re_uploaded_paths(gpu, oracle_lib):
+    """The tile split's passes (a slab of tile rows per frame; the items whose Shape misses the slab are left out before they are set up:
+    k_shape_bounds, k_slab_items) over paths that are uploaded again and again into the same Scene — the Shapes' boxes belong to an upload,
+    and to a tessellation that fitted: the octagons-to-cubics step does not, and is drawn again."""
+    r = gpu.Renderer(gpu.Configuration(msaa_sample_count=1, winding_counter_bits=4), device=0)
+    n = 300
+    slabs = [(0, 176), (176, 336), (336, 512)]
+    frames = []
+    for a, b in slabs:
+        f = gpu.Frame(r, 512, 512)
+        f.set_tile_rows(a, b)
+        frames.append(f)
+    scene = None
+    for step, (kind, seed) in enumerate([(0, 4), (0, 5), (1, 1), (1, 2), (0, 8), (1, 3)]):
+        batch, transforms, colors = _wobbly_scene(n, seed, kind)
+        oracle = oracle_lib.Oracle(batch, 4)
+        assert oracle.status() == 0
+        scene = gpu.Scene(r, batch, tessellate=False, existing=scene)
+        scene.set_instances(transforms, colors)
+        scene.tessellate()
+        for f in frames:
+            f.clear()
+            scene.render(f)
+        expect = oracle.render(512, 512, 1, 4, transforms, colors)
+        for (a, b), f in zip(slabs, frames):
+            image = f.download()
+            assert np.array_equal(image[a:b], expect[a:b]), f"step {step} (kind {kind}), rows {a}..{b}: {(image[a:b] != expect[a:b]).any(axis=2).sum()} pixels differ"
+        assert scene.status() == 0
