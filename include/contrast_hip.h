@@ -175,7 +175,12 @@ crh_status crh_convert_dynamic_stroke_options(const crh_dynamic_stroke_options* 
 /* Host -> HBM: validates (finite, stroke-group bounds renderer.rs:188-191, dash count renderer.rs:32-34),
  * canonicalises -0, lays the batch out for the kernels and copies it to the device. This is the part of
  * from_paths that is not arithmetic; it is outside bench.py's timed region. `existing` may be NULL; when
- * given, its device allocations are reused if large enough (Buffer::update, renderer.rs:89-95). */
+ * given, its device allocations are reused if large enough (Buffer::update, renderer.rs:89-95). Paths of the
+ * STRUCTURE `existing` holds (as many Shapes, paths and segments, stroked or not — an animation of control
+ * points) also keep the capacities of its vertex streams: the next crh_scene_tessellate does not wait for
+ * the totals of the new paths; a tessellation that does not fit after all is noticed when a frame drawn from
+ * it is settled (crh_frame_synchronize, crh_frame_download, ...) or by crh_scene_status, sized and repeated,
+ * the frame drawn again. The host arrays of `batch` are copied before the call returns. */
 crh_status crh_scene_upload(crh_renderer* renderer, const crh_path_batch* batch, crh_scene* existing, crh_scene** out);
 /* The arithmetic of from_paths for every shape of the scene, on the GPU:
  * StrokeBuilder::add_path (stroke.rs:205-465), FillBuilder::add_path (fill.rs:263-367),

@@ -11,6 +11,7 @@ python bench.py --reupload --no-cpu-baseline > gpurun_out/bench_r05_reupload.jso
 python bench.py --gpus 2 --backend gloo --same-device --steps 10 --no-cpu-baseline > gpurun_out/bench_r05_gpus2_same_device.json 2> gpurun_out/bench_r05_gpus2.err
 for w in cubic s100k; do python tools/r05_slab_step.py $w > gpurun_out/r05_slab_step_$w.txt 2>/dev/null; done
 CRH_EDGE_PASS=1 python tools/r05_animated_check.py cubic > gpurun_out/r05_animated_check.txt 2>/dev/null
+python -c 'import __graft_entry__ as g; g.smoke()' > gpurun_out/r05_smoke.txt 2>&1; tail -1 gpurun_out/r05_smoke.txt
 cat gpurun_out/pytest_r05.log
 for f in gpurun_out/bench_r05_*.json; do echo "== $f"; python - $f <<'PY'
 import json, sys
