@@ -612,6 +612,39 @@ CRH_D void bitonic_stage(float2& p, uint32_t lane) {
     bitonic_step<1>(p, lane, K);
 }
 
+// The Shapes beyond k_hull_small's 64 candidates, listed for the kernels behind it: queue 0 up to kHullMid candidates (small LDS footprint), queue 1
+// up to kHullMax, queue 2 global memory. One lane per Shape, ONE returning atomic per queue and block of 256 Shapes: until the end of round 5
+// k_hull_small queued its large Shapes itself, an atomic each on one counter — returning atomics on one address are served at the memory side,
+// ≈ 25 ns apiece, and the 6 000 large Shapes of the 50 000 glyph scene made that queue half of the kernel's 0.12 ms (without its sorts the
+// kernel took 0.117 ms, without its chain walks 0.078: neither was what it waited for).
+__global__ __launch_bounds__(256) void k_hull_queues(SceneDev s) {
+    __shared__ uint32_t wave_count[4][3], block_base[3];
+    if (!fits(s)) return;
+    const uint32_t shape = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t n = 0;
+    if (shape < s.n_shapes) n = s.shape_base[shape * kShapeRow + NCH + CH_HULL] - s.shape_base[shape * kShapeRow + CH_HULL];
+    const uint32_t queue = n > kHullMax ? 2u : (n > kHullMid ? 1u : (n > kHullSmall ? 0u : 3u)); // 3: k_hull_small's own
+    unsigned long long members[3];
+#pragma unroll
+    for (uint32_t q = 0; q < 3u; ++q) {
+        members[q] = __ballot(queue == q);
+        if (lane == 0u) wave_count[wave][q] = (uint32_t)__popcll(members[q]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {
+        const uint32_t q = threadIdx.x, total = wave_count[0][q] + wave_count[1][q] + wave_count[2][q] + wave_count[3][q];
+        block_base[q] = total ? atomicAdd(s.hull_large_count + q, total) : 0u;
+    }
+    __syncthreads();
+    if (queue < 3u) {
+        uint32_t at = block_base[queue];
+        for (uint32_t w = 0; w < wave; ++w) at += wave_count[w][queue];
+        const unsigned long long mine = queue == 0u ? members[0] : (queue == 1u ? members[1] : members[2]);
+        at += (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+        s.hull_large_list[queue * s.n_shapes + at] = shape;
+    }
+}
+
 __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
     __shared__ float2 sorted[kHullBatch][kHullRow];         // sorted candidates of the batch's Shapes
     __shared__ uint8_t stack[kHullBatch][2 * kHullSmall];   // the monotone chain as indices into `sorted`
@@ -645,11 +678,7 @@ __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
         const uint32_t slot = wave + kHullWaves * u, shape = first_shape + slot;
         uint32_t n = n_of[u];
         if (shape < s.n_shapes) {
-            if (n > kHullSmall) { // queue 0: up to kHullMid candidates (small LDS footprint), queue 1: up to kHullMax, queue 2: global memory
-                const uint32_t queue = n > kHullMax ? 2u : (n > kHullMid ? 1u : 0u);
-#if CRH_ABLATE_HULL != 2
-                if (lane == 0) s.hull_large_list[queue * s.n_shapes + atomicAdd(s.hull_large_count + queue, 1u)] = shape;
-#endif
+            if (n > kHullSmall) { // (k_hull_queues has put it on the list of a kernel behind this one)
                 n = 0;
             } else if (n == 0) {
                 if (lane == 0) s.hull_count[shape] = 0;
@@ -920,7 +949,10 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
         hipLaunchKernelGGL(k_stroke_lengths, dim3((s.n_paths + 63) / 64), dim3(64), 0, stream, s);
         if (mark) mark(ctx, "stroke_lengths", 0);
     }
-    (void)hipMemsetAsync(s.hull_large_count, 0, 16, stream);
+    if (has_stroke || big_shapes) { // (some Shape may have more than 64 hull candidates)
+        (void)hipMemsetAsync(s.hull_large_count, 0, 16, stream);
+        hipLaunchKernelGGL(k_hull_queues, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s);
+    }
     hipLaunchKernelGGL(k_hull_small, dim3((s.n_shapes + kHullBatch - 1u) / kHullBatch), dim3(64 * kHullWaves), 0, stream, s);
     if (mark) mark(ctx, "tess_hull", bytes[3]);
     if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
