@@ -10,14 +10,14 @@ from contrast_renderer_amd.renderer import Configuration, Frame, Renderer, Scene
 
 sc = scenes.scene_cubic_fill(10000)
 r = Renderer(Configuration(1, 4, 4), device=0)
-pair = [Scene(r, sc["batch"]), Scene(r, sc["batch"])]
+pair = [Scene(r, sc["batch"]) for _ in range(int(os.environ.get("SCENES", "2")))]
 frames = [Frame(r, 4096, 4096) for _ in range(int(os.environ.get("FRAMES", "2")))]
-frames = frames * 2 if len(frames) == 1 else frames
+frames = frames * len(pair) if len(frames) == 1 else frames
 
 
 def loop(n, acc):
     for i in range(n):
-        k = i % 2
+        k = i % len(pair)
         t0 = time.perf_counter()
         pair[k] = Scene(r, sc["batch"], tessellate=False, existing=pair[k])
         t1 = time.perf_counter()
