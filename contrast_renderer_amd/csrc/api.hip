@@ -690,6 +690,8 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     }
     const uint64_t bytes[4] = {sc->input_bytes, 0, sc->input_bytes + sc->emitted_bytes, 0};
     // (the one-pass path counts once per upload — elem_cnt, run_base —, the two-pass path every time)
+    if (!sc->capacity_known)
+        for (int c = 0; c < NCH; ++c) d.capacity[c] = 0u; // (not known: the counting kernels must not take the streams' old sizes for a verdict — k_shape_rows)
     // CRH_TESS_COUNT_EVERY_RUN (read per run: bench.py's `recount` side block switches it inside one process): the counts and bases are not kept —
     // k_tess_count_runs and k_scan_runs run in front of every k_tess_runs, as they do for new paths
     launch_tessellate(d, ts, r->mark_fn_tess(), r, bytes, sc->has_stroke, !sc->capacity_known || !sc->counts_valid || getenv("CRH_TESS_COUNT_EVERY_RUN") != nullptr);

@@ -247,6 +247,14 @@ __global__ __launch_bounds__(64) void k_scan_groups(SceneDev s) {
 __global__ __launch_bounds__(256) void k_shape_rows(SceneDev s) {
     const uint32_t shape = blockIdx.x * 256u + threadIdx.x;
     if (shape >= s.n_shapes) return;
+    // (streams that do not hold these totals — new paths uploaded over the capacities of the ones before, api.hip crh_scene::optimistic — get no
+    // records from k_emit: the rows of the run before stay, so that a pass drawn before the host has sized the streams reads inside them)
+    if (s.capacity[0] | s.capacity[1] | s.capacity[2] | s.capacity[3] | s.capacity[4] | s.capacity[5] | s.capacity[6] | s.capacity[7] | s.capacity[8] | s.capacity[9]) {
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) ok = ok && s.totals[c] <= s.capacity[c];
+        if (!ok) return;
+    }
     const uint32_t e0 = s.shape_elem_begin[shape], e1 = s.shape_elem_begin[shape + 1u];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

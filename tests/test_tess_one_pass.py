@@ -173,12 +173,15 @@ def _wobbly_scene(n_shapes, seed, kind, size=(512, 512)):
     return batch, transforms, colors
 
 
-@pytest.mark.parametrize("optimistic", [True, False])
+@pytest.mark.parametrize("optimistic", [True, False, "two passes"])
 def test_new_paths_of_the_same_structure_keep_the_capacities(gpu, oracle_lib, optimistic, monkeypatch, capfd):
     """crh_scene_upload into an existing Scene with paths of the structure it holds: no wait for the totals (api.hip: crh_scene::optimistic).
     Control points that move (the counts change a little: the headroom), then polygons replaced by cubics of the same structure (several
     times the records: the run does not fit, the frame finds the overflow code among its flags, everything is sized and drawn again), then
     back. Every frame and every Shape's bytes against the oracle; CRH_NO_OPTIMISTIC_UPLOAD is the old way."""
+    if optimistic == "two passes":  # (the two-pass tessellation under optimistic uploads: k_shape_rows must leave the rows of a run that does not fit alone)
+        monkeypatch.setenv("CRH_TESS_TWO_PASS", "1")
+        optimistic = True
     if not optimistic:
         monkeypatch.setenv("CRH_NO_OPTIMISTIC_UPLOAD", "1")
     monkeypatch.setenv("CRH_PASS_VERBOSE", "1")  # (the library says on stderr when a frame finds its tessellation's overflow code)
