@@ -2557,8 +2557,12 @@ CRH_D void blend_rows(float (&c)[4][4], const unsigned long long (&mask)[4], flo
 }
 // bit `bit` of `rows` clear -> the sign bit set in x (a sample row that is left out fails every  x >= 0 / x >= 1  test): v_lshlrev_b32 + v_and_or_b32
 CRH_D int reject_unless_row(int x, uint32_t not_rows, int bit) { return (int)(((not_rows << (31 - bit)) & 0x80000000u) | (uint32_t)x); }
-template <bool LONG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRH_EDGE_TILE_WAVES))) void k_raster_fill(SceneDev s, RasterParams r) {
+// WAVES: wavefronts per SIMD the build is held to — 5 (no scratch memory) or 6 (80 registers, 20 B of scratch). Alone the six-wave build is the
+// faster one (S10k 0.157 against 0.167 ms, 100 000 paths @ 8192^2 1.01 against 1.09), but a fuller raster grid gives the workgroups of the next
+// frame's binning their slots later: the metric's pipelined step is 0.308 against 0.301 ms with it, config 4's 1.96 against 2.01. The host takes
+// six for frames of long lists (RasterParams::long_lists: 40 entries per tile and more), five otherwise; CRH_FILL_WAVES pins it.
+template <bool LONG, int WAVES = CRH_EDGE_TILE_WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_raster_fill(SceneDev s, RasterParams r) {
     constexpr int ROWS = 4;
     const uint32_t bid = blockIdx.x; // the workgroup's place in the frame's tile order
     extern __shared__ uint32_t sort_buffer[];
@@ -3889,7 +3893,11 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
     } else if (fill_kernel) {
         // (always the variant that looks for its late start across the chunks of a long list: measured on the 10 000 path scene — few lists
         // beyond one chunk — it is as fast as the one without, 0.1655 against 0.168 ms, and it is the build without scratch memory)
-        hipLaunchKernelGGL((k_raster_fill<true>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
+        const char* fill_waves = getenv("CRH_FILL_WAVES"); // (A/B runs, tests; read per launch)
+        if (fill_waves ? atoi(fill_waves) == 6 : r.long_lists != 0u)
+            hipLaunchKernelGGL((k_raster_fill<true, 6>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
+        else
+            hipLaunchKernelGGL((k_raster_fill<true>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
     } else if (r.long_lists) {
         CRH_LAUNCH_EDGES(1, 4, false, true);
     } else {
