@@ -41,11 +41,13 @@ def mark_to_kernel(workload, triangle_pass=False):
     return {
         # (the last argument: the variant that looks for its late start across the chunks of long tile lists — the host picks it for frames with
         # many entries per tile and opaque whole-tile covers: the 100 000 path scene)
-        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else "crh::k_raster_fill<true>",
+        # (k_raster_fill<LONG, WAVES>: frames of long lists — the 100 000 path scene — take the six-wave build)
+        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_fill<true, 6>" if workload == "s100k" else "crh::k_raster_fill<true, 5>"),
         # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
         "raster_rows": "crh::k_raster_rows<true>" if workload == "s100k" else "crh::k_raster_rows<false>",  # the row-span kernel, where the library's trial picked it
-        "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else "crh::k_bin_flat<1>",
+        "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else ("crh::k_bin_flat<1, 64u>" if workload == "s100k" else "crh::k_bin_flat<1, 128u>"),
         "raster_scatter": "crh::k_scatter",
+        "tess_fused": "crh::k_tess_runs<true, 256>" if msaa4_strokes else ("crh::k_tess_runs<false, 128>" if workload == "glyphs" else "crh::k_tess_runs<false, 256>"),
         "tess_emit": "crh::k_emit",
         "tess_count": "crh::k_count",
         "tess_hull": "crh::k_hull_small",
