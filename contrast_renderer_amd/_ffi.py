@@ -250,6 +250,7 @@ def load_library():
         "crh_frame_format": (C.c_int, [V, C.POINTER(C.c_uint32)]),
         "crh_frame_destroy": (None, [V]),
         "crh_frame_clear": (C.c_int, [V]),
+        "crh_frame_keep_pass_state": (C.c_int, [V]),
         "crh_frame_synchronize": (C.c_int, [V]),
         "crh_frame_set_tile_rows": (C.c_int, [V, C.c_uint32, C.c_uint32]),
         "crh_frame_clear_depth": (C.c_int, [V, C.c_float]),

@@ -3,6 +3,7 @@
 // CPU fallback here and nothing under oracle/ is referenced.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -25,6 +26,7 @@ void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hip
 void launch_raster(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, uint64_t raster_bytes, bool has_stroke);
 void launch_item_ranges(const SceneDev& s, const RasterParams& r, uint32_t* item_ncand, uint32_t* item_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream);
+void launch_state_colors_from_image(const RasterParams& r, uint32_t samples, hipStream_t stream);
 // raster_edges.hip: the plain Stencil + Color pass as boundary edges + backdrop, binned in one traversal
 void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_items, uint32_t* item_nslots, uint32_t* slot_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_bin);
@@ -319,6 +321,14 @@ struct crh_frame {
     bool items_ranges_valid = false;
     bool items_need_ops = false;   // the pass uses more than Stencil / Color at clip depth 0 (otherwise the plain raster kernel serves it)
     DevBuf depth;                  // [height][width][samples] f32, when the configuration tests or writes depth
+    // Pass state that outlives a pass (RasterParams::state_*; renderer.rs:148-158, 257-266, 932-985: the reference's stencil attachment and alpha
+    // layers are caller-owned textures, so `shape_a.render(Clip)` clips whatever Shapes are rendered afterwards until `shape_a.render(UnClip)`).
+    // A recorded pass that ends with state left over (pass_leaves_state) makes the frame `carry`: from then on, until crh_frame_clear (the stencil's
+    // LoadOp::Clear, main.rs:217-230), every pass into it is drawn by the OPS kernel, which starts its tiles from these planes and stores them back.
+    DevBuf state_stencil, state_alpha, state_color;
+    bool carry = false;            // the frame keeps its pass state in HBM
+    bool carry_valid = false;      // ... and the planes hold what the earlier passes left (false: to be initialised in front of the next pass)
+    bool carry_recolor = false;    // the exchange wrote the frame's pixels behind the planes' back: the sample colours start from the image again
     bool cleared = true;
     bool pairs_known = false;
     // Direct tile lists (RasterParams::direct): once a pass of a Scene into this frame has been verified, the places of its lists are kept
@@ -1072,6 +1082,11 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     const bool recorded = f->n_items != 0; // crh_scene_render_draws stored a pass in the frame
     if (!recorded && !sc->instances_set) return CRH_ERR_INVALID_ARGUMENT;
     if (!sc->capacity_known) return CRH_ERR_INVALID_ARGUMENT; // tessellate first
+    if (f->carry && sc->optimistic) { // a pass into a frame that keeps its state cannot be drawn a second time: the tessellation it draws has to be known to fit
+        uint32_t word = 0;
+        const crh_status st = settle_tessellation(sc, &word);
+        if (st != CRH_OK) return st;
+    }
     HIP_TRY(hipSetDevice(r->device));
     // Three lanes: tessellation -> binning (setup, tile walks) -> raster. This frame is binned into the frame's other set of tile
     // buffers and the scene's other record buffer while the previous frame's raster kernel may still be reading its own.
@@ -1186,7 +1201,18 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.cull_mode = r->config.cull_mode;
     // The general pass keeps the reference's triangle strips (raster.hip): clip nesting / alpha contexts, perspective, depth, and face
     // culling (a cull decision is per strip triangle). Everything else is the edge pass (raster_edges.hip).
-    p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops)) ? 1u : 0u;
+    p.general = (projective || p.depth || r->config.cull_mode != CRH_CULL_NONE || (recorded && f->items_need_ops) || f->carry) ? 1u : 0u;
+    p.state_stencil = nullptr, p.state_alpha = nullptr, p.state_color = nullptr, p.state_load = 0u, p.state_layers = 0u;
+    p.winding_bits = r->config.winding_counter_bits;
+    if (f->carry) { // the frame keeps clip counters, winding counters, saved alphas and sample colours from pass to pass
+        const size_t n_samples = (size_t)f->width * f->height * r->config.msaa_sample_count;
+        HIP_TRY(f->state_stencil.ensure(n_samples));
+        HIP_TRY(f->state_alpha.ensure(std::max<size_t>(1, r->config.alpha_layer_count) * n_samples * 4));
+        HIP_TRY(f->state_color.ensure(n_samples * 16));
+        p.state_stencil = f->state_stencil.as<uint8_t>(), p.state_alpha = f->state_alpha.as<float>(), p.state_color = f->state_color.as<float>();
+        p.state_layers = std::min<uint32_t>(r->config.alpha_layer_count, 4u);
+        p.state_load = f->carry_valid ? 1u : 0u;
+    }
     int timed = -1;
     const int pass = p.general == 0u ? choose_pass(sc, f, &timed) : 2;
     const bool edges = pass != 2;
@@ -1218,8 +1244,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // Rendering over existing content is not repeatable (the target is read and overwritten), so the optimistic tile-list capacity with a
     // transparent re-run after the fact is only used for cleared frames; otherwise the pair count is checked before the raster kernel runs.
     // ... and a pass that writes depth is not repeatable either: the first attempt's depth writes would be tested against by the redraw
-    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled)) f->pairs_known = false;
-    static const bool no_direct = getenv("CRH_NO_DIRECT_LISTS") != nullptr; // A/B runs
+    // ... nor is a pass that starts from the state its predecessors left with the frame and stores its own
+    if (!f->cleared || (f->depth.p && r->config.depth_write_enabled) || f->carry) f->pairs_known = false;
+    const bool no_direct = getenv("CRH_NO_DIRECT_LISTS") != nullptr; // A/B runs and tests (read per pass: a test switches it inside one process)
     // Geometry that has stayed for two passes without its lists in place (a Scene drawn into this frame after another one, paths uploaded
     // again into the Scene): one verified pass more, which puts them in place. (Not at once: a caller that uploads new paths for every
     // frame would pay a read-back per frame for places it never uses.)
@@ -1347,6 +1374,12 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
         if (direct && f->places_instances != sc->instances_version) { // the places of the next pass into this frame, from this pass' counts: behind the event the raster kernel waits for, beside that kernel (resident instances: the same counts, the same places)
             f->places_instances = sc->instances_version;
             uint32_t* const next_places = (f->base_cur ? f->tile_base : f->tile_base_b).as<uint32_t>();
+            //  The buffer written here is the one the raster kernel of the PREVIOUS pass into this frame may still be reading its
+            // places from (r.tile_base[tile] at workgroup start) when the target is not consumed between two passes: the binning stream has
+            // only waited for the pass before that one (the other BinSet). Nothing else on this stream runs before that kernel is through
+            // anyway — the next pass' binning waits for the same event when it takes that pass' BinSet.
+            const crh_frame::BinSet& previous = f->sets[f->last_set];
+            if (previous.used && &previous != &set) HIP_TRY(hipStreamWaitEvent(bin, previous.raster_done, 0));
             launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), next_places, p.scan_scratch, p.n_tiles, p.tiles_x, f->moving ? kMovingListRadius : 0u, bin);
             f->base_cur ^= 1;
         }
@@ -1361,6 +1394,17 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     // algorithmic bytes of the raster step: every emitted byte read once + 64 B transform + 16 B colour per shape,
     // the framebuffer written once
     const uint64_t raster_bytes = sc->emitted_bytes + (uint64_t)p.n_items * 80 + (uint64_t)f->image_bytes();
+    if (f->carry && (!f->carry_valid || f->carry_recolor)) { // on the raster stream: behind every earlier pass into the frame, in front of this one
+        const size_t n_samples = (size_t)f->width * f->height * r->config.msaa_sample_count;
+        if (!f->carry_valid) {
+            HIP_TRY(hipMemsetAsync(f->state_stencil.p, 0, n_samples, r->stream));
+            HIP_TRY(hipMemsetAsync(f->state_alpha.p, 0, std::max<size_t>(1, r->config.alpha_layer_count) * n_samples * 4, r->stream));
+        }
+        if (p.load_existing) launch_state_colors_from_image(p, r->config.msaa_sample_count, r->stream);
+        else HIP_TRY(hipMemsetAsync(f->state_color.p, 0, n_samples * 16, r->stream));
+        f->carry_valid = true, f->carry_recolor = false;
+        p.state_load = 1u; // (the planes now hold the frame's state: zero counters, the image's colours)
+    }
     if (edges)
         launch_raster_edges(sc->d, p, r->config.msaa_sample_count, r->stream, r->mark_fn(), r, raster_bytes, sc->has_stroke);
     else
@@ -2137,7 +2181,13 @@ void crh_frame_destroy(crh_frame* f) {
 crh_status crh_frame_clear(crh_frame* f) {
     if (!f) return CRH_ERR_INVALID_ARGUMENT;
     f->cleared = true; // LoadOp::Clear: the next render does not read the target, every tile is written
+    f->carry = f->carry_valid = f->carry_recolor = false; // ... and the stencil attachment and the alpha layers start from zero (main.rs:217-230)
     return f->depth.p ? crh_frame_clear_depth(f, 1.0f) : CRH_OK;
+}
+crh_status crh_frame_keep_pass_state(crh_frame* f) {
+    if (!f) return CRH_ERR_INVALID_ARGUMENT;
+    f->carry = true; // (the planes are allocated and initialised — from the image, if the frame shows one — in front of the next pass: render_impl)
+    return CRH_OK;
 }
 crh_status crh_frame_clear_depth(crh_frame* f, float value) {
     if (!f || !f->depth.p || !std::isfinite(value)) return CRH_ERR_INVALID_ARGUMENT;
@@ -2225,6 +2275,46 @@ crh_status crh_scene_render_resident(crh_scene* sc, crh_frame* f) {
     f->n_items = 0; // the plain pass: Stencil + Color of every Shape
     return render_impl(sc, f);
 }
+namespace {
+// Does a recorded pass leave state in the stencil attachment or the alpha layers when it ends — state the reference would hand to the next
+// Shape::render call into the same attachments (renderer.rs:148-158, 257-266)? Decided on the host from the draws alone, conservatively:
+//   Stencil leaves winding counters until a Color or Clip cover of the same Shape and instance resets them (renderer.rs:747-752 pass / fail -> Zero;
+//   :703-708 Replace(ref), whose winding bits are zero) — the alpha-context covers write no stencil (write_mask 0, renderer.rs:761-766);
+//   Clip leaves a nesting level until the UnClip of the same Shape and instance (renderer.rs:722-727); SaveAlphaContext leaves a layer until
+//   its RestoreAlphaContext. Anything unmatched, or matched out of order, counts as left over.
+bool pass_leaves_state(const crh_draw* draws, uint32_t n_draws) {
+    std::vector<std::pair<uint32_t, uint32_t>> stencils, clips;
+    uint32_t open_layers = 0;
+    for (uint32_t i = 0; i < n_draws; ++i) {
+        const crh_draw& d = draws[i];
+        const std::pair<uint32_t, uint32_t> who(d.shape, d.instance);
+        switch (d.op) {
+            case CRH_OP_STENCIL:
+                if (std::find(stencils.begin(), stencils.end(), who) == stencils.end()) stencils.push_back(who);
+                break;
+            case CRH_OP_COLOR:
+                stencils.erase(std::remove(stencils.begin(), stencils.end(), who), stencils.end());
+                break;
+            case CRH_OP_CLIP:
+                stencils.erase(std::remove(stencils.begin(), stencils.end(), who), stencils.end());
+                clips.push_back(who);
+                break;
+            case CRH_OP_UNCLIP:
+                if (clips.empty() || clips.back() != who) return true; // closes a level this pass did not open (or not in this order)
+                clips.pop_back();
+                break;
+            case CRH_OP_SAVE_ALPHA_CONTEXT: open_layers |= 1u << (d.alpha_layer & 31u); break;
+            case CRH_OP_RESTORE_ALPHA_CONTEXT:
+                if (!(open_layers >> (d.alpha_layer & 31u) & 1u)) return true; // restores a context an earlier pass saved
+                open_layers &= ~(1u << (d.alpha_layer & 31u));
+                break;
+            default: break; // ScaleAlphaContext reads and writes the colour attachment only
+        }
+        if (d.clip_depth > clips.size()) return true; // drawn at a clip level an earlier pass opened: the frame holds state
+    }
+    return !stencils.empty() || !clips.empty() || open_layers != 0u;
+}
+} // namespace
 crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* transforms, const float* colors, uint32_t n_instances, const crh_draw* draws,
                                   uint32_t n_draws) {
     if (!sc || !f || f->renderer != sc->renderer || (n_instances && (!transforms || !colors)) || (n_draws && !draws)) return CRH_ERR_INVALID_ARGUMENT;
@@ -2267,6 +2357,7 @@ crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* tran
         return CRH_OK;
     }
     f->items_need_ops = need_ops;
+    if (pass_leaves_state(draws, n_draws)) f->carry = true; // from here until crh_frame_clear the frame keeps clip / winding counters, saved alphas and sample colours in HBM
     const bool same_pass = f->items_ranges_valid && f->items_scene == sc && f->items_generation == sc->generation && f->n_items == items.size() &&
                            f->items_host.size() == items.size() && memcmp(f->items_host.data(), items.data(), items.size() * sizeof(DrawItem)) == 0 &&
                            f->item_transforms.cap >= (size_t)n_instances * 64 && f->item_colors.cap >= (size_t)n_instances * 16;
@@ -2415,6 +2506,7 @@ crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written) {
     if (written) {
         f->counts_describe_pixels = false;
         f->ext_write_set = true;
+        f->carry_recolor = f->carry;
         f->cleared = false; // it now shows an image, nothing of its own is pending
         f->check_pending = false;
         f->last_scene = nullptr;

@@ -640,6 +640,31 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
     uint32_t n = r.overflow[0] ? 0u : r.tile_offset[tile + 1] - list_begin;
     constexpr uint32_t kLdsSortMax = kSortBytesMax / (4u * (4u / ROWS));
     if (n > r.sort_capacity && n <= kLdsSortMax) n = 0; // the host sizes the sort buffer from overflow[3] (the longest list) and runs the frame again
+    // Pass state kept with the frame (renderer.rs:148-158, 257-266: the stencil attachment and the alpha layers outlive a Shape::render call):
+    // the tile starts from what the earlier passes left — stencil byte = clip nesting counter << winding bits | winding counter
+    // (renderer.rs:565-566, 936), the saved alphas, the colour of every SAMPLE — and leaves its own behind (below, in front of the resolve).
+    const bool keeps_state = OPS && r.state_stencil != nullptr;
+    if (keeps_state && r.state_load) {
+        if (n == 0u && r.load_existing) return; // nothing of this pass touches the tile: planes and pixels stay as they are (a cleared frame's tiles are all written)
+#pragma unroll
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
+            if (gx < r.width && gy < r.height) {
+                const size_t at = ((size_t)gy * r.width + gx) * S;
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const uint32_t st = r.state_stencil[at + k];
+                    winding[b][k] = (int)(st & r.winding_mask);
+                    clipc[OPS ? b : 0][OPS ? k : 0] = (int)((st >> r.winding_bits) & r.clip_mask_count);
+                    const float4 c = reinterpret_cast<const float4*>(r.state_color)[at + k];
+                    col[b][k][0] = c.x, col[b][k][1] = c.y, col[b][k][2] = c.z, col[b][k][3] = c.w;
+#pragma unroll
+                    for (int l = 0; l < kMaxAlphaLayers; ++l)
+                        if ((uint32_t)l < r.state_layers) saved[OPS ? b : 0][OPS ? k : 0][l] = r.state_alpha[(size_t)l * r.width * r.height * S + at + k];
+                }
+            }
+        }
+    }
     // ---- draw order = ascending prim id: bitonic network in registers (<= 64 entries), in LDS, or — a list longer than LDS holds — in
     //      place in global memory
     uint32_t my_key = 0xFFFFFFFFu;
@@ -1024,6 +1049,23 @@ __global__ __launch_bounds__(64 * (4 / ROWS)) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    if (keeps_state) { // what this pass leaves to the next one (the winding counter wraps inside its bits: IncrementWrap / DecrementWrap under the write mask, renderer.rs:577-582)
+#pragma unroll
+        for (int b = 0; b < ROWS; ++b) {
+            const uint32_t gy = ty * kTile + first_row + 4u * b + rq;
+            if (gx < r.width && gy < r.height) {
+                const size_t at = ((size_t)gy * r.width + gx) * S;
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    r.state_stencil[at + k] = (uint8_t)(((uint32_t)winding[b][k] & r.winding_mask) | (((uint32_t)clipc[OPS ? b : 0][OPS ? k : 0] & r.clip_mask_count) << r.winding_bits));
+                    reinterpret_cast<float4*>(r.state_color)[at + k] = make_float4(col[b][k][0], col[b][k][1], col[b][k][2], col[b][k][3]);
+#pragma unroll
+                    for (int l = 0; l < kMaxAlphaLayers; ++l)
+                        if ((uint32_t)l < r.state_layers) r.state_alpha[(size_t)l * r.width * r.height * S + at + k] = saved[OPS ? b : 0][OPS ? k : 0][l];
+                }
+            }
+        }
+    }
     // ---- MSAA resolve (box average) + RGBA8 unorm store
 #pragma unroll
     for (int b = 0; b < ROWS; ++b) {
@@ -1060,6 +1102,14 @@ __global__ __launch_bounds__(256) void k_composite(const uint8_t* const* layers,
         packed |= (uint32_t)(int)(x * 255.0f + 0.5f) << (8 * c);
     }
     reinterpret_cast<uint32_t*>(dst)[i] = packed;
+}
+
+__global__ __launch_bounds__(256) void k_state_colors_from_image(RasterParams r, uint32_t samples) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint64_t)r.width * r.height) return;
+    const uint32_t gy = (uint32_t)(i / r.width), gx = (uint32_t)(i - (uint64_t)gy * r.width);
+    const float4 c = load_pixel(r, gx, gy);
+    for (uint32_t k = 0; k < samples; ++k) reinterpret_cast<float4*>(r.state_color)[i * samples + k] = c;
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
@@ -1170,6 +1220,12 @@ void launch_scan_tiles(const RasterParams& r, hipStream_t stream) { // tile_coun
     const ScanJob j = scan_job(r.tile_count, r.tile_offset, r.scan_scratch, r.n_tiles, r.overflow + 3);
     hipLaunchKernelGGL(k_scan_local, dim3(j.blocks), dim3(256), 0, stream, j);
     hipLaunchKernelGGL(k_scan_add, dim3(j.blocks), dim3(256), 0, stream, j, r, 1);
+}
+// A frame that starts keeping its pass state while it already shows an image: every sample of a pixel starts from the pixel's resolved colour
+// (what a pass over existing content has always read, load_pixel).
+void launch_state_colors_from_image(const RasterParams& r, uint32_t samples, hipStream_t stream) {
+    const uint64_t n = (uint64_t)r.width * r.height;
+    hipLaunchKernelGGL(k_state_colors_from_image, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, r, samples);
 }
 void launch_composite(const uint8_t* const* layers_dev, uint32_t n_layers, uint64_t n_pixels, uint8_t* dst, hipStream_t stream) {
     hipLaunchKernelGGL(k_composite, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, stream, layers_dev, n_layers, n_pixels, dst);

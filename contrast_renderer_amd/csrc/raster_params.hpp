@@ -86,6 +86,16 @@ struct RasterParams {
     const uint8_t* item_elsewhere;    // [n_items] 1: the item misses this pass' slab (k_slab_items), or nullptr
     const float* shape_bounds;        // [n_shapes][4] min x, min y, max x, max y of everything a Shape draws, in its own coordinates (k_shape_bounds), or nullptr — a pass with a slab:
                                       // the binning kernels leave out an item whose box on the frame misses the slab's rows BEFORE they set its primitives up
+    // ---- pass state that outlives a pass (renderer.rs:148-158, 257-266, 932-985: the stencil attachment and the alpha layers are caller-owned and
+    //      persist from one Shape::render call to the next, whatever Shape it belongs to). A frame whose recorded pass ends with state left over
+    //      (an open Clip, a Stencil without its cover, a saved alpha context) keeps it in HBM from then on until it is cleared: the OPS raster
+    //      kernel starts every tile from these planes and leaves them behind (api.hip crh_frame::carry).
+    uint8_t* state_stencil;           // [height][width][samples] the stencil byte (clip nesting counter << winding bits | winding counter), or nullptr: registers only
+    float* state_alpha;               // [alpha layers][height][width][samples] the saved alphas (the R8 targets of renderer.rs:892-927, f32 like the colours)
+    float* state_color;               // [height][width][samples][4] the colour attachment per SAMPLE, f32 (the resolved image keeps one value per pixel)
+    uint32_t state_load;              // the planes hold what earlier passes left (0: first pass with state — the planes were initialised, nothing to read but the colours of a frame that was not cleared)
+    uint32_t state_layers;            // alpha layers in state_alpha (Configuration::alpha_layer_count, <= 4)
+    uint32_t winding_bits;            // Configuration::winding_counter_bits (the shift of the clip nesting counter inside the stencil byte)
     uint32_t fill_cells;              // no tile list of this frame has shown 16 384 entries: k_raster_fill's packed counters (fill + 65536 * hull per sample) are exact; 0: k_raster_edges
 };
 

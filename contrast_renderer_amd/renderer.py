@@ -115,6 +115,11 @@ class Frame:
     def clear(self):
         check(self.lib.crh_frame_clear(self.handle))
 
+    def keep_pass_state(self):
+        """From now until clear(): clip / winding counters, saved alphas and the f32 colour of every sample stay with the frame between
+        passes (the reference's caller-owned stencil attachment and alpha layers, renderer.rs:148-158, 257-266)."""
+        check(self.lib.crh_frame_keep_pass_state(self.handle))
+
     def synchronize(self):
         """Waits for the last render into this frame only (the next frame of a double-buffered loop keeps running)."""
         check(self.lib.crh_frame_synchronize(self.handle))
@@ -351,6 +356,62 @@ class Shape(Scene):
     def buffers(self):
         return self.shape(0)
 
+    def render_in(self, render_pass: "RenderPass", instance_indices, render_operation):
+        """Shape::render(&self, &renderer, &mut render_pass, instance_indices, render_operation), renderer.rs:267-273."""
+        render_pass.render(self, instance_indices, render_operation, 0)
+
     def render_instance(self, frame: Frame, transform, color):
         """render(Stencil) followed by render(Color) for one instance."""
         self.render(frame, np.asarray(transform, dtype=np.float32).reshape(1, 16), np.asarray(color, dtype=np.float32).reshape(1, 4))
+
+
+class RenderPass:
+    """wgpu::RenderPass stand-in: records `Shape::render(&renderer, &mut render_pass, instance_indices, operation)` calls (renderer.rs:267-273)
+    with the pass state they see — the stencil reference of Renderer::set_clip_depth (renderer.rs:932-938), the layer of save_ / restore_alpha_context
+    (renderer.rs:941-985) — and submits them in order. The Shapes may be different objects (a Shape, a Scene): the frame keeps clip nesting counters,
+    winding counters, saved alphas and sample colours between the submissions (crh_frame: `carry`), so the documented pattern works as it does in
+    the reference (renderer.rs:257-266):
+
+        a.render(pass, range(0, 1), Op.Stencil); pass.set_clip_depth(1); a.render(pass, range(0, 1), Op.Clip)
+        b.render(pass, ...Stencil); b.render(pass, ...Color)        # another Shape object, clipped by a
+        pass.set_clip_depth(0); a.render(pass, range(0, 1), Op.UnClip)
+    """
+
+    def __init__(self, renderer: Renderer, frame: Frame):
+        self.renderer, self.frame = renderer, frame
+        self.transforms, self.colors, self.draws = [], [], []  # draws: (scene, shape, instance, op, clip_depth, alpha_layer)
+        self.clip_depth = self.alpha_layer = 0
+
+    def push_instance(self, transform, color):
+        """Instance data of the pass (the instance buffers bound at slots 0 / 2, renderer.rs:462-466): returns the instance index."""
+        self.transforms.append(np.asarray(transform, dtype=np.float32).reshape(16))
+        self.colors.append(np.asarray(color, dtype=np.float32).reshape(4))
+        return len(self.colors) - 1
+
+    def set_clip_depth(self, clip_depth):  # Renderer::set_clip_depth, renderer.rs:932-938
+        if clip_depth >= (1 << self.renderer.config.clip_nesting_counter_bits):
+            raise ContrastError(_ffi.ERR_CLIP_STACK_OVERFLOW, "ClipStackOverflow")
+        self.clip_depth = int(clip_depth)
+
+    def set_alpha_layer(self, alpha_layer):  # the layer save_alpha_context / restore_alpha_context bind, renderer.rs:941-985
+        if alpha_layer >= self.renderer.config.alpha_layer_count:
+            raise ContrastError(_ffi.ERR_TOO_MANY_NESTED_OPACITY_GROUPS, "TooManyNestedOpacityGroups")
+        self.alpha_layer = int(alpha_layer)
+
+    def render(self, scene: "Scene", instance_indices, operation, shape_index=0):
+        for i in instance_indices:
+            self.draws.append((scene, int(shape_index), int(i), int(operation), self.clip_depth, self.alpha_layer))
+
+    def submit(self):
+        """End of the pass: everything recorded executes in order, one crh_scene_render_draws per run of draws of the same Scene object."""
+        if any(d[0] is not self.draws[0][0] for d in self.draws):
+            self.frame.keep_pass_state()  # the pass spans objects: every sample's colour and stencil stay with the frame from its first draw on
+        begin = 0
+        while begin < len(self.draws):
+            end = begin
+            while end < len(self.draws) and self.draws[end][0] is self.draws[begin][0]:
+                end += 1
+            self.draws[begin][0].render_draws(self.frame, np.stack(self.transforms), np.stack(self.colors), [d[1:] for d in self.draws[begin:end]])
+            begin = end
+        self.draws = []
+

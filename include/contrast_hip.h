@@ -228,6 +228,15 @@ crh_status crh_frame_format(const crh_frame* frame, uint32_t* format);
 void crh_frame_destroy(crh_frame* frame);
 /* LoadOp::Clear(TRANSPARENT) + depth clear 1.0 + stencil clear 0 (examples/showcase/main.rs:217-230) */
 crh_status crh_frame_clear(crh_frame* frame);
+/* The stencil attachment and the alpha layers of the reference are caller-owned textures: what one Shape::render call leaves in them
+ * — an open Clip, the winding of a Stencil without its cover, a saved alpha context — is seen by the next call, whatever Shape (object) it
+ * belongs to (renderer.rs:148-158, 257-266, 932-985). A frame keeps that state across crh_scene_render* calls, in HBM: the stencil byte
+ * (clip nesting counter << winding bits | winding counter, renderer.rs:565-566, 936), the saved alphas and the f32 colour of every sample.
+ * It starts to do so by itself at the first recorded pass that ENDS with state left over; this call starts it now — a pass that will
+ * span several Shape / Scene objects calls it in front of its first crh_scene_render_draws, so that colours drawn before the state
+ * appears are kept per sample and unrounded too (CRH_FORMAT_RGBA8 rounds once, at the resolve — as within one crh_scene_render_draws).
+ * In force until crh_frame_clear. Passes into such a frame are drawn by the general (triangle) formulation. */
+crh_status crh_frame_keep_pass_state(crh_frame* frame);
 /* The depth attachment (f32 per sample, [height][width][msaa_sample_count]); it exists when the renderer's configuration tests or
  * writes depth. clear_depth = LoadOp::Clear(value) (main.rs:223-226); upload_depth places the depth of a 3-D scene the Shapes are
  * decals in (README.md:8-12): `depth` = [height][width] host floats, replicated to every sample; download_depth copies all samples out. */

@@ -447,6 +447,7 @@ class Frame {
     Frame(const Frame&) = delete;
     Frame& operator=(const Frame&) = delete;
     void clear() { check(crh_frame_clear(handle_)); } // LoadOp::Clear(TRANSPARENT) + depth clear 1.0 + stencil clear
+    void keep_pass_state() { check(crh_frame_keep_pass_state(handle_)); } // stencil, alpha layers and sample colours stay with the frame between passes, until clear()
     void set_tile_rows(uint32_t row_begin, uint32_t row_end) { check(crh_frame_set_tile_rows(handle_, row_begin, row_end)); } // the tile split of the multi-GPU path: draw these pixel rows only
     // the depth attachment (present when the Configuration tests or writes depth): LoadOp::Clear(value), the depth of the 3-D scene
     // the Shapes are decals in ([height][width], replicated to the samples), and read back of every sample
@@ -555,24 +556,37 @@ class RenderPass {
         alpha_layer_ = (uint32_t)alpha_layer;
     }
     // Shape::render(&renderer, &mut render_pass, instance_indices, render_operation) (renderer.rs:267-273) for Shape `shape` of `scene`
+    // The Scenes / Shapes of a pass may be different objects: the frame keeps clip nesting counters, winding counters, saved alphas and sample
+    // colours between the submissions, as the caller-owned stencil attachment and alpha layers of the reference do (renderer.rs:148-158, 257-266).
     void render(const Scene& scene, uint32_t shape, uint32_t first_instance, uint32_t end_instance, RenderOperation op) {
-        if (scene_ && scene_ != &scene) throw Error(CRH_ERR_UNSUPPORTED); // one Scene per pass
-        scene_ = &scene;
-        for (uint32_t i = first_instance; i < end_instance; ++i) draws_.push_back(crh_draw{shape, i, (uint32_t)op, clip_depth_, alpha_layer_});
+        for (uint32_t i = first_instance; i < end_instance; ++i) {
+            draws_.push_back(crh_draw{shape, i, (uint32_t)op, clip_depth_, alpha_layer_});
+            scenes_.push_back(&scene);
+        }
     }
-    // end of the pass: everything recorded executes in order
+    // end of the pass: everything recorded executes in order, one crh_scene_render_draws per run of draws of the same object
     void submit() {
-        if (!scene_) return;
-        check(crh_scene_render_draws(scene_->raw(), frame_.raw(), transforms_.data(), colors_.data(), (uint32_t)(colors_.size() / 4), draws_.data(), (uint32_t)draws_.size()));
+        for (const Scene* scene : scenes_)
+            if (scene != scenes_.front()) {
+                frame_.keep_pass_state(); // the pass spans objects: every sample's colour and stencil stay with the frame from its first draw on
+                break;
+            }
+        for (size_t begin = 0; begin < draws_.size();) {
+            size_t end = begin;
+            while (end < draws_.size() && scenes_[end] == scenes_[begin]) ++end;
+            check(crh_scene_render_draws(scenes_[begin]->raw(), frame_.raw(), transforms_.data(), colors_.data(), (uint32_t)(colors_.size() / 4), draws_.data() + begin, (uint32_t)(end - begin)));
+            begin = end;
+        }
         draws_.clear();
+        scenes_.clear();
     }
 
   private:
     Configuration config_;
     Frame& frame_;
-    const Scene* scene_ = nullptr;
     std::vector<float> transforms_, colors_;
     std::vector<crh_draw> draws_;
+    std::vector<const Scene*> scenes_; // the object every draw belongs to
     uint32_t clip_depth_ = 0, alpha_layer_ = 0;
 };
 

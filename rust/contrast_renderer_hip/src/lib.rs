@@ -30,11 +30,6 @@ pub enum Error {
     TooManyNestedOpacityGroups,
     TooManyDashIntervals,
     DynamicStrokeOptionsIndexOutOfBounds,
-    /// Not a reference state (keep it last: the first five are statuses 1-5 of the C ABI). A recorded pass whose clip nesting or alpha
-    /// contexts are still open when the pass moves on to ANOTHER Shape object: the library keeps those per-sample counters for the
-    /// duration of one `crh_scene_render_draws` call over one scene, so such a pass has to be recorded against one [`Scene`] that holds
-    /// all its Shapes (`Scene::render` with real shape indices) instead of separate `Shape`s.
-    PassStateSpansShapes,
 }
 
 fn last_error() -> String {
@@ -602,37 +597,15 @@ impl<'a> RenderPass<'a> {
         self.alpha_layer = alpha_layer as u32;
         Ok(())
     }
-    /// Runs the recorded draws, in order, as one pass per run of draws of the same Shape object (one `crh_scene_render_draws` each).
-    /// Clip counters and saved alpha contexts live for one such call: a run must leave them as it found them (every Clip matched by an
-    /// UnClip, every SaveAlphaContext by its RestoreAlphaContext, clip depth 0 at its borders) — otherwise `Err(PassStateSpansShapes)`,
-    /// and NOTHING of the pass is drawn. The reference's pattern "Clip shape A, Color shape B, UnClip shape A" needs A and B in one
-    /// [`Scene`].
+    /// Runs the recorded draws, in order, as one `crh_scene_render_draws` per run of draws of the same Shape object. Clip nesting counters,
+    /// winding counters, saved alpha contexts and the colour of every sample stay with the [`Frame`] between those calls (the library keeps
+    /// them in HBM from the first pass that ends with state left over until `Frame::clear`), so the reference's pattern — `a.render(Stencil)`,
+    /// `set_clip_depth(1)`, `a.render(Clip)`, other Shapes, `set_clip_depth(0)`, `a.render(UnClip)` (renderer.rs:257-266) — works with `a`
+    /// and the clipped Shapes as separate objects, as does an opacity group around other Shapes (renderer.rs:941-985).
     pub fn submit(self) -> Result<(), Error> {
-        let spans_shapes = self.draws.windows(2).any(|pair| pair[0].0 != pair[1].0);
-        if spans_shapes {
-            let mut begin = 0;
-            while begin < self.draws.len() {
-                let scene = self.draws[begin].0;
-                let (mut end, mut clips, mut saves) = (begin, 0i64, 0i64);
-                while end < self.draws.len() && self.draws[end].0 == scene {
-                    let draw = &self.draws[end].1;
-                    match draw.op {
-                        1 => clips += 1,  // RenderOperation::Clip
-                        2 => clips -= 1,  // UnClip
-                        4 => saves += 1,  // SaveAlphaContext
-                        6 => saves -= 1,  // RestoreAlphaContext
-                        _ => {}
-                    }
-                    if clips < 0 || saves < 0 || (draw.clip_depth != 0 && (end == begin || end + 1 == self.draws.len() || self.draws[end + 1].0 != scene)) {
-                        return Err(Error::PassStateSpansShapes);
-                    }
-                    end += 1;
-                }
-                if clips != 0 || saves != 0 {
-                    return Err(Error::PassStateSpansShapes);
-                }
-                begin = end;
-            }
+        if self.draws.windows(2).any(|pair| pair[0].0 != pair[1].0) {
+            // the pass spans objects: every sample's colour and stencil stay with the frame from its first draw on
+            status(unsafe { ffi::crh_frame_keep_pass_state(self.frame.raw) })?;
         }
         let mut begin = 0;
         while begin < self.draws.len() {

@@ -97,15 +97,18 @@ int main(int argc, char** argv) {
         }
         const float m5[16] = {0.3f, 0, 0, 0, 0, 0.3f, 0, 0, 0, 0, 1, 0, 0.6f, -0.6f, 0, 1}, c5[4] = {0.0f, 0.0f, 1.0f, 1.0f};
         pass.push_instance(m5, c5);
-        pass.render(scene, 0, 0, 1, RenderOperation::Stencil);
+        // the clip is a Shape OBJECT OF ITS OWN (the same rectangle as Shape 0 of the Scene): what it leaves in the stencil attachment clips the
+        // Scene's Shapes rendered behind it, as in the reference (renderer.rs:257-266) — the frame keeps the pass state between the objects
+        Shape clip = Shape::from_paths(renderer, {}, {Path::from_rect({0.0f, 0.0f}, {0.75f, 0.5f})});
+        clip.render(pass, 0, 1, RenderOperation::Stencil);
         pass.set_clip_depth(1);
-        pass.render(scene, 0, 0, 1, RenderOperation::Clip);
+        clip.render(pass, 0, 1, RenderOperation::Clip);
         pass.render(scene, 3, 3, 4, RenderOperation::Stencil);
         pass.render(scene, 3, 3, 4, RenderOperation::Color);
         pass.render(scene, 4, 4, 5, RenderOperation::Stencil);
         pass.render(scene, 4, 4, 5, RenderOperation::Color);
         pass.set_clip_depth(0);
-        pass.render(scene, 0, 0, 1, RenderOperation::UnClip);
+        clip.render(pass, 0, 1, RenderOperation::UnClip);
         pass.render(scene, 1, 1, 2, RenderOperation::Stencil);
         pass.render(scene, 1, 1, 2, RenderOperation::Color);
         pass.render(scene, 2, 2, 3, RenderOperation::Stencil);

@@ -229,3 +229,110 @@ def test_rgba8_attachment_rounds_at_every_blend(msaa, oracle_lib):
             one = R.Scene(r, sc["batch"].slice_shapes(k, k + 1))
             one.render(plain, sc["transforms"][k:k + 1], colors[k:k + 1])
         assert np.array_equal(plain.download(), expect)
+
+
+# ---- pass state that spans Shape objects (renderer.rs:148-158, 257-266: the stencil attachment and the alpha layers are caller-owned, so
+#      `a.render(Clip)` clips whatever Shapes are rendered afterwards, until `a.render(UnClip)`). The device draws every Shape from an object of
+#      its own (Shape.from_paths, one crh_scene_render_draws per run of draws of one object); the oracle draws the same draws in one pass over one batch.
+def _separate_shapes(r, shapes):
+    from contrast_renderer_amd import renderer as R
+    return [R.Shape.from_paths(r, opts, paths) for opts, paths in shapes]
+
+
+def _submit_per_shape(r, frame, objects, t, c, draws):
+    from contrast_renderer_amd import renderer as R
+    rp = R.RenderPass(r, frame)
+    for i in range(len(t)):
+        rp.push_instance(t[i], c[i])
+    for shape, instance, op, clip_depth, layer in draws:
+        rp.set_clip_depth(clip_depth)
+        rp.set_alpha_layer(layer)
+        objects[shape].render_in(rp, range(instance, instance + 1), op)
+    rp.submit()
+
+
+def _shapes_of(case):
+    if case == "clip":
+        return [([], [Path.from_regular_polygon((0.0, 0.0), 0.6, 0.0, 24)]), rect(-0.3, 0.0, 0.5, 0.2), rect(0.3, 0.3, 0.5, 0.2), rect(0.0, 0.0, 0.25, 0.9), rect(0.0, -0.6, 0.9, 0.1)]
+    return [rect(0.0, 0.0, 0.9, 0.9), rect(0.0, 0.0, 0.6, 0.6), rect(-0.2, 0.1, 0.3, 0.5), rect(0.3, -0.2, 0.4, 0.2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["clip", "alpha"])
+@pytest.mark.parametrize("msaa", [1, 4])
+@pytest.mark.parametrize("fmt", ["rgba8", "attachment"])
+def test_pass_state_spans_shape_objects(case, msaa, fmt, oracle_lib):
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle, render_pass
+    batch, t, c, draws = CASES[case]()
+    # rotate / shift a little so that edges cross sample positions of the 4x pattern
+    t = t.copy().reshape(-1, 4, 4)
+    t[:, 0, 1] = 0.07
+    t[:, 1, 0] = -0.05
+    t = t.reshape(-1, 16)
+    r = R.Renderer(R.Configuration(msaa_sample_count=msaa, clip_nesting_counter_bits=4, winding_counter_bits=4, alpha_layer_count=2), device=0)
+    objects = _separate_shapes(r, _shapes_of(case))
+    frame = R.Frame(r, 192, 192, R.FORMAT_RGBA8_ATTACHMENT if fmt == "attachment" else R.FORMAT_RGBA8)
+    for _ in range(2):  # twice: crh_frame_clear drops the state the first round left (LoadOp::Clear of the stencil, main.rs:217-230)
+        frame.clear()
+        _submit_per_shape(r, frame, objects, t, c, draws)
+        image = frame.download()
+        expect, _ = render_pass(Oracle(batch), 192, 192, msaa, 4, 4, 2, t, c, [tuple(int(v) for v in d) for d in draws], attachment8=fmt == "attachment")
+        diff = (image != expect).any(axis=2)
+        assert not diff.any(), f"{case} msaa {msaa} {fmt}: {diff.sum()} pixels differ"
+        assert (image[..., 3] > 0).mean() > 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("msaa", [1, 4])
+def test_an_open_clip_confines_later_passes_of_any_kind(msaa, oracle_lib):
+    """Clip by Shape A in one pass; a whole Scene drawn at clip depth 1 in the next is confined to A; the winding a Stencil leaves without its
+    cover stays for the pass after it (Shape::render(Stencil) in one pass, render(Color) in the next); after UnClip the plain Stencil + Color loop
+    (crh_scene_render — the pass the benchmark times, otherwise the edge formulation) draws over what is there, unconfined."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle, render_pass
+    rng = np.random.RandomState(11)
+    content = []
+    for i in range(14):
+        cx, cy = rng.uniform(30, 162, 2)
+        content.append(([], [Path.from_regular_polygon((cx, cy), rng.uniform(8, 40), rng.uniform(0, 1), 3 + i % 6)]) if i % 2 else rect(cx, cy, rng.uniform(5, 45), rng.uniform(5, 30)))
+    n = len(content)
+    clip = ([], [Path.from_regular_polygon((96.0, 96.0), 70.0, 0.3, 7)])
+    late = rect(96.0, 40.0, 80.0, 12.0)
+    pix = np.array([2.0 / 192, 0.003, 0, 0, -0.002, 2.0 / 192, 0, 0, 0, 0, 1, 0, -1, -1, 0, 1], dtype=np.float32)
+    t_scene = np.tile(pix, (n, 1))
+    c_scene = np.concatenate([rng.uniform(0, 1, (n, 3)), rng.uniform(0.3, 1, (n, 1))], axis=1).astype(np.float32)
+    c_scene[::3, 3] = 1.0
+    one_t, col_a, col_b = pix.reshape(1, 16), np.array([[1, 1, 1, 1]], dtype=np.float32), np.array([[0.9, 0.2, 0.1, 0.6]], dtype=np.float32)
+    r = R.Renderer(R.Configuration(msaa_sample_count=msaa, clip_nesting_counter_bits=2, winding_counter_bits=4, alpha_layer_count=0), device=0)
+    a, b = R.Shape.from_paths(r, *clip), R.Shape.from_paths(r, *late)
+    scene = R.Scene(r, batch_from_shapes(content))
+    frame = R.Frame(r, 192, 192, R.FORMAT_RGBA8_ATTACHMENT)
+    frame.clear()
+    a.render_draws(frame, one_t, col_a, [(0, 0, Op.Stencil, 0, 0), (0, 0, Op.Clip, 1, 0)])
+    inside = []
+    for i in range(n):
+        inside += [(i, i, Op.Stencil, 1, 0), (i, i, Op.Color, 1, 0)]
+    scene.render_draws(frame, t_scene, c_scene, inside)
+    b.render_draws(frame, one_t, col_b, [(0, 0, Op.Stencil, 1, 0)])   # the Stencil alone ...
+    b.render_draws(frame, one_t, col_b, [(0, 0, Op.Color, 1, 0)])     # ... its cover in the next pass
+    a.render_draws(frame, one_t, col_a, [(0, 0, Op.UnClip, 0, 0)])
+    scene.render(frame, t_scene, c_scene)                             # the plain loop over what is there, unconfined
+    image = frame.download()
+    # the oracle: everything in one batch, one pass
+    batch = batch_from_shapes(content + [clip, late])
+    t = np.concatenate([t_scene, one_t, one_t])
+    c = np.concatenate([c_scene, col_a, col_b])
+    ia, ib = n, n + 1
+    draws = [(ia, ia, Op.Stencil, 0, 0), (ia, ia, Op.Clip, 1, 0)] + inside + [(ib, ib, Op.Stencil, 1, 0), (ib, ib, Op.Color, 1, 0), (ia, ia, Op.UnClip, 0, 0)]
+    for i in range(n):
+        draws += [(i, i, Op.Stencil, 0, 0), (i, i, Op.Color, 0, 0)]
+    expect, _ = render_pass(Oracle(batch), 192, 192, msaa, 4, 2, 0, t, c, [tuple(int(v) for v in d) for d in draws], attachment8=True)
+    diff = (image != expect).any(axis=2)
+    assert not diff.any(), f"msaa {msaa}: {diff.sum()} pixels differ"
+    confined = oracle_image(batch, t, c, draws[:2 + len(inside)], size=192, msaa=1, clip_bits=2, layers=0)
+    assert (confined[..., 3] > 0).any() and not (confined[:20, :, 3] > 0).any()  # (the clip does confine something in this scene)

@@ -58,9 +58,9 @@ def test_the_shim_keeps_the_reference_signatures_and_calls_only_declared_functio
     # Error variants in the reference's order (error.rs:5-16) = statuses 1..5
     body = re.sub(r"//[^\n]*", "", re.search(r"pub enum Error \{(.*?)\n\}", lib, flags=re.S).group(1))
     variants = body.replace(",", " ").split()
-    # ... followed by the shim's own state (a recorded pass whose clip / alpha state would have to outlive one crh_scene_render_draws call)
-    assert variants == ["NumberOfStencilBitsIsUnsupported", "ClipStackOverflow", "TooManyNestedOpacityGroups", "TooManyDashIntervals", "DynamicStrokeOptionsIndexOutOfBounds",
-                        "PassStateSpansShapes"]
+    # ... and nothing of the shim's own: clip / alpha state outlives a crh_scene_render_draws call (the frame keeps it), so a pass may span Shape objects
+    assert variants == ["NumberOfStencilBitsIsUnsupported", "ClipStackOverflow", "TooManyNestedOpacityGroups", "TooManyDashIntervals", "DynamicStrokeOptionsIndexOutOfBounds"]
+    assert "PassStateSpansShapes" not in lib
     # enum discriminants that cross the ABI as integers
     for name, items in (("SegmentType", ["Line = 0", "IntegralQuadraticCurve = 1", "IntegralCubicCurve = 2", "RationalQuadraticCurve = 3", "RationalCubicCurve = 4"]),
                         ("RenderOperation", ["Stencil = 0", "Clip = 1", "UnClip = 2", "Color = 3", "SaveAlphaContext = 4", "ScaleAlphaContext = 5", "RestoreAlphaContext = 6"]),
