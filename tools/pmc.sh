@@ -7,7 +7,7 @@ shift
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -f csv -d $out/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --workload ${WORKLOAD:-cubic} > $out/p$i.log 2>&1
+  timeout ${PMC_TIMEOUT:-420} rocprofv3 --kernel-trace --pmc $set -f csv -d $out/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-animated --no-side-workloads --repeats 0 --workload ${WORKLOAD:-cubic} > $out/p$i.log 2>&1
   f=$(find $out/p$i -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import sys, csv, collections
