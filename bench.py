@@ -187,6 +187,22 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
+def _rocminfo_gpu():
+    """Compute units and clock of the first GPU agent as `rocminfo` prints them (torch's device properties leave the clocks at 0 on this stack)."""
+    import re
+    import subprocess
+    try:
+        text = subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True, timeout=20).stdout
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    for block in text.split("*******")[1:]:
+        if "gfx" in block and re.search(r"Device Type:\s+GPU", block):
+            grab = lambda pat: (re.search(pat, block) or [None, None])[1]
+            return {"name": grab(r"Name:\s+(gfx\w+)"), "marketing_name": (grab(r"Marketing Name:\s+(.+)") or "").strip(), "compute_units": int(grab(r"Compute Unit:\s+(\d+)") or 0),
+                    "max_clock_mhz": int(grab(r"Max Clock Freq\. \(MHz\):\s+(\d+)") or 0), "wavefront_size": int(grab(r"Wavefront Size:\s+(\d+)") or 0)}
+    return {"error": "no GPU agent in rocminfo's output"}
+
+
 def _frame_crc(workload, image):
     """-> (crc32 of the frame, the oracle's committed crc32 for this workload's default scene or None)"""
     import zlib
@@ -1100,7 +1116,7 @@ def main():
         out["device"] = {"name": props.name, "arch": getattr(props, "gcnArchName", None), "compute_units": int(props.multi_processor_count),
                          "engine_clock_mhz": getattr(props, "clock_rate", 0) / 1e3, "memory_clock_mhz": getattr(props, "memory_clock_rate", 0) / 1e3,
                          "memory_bus_bits": int(getattr(props, "memory_bus_width", 0)), "memory_bytes": int(props.total_memory),
-                         "hbm_peak_gbs_used": HBM_PEAK_GBS,
+                         "hbm_peak_gbs_used": HBM_PEAK_GBS, "rocminfo": _rocminfo_gpu(),
                          "note": "hipDeviceProp as torch reports it; `roofline.peak` is the MI355X HBM3E figure of /opt/skills/guides/MI355X_MICROARCH.md (8 TB/s), not derived from these clocks"}
     except Exception as e:
         out["device"] = {"error": f"{type(e).__name__}: {e}"}

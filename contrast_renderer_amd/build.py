@@ -11,6 +11,12 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ("tessellate.hip", "raster.hip", "raster_edges.hip", "api.hip", "comm.hip", "text.cpp", "path.cpp")  # text.cpp / path.cpp: host-only (text.rs, path.rs:639-708)
 HEADERS = ("ga.hpp", "fill.hpp", "stroke.hpp", "scene.hpp", "raster_params.hpp", "raster_common.hpp", "../../include/contrast_hip.h", "../../include/crh_fmath.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+# Per-file flags. raster_edges.hip without LLVM's SLP vectorizer (round 6): it packs pairs of independent f32 operations of the per-sample code into
+# v_pk_* instructions, whose operands are register PAIRS — lane-invariant values (sample positions, the tile's origin) end up duplicated in pairs that live
+# for the whole kernel, and the raster kernels spilled exactly those (k_raster_edges<4,1,true,false>: 100 B of scratch per lane -> 12, 96 -> 95 registers;
+# k_raster_fill 94 -> 76 registers; k_raster_rows 112 -> 95). Same results bit for bit (no contraction either way); S10k raster kernel 0.166 -> 0.151 ms alone,
+# dashed scene 1.557 -> 1.481 (profiles/r06_experiments.txt). CRH_FILE_FLAGS="file.hip:-flag,-flag;..." replaces the table (A/B runs).
+FILE_FLAGS = {"raster_edges.hip": ["-fno-slp-vectorize"], "raster.hip": ["-fno-slp-vectorize"], "tessellate.hip": ["-fno-slp-vectorize"]}  # (raster.hip: k_raster_tile<4,1,true,true> 150 -> 127 registers; tessellate.hip: k_tess_runs<true> 182 -> 146)
 OUT = os.path.join(HERE, "libcontrast_hip.so")
 
 
@@ -19,6 +25,17 @@ def _newer(target, deps):
         return False
     t = os.path.getmtime(target)
     return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
+def file_flags():
+    table = os.environ.get("CRH_FILE_FLAGS")
+    if table is None:
+        return FILE_FLAGS
+    out = {}
+    for entry in filter(None, table.split(";")):
+        name, _, flags = entry.partition(":")
+        out[name] = [f for f in flags.split(",") if f]
+    return out
 
 
 def build_library(force=False, verbose=False):
@@ -33,6 +50,7 @@ def build_library(force=False, verbose=False):
         if not force and _newer(obj, [os.path.join(CSRC, src)] + headers):
             continue
         flags = (FLAGS + os.environ.get("CRH_EXTRA_FLAGS", "").split()) if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]  # plain C++ for host-only files
+        flags = flags + file_flags().get(src, [])
         cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -2,7 +2,6 @@
 // parity taps). Every arithmetic step of the hot path runs in the HIP kernels of tessellate.hip / raster.hip; there is no
 // CPU fallback here and nothing under oracle/ is referenced.
 #include <hip/hip_runtime.h>
-#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -11,11 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <condition_variable>
 #include <functional>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "raster_params.hpp"
@@ -402,6 +398,7 @@ struct crh_scene {
     SceneDev d;
     uint32_t n_segments = 0;
     bool has_stroke = false, big_shapes = false;
+    uint64_t structure_hash = 0; // of shape_path_begin and path_segment_begin of the uploaded batch (crh_scene_upload: same_structure)
     bool capacity_known = false;
     uint64_t instances_version = 0; // counts crh_scene_set_instances calls
     uint64_t input_bytes = 0, emitted_bytes = 0;
@@ -526,90 +523,6 @@ struct crh_scene {
 };
 
 namespace {
-// Host threads for crh_scene_upload (round 6): the call is what stands between new paths every frame and the GPU — validation,
-// -0 canonicalisation (SafeFloat::from, safe_float.rs:44-52: its failure is this call's return value, so it stays on the host) and the element stream, 2.7 MB
-// for the metric's scene, 0.32 ms on one core. The work is cut by contiguous path ranges; a worker that has just finished a job keeps looking for the
-// next one for a moment before it goes to sleep (an upload runs two jobs back to back, and an application uploads every frame).
-class HostPool {
-  public:
-    static HostPool& instance() {
-        static HostPool pool;
-        return pool;
-    }
-    unsigned workers() const { return (unsigned)threads_.size() + 1u; } // (the calling thread is one of them)
-    // fn(worker, n_workers) on every worker, the caller included; returns when all are through
-    void run(const std::function<void(unsigned, unsigned)>& fn) {
-        const unsigned n = workers();
-        if (n == 1u) return fn(0u, 1u);
-        std::lock_guard<std::mutex> one_job(job_lock_); // (two application threads uploading at once take turns)
-        job_ = &fn;
-        pending_.store(n - 1u, std::memory_order_relaxed);
-        epoch_.fetch_add(1u, std::memory_order_release);
-        if (sleepers_.load(std::memory_order_acquire) != 0) {
-            std::lock_guard<std::mutex> lock(sleep_lock_);
-            wake_.notify_all();
-        }
-        fn(0u, n);
-        while (pending_.load(std::memory_order_acquire) != 0u) cpu_relax();
-    }
-
-  private:
-    HostPool() {
-        unsigned want = 8u;
-        if (const char* e = std::getenv("CRH_UPLOAD_THREADS")) want = (unsigned)std::max(1, std::atoi(e));
-        unsigned have = std::thread::hardware_concurrency();
-#if defined(__linux__)
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) have = (unsigned)CPU_COUNT(&set); // (the CPUs this process may run on, not the host's)
-#endif
-        const unsigned n = std::max(1u, std::min(want, have ? have : 1u));
-        for (unsigned k = 1; k < n; ++k) threads_.emplace_back([this, k] { loop(k); });
-    }
-    ~HostPool() {
-        stop_.store(true);
-        epoch_.fetch_add(1u);
-        {
-            std::lock_guard<std::mutex> lock(sleep_lock_);
-            wake_.notify_all();
-        }
-        for (std::thread& t : threads_) t.join();
-    }
-    static void cpu_relax() {
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-    }
-    void loop(unsigned k) {
-        uint64_t seen = 0;
-        for (;;) {
-            // look for the next job for about 0.2 ms, then sleep
-            const auto t0 = std::chrono::steady_clock::now();
-            uint32_t spins = 0;
-            while (epoch_.load(std::memory_order_acquire) == seen) {
-                cpu_relax();
-                if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) {
-                    std::unique_lock<std::mutex> lock(sleep_lock_);
-                    sleepers_.fetch_add(1);
-                    wake_.wait(lock, [&] { return epoch_.load(std::memory_order_acquire) != seen; });
-                    sleepers_.fetch_sub(1);
-                }
-            }
-            seen = epoch_.load(std::memory_order_acquire);
-            if (stop_.load()) return;
-            (*job_)(k, workers());
-            pending_.fetch_sub(1u, std::memory_order_release);
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex job_lock_, sleep_lock_;
-    std::condition_variable wake_;
-    const std::function<void(unsigned, unsigned)>* job_ = nullptr;
-    std::atomic<uint64_t> epoch_{0};
-    std::atomic<unsigned> pending_{0};
-    std::atomic<int> sleepers_{0};
-    std::atomic<bool> stop_{false};
-};
-
 const int kSegmentFloats[5] = {2, 4, 6, 5, 10};
 
 // renderer.rs:29-60
@@ -1671,12 +1584,19 @@ crh_status crh_renderer_create(const crh_config* config, int device_ordinal, crh
     // priorities had measured within noise). Starting it behind that binning instead — beside the raster kernel — leaves it without wave
     // slots until that grid drains, at any priority: 0.398.
     int lane_priority[3] = {1, 0, 0};
-    if (const char* e = getenv("CRH_LANE_PRIORITY")) (void)sscanf(e, "%d %d %d", &lane_priority[0], &lane_priority[1], &lane_priority[2]);
+    if (const char* e = getenv("CRH_LANE_PRIORITY")) { // (three values out of -1, 0, 1, or the variable is ignored)
+        int p[3] = {0, 0, 0};
+        if (sscanf(e, "%d %d %d", &p[0], &p[1], &p[2]) == 3 && p[0] >= -1 && p[0] <= 1 && p[1] >= -1 && p[1] <= 1 && p[2] >= -1 && p[2] <= 1) lane_priority[0] = p[0], lane_priority[1] = p[1], lane_priority[2] = p[2];
+        else std::fprintf(stderr, "[contrast-hip] CRH_LANE_PRIORITY=\"%s\" is not three values out of -1, 0, 1: ignored\n", e);
+    }
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    // A stream is created with a CU mask OR with a priority (HIP offers no call for both): a requested CU partition (CRH_CU_SPLIT, an experiment) comes first
+    // for the lanes it concerns — their priorities are then not applied (the tessellation lane's default low priority used to switch its mask off silently).
+    const bool partition = r->pipeline && front_cus > 0 && front_cus < n_cus;
     auto make_stream = [&](hipStream_t* st, int lane, int priority = 0) -> bool { // lane 0: unrestricted, 1: front lanes, 2: raster lane
-        if (priority != 0) return hip_ok(hipStreamCreateWithPriority(st, hipStreamNonBlocking, priority < 0 ? prio_high : prio_low), "hipStreamCreateWithPriority");
-        if (!r->pipeline || front_cus <= 0 || front_cus >= n_cus || lane == 0) return hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
+        if (priority != 0 && !(partition && lane != 0)) return hip_ok(hipStreamCreateWithPriority(st, hipStreamNonBlocking, priority < 0 ? prio_high : prio_low), "hipStreamCreateWithPriority");
+        if (!partition || lane == 0) return hip_ok(hipStreamCreateWithFlags(st, hipStreamNonBlocking), "hipStreamCreate");
         std::vector<uint32_t> mask((size_t)(n_cus + 31) / 32, 0u);
         for (int c = 0; c < n_cus; ++c)
             if ((c < front_cus) == (lane == 1)) mask[(size_t)c / 32] |= 1u << (c % 32);
@@ -1728,12 +1648,19 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         if (phase_timing) std::fprintf(stderr, "[upload] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), name);
     };
     if (!r || !b || !out) return CRH_ERR_INVALID_ARGUMENT;
+    uint64_t structure_hash = 0xCBF29CE484222325ull;
     // ---- structure of the batch: a C ABI cannot trust its index arrays (the Rust types make these states unrepresentable)
     {
-        auto prefix_ok = [](const uint32_t* a, uint32_t n, uint32_t total) {
+        // (... and, on the way, a hash of the two index arrays: paths "of the structure the Scene holds" are paths with the same Shapes of the same paths of
+        // as many segments each, not just the same totals — ADVICE r05: kept places, batches and capacities were reused on scene-wide counts alone)
+        auto prefix_ok = [&](const uint32_t* a, uint32_t n, uint32_t total) {
             if (!a || a[0] != 0u || a[n] != total) return false;
-            for (uint32_t i = 0; i < n; ++i)
+            uint64_t h = structure_hash;
+            for (uint32_t i = 0; i < n; ++i) {
                 if (a[i] > a[i + 1]) return false;
+                h = (h ^ a[i + 1]) * 0x100000001B3ull;
+            }
+            structure_hash = h;
             return true;
         };
         if (!prefix_ok(b->shape_path_begin, b->n_shapes, b->n_paths) || !prefix_ok(b->path_segment_begin, b->n_paths, b->n_segments)) return CRH_ERR_INVALID_ARGUMENT;
@@ -1742,18 +1669,17 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
             (b->n_stroke_options && !b->stroke_options) || (b->n_dynamic_stroke_options && !b->dynamic_stroke_options))
             return CRH_ERR_INVALID_ARGUMENT;
     }
-    // The paths in contiguous ranges, one per host thread (small batches: the calling thread alone). First job: every range's segment types are
-    // valid and how many control floats they stand for — the ranges' places in control_data and in the pool follow from the sums.
-    HostPool* const pool_threads = ((uint64_t)b->n_control_floats + b->n_segments >= 65536ull) ? &HostPool::instance() : nullptr;
-    const unsigned n_ranges = pool_threads ? pool_threads->workers() : 1u;
-    auto run_ranges = [&](const std::function<void(unsigned, unsigned)>& fn) {
-        if (pool_threads) pool_threads->run(fn);
-        else fn(0u, 1u);
+    // Every segment type is valid, and the types stand for as many control floats as the batch says it holds. (Round 6 cut this loop and the
+    // element stream's below into chunks of paths for a pool of host threads — measured on the GPU box, profiles/r06_experiments.txt: no faster at
+    // two to six threads, 0.32 ms either way, and the threads' wake-ups made the calls around the upload slower; the loops are one range again.)
+    const unsigned n_ranges = 1u;
+    auto run_ranges = [&](const std::function<void(uint32_t)>& fn) {
+        for (unsigned k = 0; k < n_ranges; ++k) fn(k);
     };
     auto range_begin = [&](unsigned k) { return (uint32_t)((uint64_t)b->n_paths * k / n_ranges); };
     std::vector<uint64_t> range_floats(n_ranges + 1u, 0u);
     std::atomic<uint32_t> bad_type{0};
-    run_ranges([&](unsigned k, unsigned) {
+    run_ranges([&](uint32_t k) {
         uint64_t floats = 0;
         uint32_t wrong = 0;
         const uint32_t g0 = b->path_segment_begin[range_begin(k)], g1 = b->path_segment_begin[range_begin(k + 1u)];
@@ -1865,11 +1791,11 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         uint32_t* const path_elem_begin = reinterpret_cast<uint32_t*>(arena + part[P_PATH_BEGIN].at);
         uint32_t* const path_shape = reinterpret_cast<uint32_t*>(arena + part[P_PATH_SHAPE].at);
         uint32_t* const shape_elem_begin = reinterpret_cast<uint32_t*>(arena + part[P_SHAPE_BEGIN].at);
-        // Second job: every range builds its elements and its part of the pool — where they begin follows from the index arrays and the ranges' float
+        // Then: every chunk builds its elements and its part of the pool — where they begin follows from the index arrays and the chunks' float
         // sums — and canonicalises what it has just copied while it is in cache (SafeFloat::from, safe_float.rs:44-52: finite, and -0 -> +0:
         // x + 0 is x for every x but -0).
         std::atomic<uint32_t> any_bad{0};
-        run_ranges([&](unsigned k, unsigned) {
+        run_ranges([&](uint32_t k) {
             const uint32_t p_begin = range_begin(k), p_end = range_begin(k + 1u);
             uint32_t bad = 0;
             size_t cursor = (size_t)range_floats[k]; // float of control_data
@@ -1955,7 +1881,8 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
     // stay, no wait for the totals (crh_scene::optimistic). CRH_NO_OPTIMISTIC_UPLOAD: A/B runs and the tests of the other way.
     const uint32_t new_runs = (runs.empty() || n_elems == 0u) ? 0u : (uint32_t)runs.size() - 1u;
     const bool same_structure = existing && sc->capacity_known && sc->d.n_elems == n_elems && sc->d.n_paths == b->n_paths && sc->d.n_shapes == b->n_shapes && sc->has_stroke == has_stroke &&
-                                sc->d.n_runs == new_runs && sc->d.run_block == run_block && n_elems != 0u && std::getenv("CRH_NO_OPTIMISTIC_UPLOAD") == nullptr;
+                                sc->d.n_runs == new_runs && sc->d.run_block == run_block && n_elems != 0u && sc->structure_hash == structure_hash && std::getenv("CRH_NO_OPTIMISTIC_UPLOAD") == nullptr;
+    sc->structure_hash = structure_hash;
     sc->rendered_once = false;
     sc->last_render_one_event = false;
     if (sc->shadow.allocated && !same_structure) { // sized for the previous contents
@@ -2609,6 +2536,13 @@ crh_status crh_frame_device_pointer(crh_frame* f, void** out) {
 crh_status crh_internal_frame_geometry(crh_frame* f, uint32_t* width, uint32_t* height, uint32_t* format, int* device) { // no waiting, cannot fail for a live frame
     if (!f || !f->renderer || !width || !height || !format || !device) return CRH_ERR_INVALID_ARGUMENT;
     *width = f->width, *height = f->height, *format = f->format, *device = f->renderer->device;
+    return CRH_OK;
+}
+// the pixel rows the frame's passes draw (crh_frame_set_tile_rows; the whole frame by default)
+crh_status crh_internal_frame_slab(crh_frame* f, uint32_t* row_begin, uint32_t* row_end) {
+    if (!f || !row_begin || !row_end) return CRH_ERR_INVALID_ARGUMENT;
+    *row_begin = std::min(f->height, f->slab_ty0 * 16u);
+    *row_end = f->slab_ty1 == 0xFFFFFFFFu ? f->height : std::min(f->height, f->slab_ty1 * 16u);
     return CRH_OK;
 }
 crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device) {

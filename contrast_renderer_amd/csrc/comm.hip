@@ -39,6 +39,7 @@ void set_last_error(const std::string& text);
 extern "C" crh_status crh_internal_frame_geometry(crh_frame* f, uint32_t* width, uint32_t* height, uint32_t* format, int* device);
 extern "C" crh_status crh_internal_frame_info(crh_frame* f, void** rgba8, uint32_t* width, uint32_t* height, int* device);
 extern "C" crh_status crh_internal_frame_touched(crh_frame* f, void* stream, int written);
+extern "C" crh_status crh_internal_frame_slab(crh_frame* f, uint32_t* row_begin, uint32_t* row_end);
 extern "C" crh_status crh_internal_frame_tile_counts(crh_frame* f, const uint32_t** counts, uint32_t* n_tiles, uint32_t* first_tile, uint32_t* end_tile);
 extern "C" int crh_internal_renderer_device(crh_renderer* r);
 
@@ -872,47 +873,62 @@ void mark_all_phases(crh_comm* c) { // (crh_comm_last_timing reads every phase: 
 }
 } // namespace
 crh_status crh_frame_gather_slabs(crh_comm* c, crh_frame* layer, crh_frame* result) {
-    if (!c || !layer || !c->nccl || (c->rank == 0) != (result != nullptr)) return CRH_ERR_INVALID_ARGUMENT;
+    if (!c || !c->nccl) return CRH_ERR_INVALID_ARGUMENT; // (no communicator: nobody is waiting for this rank)
     Rccl* api = rccl();
     c->timed = false;
+    // Everything that can be wrong on THIS rank — its arguments, its layer, rank 0's result frame, the layer's slab — becomes a status word that travels
+    // with the header, so that every rank leaves the call together instead of one returning early from in front of a collective the others are already
+    // in (rank 0 used to return before the all-gather on a result frame of another size, and behind it when the result could not be read).
     uint32_t w = 0, h = 0, format = 0, rw = 0, rh = 0, rformat = 0;
-    int device = 0;
-    crh_status st = crh_internal_frame_geometry(layer, &w, &h, &format, &device);
-    if (st != CRH_OK) return st;
-    if (device != c->device || format == CRH_FORMAT_RGBA16F) return CRH_ERR_INVALID_ARGUMENT;
-    if (result && ((st = crh_internal_frame_geometry(result, &rw, &rh, &rformat, &device)) != CRH_OK || rw != w || rh != h || rformat == CRH_FORMAT_RGBA16F || device != c->device))
-        return st != CRH_OK ? st : CRH_ERR_INVALID_ARGUMENT;
+    int device = c->device;
+    crh_status mine = (!layer || (c->rank == 0) != (result != nullptr)) ? CRH_ERR_INVALID_ARGUMENT : CRH_OK;
+    if (mine == CRH_OK) mine = crh_internal_frame_geometry(layer, &w, &h, &format, &device);
+    if (mine == CRH_OK && (device != c->device || format == CRH_FORMAT_RGBA16F)) mine = CRH_ERR_INVALID_ARGUMENT;
+    if (mine == CRH_OK && result) {
+        mine = crh_internal_frame_geometry(result, &rw, &rh, &rformat, &device);
+        if (mine == CRH_OK && (rw != w || rh != h || rformat == CRH_FORMAT_RGBA16F || device != c->device)) mine = CRH_ERR_INVALID_ARGUMENT;
+    }
     HIP_TRY(hipSetDevice(c->device));
-    void* pixels = nullptr;
-    const crh_status layer_status = crh_internal_frame_info(layer, &pixels, &w, &h, &device); // settles the layer: its pixels are final
-    // the ranks' transfers only match when their frames have one size, and a failed layer must fail every rank: 16 bytes all-gathered, read on
-    // the host when this rank's geometry (or the first exchange) asks for it, and always for the status word
+    void *pixels = nullptr, *out = nullptr;
+    if (mine == CRH_OK) mine = crh_internal_frame_info(layer, &pixels, &w, &h, &device); // settles the layer: its pixels are final
+    if (mine == CRH_OK && result) mine = crh_internal_frame_info(result, &out, &rw, &rh, &device);
+    if (mine == CRH_OK) { // the layer draws exactly this rank's slab of rows (crh_frame_set_tile_rows(crh_comm_slab_rows(...))): anything else would gather transparent or partial rows
+        uint32_t row0 = 0, row1 = 0, slab0 = 0, slab1 = 0;
+        mine = crh_internal_frame_slab(layer, &slab0, &slab1);
+        if (mine == CRH_OK) mine = crh_comm_slab_rows(h, c->rank, c->world, &row0, &row1);
+        if (mine == CRH_OK && row0 != row1 && (slab0 != row0 || slab1 != row1)) {
+            set_last_error("crh_frame_gather_slabs: the layer of rank " + std::to_string(c->rank) + " draws rows " + std::to_string(slab0) + " .. " + std::to_string(slab1) + ", its slab is " + std::to_string(row0) +
+                           " .. " + std::to_string(row1));
+            mine = CRH_ERR_INVALID_ARGUMENT;
+        }
+    }
+    // the ranks' transfers only match when their frames have one size, and a failed rank must fail every rank: 16 bytes all-gathered and read on the host
     HIP_TRY(c->host_header.ensure(kHeaderWords * 4));
     HIP_TRY(c->bitmap.ensure(kHeaderWords * 4));
     HIP_TRY(c->headers_all.ensure((size_t)c->world * kHeaderWords * 4));
     HIP_TRY(c->host_headers.ensure((size_t)c->world * kHeaderWords * 4));
     uint32_t* header = c->host_header.as<uint32_t>();
-    header[0] = kMagic, header[1] = w, header[2] = h, header[3] = (uint32_t)layer_status;
+    header[0] = kMagic, header[1] = w, header[2] = h, header[3] = (uint32_t)mine;
     HIP_TRY(hipMemcpyAsync(c->bitmap.p, header, kHeaderWords * 4, hipMemcpyHostToDevice, c->stream));
     mark_all_phases(c);
     NCCL_TRY(api->AllGather(c->bitmap.p, c->headers_all.p, kHeaderWords * 4, ncclUint8, c->nccl, c->stream));
     HIP_TRY(hipMemcpyAsync(c->host_headers.p, c->headers_all.p, (size_t)c->world * kHeaderWords * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(c->bitmaps_on_host, c->stream));
     HIP_TRY(hipEventSynchronize(c->bitmaps_on_host));
+    if (mine != CRH_OK) return mine; // (this rank's own reason; the others read it below)
     for (uint32_t k = 0; k < c->world; ++k) {
         const uint32_t* hd = c->host_headers.as<uint32_t>() + (size_t)k * kHeaderWords;
+        if (hd[0] == kMagic && hd[3] != (uint32_t)CRH_OK) {
+            set_last_error("crh_frame_gather_slabs: rank " + std::to_string(k) + " cannot take part (status " + std::to_string(hd[3]) + ")");
+            return (crh_status)hd[3]; // on every rank
+        }
         if (hd[0] != kMagic || hd[1] != w || hd[2] != h) {
             set_last_error("crh_frame_gather_slabs: rank " + std::to_string(k) + " gathers a layer of another size");
             return CRH_ERR_INVALID_ARGUMENT; // on every rank
         }
-        if (hd[3] != (uint32_t)CRH_OK) {
-            set_last_error("crh_frame_gather_slabs: the layer of rank " + std::to_string(k) + " could not be read");
-            return (crh_status)hd[3]; // on every rank
-        }
     }
     c->gather_agreed = true, c->gather_width = w, c->gather_height = h;
-    void* out = nullptr;
-    if (result && (st = crh_internal_frame_info(result, &out, &rw, &rh, &device)) != CRH_OK) return st;
+    crh_status st = CRH_OK;
     begin_phase(c, kGather);
     bool ok = nccl_ok(api->GroupStart(), "ncclGroupStart");
     if (!ok) return CRH_ERR_HIP;

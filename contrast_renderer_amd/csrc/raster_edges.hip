@@ -2557,11 +2557,17 @@ CRH_D void blend_rows(float (&c)[4][4], const unsigned long long (&mask)[4], flo
 }
 // bit `bit` of `rows` clear -> the sign bit set in x (a sample row that is left out fails every  x >= 0 / x >= 1  test): v_lshlrev_b32 + v_and_or_b32
 CRH_D int reject_unless_row(int x, uint32_t not_rows, int bit) { return (int)(((not_rows << (31 - bit)) & 0x80000000u) | (uint32_t)x); }
-// WAVES: wavefronts per SIMD the build is held to — 5 (no scratch memory) or 6 (80 registers, 20 B of scratch). Alone the six-wave build is the
-// faster one (S10k 0.157 against 0.167 ms, 100 000 paths @ 8192^2 1.01 against 1.09), but a fuller raster grid gives the workgroups of the next
-// frame's binning their slots later: the metric's pipelined step is 0.308 against 0.301 ms with it, config 4's 1.96 against 2.01. The host takes
-// six for frames of long lists (RasterParams::long_lists: 40 entries per tile and more), five otherwise; CRH_FILL_WAVES pins it.
-template <bool LONG, int WAVES = CRH_EDGE_TILE_WAVES>
+// WAVES: wavefronts per SIMD the build is held to. Round 6: SEVEN (72 registers, no scratch memory), for every frame. Until then the kernel was built twice —
+// five waves (91 registers, no scratch) and, for frames of long lists, six (80 registers, 20 B of scratch: a pair of scratch stores per wavefront, as many
+// bytes as the tile it draws) — because LLVM's SLP vectorizer kept the lane-invariant operands of its v_pk_* instructions duplicated in register pairs for
+// the whole kernel. Without that pass (build.py FILE_FLAGS) the kernel needs 76 registers at any occupancy, 72 when held to seven waves, and spills from
+// eight on (64 registers, 12 B). Same box, S10k @ 4096^2 / 100 000 paths @ 8192^2, raster kernel alone and pipelined step in ms (profiles/r06_experiments.txt):
+//   round 5 (SLP, 5 / 6 waves)  0.166, 0.302 / 1.008, 1.950      no SLP, held to 5 or 6   0.150, 0.298 - 0.306 / 0.977, 1.93 - 1.95
+//   no SLP, held to 7           0.142, 0.289 - 0.293 / 0.920, 1.877                      held to 8 (spills)       0.142, 0.299 / 0.976, 1.956
+#ifndef CRH_FILL_TILE_WAVES
+#define CRH_FILL_TILE_WAVES 7
+#endif
+template <bool LONG, int WAVES = CRH_FILL_TILE_WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) void k_raster_fill(SceneDev s, RasterParams r) {
     constexpr int ROWS = 4;
     const uint32_t bid = blockIdx.x; // the workgroup's place in the frame's tile order
@@ -2582,7 +2588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     uint32_t* __restrict__ keys = sort_buffer;
     const uint32_t px = lane & 15u, rq = lane >> 4;
     const uint32_t gx = tx * kTile + px;
-    const float tx0 = (float)(tx * kTile), ty0 = (float)(ty * kTile);
+    const float tile_y0 = (float)(ty * kTile); // (the walk derives the tile's origin again per chunk, below)
     const int tpx = (int)(tx * kTile), tpy = (int)(ty * kTile);
     const float sx = (float)px + 0.5f, sy0 = (float)rq + 0.5f; // the lane's samples: column px, rows rq + 4 b
     int cell[ROWS];        // fill winding + 65536 * hull winding of sample row rq + 4 b
@@ -2679,7 +2685,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     // Cooperative row evaluation of an edge entry: lane j < 16 evaluates sample row j at the left tile boundary, lane 16 the backdrop row q0
     const uint32_t row_j = lane & 15u;
     const float ry_row = lane == 16u ? 0.5f : (float)row_j + 0.5f;
-    const float sy_row = ty0 + ry_row;
+    const float sy_row = tile_y0 + ry_row;
     auto key_of = [&](uint32_t i) -> uint32_t { return sorted_in_place ? __hip_atomic_load(segment + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : keys[i]; };
     uint32_t walk_from = 0, verify_entry = 0xFFFFFFFFu; // absolute positions in the list
     if (LONG && n > 64u && !r.load_existing) { // the late start of a list of several chunks (k_raster_edges: X, the last opaque whole-tile cover; R, the last whole-tile reset before it)
@@ -2722,6 +2728,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
     uint32_t first_j = walk_from & 63u;
     bool again_from_the_top = false;
     for (uint32_t q0 = LONG ? walk_from & ~63u : 0u; q0 < n; q0 += 64u) {
+        // The tile's origin as floats, derived from the scalar tile coordinates HERE, per chunk: as values of the whole kernel the compiler kept
+        // them duplicated in vector register pairs (operands of packed adds) and, in the six-wave build, spilled those — 16 bytes per lane, one
+        // pair of scratch stores per wavefront: as many bytes as the tile it draws (WRITE_SIZE 1.95 x the frame at 8192^2).
+        uint32_t tx_here = tx, ty_here = ty;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(tx_here), "+s"(ty_here));
+#endif
+        const float tx0 = (float)(tx_here * kTile), ty0 = (float)(ty_here * kTile);
         // (loads at a clamped index and a select, not a load under a lane-dependent condition: the loop has no divergent branch, see the set-up)
         if (sorted_in_place) {
             const uint32_t k_at = __hip_atomic_load(segment + min(q0 + lane, n - 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3025,11 +3039,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES))) voi
             q0 = 0u - 64u;
         }
     }
-    // ---- RGBA8 unorm / binary16 store
+    // ---- RGBA8 unorm / binary16 store (the lane's column derived again from the scalar tile coordinate: kept from the top of the kernel it was the six-wave
+    //      build's last spilled register)
+    uint32_t tx_end = tx, all_lanes = ~0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(tx_end), "+s"(all_lanes)); // (opaque operands: neither value is the one computed at the top of the kernel and kept alive since)
+    const uint32_t lane_end = __builtin_amdgcn_mbcnt_hi(all_lanes, __builtin_amdgcn_mbcnt_lo(all_lanes, 0u)); // the lane's number (= threadIdx.x: one wavefront per workgroup)
+#else
+    const uint32_t lane_end = threadIdx.x;
+#endif
+    const uint32_t gx_end = tx_end * kTile + (lane_end & 15u);
 #pragma unroll
     for (int b = 0; b < ROWS; ++b) {
         const uint32_t gy = ty * kTile + 4u * b + rq;
-        if (gx < r.width && gy < r.height) store_pixel(r, gx, gy, col[b][0], col[b][1], col[b][2], col[b][3]);
+        if (gx_end < r.width && gy < r.height) store_pixel(r, gx_end, gy, col[b][0], col[b][1], col[b][2], col[b][3]);
     }
 }
 
@@ -3893,11 +3916,8 @@ void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samp
     } else if (fill_kernel) {
         // (always the variant that looks for its late start across the chunks of a long list: measured on the 10 000 path scene — few lists
         // beyond one chunk — it is as fast as the one without, 0.1655 against 0.168 ms, and it is the build without scratch memory)
-        const char* fill_waves = getenv("CRH_FILL_WAVES"); // (A/B runs, tests; read per launch)
-        if (fill_waves ? atoi(fill_waves) == 6 : r.long_lists != 0u)
-            hipLaunchKernelGGL((k_raster_fill<true, 6>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
-        else
-            hipLaunchKernelGGL((k_raster_fill<true>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
+        // (... and ONE build for every frame: round 5's six-wave build for frames of long lists is gone with its reason, see CRH_FILL_TILE_WAVES)
+        hipLaunchKernelGGL((k_raster_fill<true>), grid, dim3(64), r.sort_capacity * 4u, stream, s, r);
     } else if (r.long_lists) {
         CRH_LAUNCH_EDGES(1, 4, false, true);
     } else {

@@ -445,40 +445,49 @@ __global__ __launch_bounds__(BLOCK) CRH_TESS_OCCUPANCY void k_tess_count_runs(Sc
     }
 }
 
-// the runs' totals -> where every run begins (in place), the totals behind the last run and in totals[]: one workgroup, 256 runs a turn
-__global__ __launch_bounds__(256) void k_scan_runs(SceneDev s) {
-    __shared__ uint32_t wave_total[4][NCH];
-    __shared__ uint32_t carry[NCH];
+// the runs' totals -> where every run begins (in place), the totals behind the last run and in totals[]. ONE workgroup of 1 024 lanes, every lane a
+// stretch of consecutive runs: sum them, one scan over the lanes' sums, write the stretch's prefixes. (Until round 6: 256 runs a turn, three barriers and
+// a round trip to memory per turn — the 6 300 runs of the 50 000 glyph scene took 25 turns, 0.28 ms under the profiler; VERDICT r05 item 8. A scan that
+// looks back across workgroups is not needed: at 100 000 runs a lane still has fewer than a hundred rows.)
+constexpr uint32_t kScanRunsThreads = 1024;
+__global__ __launch_bounds__(kScanRunsThreads) void k_scan_runs(SceneDev s) {
+    __shared__ uint32_t wave_total[kScanRunsThreads / 64][NCH];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid < NCH) carry[tid] = 0u;
-    __syncthreads();
-    for (uint32_t first = 0; first < s.n_runs; first += 256u) {
-        const uint32_t run = first + tid;
-        uint32_t mine[NCH], incl[NCH];
+    const uint32_t per = (s.n_runs + kScanRunsThreads - 1u) / kScanRunsThreads, first = min(s.n_runs, tid * per), last = min(s.n_runs, first + per);
+    uint32_t sum[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            mine[c] = run < s.n_runs ? s.run_base[run * NCH + c] : 0u;
-            uint32_t v = mine[c];
+    for (int c = 0; c < NCH; ++c) sum[c] = 0u;
+    for (uint32_t run = first; run < last; ++run)
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(v, d, 64);
-                if (lane >= (uint32_t)d) v += up;
-            }
-            incl[c] = v;
-            if (lane == 63u) wave_total[wave][c] = v;
+        for (int c = 0; c < NCH; ++c) sum[c] += s.run_base[run * NCH + c];
+    uint32_t begin[NCH]; // where the lane's stretch begins
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        uint32_t v = sum[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(v, d, 64);
+            if (lane >= (uint32_t)d) v += up;
         }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            uint32_t base = carry[c];
-            for (uint32_t w = 0; w < wave; ++w) base += wave_total[w][c];
-            if (run < s.n_runs) s.run_base[run * NCH + c] = base + incl[c] - mine[c];
-        }
-        __syncthreads();
-        if (tid < NCH) carry[tid] += wave_total[0][tid] + wave_total[1][tid] + wave_total[2][tid] + wave_total[3][tid];
-        __syncthreads();
+        begin[c] = v - sum[c];
+        if (lane == 63u) wave_total[wave][c] = v;
     }
-    if (tid < NCH) s.run_base[s.n_runs * NCH + tid] = carry[tid], s.totals[tid] = carry[tid];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        for (uint32_t w = 0; w < wave; ++w) begin[c] += wave_total[w][c];
+    for (uint32_t run = first; run < last; ++run)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const uint32_t mine = s.run_base[run * NCH + c];
+            s.run_base[run * NCH + c] = begin[c];
+            begin[c] += mine;
+        }
+    if (tid < NCH) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < kScanRunsThreads / 64u; ++w) total += wave_total[w][tid];
+        s.run_base[s.n_runs * NCH + tid] = total, s.totals[tid] = total;
+    }
 }
 
 template <bool STROKES, int BLOCK>
@@ -926,7 +935,7 @@ void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*
             else hipLaunchKernelGGL((k_tess_count_runs<false, kTessBlock>), dim3(s.n_runs), dim3(kTessBlock), 0, stream, s);
         }
         if (mark) mark(ctx, "tess_count", bytes[0]);
-        hipLaunchKernelGGL(k_scan_runs, dim3(1), dim3(256), 0, stream, s);
+        hipLaunchKernelGGL(k_scan_runs, dim3(1), dim3(kScanRunsThreads), 0, stream, s);
         if (mark) mark(ctx, "tess_scan", bytes[1]);
         return;
     }

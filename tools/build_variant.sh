@@ -10,5 +10,5 @@ for f in $files; do touch contrast_renderer_amd/csrc/$f; done
 CRH_EXTRA_FLAGS="$flags" python contrast_renderer_amd/build.py > /dev/null 2>&1
 cp contrast_renderer_amd/libcontrast_hip.so contrast_renderer_amd/build/variants/lib_$name.so
 for f in $files; do touch contrast_renderer_amd/csrc/$f; done
-python contrast_renderer_amd/build.py > /dev/null 2>&1
+env -u CRH_FILE_FLAGS -u CRH_EXTRA_FLAGS python contrast_renderer_amd/build.py > /dev/null 2>&1  # (the tree's own library again, with the tree's own flags)
 echo "built lib_$name.so ($flags)"

@@ -9,12 +9,12 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, ".."))
-from contrast_renderer_amd.build import CSRC, FLAGS  # noqa: E402
+from contrast_renderer_amd.build import CSRC, FLAGS, file_flags  # noqa: E402
 
 
 def usage(src, extra=()):
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.path.join(tmp, "x.o")]
+        cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + file_flags().get(src, []) + list(extra) + ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.path.join(tmp, "x.o")]
         err = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True).stderr
     rows, cur = [], None
     for line in err.splitlines():
