@@ -41,8 +41,8 @@ def mark_to_kernel(workload, triangle_pass=False):
     return {
         # (the last argument: the variant that looks for its late start across the chunks of long tile lists — the host picks it for frames with
         # many entries per tile and opaque whole-tile covers: the 100 000 path scene)
-        # (k_raster_fill<LONG, WAVES>: frames of long lists — the 100 000 path scene — take the six-wave build)
-        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else ("crh::k_raster_fill<true, 6>" if workload == "s100k" else "crh::k_raster_fill<true, 5>"),
+        # (k_raster_fill<LONG, WAVES>: one build at seven wavefronts per SIMD since round 6)
+        "raster_tiles": "crh::k_raster_edges<4, 1, true, false>" if msaa4_strokes else "crh::k_raster_fill<true, 7>",
         # a pass whose average item is beyond a batch of k_bin_flat (the dashed strokes) is binned item by item
         "raster_rows": "crh::k_raster_rows<true>" if workload == "s100k" else "crh::k_raster_rows<false>",  # the row-span kernel, where the library's trial picked it
         "raster_bin": "crh::k_bin_edges<4, false>" if msaa4_strokes else ("crh::k_bin_flat<1, 64u>" if workload == "s100k" else "crh::k_bin_flat<1, 128u>"),
@@ -63,6 +63,10 @@ def kernel_source_hash():
         if name.endswith((".hip", ".hpp")):
             with open(os.path.join(csrc, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
+    with open(os.path.join(ROOT, "contrast_renderer_amd", "build.py"), "rb") as f:  # (the compile flags make the kernels as much as their sources do: round 6's -fno-slp-vectorize)
+        h.update(b"build.py\0" + f.read())
+    with open(os.path.join(ROOT, "include", "crh_fmath.h"), "rb") as f:
+        h.update(b"crh_fmath.h\0" + f.read())
     return h.hexdigest()[:16]
 
 

@@ -10,7 +10,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 #include <string>
 #include <vector>
 
@@ -21,6 +20,7 @@ namespace crh {
 typedef void (*MarkFn)(void*, const char*, uint64_t);
 void launch_tessellate(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool need_totals);
 void launch_emit(const SceneDev& s, hipStream_t stream, MarkFn mark, void* ctx, const uint64_t bytes[4], bool has_stroke, bool big_shapes, const uint32_t* hull_queued);
+void launch_build_elements(const UploadBuild& u, hipStream_t stream);
 void launch_prim_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* scratch, hipStream_t stream);
 void launch_bin(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_setup);
 void launch_fill(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, MarkFn mark, void* ctx, hipEvent_t after_fill);
@@ -441,6 +441,7 @@ struct crh_scene {
     PinnedArena geometry_stage;          // crh_scene_upload's element stream on its way to the device
     hipEvent_t geometry_ready = nullptr; // behind those copies (on the renderer's stream); the next tessellation waits for it once
     bool geometry_pending = false, tessellated_once_before_upload = false;
+    UploadBuild pending_build = {}; // what the first tessellation behind an upload builds the element stream from (launch_build_elements)
     InstanceSlot slot[2];
     int instances_cur = 0;
     uint64_t generation = 0;            // bumped by every upload: what a frame's cached recorded pass was built against
@@ -688,8 +689,12 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     const hipStream_t ts = r->tessellation_stream();
     // the previous frame's k_prim_setup must have consumed the vertex streams this run overwrites; its binning and raster may still run
     if (sc->rendered_once) HIP_TRY(hipStreamWaitEvent(ts, sc->vertices_free, 0));
-    if (sc->geometry_pending) { // the element stream of the last crh_scene_upload is still on its way (asynchronous copies out of pinned staging memory)
+    if (sc->geometry_pending) { // the batch of the last crh_scene_upload is still on its way (an asynchronous copy out of pinned staging memory)
         HIP_TRY(hipStreamWaitEvent(ts, sc->geometry_ready, 0));
+        // ... and its element stream is built from it HERE, in front of the kernels that read it, on their stream. (On the upload stream the kernel had a
+        // compute queue of its own to wait in: at normal priority new paths every frame took 0.8 ms per step instead of 0.44, at high priority the mere
+        // existence of the stream slowed every OTHER renderer of the process down by half — profiles/r06_experiments.txt.)
+        launch_build_elements(sc->pending_build, ts);
         sc->geometry_pending = false;
     }
     if (r->raster_exclusive && r->raster_events[1]) HIP_TRY(hipStreamWaitEvent(ts, r->raster_events[1], 0));
@@ -1669,30 +1674,26 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
             (b->n_stroke_options && !b->stroke_options) || (b->n_dynamic_stroke_options && !b->dynamic_stroke_options))
             return CRH_ERR_INVALID_ARGUMENT;
     }
-    // Every segment type is valid, and the types stand for as many control floats as the batch says it holds. (Round 6 cut this loop and the
-    // element stream's below into chunks of paths for a pool of host threads — measured on the GPU box, profiles/r06_experiments.txt: no faster at
-    // two to six threads, 0.32 ms either way, and the threads' wake-ups made the calls around the upload slower; the loops are one range again.)
-    const unsigned n_ranges = 1u;
-    auto run_ranges = [&](const std::function<void(uint32_t)>& fn) {
-        for (unsigned k = 0; k < n_ranges; ++k) fn(k);
-    };
-    auto range_begin = [&](unsigned k) { return (uint32_t)((uint64_t)b->n_paths * k / n_ranges); };
-    std::vector<uint64_t> range_floats(n_ranges + 1u, 0u);
-    std::atomic<uint32_t> bad_type{0};
-    run_ranges([&](uint32_t k) {
+    // every segment type is valid, and the types stand for as many control floats as the batch says it holds; on the way, where every segment's record
+    // begins in control_data (the device builds the element stream from it: launch_build_elements)
+    static thread_local std::vector<uint32_t> seg_prefix, seg_path; // (... and whose path every segment is: one coalesced load on the device instead of a search)
+    {
+        if ((uint64_t)b->n_control_floats >= 0xFFFFFFF0ull) return CRH_ERR_UNSUPPORTED; // (32-bit pool offsets, as below)
+        seg_prefix.resize((size_t)b->n_segments + 1u);
+        seg_path.resize((size_t)b->n_segments + 1u);
         uint64_t floats = 0;
         uint32_t wrong = 0;
-        const uint32_t g0 = b->path_segment_begin[range_begin(k)], g1 = b->path_segment_begin[range_begin(k + 1u)];
-        for (uint32_t g = g0; g < g1; ++g) {
-            const uint8_t t = b->segment_types[g];
-            wrong |= (uint32_t)(t > 4);
-            floats += (uint64_t)kSegmentFloats[t > 4 ? 0 : t];
-        }
-        range_floats[k + 1u] = floats;
-        if (wrong) bad_type.store(1u);
-    });
-    for (unsigned k = 0; k < n_ranges; ++k) range_floats[k + 1u] += range_floats[k];
-    if (bad_type.load() != 0u || range_floats[n_ranges] != b->n_control_floats) return CRH_ERR_INVALID_ARGUMENT;
+        for (uint32_t p = 0; p < b->n_paths; ++p)
+            for (uint32_t g = b->path_segment_begin[p], g1 = b->path_segment_begin[p + 1]; g < g1; ++g) {
+                const uint8_t t = b->segment_types[g];
+                wrong |= (uint32_t)(t > 4);
+                seg_prefix[g] = (uint32_t)floats;
+                seg_path[g] = p;
+                floats += (uint64_t)kSegmentFloats[t > 4 ? 0 : t];
+            }
+        seg_prefix[b->n_segments] = (uint32_t)floats;
+        if (wrong != 0u || floats != b->n_control_floats) return CRH_ERR_INVALID_ARGUMENT;
+    }
     // ---- validation: what the reference rejects with Err(..) before any arithmetic (renderer.rs:188-191, :210-215)
     std::vector<crh_dynamic_stroke_descriptor> descriptors(b->n_dynamic_stroke_options);
     for (uint32_t i = 0; i < b->n_dynamic_stroke_options; ++i) {
@@ -1764,92 +1765,57 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
             else runs = wide;
         }
     }
-    Part part[13];
+    // The Scene's arena on the device: what the tessellation reads (built there: the element stream and the pool, launch_build_elements), scratch of that
+    // build, then — one contiguous range, staged on the host and copied in one piece — the arrays the host fills and the batch as the caller handed it over.
+    enum { P_TYPE, P_OFF, P_PREV, P_PATH, P_POOL, P_PATH_BEGIN, P_PATH_SHAPE, P_SHAPE_BEGIN,                                                              // built on the device
+           P_PATH_STROKE, P_DYN_BEGIN, P_OPTIONS, P_DESCRIPTORS, P_RUNS, R_CONTROL, R_START, R_TYPES, R_PATH_SEG, R_SHAPE_PATH, R_SEG_PREFIX, R_SEG_PATH, N_PARTS, P_FIRST_STAGED = P_PATH_STROKE }; // staged by the host
+    Part part[N_PARTS];
     size_t arena_bytes = 0;
     {
-        const size_t sizes[13] = {(size_t)n_elems, (size_t)n_elems * 4, (size_t)n_elems * 4, (size_t)n_elems * 4, n_pool * 4, ((size_t)b->n_paths + 1) * 4, (size_t)b->n_paths * 4,
-                                  (size_t)b->n_paths * 4, ((size_t)b->n_shapes + 1) * 4, ((size_t)b->n_shapes + 1) * 4, (size_t)b->n_stroke_options * sizeof(crh_stroke_options),
-                                  (size_t)b->n_dynamic_stroke_options * sizeof(crh_dynamic_stroke_descriptor), runs.size() * 4};
-        for (int k = 0; k < 13; ++k) {
+        const size_t sizes[N_PARTS] = {(size_t)n_elems, (size_t)n_elems * 4, (size_t)n_elems * 4, (size_t)n_elems * 4, n_pool * 4, ((size_t)b->n_paths + 1) * 4, (size_t)b->n_paths * 4, ((size_t)b->n_shapes + 1) * 4,
+                                       (size_t)b->n_paths * 4, ((size_t)b->n_shapes + 1) * 4, (size_t)b->n_stroke_options * sizeof(crh_stroke_options),
+                                       (size_t)b->n_dynamic_stroke_options * sizeof(crh_dynamic_stroke_descriptor), runs.size() * 4,
+                                       (size_t)b->n_control_floats * 4, (size_t)b->n_paths * 8, (size_t)b->n_segments, ((size_t)b->n_paths + 1) * 4, ((size_t)b->n_shapes + 1) * 4, ((size_t)b->n_segments + 1) * 4, (size_t)b->n_segments * 4};
+        for (int k = 0; k < N_PARTS; ++k) {
             part[k] = Part{arena_bytes, sizes[k]};
             arena_bytes += (sizes[k] + 255u) & ~(size_t)255u;
         }
     }
-    enum { P_TYPE, P_OFF, P_PREV, P_PATH, P_POOL, P_PATH_BEGIN, P_PATH_SHAPE, P_PATH_STROKE, P_SHAPE_BEGIN, P_DYN_BEGIN, P_OPTIONS, P_DESCRIPTORS, P_RUNS };
-    uint8_t* arena = nullptr;
+    const size_t staged_begin = part[P_FIRST_STAGED].at, staged_bytes = arena_bytes - staged_begin;
+    uint8_t* staged = nullptr; // the host's copy of the range [staged_begin, arena_bytes) of the arena
     phase("runs");
-    if (!hip_ok(sc->geometry_stage.begin(arena_bytes + 256u, &arena), "hipHostMalloc")) {
+    if (!hip_ok(sc->geometry_stage.begin(staged_bytes + 256u, &staged), "hipHostMalloc")) {
         if (!existing) delete sc;
         return CRH_ERR_HIP;
     }
+    uint8_t* const arena = staged - staged_begin; // (so that arena + part[k].at addresses the staged parts; the device-built parts have no host copy)
     {
-        uint8_t* const elem_type = arena + part[P_TYPE].at;
-        uint32_t* const elem_off = reinterpret_cast<uint32_t*>(arena + part[P_OFF].at);
-        uint32_t* const elem_prev_off = reinterpret_cast<uint32_t*>(arena + part[P_PREV].at); // the point stored just before the record: end of the previous segment, or Path::start
-        uint32_t* const elem_path = reinterpret_cast<uint32_t*>(arena + part[P_PATH].at);
-        float* const pool = reinterpret_cast<float*>(arena + part[P_POOL].at);
-        uint32_t* const path_elem_begin = reinterpret_cast<uint32_t*>(arena + part[P_PATH_BEGIN].at);
-        uint32_t* const path_shape = reinterpret_cast<uint32_t*>(arena + part[P_PATH_SHAPE].at);
-        uint32_t* const shape_elem_begin = reinterpret_cast<uint32_t*>(arena + part[P_SHAPE_BEGIN].at);
-        // Then: every chunk builds its elements and its part of the pool — where they begin follows from the index arrays and the chunks' float
-        // sums — and canonicalises what it has just copied while it is in cache (SafeFloat::from, safe_float.rs:44-52: finite, and -0 -> +0:
-        // x + 0 is x for every x but -0).
-        std::atomic<uint32_t> any_bad{0};
-        run_ranges([&](uint32_t k) {
-            const uint32_t p_begin = range_begin(k), p_end = range_begin(k + 1u);
+        // SafeFloat::from (safe_float.rs:44-52) over every coordinate of the batch, on the way into the staging memory: finite, and -0 -> +0 (x + 0 is x
+        // for every x but -0). One pass over contiguous floats — round 5 went path by path (a memcpy each) and then over the pool a second time.
+        auto canonical = [](float* dst, const float* src, size_t n) {
             uint32_t bad = 0;
-            size_t cursor = (size_t)range_floats[k]; // float of control_data
-            for (uint32_t p = p_begin; p < p_end; ++p) {
-                const uint32_t g0 = b->path_segment_begin[p], g1 = b->path_segment_begin[p + 1];
-                uint32_t e = g0 + 2u * p, at = (uint32_t)cursor + 2u * p; // element, float of the pool
-                path_elem_begin[p] = e;
-                elem_type[e] = ELEM_MOVE, elem_off[e] = at, elem_prev_off[e] = at >= 2u ? at - 2u : 0u, elem_path[e] = p;
-                ++e;
-                pool[at] = b->path_start[2 * (size_t)p], pool[at + 1] = b->path_start[2 * (size_t)p + 1];
-                const uint32_t start = at;
-                at += 2u;
-                const uint32_t first = at;
-                for (uint32_t g = g0; g < g1; ++g) {
-                    const uint8_t t = b->segment_types[g]; // (<= 4: checked above)
-                    elem_type[e] = t, elem_off[e] = at, elem_prev_off[e] = at - 2u, elem_path[e] = p;
-                    ++e;
-                    at += (uint32_t)kSegmentFloats[t];
-                }
-                if (at != first) std::memcpy(pool + first, b->control_data + cursor, (size_t)(at - first) * 4); // a path's records are contiguous in the batch
-                cursor += at - first;
-                elem_type[e] = ELEM_END, elem_off[e] = at, elem_prev_off[e] = at - 2u, elem_path[e] = p;
-                for (uint32_t i = start; i < at; ++i) {
-                    uint32_t u;
-                    std::memcpy(&u, &pool[i], 4);
-                    bad |= (uint32_t)((u & 0x7F800000u) == 0x7F800000u);
-                    pool[i] = pool[i] + 0.0f;
-                }
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t u;
+                std::memcpy(&u, &src[i], 4);
+                bad |= (uint32_t)((u & 0x7F800000u) == 0x7F800000u);
+                dst[i] = src[i] + 0.0f;
             }
-            if (bad) any_bad.store(1u);
-            // the Shapes whose first path lies in this range: where their elements begin, and whose paths are whose
-            const uint32_t* const first_shape = std::lower_bound(b->shape_path_begin, b->shape_path_begin + b->n_shapes, p_begin);
-            for (uint32_t sh = (uint32_t)(first_shape - b->shape_path_begin); sh < b->n_shapes && b->shape_path_begin[sh] < p_end; ++sh) {
-                const uint32_t p0 = b->shape_path_begin[sh], p1 = b->shape_path_begin[sh + 1];
-                shape_elem_begin[sh] = b->path_segment_begin[p0] + 2u * p0;
-                for (uint32_t p = p0; p < p1; ++p) path_shape[p] = sh;
-            }
-        });
-        // (Shapes without a path begin where the next path's elements do — also those behind the last path)
-        for (uint32_t sh = b->n_shapes; sh-- > 0u;)
-            if (b->shape_path_begin[sh] == b->shape_path_begin[sh + 1]) shape_elem_begin[sh] = b->shape_path_begin[sh] < b->n_paths ? b->path_segment_begin[b->shape_path_begin[sh]] + 2u * b->shape_path_begin[sh] : n_elems;
-        path_elem_begin[b->n_paths] = n_elems;
-        shape_elem_begin[b->n_shapes] = n_elems;
-        const uint32_t bad = any_bad.load();
-        const size_t cursor = b->n_control_floats;
-        const uint32_t e = n_elems;
-        const size_t at = n_pool;
-        if (bad != 0u || cursor != b->n_control_floats || e != n_elems || at != n_pool) {
+            return bad;
+        };
+        uint32_t bad = canonical(reinterpret_cast<float*>(arena + part[R_CONTROL].at), b->control_data, b->n_control_floats);
+        bad |= canonical(reinterpret_cast<float*>(arena + part[R_START].at), b->path_start, 2u * (size_t)b->n_paths);
+        if (bad != 0u) {
             if (!existing) {
                 sc->geometry_stage.release();
                 delete sc;
             }
-            return bad ? CRH_ERR_NON_FINITE : CRH_ERR_INVALID_ARGUMENT; // the reference panics in SafeFloat::from (safe_float.rs:46,114)
+            return CRH_ERR_NON_FINITE; // the reference panics in SafeFloat::from (safe_float.rs:46,114)
         }
+        if (b->n_segments) std::memcpy(arena + part[R_TYPES].at, b->segment_types, b->n_segments);
+        std::memcpy(arena + part[R_PATH_SEG].at, b->path_segment_begin, ((size_t)b->n_paths + 1) * 4);
+        std::memcpy(arena + part[R_SHAPE_PATH].at, b->shape_path_begin, ((size_t)b->n_shapes + 1) * 4);
+        std::memcpy(arena + part[R_SEG_PREFIX].at, seg_prefix.data(), ((size_t)b->n_segments + 1) * 4);
+        if (b->n_segments) std::memcpy(arena + part[R_SEG_PATH].at, seg_path.data(), (size_t)b->n_segments * 4);
         if (b->n_paths) std::memcpy(arena + part[P_PATH_STROKE].at, b->path_stroke_options, (size_t)b->n_paths * 4);
         uint32_t* const dyn_begin = reinterpret_cast<uint32_t*>(arena + part[P_DYN_BEGIN].at);
         if (b->shape_dynamic_begin) std::memcpy(dyn_begin, b->shape_dynamic_begin, ((size_t)b->n_shapes + 1) * 4);
@@ -1961,8 +1927,20 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         // (the element offsets exist twice on the device when a path is stroked: k_stroke_records rewrites elem_off, elem_off0 stays)
         const size_t second_off = has_stroke ? ((part[P_OFF].bytes + 255u) & ~(size_t)255u) : 0u;
         ok = ok && hip_ok(sc->geometry.ensure(arena_bytes + second_off + 256u), "hipMalloc");
-        if (ok && arena_bytes) ok = hip_ok(hipMemcpyAsync(sc->geometry.p, arena, arena_bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
-        if (ok && second_off) ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(sc->geometry.p) + arena_bytes, arena + part[P_OFF].at, part[P_OFF].bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        if (ok && staged_bytes) ok = hip_ok(hipMemcpyAsync(static_cast<uint8_t*>(sc->geometry.p) + staged_begin, staged, staged_bytes, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+        if (ok) { // ... and the element stream and the pool are built from it on the device
+            uint8_t* const g = static_cast<uint8_t*>(sc->geometry.p);
+            UploadBuild u = {};
+            u.control = reinterpret_cast<const float*>(g + part[R_CONTROL].at), u.start = reinterpret_cast<const float*>(g + part[R_START].at), u.types = g + part[R_TYPES].at;
+            u.path_seg = reinterpret_cast<const uint32_t*>(g + part[R_PATH_SEG].at), u.shape_path = reinterpret_cast<const uint32_t*>(g + part[R_SHAPE_PATH].at);
+            u.n_segments = b->n_segments, u.n_paths = b->n_paths, u.n_shapes = b->n_shapes, u.n_elems = n_elems;
+            u.seg_prefix = reinterpret_cast<const uint32_t*>(g + part[R_SEG_PREFIX].at), u.seg_path = reinterpret_cast<const uint32_t*>(g + part[R_SEG_PATH].at);
+            u.elem_type = g + part[P_TYPE].at, u.elem_off = reinterpret_cast<uint32_t*>(g + part[P_OFF].at), u.elem_off_again = second_off ? reinterpret_cast<uint32_t*>(g + arena_bytes) : nullptr;
+            u.elem_prev_off = reinterpret_cast<uint32_t*>(g + part[P_PREV].at), u.elem_path = reinterpret_cast<uint32_t*>(g + part[P_PATH].at), u.pool = reinterpret_cast<float*>(g + part[P_POOL].at);
+            u.path_elem_begin = reinterpret_cast<uint32_t*>(g + part[P_PATH_BEGIN].at), u.path_shape = reinterpret_cast<uint32_t*>(g + part[P_PATH_SHAPE].at);
+            u.shape_elem_begin = reinterpret_cast<uint32_t*>(g + part[P_SHAPE_BEGIN].at);
+            sc->pending_build = u; // (launched by the tessellation that waits for geometry_ready: run_tessellation)
+        }
         // the status word: cleared IN FRONT of geometry_ready — the tessellation stream waits for that event only, then clears the word itself and
         // lets its kernels write error codes; a memset enqueued behind the event would be unordered against those writes
         if (ok) ok = hip_ok(sc->status.ensure(4), "hipMalloc") && hip_ok(hipMemsetAsync(sc->status.p, 0xFF, 4, st), "hipMemset");

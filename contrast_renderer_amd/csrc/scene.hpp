@@ -11,6 +11,26 @@ namespace crh {
 // Element stream: every Path becomes  MOVE, segment, segment, ..., END  — one lane per element.
 enum : uint8_t { ELEM_LINE = 0, ELEM_IQ = 1, ELEM_IC = 2, ELEM_RQ = 3, ELEM_RC = 4, ELEM_MOVE = 5, ELEM_END = 6 };
 
+// crh_scene_upload, round 6: the element stream is built ON THE DEVICE from the caller's struct-of-arrays batch (the host copies the batch's arrays —
+// the floats canonicalised on the way, SafeFloat::from — and checks its structure; what used to be a loop over every element on the calling thread is
+// one small kernel on the upload stream: csrc/tessellate.hip launch_build_elements).
+struct UploadBuild {
+    // the batch as the host staged it (device copies)
+    const float* control;        // [n_control_floats] crh_path_batch::control_data, -0 canonicalised
+    const float* start;          // [n_paths][2] crh_path_batch::path_start, -0 canonicalised
+    const uint8_t* types;        // [n_segments]
+    const uint32_t* path_seg;    // [n_paths + 1] crh_path_batch::path_segment_begin
+    const uint32_t* shape_path;  // [n_shapes + 1] crh_path_batch::shape_path_begin
+    uint32_t n_segments, n_paths, n_shapes, n_elems;
+    const uint32_t* seg_prefix;  // [n_segments + 1] where a segment's record begins in control (the host sums the segments' float counts anyway, to check them against the batch's total)
+    const uint32_t* seg_path;    // [n_segments] the path of every segment (from the same loop)
+    // what the tessellation reads (SceneDev's pointers of the same names)
+    uint8_t* elem_type;
+    uint32_t *elem_off, *elem_off_again /* the second copy k_stroke_records rewrites, or nullptr */, *elem_prev_off, *elem_path;
+    float* pool;
+    uint32_t *path_elem_begin, *path_shape, *shape_elem_begin;
+};
+
 // Scan channels: how many records of each output stream an element emits.
 enum {
     CH_LINE_V = 0,   // stroke line vertices (Vertex2f1i, 20 B)

@@ -445,22 +445,23 @@ __global__ __launch_bounds__(BLOCK) CRH_TESS_OCCUPANCY void k_tess_count_runs(Sc
     }
 }
 
-// the runs' totals -> where every run begins (in place), the totals behind the last run and in totals[]. ONE workgroup of 1 024 lanes, every lane a
-// stretch of consecutive runs: sum them, one scan over the lanes' sums, write the stretch's prefixes. (Until round 6: 256 runs a turn, three barriers and
-// a round trip to memory per turn — the 6 300 runs of the 50 000 glyph scene took 25 turns, 0.28 ms under the profiler; VERDICT r05 item 8. A scan that
-// looks back across workgroups is not needed: at 100 000 runs a lane still has fewer than a hundred rows.)
-constexpr uint32_t kScanRunsThreads = 1024;
+// the runs' totals -> where every run begins (in place), the totals behind the last run and in totals[]. ONE WAVEFRONT, every lane a stretch of
+// consecutive runs: sum them, one scan over the lanes' sums (shuffles: no LDS, no barrier), write the stretch's prefixes. (Until round 6: a 256-thread
+// workgroup, 256 runs a turn, three barriers and a round trip to memory per turn — the 6 300 runs of the 50 000 glyph scene took 25 turns, 0.28 ms
+// under the profiler; VERDICT r05 item 8. The first rewrite used 1 024 lanes: beside the raster kernel of the frame in front — new paths every frame — a
+// sixteen-wave workgroup waits for sixteen free slots on ONE compute unit, i.e. for that grid to drain: the step of tools/r05_reupload_calls.py went from
+// 0.48 to 0.97 ms. A single wavefront takes the first slot that frees. A scan that looks back across workgroups is not needed: 100 000 runs are 1 600 rows a lane.)
+constexpr uint32_t kScanRunsThreads = 64;
 __global__ __launch_bounds__(kScanRunsThreads) void k_scan_runs(SceneDev s) {
-    __shared__ uint32_t wave_total[kScanRunsThreads / 64][NCH];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per = (s.n_runs + kScanRunsThreads - 1u) / kScanRunsThreads, first = min(s.n_runs, tid * per), last = min(s.n_runs, first + per);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t per = (s.n_runs + kScanRunsThreads - 1u) / kScanRunsThreads, first = min(s.n_runs, lane * per), last = min(s.n_runs, first + per);
     uint32_t sum[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) sum[c] = 0u;
     for (uint32_t run = first; run < last; ++run)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) sum[c] += s.run_base[run * NCH + c];
-    uint32_t begin[NCH]; // where the lane's stretch begins
+    uint32_t begin[NCH], total[NCH]; // where the lane's stretch begins; the scene's totals
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         uint32_t v = sum[c];
@@ -470,12 +471,8 @@ __global__ __launch_bounds__(kScanRunsThreads) void k_scan_runs(SceneDev s) {
             if (lane >= (uint32_t)d) v += up;
         }
         begin[c] = v - sum[c];
-        if (lane == 63u) wave_total[wave][c] = v;
+        total[c] = (uint32_t)__shfl((int)v, 63, 64);
     }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        for (uint32_t w = 0; w < wave; ++w) begin[c] += wave_total[w][c];
     for (uint32_t run = first; run < last; ++run)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -483,10 +480,9 @@ __global__ __launch_bounds__(kScanRunsThreads) void k_scan_runs(SceneDev s) {
             s.run_base[run * NCH + c] = begin[c];
             begin[c] += mine;
         }
-    if (tid < NCH) {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < kScanRunsThreads / 64u; ++w) total += wave_total[w][tid];
-        s.run_base[s.n_runs * NCH + tid] = total, s.totals[tid] = total;
+    if (lane == 0u) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s.run_base[s.n_runs * NCH + c] = total[c], s.totals[c] = total[c];
     }
 }
 
@@ -922,6 +918,55 @@ void launch_stroke_records(const SceneDev& s, hipStream_t stream, void (*mark)(v
 }
 // need_totals: the capacities of the streams are not known yet (new paths). The two-pass path counts and scans in any case; the one-pass kernel
 // counts (k_tess_count_runs, k_scan_runs) only then: per upload, not per frame.
+// ---------------------------------------------------------------------------------------------- the element stream of an upload (round 6)
+// Every Path becomes  MOVE, segment, ..., END;  the pool holds a path's start point followed by its segments' records (path.rs:15-52 layouts), so the
+// point in front of a record is the end of the segment before it. Element numbers and pool offsets follow from the batch's index arrays and the
+// prefix of the segments' float counts:   path p with segments [g0, g1):  MOVE = element g0 + 2 p at pool offset prefix[g0] + 2 p;  segment g = element
+// g + 2 p + 1 at prefix[g] + 2 (p + 1);  END = element g1 + 2 p + 1 at prefix[g1] + 2 (p + 1) — what the host loop of rounds 1 - 5 counted out one by one.
+CRH_D uint32_t last_not_above(const uint32_t* begin, uint32_t n, uint32_t x) { // the largest i <= n - 1 with begin[i] <= x (begin non-decreasing, begin[0] <= x)
+    uint32_t lo = 0, hi = n; // invariant: begin[lo] <= x, (hi == n or begin[hi] > x)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (begin[mid] <= x) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+// ONE launch: lane i builds segment i, path i and Shape i, whichever exist. (A first version ran the segments' prefix as a device scan and the three parts as
+// kernels of their own: five launches on the upload stream, each waiting for wave slots beside the raster kernel of the frame in front — new paths every
+// frame went from 0.44 to 0.51 ms per step. The copy engine had never had to queue for compute units; one launch does so once.)
+__global__ __launch_bounds__(256) void k_upload_build(UploadBuild u) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < u.n_segments) {
+        const uint32_t g = i;
+        const uint32_t p = u.seg_path[g];
+        const uint32_t e = g + 2u * p + 1u, from = u.seg_prefix[g], n = u.seg_prefix[g + 1u] - from, off = from + 2u * (p + 1u);
+        u.elem_type[e] = u.types[g], u.elem_off[e] = off, u.elem_prev_off[e] = off - 2u, u.elem_path[e] = p;
+        if (u.elem_off_again) u.elem_off_again[e] = off;
+        for (uint32_t k = 0; k < n; ++k) u.pool[off + k] = u.control[from + k];
+    }
+    if (i < u.n_paths) {
+        const uint32_t p = i, g0 = u.path_seg[p], g1 = u.path_seg[p + 1u];
+        const uint32_t e0 = g0 + 2u * p, at0 = u.seg_prefix[g0] + 2u * p, e1 = g1 + 2u * p + 1u, at1 = u.seg_prefix[g1] + 2u * (p + 1u);
+        u.elem_type[e0] = ELEM_MOVE, u.elem_off[e0] = at0, u.elem_prev_off[e0] = at0 >= 2u ? at0 - 2u : 0u, u.elem_path[e0] = p;
+        u.elem_type[e1] = ELEM_END, u.elem_off[e1] = at1, u.elem_prev_off[e1] = at1 - 2u, u.elem_path[e1] = p;
+        if (u.elem_off_again) u.elem_off_again[e0] = at0, u.elem_off_again[e1] = at1;
+        u.pool[at0] = u.start[2u * p], u.pool[at0 + 1u] = u.start[2u * p + 1u];
+        u.path_elem_begin[p] = e0;
+        if (p + 1u == u.n_paths) u.path_elem_begin[u.n_paths] = u.n_elems;
+        u.path_shape[p] = last_not_above(u.shape_path, u.n_shapes, p);
+    }
+    if (i <= u.n_shapes) {
+        const uint32_t p0 = i < u.n_shapes ? u.shape_path[i] : u.n_paths;
+        u.shape_elem_begin[i] = p0 < u.n_paths ? u.path_seg[p0] + 2u * p0 : u.n_elems; // (a Shape without paths begins where the next path's elements do)
+    }
+    if (i == 0u && u.n_paths == 0u) u.path_elem_begin[0] = u.n_elems;
+}
+void launch_build_elements(const UploadBuild& u, hipStream_t stream) {
+    const uint32_t lanes = max(max(u.n_segments, u.n_paths), u.n_shapes + 1u);
+    hipLaunchKernelGGL(k_upload_build, dim3((lanes + 255u) / 256u), dim3(256), 0, stream, u);
+}
+
 void launch_tessellate(const SceneDev& s, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx, const uint64_t bytes[4], bool has_stroke, bool need_totals) {
     if (s.n_elems == 0) return;
     if (has_stroke) launch_stroke_records(s, stream, mark, ctx);

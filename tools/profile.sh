@@ -7,10 +7,10 @@
 tag=$1
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload ${WORKLOAD:-cubic}"
-rocprofv3 --kernel-trace --stats -f csv -d $out/stats -o r -- $BENCH > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $out/fetch -o r -- $BENCH > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $out/write -o r -- $BENCH > $out/write.log 2>&1
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-side-workloads --no-animated --repeats 0 --workload ${WORKLOAD:-cubic}"
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $out/stats -o r -- $BENCH > $out/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $out/fetch -o r -- $BENCH > $out/fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $out/write -o r -- $BENCH > $out/write.log 2>&1
 python - $out <<'PY'
 import sys, csv, glob, json, collections
 out = sys.argv[1]
