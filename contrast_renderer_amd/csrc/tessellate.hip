@@ -570,7 +570,11 @@ __global__ __launch_bounds__(BLOCK) CRH_TESS_OCCUPANCY void k_tess_runs(SceneDev
 #endif
 constexpr uint32_t kHullSmall = 64;
 constexpr uint32_t kHullMid = 256;
-constexpr uint32_t kHullMax = 2048; // candidates per Shape that fit the large LDS sort (16 KiB + 32 KiB chain stack)
+constexpr uint32_t kHullMax = 2048; // candidates per Shape that fit the large LDS sort (16 KiB of points + 8 KiB of chain indices)
+#ifndef CRH_HULL_PACK
+#define CRH_HULL_PACK 2 // glyph scene, step / latency / kernel alone in ms — 1: 0.632 / 0.879 / 0.105, 2: 0.624 / 0.890, 4: 0.617 - 0.628 / 0.916 / 0.141, 8: 0.655 / 0.962 (profiles/r06_experiments.txt)
+#endif
+constexpr uint32_t kHullPack = CRH_HULL_PACK; // Shapes of 65 .. kHullMid candidates per wavefront of k_hull_large
 
 CRH_D bool lex_less(float2 a, float2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
 CRH_D float turn(float2 a, float2 b, float2 c) { return triple(vec_to_point(a.x, a.y), vec_to_point(b.x, b.y), vec_to_point(c.x, c.y)); }
@@ -757,67 +761,85 @@ __global__ __launch_bounds__(64 * kHullWaves) void k_hull_small(SceneDev s) {
     if (!upper) s.hull_count[shape] = h;
 }
 
-template <uint32_t CAP, uint32_t QUEUE>
+// PACK Shapes per wavefront (round 6): the sorts one after the other, all lanes on one Shape; then the chain walks of ALL of them at once, a lane pair per
+// Shape — the walk is serial and two lanes wide, and a wavefront's instruction is issued whether two lanes or eight take part: with one Shape per wavefront
+// the 6 000 Shapes of the 50 000 glyph scene beyond 64 candidates spent four fifths of their instructions on it (a hundred points a Shape, forty instructions a
+// point). The chains hold 16-bit indices into the sorted points (k_hull_small's bytes), not the points: 3 KB of LDS per Shape instead of 6.
+template <uint32_t CAP, uint32_t QUEUE, uint32_t PACK>
 __global__ __launch_bounds__(64) void k_hull_large(SceneDev s) {
-    __shared__ float2 pts[CAP];
-    __shared__ float2 chain[2 * CAP]; // [0, CAP): lower chain, [CAP, 2 CAP): upper chain
-    __shared__ uint32_t chain_m[2];
+    __shared__ float2 pts[PACK][CAP];
+    __shared__ uint16_t chain[PACK][2][CAP]; // [.][0]: lower chain, [.][1]: upper chain
+    __shared__ uint32_t chain_m[PACK][2], count[PACK], first_v[PACK], shape_of[PACK];
     if (!fits(s)) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t queued = s.hull_large_count[QUEUE];
-    for (uint32_t q = blockIdx.x; q < queued; q += gridDim.x) {
-        const uint32_t shape = s.hull_large_list[QUEUE * s.n_shapes + q];
-        const uint32_t base = s.shape_base[shape * kShapeRow + CH_HULL];
-        const uint32_t n = s.shape_base[shape * kShapeRow + NCH + CH_HULL] - base;
-        uint32_t padded = 1;
-        while (padded < n) padded <<= 1;
+    for (uint32_t q0 = blockIdx.x * PACK; q0 < queued; q0 += gridDim.x * PACK) {
         const float inf = __uint_as_float(0x7f800000u);
-        for (uint32_t i = lane; i < padded; i += 64) pts[i] = i < n ? make_float2(s.hull_cand[base + i].x, s.hull_cand[base + i].y) : make_float2(inf, inf);
-        __syncthreads();
-        for (uint32_t k = 2; k <= padded; k <<= 1) {
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = lane; i < padded; i += 64) {
-                    const uint32_t partner = i ^ j;
-                    if (partner > i) {
-                        const float2 a = pts[i], b = pts[partner];
-                        const bool ascending = (i & k) == 0;
-                        if (ascending ? lex_less(b, a) : lex_less(a, b)) {
-                            pts[i] = b;
-                            pts[partner] = a;
+        for (uint32_t k = 0; k < PACK; ++k) { // ---- the sorts
+            uint32_t n = 0, base = 0, shape = 0;
+            if (q0 + k < queued) {
+                shape = s.hull_large_list[QUEUE * s.n_shapes + q0 + k];
+                base = s.shape_base[shape * kShapeRow + CH_HULL];
+                n = s.shape_base[shape * kShapeRow + NCH + CH_HULL] - base;
+            }
+            if (lane == 0u) count[k] = n, first_v[k] = base, shape_of[k] = shape;
+            if (n == 0u) continue; // (uniform)
+            uint32_t padded = 1;
+            while (padded < n) padded <<= 1;
+            float2* const p = pts[k];
+            for (uint32_t i = lane; i < padded; i += 64) p[i] = i < n ? make_float2(s.hull_cand[base + i].x, s.hull_cand[base + i].y) : make_float2(inf, inf);
+            __syncthreads();
+            for (uint32_t kk = 2; kk <= padded; kk <<= 1) {
+                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = lane; i < padded; i += 64) {
+                        const uint32_t partner = i ^ j;
+                        if (partner > i) {
+                            const float2 a = p[i], b = p[partner];
+                            const bool ascending = (i & kk) == 0;
+                            if (ascending ? lex_less(b, a) : lex_less(a, b)) {
+                                p[i] = b;
+                                p[partner] = a;
+                            }
                         }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
-        }
-        if (lane < 2) {
-            // The two monotone chains of Andrew's scan are independent — the upper one starts from the last point on a stack floor of its
-            // own (convex_hull.rs:24-33) — so lane 0 builds the lower and lane 1 the upper chain at the same time, each with its two top
-            // points in registers (LDS is read only when a point is popped). The hull is lower[0 .. ml-1) ++ upper[0 .. mu-1).
-            float2* mine = chain + lane * CAP;
-            uint32_t m = 0;
-            float2 below = make_float2(0.0f, 0.0f), top = make_float2(0.0f, 0.0f); // mine[m - 2], mine[m - 1]
-            for (uint32_t i = 0; i < n; ++i) {
-                const float2 p = pts[lane == 0 ? i : n - 1u - i];
-                while (m > 1 && turn(below, top, p) <= kErrorMargin) {
-                    m -= 1;
-                    top = below;
-                    if (m > 1) below = mine[m - 2];
-                }
-                mine[m++] = p;
-                below = top;
-                top = p;
-            }
-            chain_m[lane] = m - 1; // without the last point, which opens the other chain
         }
         __syncthreads();
-        const uint32_t ml = chain_m[0], h = ml + chain_m[1];
-        for (uint32_t i = lane; i < h; i += 64) {
-            const uint32_t c = fan_to_strip_source(i, h);
-            const float2 p = c < ml ? chain[c] : chain[CAP + (c - ml)];
-            s.hull_v[base + i] = {p.x, p.y};
+        if (lane < 2u * PACK) { // ---- the walks: the two monotone chains of Andrew's scan are independent — the upper one starts from the last point on a
+            // stack floor of its own (convex_hull.rs:24-33) — so the even lane of a pair builds the lower and the odd lane the upper chain, each with its two top
+            // points in registers (LDS is read only when a point is popped). The hull is lower[0 .. ml-1) ++ upper[0 .. mu-1).
+            const uint32_t k = lane >> 1, upper = lane & 1u, n = count[k];
+            const float2* const p = pts[k];
+            uint16_t* const mine = chain[k][upper];
+            uint32_t m = 0;
+            float2 below = make_float2(0.0f, 0.0f), top = make_float2(0.0f, 0.0f); // p[mine[m - 2]], p[mine[m - 1]]
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t at = upper ? n - 1u - i : i;
+                const float2 c = p[at];
+                while (m > 1 && turn(below, top, c) <= kErrorMargin) {
+                    m -= 1;
+                    top = below;
+                    if (m > 1) below = p[mine[m - 2]];
+                }
+                mine[m++] = (uint16_t)at;
+                below = top;
+                top = c;
+            }
+            chain_m[k][upper] = n ? m - 1u : 0u; // without the last point, which opens the other chain
         }
-        if (lane == 0) s.hull_count[shape] = h;
+        __syncthreads();
+        for (uint32_t k = 0; k < PACK; ++k) { // ---- the hulls, in the strip order of triangle_fan_to_strip
+            if (count[k] == 0u) continue;
+            const uint32_t ml = chain_m[k][0], h = ml + chain_m[k][1], base = first_v[k];
+            for (uint32_t i = lane; i < h; i += 64) {
+                const uint32_t c = fan_to_strip_source(i, h);
+                const float2 v = pts[k][c < ml ? chain[k][0][c] : chain[k][1][c - ml]];
+                s.hull_v[base + i] = {v.x, v.y};
+            }
+            if (lane == 0) s.hull_count[shape_of[k]] = h;
+        }
         __syncthreads();
     }
 }
@@ -1019,8 +1041,9 @@ void launch_emit(const SceneDev& s, hipStream_t stream, void (*mark)(void*, cons
     if (mark) mark(ctx, "tess_hull", bytes[3]);
     if (has_stroke || big_shapes) { // some Shape may have more than 64 hull candidates: drain the queue
         // (a kernel whose queue is known to be empty is not launched: it would execute nothing, but wait for wave slots beside the raster grid)
-        if (!hull_queued || hull_queued[0]) hipLaunchKernelGGL((k_hull_large<kHullMid, 0>), dim3(min(hull_queued ? hull_queued[0] : s.n_shapes, 16384u)), dim3(64), 0, stream, s); // (6 KB of LDS each: the GPU holds 6 600 at once; 4096 made a wave take two Shapes one after the other)
-        if (!hull_queued || hull_queued[1]) hipLaunchKernelGGL((k_hull_large<kHullMax, 1>), dim3(min(hull_queued ? hull_queued[1] : s.n_shapes, 1024u)), dim3(64), 0, stream, s);
+        // (kHullPack Shapes of up to 256 candidates per wavefront, 3 KB of LDS each)
+        if (!hull_queued || hull_queued[0]) hipLaunchKernelGGL((k_hull_large<kHullMid, 0, kHullPack>), dim3(min(((hull_queued ? hull_queued[0] : s.n_shapes) + kHullPack - 1u) / kHullPack, 16384u)), dim3(64), 0, stream, s);
+        if (!hull_queued || hull_queued[1]) hipLaunchKernelGGL((k_hull_large<kHullMax, 1, 1>), dim3(min(hull_queued ? hull_queued[1] : s.n_shapes, 1024u)), dim3(64), 0, stream, s);
         if (!hull_queued || hull_queued[2]) hipLaunchKernelGGL(k_hull_huge, dim3(min(hull_queued ? hull_queued[2] : s.n_shapes, 256u)), dim3(256), 0, stream, s);
         if (mark) mark(ctx, "tess_hull_large", 0);
     }
