@@ -1146,7 +1146,7 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
     p.tile_offset = set.tile_offset.as<uint32_t>();
     p.shape_ncand = sc->shape_ncand.as<uint32_t>();
     p.shape_prim_begin = sc->shape_prim_begin.as<uint32_t>();
-    HIP_TRY(set.scan_scratch.ensure(((size_t)(f->n_tiles + 1023) / 1024 + 2) * 4));
+    HIP_TRY(set.scan_scratch.ensure(((size_t)(f->n_tiles + 511) / 512 + 2) * 4)); // (launch_tile_bases takes a sum per 512 tiles, the other scans one per 1 024)
     if (recorded) {
         // primitive ranges per draw item; a Shape may be drawn many times, so the record capacity comes from the scan's total
         HIP_TRY(f->item_ncand.ensure((size_t)f->n_items * 4 + 4));
@@ -1386,7 +1386,9 @@ crh_status render_impl(crh_scene* sc, crh_frame* f, bool again = false) {
             // only waited for the pass before that one (the other BinSet). Nothing else on this stream runs before that kernel is through
             // anyway — the next pass' binning waits for the same event when it takes that pass' BinSet.
             const crh_frame::BinSet& previous = f->sets[f->last_set];
-            if (previous.used && &previous != &set) HIP_TRY(hipStreamWaitEvent(bin, previous.raster_done, 0));
+            // (asked on the host first: a wait packet costs the binning lane 5 - 10 us whether it is satisfied or not, and with two targets in turn — an
+            // animation — the pass in question finished a step ago)
+            if (previous.used && &previous != &set && hipEventQuery(previous.raster_done) != hipSuccess) HIP_TRY(hipStreamWaitEvent(bin, previous.raster_done, 0));
             launch_tile_bases(p.tile_count, f->tile_caps.as<uint32_t>(), next_places, p.scan_scratch, p.n_tiles, p.tiles_x, f->moving ? kMovingListRadius : 0u, bin);
             f->base_cur ^= 1;
         }

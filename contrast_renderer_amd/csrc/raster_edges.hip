@@ -3878,8 +3878,13 @@ constexpr uint32_t kListSlack = 64u;
 // ... of the LONGEST list within `radius` tiles (round 5): a camera that moves shifts the content by whole tiles between two passes into the same target —
 // a zoom of 1 % per frame about the centre of 4096^2 moves the border by 40 pixels from one pass into a target to the next —, so a tile's next
 // list resembles a neighbour's, not its own. 49 counts per tile out of L2, beside the raster kernel.
-__global__ __launch_bounds__(256) void k_tile_caps(const uint32_t* count, uint32_t* caps, uint32_t n, uint32_t tiles_x, uint32_t radius) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+// SINGLE-WAVE workgroups, all three kernels of the chain (round 6): they run beside the raster kernel of the pass whose counts they read, and behind them on the same stream
+// wait the next pass' instance copies and its binning. With k_raster_fill at seven waves per SIMD (504 of a SIMD's 512 registers) a 256-thread workgroup — four wavefronts that
+// must find room on ONE compute unit at the same moment — got no slot until that grid had drained: k_tile_caps lasted 138 us, exactly as long as the raster kernel beside it
+// (rocprofv3 timeline, gpurun_out/r06_trace_moved.txt), and a scene that moves paid 0.32 - 0.34 ms per step where round 5's five-wave raster kernel had left it 0.30.
+// One wavefront takes the first slot that frees.
+__global__ __launch_bounds__(64) void k_tile_caps(const uint32_t* count, uint32_t* caps, uint32_t n, uint32_t tiles_x, uint32_t radius) {
+    const uint32_t t = blockIdx.x * 64u + threadIdx.x;
     if (t >= n) return;
     uint32_t longest = count[t];
     if (radius) {
@@ -3890,9 +3895,45 @@ __global__ __launch_bounds__(256) void k_tile_caps(const uint32_t* count, uint32
     }
     caps[t] = longest + (longest >> 1) + kListSlack;
 }
+// exclusive prefix of caps -> tile_base[0 .. n], tile_base[n] = the total: 512 items per single-wave workgroup (eight a lane), then every workgroup adds the sums in front of it
+constexpr uint32_t kBaseItems = 8, kBaseBlock = 64 * kBaseItems;
+__global__ __launch_bounds__(64) void k_tile_base_local(const uint32_t* caps, uint32_t* base, uint32_t* block_sum, uint32_t n) {
+    const uint32_t lane = threadIdx.x, i0 = blockIdx.x * kBaseBlock + lane * kBaseItems;
+    uint32_t v[kBaseItems], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kBaseItems; ++k) v[k] = i0 + k < n ? caps[i0 + k] : 0u, mine += v[k];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    uint32_t run = incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < kBaseItems; ++k) {
+        if (i0 + k < n) base[i0 + k] = run;
+        run += v[k];
+    }
+    if (lane == 63u) block_sum[blockIdx.x] = incl;
+}
+__global__ __launch_bounds__(64) void k_tile_base_add(uint32_t* base, const uint32_t* block_sum, uint32_t n, uint32_t blocks) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t k = lane; k < blockIdx.x; k += 64u) sum += block_sum[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    const uint32_t i0 = blockIdx.x * kBaseBlock + lane * kBaseItems;
+#pragma unroll
+    for (uint32_t k = 0; k < kBaseItems; ++k)
+        if (i0 + k < n) base[i0 + k] += sum;
+    if (blockIdx.x + 1u == blocks && lane == 0u) base[n] = sum + block_sum[blockIdx.x];
+}
+// (scratch: (n_tiles + 511) / 512 block sums)
 void launch_tile_bases(const uint32_t* tile_count, uint32_t* caps, uint32_t* tile_base, uint32_t* scratch, uint32_t n_tiles, uint32_t tiles_x, uint32_t radius, hipStream_t stream) {
-    hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + 255u) / 256u), dim3(256), 0, stream, tile_count, caps, n_tiles, tiles_x, radius);
-    launch_scan_u32(caps, tile_base, scratch, n_tiles, stream);
+    const uint32_t blocks = (n_tiles + kBaseBlock - 1u) / kBaseBlock;
+    hipLaunchKernelGGL(k_tile_caps, dim3((n_tiles + 63u) / 64u), dim3(64), 0, stream, tile_count, caps, n_tiles, tiles_x, radius);
+    hipLaunchKernelGGL(k_tile_base_local, dim3(blocks), dim3(64), 0, stream, caps, tile_base, scratch, n_tiles);
+    hipLaunchKernelGGL(k_tile_base_add, dim3(blocks), dim3(64), 0, stream, tile_base, scratch, n_tiles, blocks);
 }
 void launch_raster_edges(const SceneDev& s, const RasterParams& r, uint32_t samples, hipStream_t stream, void (*mark)(void*, const char*, uint64_t), void* ctx,
                          uint64_t raster_bytes, bool has_stroke) {

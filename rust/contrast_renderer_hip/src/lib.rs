@@ -422,6 +422,12 @@ impl Frame {
     pub fn clear(&mut self) {
         status(unsafe { ffi::crh_frame_clear(self.raw) }).unwrap()
     }
+    /// The reference's stencil attachment and alpha layers are caller-owned and outlive a `Shape::render` call (renderer.rs:148-158, 892-985): from this
+    /// call until `clear` the frame keeps clip / winding counters, saved alphas and the colour of every sample between passes. (It also starts by itself at
+    /// the first pass that ends with state left over; `RenderPass::submit` calls this when its draws span several objects.)
+    pub fn keep_pass_state(&mut self) {
+        status(unsafe { ffi::crh_frame_keep_pass_state(self.raw) }).unwrap()
+    }
     /// The depth of the 3-D scene the Shapes are decals in: `[height][width]`
     pub fn upload_depth(&mut self, depth: &[f32]) {
         assert_eq!(depth.len(), (self.width * self.height) as usize);
