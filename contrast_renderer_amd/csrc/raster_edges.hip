@@ -3749,23 +3749,69 @@ void launch_slot_ranges(const SceneDev& s, const RasterParams& r, uint32_t n_ite
 // The plain pass' two per-Shape ranges at the end of a tessellation — contiguous primitive ids (triangle pass) and slot ranges (edge pass) —
 // in three launches instead of six (counts of both, then the two scans side by side): small kernels on a lane that starves beside the
 // binning and raster kernels pay for every launch.
-__global__ __launch_bounds__(256) void k_shape_counts(SceneDev s, uint32_t* shape_ncand, uint32_t* shape_nslots) {
-    const uint32_t shape = blockIdx.x * 256u + threadIdx.x;
+// The tail of the tessellation lane — per Shape: candidate triangles and slots, then both prefixes — as SINGLE-WAVE workgroups (round 6). The lane of frame i + 1 runs beside
+// the raster kernel of frame i, and frame i + 1's binning waits for its end: as 256-thread workgroups k_shape_counts (6 us of work) found no four free wave slots on one compute
+// unit until the seven-wave raster grid had drained — 130 us in the rocprofv3 timeline (gpurun_out/r06_trace_steady.txt) —, and the binning started 37 us behind the raster kernel's end.
+__global__ __launch_bounds__(64) void k_shape_counts(SceneDev s, uint32_t* shape_ncand, uint32_t* shape_nslots) {
+    const uint32_t shape = blockIdx.x * 64u + threadIdx.x;
     if (shape >= s.n_shapes) return;
     uint32_t c[8];
     shape_ncand[shape] = shape_candidates(s, shape, c);
     RasterParams plain = {}; // items == nullptr: item i is Shape i, Stencil + Color
     shape_nslots[shape] = item_slots(s, item_of(plain, shape)).total;
 }
-void launch_scan_u32_pair(const uint32_t* in0, uint32_t* out0, uint32_t* block_sum0, const uint32_t* in1, uint32_t* out1, uint32_t* block_sum1, uint32_t n, hipStream_t stream); // raster.hip
+// two exclusive prefixes of n items each (blockIdx.y picks the pair), 512 items per single-wave workgroup; out[n] = the total
+struct WaveScan {
+    const uint32_t* in;
+    uint32_t* out;
+    uint32_t* block_sum;
+};
+constexpr uint32_t kWaveScanItems = 8, kWaveScanBlock = 64 * kWaveScanItems;
+__global__ __launch_bounds__(64) void k_wave_scan_local2(WaveScan a, WaveScan b, uint32_t n) {
+    const WaveScan j = blockIdx.y ? b : a;
+    const uint32_t lane = threadIdx.x, i0 = blockIdx.x * kWaveScanBlock + lane * kWaveScanItems;
+    uint32_t v[kWaveScanItems], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kWaveScanItems; ++k) v[k] = i0 + k < n ? j.in[i0 + k] : 0u, mine += v[k];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    uint32_t run = incl - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < kWaveScanItems; ++k) {
+        if (i0 + k < n) j.out[i0 + k] = run;
+        run += v[k];
+    }
+    if (lane == 63u) j.block_sum[blockIdx.x] = incl;
+}
+__global__ __launch_bounds__(64) void k_wave_scan_add2(WaveScan a, WaveScan b, uint32_t n, uint32_t blocks) {
+    const WaveScan j = blockIdx.y ? b : a;
+    const uint32_t lane = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t k = lane; k < blockIdx.x; k += 64u) sum += j.block_sum[k];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+    const uint32_t i0 = blockIdx.x * kWaveScanBlock + lane * kWaveScanItems;
+#pragma unroll
+    for (uint32_t k = 0; k < kWaveScanItems; ++k)
+        if (i0 + k < n) j.out[i0 + k] += sum;
+    if (blockIdx.x + 1u == blocks && lane == 0u) j.out[n] = sum + j.block_sum[blockIdx.x];
+}
+// (scratch0 / scratch1: (n_shapes + 511) / 512 block sums each)
 void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* shape_prim_begin, uint32_t* shape_nslots, uint32_t* shape_slot_begin, uint32_t* scratch0, uint32_t* scratch1, hipStream_t stream) {
     if (s.n_shapes == 0) {
         (void)hipMemsetAsync(shape_prim_begin, 0, 4, stream);
         (void)hipMemsetAsync(shape_slot_begin, 0, 4, stream);
         return;
     }
-    hipLaunchKernelGGL(k_shape_counts, dim3((s.n_shapes + 255u) / 256u), dim3(256), 0, stream, s, shape_ncand, shape_nslots);
-    launch_scan_u32_pair(shape_ncand, shape_prim_begin, scratch0, shape_nslots, shape_slot_begin, scratch1, s.n_shapes, stream);
+    hipLaunchKernelGGL(k_shape_counts, dim3((s.n_shapes + 63u) / 64u), dim3(64), 0, stream, s, shape_ncand, shape_nslots);
+    const uint32_t blocks = (s.n_shapes + kWaveScanBlock - 1u) / kWaveScanBlock;
+    const WaveScan a = {shape_ncand, shape_prim_begin, scratch0}, b = {shape_nslots, shape_slot_begin, scratch1};
+    hipLaunchKernelGGL(k_wave_scan_local2, dim3(blocks, 2), dim3(64), 0, stream, a, b, s.n_shapes);
+    hipLaunchKernelGGL(k_wave_scan_add2, dim3(blocks, 2), dim3(64), 0, stream, a, b, s.n_shapes, blocks);
 }
 // The items of a pass cut into runs of consecutive items that fill ONE batch of k_bin_flat each (cost: what a verified pass wrote to
 // RasterParams::item_cost). A workgroup's life is a chain of barrier-separated phases per batch, whatever the batch holds: with equal
