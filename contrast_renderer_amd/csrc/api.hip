@@ -739,7 +739,7 @@ crh_status run_tessellation(crh_scene* sc, bool again) {
     // frame's tile walks read the old ranges until its fill pass is through
     if (sc->rendered_once && !sc->last_render_one_event) HIP_TRY(hipStreamWaitEvent(ts, sc->ranges_free, 0)); // (one event stood for both: waited for above)
     launch_plain_ranges(d, sc->shape_ncand.as<uint32_t>(), sc->shape_prim_begin.as<uint32_t>(), sc->shape_nslots.as<uint32_t>(), sc->shape_slot_begin.as<uint32_t>(),
-                        sc->prim_scan_scratch.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>() + ((size_t)(d.n_shapes + 1023) / 1024 + 2), ts);
+                        sc->prim_scan_scratch.as<uint32_t>(), sc->prim_scan_scratch.as<uint32_t>() + ((size_t)(d.n_shapes + 511) / 512 + 2), ts);
     if (r->timing & 2u) crh_renderer::mark_cb_tess(r, "tess_prim_ranges", 0);
     HIP_TRY(hipEventRecord(sc->tess_done, ts));
     HIP_TRY(hipGetLastError());
@@ -1963,7 +1963,7 @@ crh_status crh_scene_upload(crh_renderer* r, const crh_path_batch* b, crh_scene*
         !hip_ok(sc->transforms.ensure((size_t)b->n_shapes * 64), "hipMalloc") || !hip_ok(sc->colors.ensure((size_t)b->n_shapes * 16), "hipMalloc") ||
         !hip_ok(sc->shape_ncand.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_prim_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
         !hip_ok(sc->shape_nslots.ensure((size_t)b->n_shapes * 4 + 4), "hipMalloc") || !hip_ok(sc->shape_slot_begin.ensure(((size_t)b->n_shapes + 1) * 4), "hipMalloc") ||
-        !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 1023) / 1024 + 2) * 8), "hipMalloc")) { // (two scans side by side)
+        !hip_ok(sc->prim_scan_scratch.ensure(((size_t)(b->n_shapes + 511) / 512 + 2) * 8), "hipMalloc")) { // (two scans side by side, a sum per 512 Shapes each)
         rc = CRH_ERR_HIP;
         goto fail;
     }
