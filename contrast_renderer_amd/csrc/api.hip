@@ -1510,6 +1510,10 @@ crh_status settle_frame(crh_frame* f) {
     if (ov[0] != 0 || ov[5] != 0 || sort_overflow || unclosed || queue_missed || tess_overflow) {
         if (tess_overflow) f->pairs_known = false; // (what the pass learned, it learned from stale rows)
         if (ov[0] != 0 || ov[5] != 0) f->pair_capacity_bytes = std::max(f->pair_capacity_bytes, grown_pair_bytes(f, ov)); // learned either way
+        // ... and the remedy is drawn the VERIFIED way (round 6): with the lists not in place (CRH_NO_DIRECT_LISTS, a frame on the exact way) an optimistic second
+        // attempt can fill one of the pair stream's 64 regions again — the whole pass draws nothing again, and nobody looked a second time: the frame stayed
+        // transparent (tests/test_gpu_parity.py::test_binning_batches_by_cost… under that pin: instances that zoom by 3 x between two passes, 69 614 -> 158 801 entries)
+        if (ov[0] != 0 || ov[5] != 0) f->pairs_known = false;
         // crh_frame_clear after the pass: what it drew is discarded anyway, and the caller's clear must stay in force for the next pass
         if (f->last_scene && !f->cleared) {
             f->cleared = true; // the pass is drawn again from scratch (only cleared frames take the optimistic path, see render_impl)
