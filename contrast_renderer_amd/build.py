@@ -69,7 +69,7 @@ def build_library(force=False, verbose=False):
     return OUT
 
 
-DEBUG_TAPS = ("crh_debug_frame_counters", "crh_debug_frame_counters16", "crh_debug_frame_words", "crh_debug_frame_bin_dump", "crh_debug_flat_batches")  # tools/ and one test read the raster kernels' counters through these
+DEBUG_TAPS = ("crh_debug_frame_counters", "crh_debug_frame_counters16", "crh_debug_frame_words", "crh_debug_frame_bin_dump", "crh_debug_flat_batches", "crh_debug_pass_leaves_state")  # tools/ and one test read the raster kernels' counters through these
 
 
 def declared_entry_points():

@@ -2192,7 +2192,7 @@ void crh_frame_destroy(crh_frame* f) {
             }
     }
     DevBuf* all[] = {&f->tile_order, &f->item_cost, &f->bin_batches, &f->tile_base, &f->tile_base_b, &f->tile_caps, &f->rgba8, &f->depth, &f->items, &f->item_transforms, &f->item_colors, &f->item_transforms_b, &f->item_colors_b, &f->item_ncand, &f->item_prim_begin, &f->item_scan_scratch,
-                     &f->item_nslots, &f->item_slot_begin};
+                     &f->item_nslots, &f->item_slot_begin, &f->state_stencil, &f->state_alpha, &f->state_color};
     for (DevBuf* b : all) b->release();
     f->item_upload_t.release();
     f->item_upload_c.release();
@@ -2352,6 +2352,8 @@ bool pass_leaves_state(const crh_draw* draws, uint32_t n_draws) {
     return !stencils.empty() || !clips.empty() || open_layers != 0u;
 }
 } // namespace
+// tests only (host code, no device): does a recorded pass leave state with the frame?
+extern "C" int crh_debug_pass_leaves_state(const crh_draw* draws, uint32_t n_draws) { return (draws || n_draws == 0u) ? (pass_leaves_state(draws, n_draws) ? 1 : 0) : -1; }
 crh_status crh_scene_render_draws(crh_scene* sc, crh_frame* f, const float* transforms, const float* colors, uint32_t n_instances, const crh_draw* draws,
                                   uint32_t n_draws) {
     if (!sc || !f || f->renderer != sc->renderer || (n_instances && (!transforms || !colors)) || (n_draws && !draws)) return CRH_ERR_INVALID_ARGUMENT;

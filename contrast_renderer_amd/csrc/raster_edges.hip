@@ -3823,7 +3823,7 @@ void launch_plain_ranges(const SceneDev& s, uint32_t* shape_ncand, uint32_t* sha
 // 10 000 paths are slower that way). CRH_BIN_FLAT_THREADS pins it (64 / 128; read per pass).
 uint32_t flat_threads_for(uint32_t n_items) {
     if (const char* e = getenv("CRH_BIN_FLAT_THREADS")) return atoi(e) == 64 ? 64u : kFlatThreads;
-    return (n_items >= 65536u && kFlatThreads == 128u) ? 64u : kFlatThreads;
+    return (n_items >= 65536u && kFlatThreads != 64u) ? 64u : kFlatThreads;
 }
 bool bin_itemwise(const RasterParams& r) { // (read per launch: tests and A/B runs switch it inside one process)
     const FlatShape shape = flat_shape(flat_threads_for(r.n_items));
@@ -3890,7 +3890,7 @@ void launch_bin_edges(const SceneDev& s, const RasterParams& r, uint32_t samples
         // same chain of phases), so the grid is sized to ONE round of resident workgroups — three per CU — as long as that leaves a batch
         // within the kernel's 32 items; what a batch cannot hold is queued and binned item by item behind it.
         const FlatShape shape = flat_shape(flat_threads_for(r.n_items));
-        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * CRH_FLAT_WAVES * (4u / (shape.threads / 64u)); // workgroups the CUs of the binning lane hold at once
+        const uint32_t resident = (getenv("CRH_BIN_CUS") ? (uint32_t)max(1, atoi(getenv("CRH_BIN_CUS"))) : 256u) * (4u * CRH_FLAT_WAVES) / (shape.threads / 64u); // workgroups the CUs of the binning lane hold at once (four SIMDs of CRH_FLAT_WAVES wavefronts each)
         // ... and within what the lanes of a batch hold (threads triangles, three times as many edges): an item that does not fit is left to the
         // workgroup's next turn, which doubles the workgroup's life — the averages of the scene keep a batch nine tenths full
         const uint32_t by_tris = r.hint_tris ? (uint32_t)((uint64_t)shape.tris * 9u / 10u * r.n_items / r.hint_tris) : shape.batch;

@@ -338,3 +338,34 @@ def test_an_open_clip_confines_later_passes_of_any_kind(msaa, oracle_lib):
     confined = oracle_image(batch, t, c, draws[:2 + len(inside)], size=192, msaa=1, clip_bits=2, layers=0)
     free = oracle_image(batch, t, c, [(i, i, op, 0, 0) for i in range(n) for op in (Op.Stencil, Op.Color)], size=192, msaa=1, clip_bits=2, layers=0)
     assert 0 < (confined[..., 3] > 0).sum() < (free[..., 3] > 0).sum()
+
+
+def test_which_recorded_passes_leave_state_with_the_frame():
+    """Host logic of the C ABI (no device): a recorded pass that ends with an open Clip, a Stencil nobody covered or a saved alpha context makes the frame
+    keep its pass state (crh_frame: `carry`); a pass that closes what it opens does not — the plain Stencil + Color loop stays on the fast formulation."""
+    import ctypes as C
+    from contrast_renderer_amd import _ffi
+    lib = _ffi.load_library()
+    lib.crh_debug_pass_leaves_state.restype = C.c_int
+    lib.crh_debug_pass_leaves_state.argtypes = [C.c_void_p, C.c_uint32]
+
+    def leaves(draws):
+        table = np.zeros((max(1, len(draws)), 5), dtype=np.uint32)
+        for i, d in enumerate(draws):
+            table[i, :len(d)] = [int(v) for v in d]
+        return lib.crh_debug_pass_leaves_state(table.ctypes.data, len(draws))
+    S, CL, UN, CO, SA, SC, RE = (int(o) for o in (Op.Stencil, Op.Clip, Op.UnClip, Op.Color, Op.SaveAlphaContext, Op.ScaleAlphaContext, Op.RestoreAlphaContext))
+    assert leaves([]) == 0
+    assert leaves([(0, 0, S, 0, 0), (0, 0, CO, 0, 0), (1, 1, S, 0, 0), (1, 1, CO, 0, 0)]) == 0                       # the plain loop
+    assert leaves([tuple(int(v) for v in d) for d in clip_scene()[3]]) == 0                                             # nested clips, all closed
+    assert leaves([tuple(int(v) for v in d) for d in alpha_scene()[3]]) == 0                                            # an opacity group, restored
+    assert leaves([(0, 0, S, 0, 0)]) == 1                                                                               # a Stencil without its cover
+    assert leaves([(0, 0, S, 0, 0), (1, 0, CO, 0, 0)]) == 1                                                             # ... covered by ANOTHER Shape's hull only
+    assert leaves([(0, 0, S, 0, 0), (0, 0, CL, 1, 0)]) == 1                                                             # an open Clip
+    assert leaves([(0, 0, UN, 0, 0)]) == 1                                                                              # closes a level an earlier pass opened
+    assert leaves([(1, 1, S, 1, 0), (1, 1, CO, 1, 0)]) == 1                                                             # drawn at a clip depth nobody opened here
+    assert leaves([(0, 0, S, 0, 0), (0, 0, CL, 1, 0), (1, 1, S, 1, 0), (1, 1, CO, 1, 0), (0, 0, UN, 0, 0)]) == 0
+    assert leaves([(0, 0, S, 0, 0), (0, 0, CL, 1, 0), (1, 1, S, 1, 0), (1, 1, CL, 2, 0), (0, 0, UN, 1, 0)]) == 1        # UnClip out of order
+    assert leaves([(0, 0, SA, 0, 0), (0, 0, SC, 0, 0)]) == 1                                                            # a saved context nobody restored
+    assert leaves([(0, 0, RE, 0, 1)]) == 1                                                                              # restores what an earlier pass saved
+    assert leaves([(0, 0, S, 0, 0), (0, 0, SA, 0, 0), (0, 0, SC, 0, 0), (0, 0, RE, 0, 0)]) == 1                         # the alpha covers write no stencil: the winding stays
