@@ -202,7 +202,7 @@ def _rocminfo_gpu():
     for block in text.split("*******")[1:]:
         if "gfx" in block and re.search(r"Device Type:\s+GPU", block):
             grab = lambda pat: (re.search(pat, block) or [None, None])[1]
-            return {"name": grab(r"Name:\s+(gfx\w+)"), "marketing_name": (grab(r"Marketing Name:\s+(.+)") or "").strip(), "compute_units": int(grab(r"Compute Unit:\s+(\d+)") or 0),
+            return {"name": grab(r"Name:\s+(gfx\w+)"), "marketing_name": (grab(r"Marketing Name:[ \t]*([^\n]*)") or "").strip(), "compute_units": int(grab(r"Compute Unit:\s+(\d+)") or 0),
                     "max_clock_mhz": int(grab(r"Max Clock Freq\. \(MHz\):\s+(\d+)") or 0), "wavefront_size": int(grab(r"Wavefront Size:\s+(\d+)") or 0)}
     return {"error": "no GPU agent in rocminfo's output"}
 
