@@ -91,6 +91,45 @@ def test_random_scene_matches_the_oracle(seed, oracle_lib):
         assert np.array_equal(frame.download_depth(), expect_depth)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CRH_FUZZ_SPLIT_SEEDS", "24"))))
+def test_a_random_pass_cut_into_pieces_at_random_draws_gives_the_same_frame(seed, oracle_lib):
+    """The recorded pass of random_case(seed) submitted as two to five passes cut at random draws (between a Stencil and its cover, inside an
+    open clip, inside an opacity group): with the pass state kept on the frame (crh_frame_keep_pass_state: the reference's caller-owned stencil
+    attachment, alpha layers and f32 colour, renderer.rs:148-158, 257-266) the frame is the single pass's, bit for bit."""
+    import torch
+    assert torch.cuda.is_available()
+    from contrast_renderer_amd import renderer as R
+    from oracle.binding import Oracle, render_pass
+    c = random_case(seed)
+    o = Oracle(c["batch"])
+    if o.status() != 0:
+        pytest.skip("the reference cannot tessellate this scene (covered by test_random_scene_matches_the_oracle)")
+    rng = np.random.RandomState(7000 + seed)
+    config = R.Configuration(msaa_sample_count=c["msaa"], clip_nesting_counter_bits=2, winding_counter_bits=c["winding_bits"], alpha_layer_count=2,
+                             cull_mode=c["state"].get("cull_mode", 0), depth_compare=c["state"].get("depth_compare", 0),
+                             depth_write_enabled=bool(c["state"].get("depth_write", 0)))
+    r = R.Renderer(config, device=0)
+    scene = R.Scene(r, c["batch"])
+    expect, expect_depth = render_pass_rect(o, c, render_pass)
+    draws = c["draws"]
+    pieces = min(len(draws), int(rng.randint(2, 6)))
+    cuts = sorted(rng.choice(np.arange(1, len(draws)), size=pieces - 1, replace=False).tolist()) if len(draws) > 1 else []
+    bounds = [0] + cuts + [len(draws)]
+    frame = R.Frame(r, c["width"], c["height"])
+    for round_ in range(2):  # the second round after a clear: the state of the first must be gone
+        frame.clear()
+        if c["depth"] is not None:
+            frame.upload_depth(c["depth"])
+        frame.keep_pass_state()
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            scene.render_draws(frame, c["transforms"], c["colors"], draws[a:b])
+        image = frame.download()
+        assert np.array_equal(image, expect), f"seed {seed} cuts {cuts} round {round_}: {(image != expect).any(axis=2).sum()} pixels differ"
+        if c["depth"] is not None:
+            assert np.array_equal(frame.download_depth(), expect_depth)
+
+
 def render_pass_rect(o, c, render_pass):
     """oracle.binding.render_pass takes (width, height); kept in one place so that the argument order cannot drift from the GPU call."""
     return render_pass(o, c["width"], c["height"], c["msaa"], c["winding_bits"], 2, 2, c["transforms"], c["colors"], [tuple(int(v) for v in d) for d in c["draws"]],
