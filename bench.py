@@ -511,7 +511,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     if args.same_device:
-        args.exchange = "torch"  # RCCL refuses two ranks on one device
+        args.exchange = "torch"  # RCCL refuses two ranks on one device ...
+        args.backend = "gloo"    # ... for the process group as well ("Duplicate GPU detected")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
