@@ -5,6 +5,8 @@ What an element emits is counted once per upload (k_tess_count_runs, k_scan_runs
 workgroups that scans in LDS and analyses each element once. The parity surface — every Shape's byte image, renderer.rs:198-209 — and the
 pixels must be the oracle's on either path. CRH_TESS_TWO_PASS=1 (read per upload) keeps a Scene on k_count / k_scan_* / k_emit; a Shape with
 more elements than a workgroup has lanes takes that path by itself. Which path ran is read off the kernel marks."""
+import os
+
 import numpy as np
 import pytest
 
@@ -60,6 +62,7 @@ def test_both_tessellation_paths_match_the_oracle(gpu, oracle_lib, case, two_pas
         two_pass = False
     if two_pass:
         monkeypatch.setenv("CRH_TESS_TWO_PASS", "1")
+    two_pass = two_pass or bool(os.environ.get("CRH_TESS_TWO_PASS"))  # (the suite run under the pin, tools/r06_pins.sh: every case takes that path)
     r = _renderer(gpu, sc)
     scene = gpu.Scene(r, sc["batch"])
     oracle = oracle_lib.Oracle(sc["batch"], 4)
@@ -123,7 +126,7 @@ def test_a_shape_beyond_one_workgroup_takes_the_two_pass_path(gpu, oracle_lib, n
     scene.render(frame, transforms, colors)
     assert np.array_equal(frame.download(), oracle.render(256, 256, 1, 4, transforms, colors))
     names = _marks(r, scene)
-    assert ("tess_fused" in names) == fused, names
+    assert ("tess_fused" in names) == (fused and not os.environ.get("CRH_TESS_TWO_PASS")), names  # (the suite under the pin: never)
 
 
 def test_stale_capacities_are_caught_and_sized_again(gpu, oracle_lib):
